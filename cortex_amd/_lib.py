@@ -1,0 +1,71 @@
+"""ctypes binding of include/cortex_hip.h.  No fallback: a missing library is an error."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcortex_hip.so")
+
+
+class cx_filter(C.Structure):
+    _fields_ = [
+        ("has_exclude", C.c_int32), ("n_exclude", C.c_uint64), ("exclude_ids", C.c_void_p),
+        ("has_kinds", C.c_int32), ("n_kinds", C.c_uint64), ("kind_codes", C.c_void_p),
+        ("has_agent", C.c_int32), ("agent_code", C.c_uint32),
+    ]
+
+
+_P = C.c_void_p
+_U64 = C.c_uint64
+_U32 = C.c_uint32
+
+# name -> (restype, argtypes): every symbol include/cortex_hip.h declares
+SIGNATURES = {
+    "cx_last_error": (C.c_char_p, []),
+    "cx_device_count": (C.c_int, []),
+    "cx_create": (_P, [_U32, C.c_int]),
+    "cx_destroy": (None, [_P]),
+    "cx_reserve": (C.c_int, [_P, _U64]),
+    "cx_upsert": (C.c_int, [_P, _P, _P, _U64]),
+    "cx_upsert_batch": (C.c_int, [_P, _U64, _P, _P, _U64]),
+    "cx_upsert_batch_dev": (C.c_int, [_P, _U64, _P, _P, _U64]),
+    "cx_remove": (C.c_int, [_P, _P]),
+    "cx_set_metadata": (C.c_int, [_P, _P, _U32, _U32]),
+    "cx_intern": (_U32, [_P, C.c_char_p, _U64]),
+    "cx_rebuild": (C.c_int, [_P]),
+    "cx_len": (_U64, [_P]),
+    "cx_dimension": (_U32, [_P]),
+    "cx_row_count": (_U64, [_P]),
+    "cx_row_id": (C.c_int, [_P, _U64, _P]),
+    "cx_search": (C.c_int, [_P, _P, _U64, _U64, _P, _P, _P, _P, _P]),
+    "cx_search_threshold": (C.c_int, [_P, _P, _U64, C.c_float, _P, _U64, _P, _P, _P, _P, _P]),
+    "cx_search_batch": (C.c_int, [_P, _U64, _P, _U64, _U64, _P, _P, _P, _P, _P]),
+    "cx_search_dev": (C.c_int, [_P, _P, _U64, _P, _P, _P, _P, _P, _P]),
+    "cx_search_batch_dev": (C.c_int, [_P, _U64, _P, _U64, _P, _P, _P, _P, _P, _P]),
+    "cx_merge_topk_dev": (C.c_int, [C.c_int, _U64, _U64, _U64, _U64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "cx_profile_enable": (C.c_int, [_P, C.c_int]),
+    "cx_profile_read": (C.c_int, [_P, _P, _P, C.c_int]),
+    "cx_device_rows": (_P, [_P]),
+    # include/cortex_hip_synth.h
+    "cx_synth_fill_dev": (C.c_int, [C.c_int, _P, _U64, _U64, _U64, _U64, _U64, _U64, _U32, _U32]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libcortex_hip.so (built by cortex_amd.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(cortex_amd has no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the header and the library disagree
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib

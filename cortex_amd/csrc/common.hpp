@@ -1,0 +1,93 @@
+// common.hpp — error plumbing and shared device-side types for libcortex_hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/cortex_hip.h"
+
+namespace cx {
+
+// Thread-local message behind cx_last_error(); mapped to
+// CortexError::Validation(String) by the caller's shim.
+char *err_buf();
+int set_err(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define CX_HIP(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e__ = (expr);                                                           \
+        if (e__ != hipSuccess)                                                             \
+            return ::cx::set_err(CX_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr,            \
+                                 hipGetErrorString(e__), __FILE__, __LINE__);              \
+    } while (0)
+
+// A candidate's order key: (ord(score) << 32) | ~row.  Larger = better, so
+// "score descending, then row ascending"; 0 = empty slot.  ord() maps a
+// clamped score to an integer that grows with it: NaN -> 1 (after every
+// number), x >= +0.0 -> bits(x) + 2.
+__host__ __device__ inline uint32_t score_ord(float score) {
+    if (score != score) return 1u;
+    uint32_t b;
+    memcpy(&b, &score, 4);
+    return b + 2u;
+}
+__host__ __device__ inline uint64_t make_key(float score, uint32_t row) {
+    return ((uint64_t)score_ord(score) << 32) | (uint32_t)(~row);
+}
+__host__ __device__ inline uint32_t key_row(uint64_t key) { return ~(uint32_t)key; }
+
+// Device-side view of a VectorFilter plus per-row metadata
+// (vector/index.rs:225-251).  meta[row]: bit0 = removed, bit1 = has metadata,
+// bits 8.. = kind code; agent[row] = agent code.
+struct DevFilter {
+    const uint32_t *meta;          // [rows] never null once rows exist
+    const uint32_t *agent;         // [rows]
+    const uint32_t *exclude_rows;  // sorted ascending, n_exclude entries (device)
+    const uint32_t *kind_codes;    // n_kinds entries (device)
+    uint32_t n_exclude;
+    uint32_t n_kinds;
+    uint32_t has_kinds;
+    uint32_t has_agent;
+    uint32_t agent_code;
+};
+
+constexpr uint32_t META_REMOVED = 1u;
+constexpr uint32_t META_HAS = 2u;
+
+__device__ inline bool row_passes(const DevFilter &f, uint32_t row) {
+    const uint32_t m = f.meta[row];
+    if (m & META_REMOVED) return false;
+    for (uint32_t i = 0; i < f.n_exclude; i++)
+        if (f.exclude_rows[i] == row) return false;
+    if (m & META_HAS) {  // filters bind only where metadata exists (:234)
+        if (f.has_kinds) {
+            const uint32_t kind = m >> 8;
+            bool found = false;
+            for (uint32_t i = 0; i < f.n_kinds; i++) found |= (f.kind_codes[i] == kind);
+            if (!found) return false;
+        }
+        if (f.has_agent && f.agent[row] != f.agent_code) return false;
+    }
+    return true;
+}
+
+// The reference's epilogue, one IEEE operation per step
+// (vector/index.rs:173-177 and :254-256).
+__device__ inline float cosine_from_sums(float dot, float qq, float rr) {
+    const float norm_a = __fsqrt_rn(qq);
+    const float norm_b = __fsqrt_rn(rr);
+    return __fdiv_rn(dot, __fmul_rn(norm_a, norm_b));
+}
+__host__ __device__ inline float distance_of(float sim) { return 1.0f - sim; }
+__host__ __device__ inline float score_of(float distance) {
+    float s = 1.0f - distance;
+    if (s < 0.0f) s = 0.0f;
+    if (s > 1.0f) s = 1.0f;
+    return s;  // NaN falls through both compares
+}
+
+}  // namespace cx

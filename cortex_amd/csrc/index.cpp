@@ -1,0 +1,770 @@
+// index.cpp — host side of libcortex_hip: the embedding store (id <-> row map,
+// tombstones, metadata codes, HBM row store) and the C ABI of
+// include/cortex_hip.h.  The arithmetic lives in the .hip files; this file
+// only moves bytes, keeps the maps and launches kernels.
+//
+// HBM layout per index (one index = one shard on one device):
+//   d_rows  f32 [cap][dim]  row-major, rows in insertion order (append-only;
+//                            an upsert of a known id rewrites its row in place)
+//   d_meta  u32 [cap]       bit0 removed, bit1 has-metadata, bits 8.. kind code
+//   d_agent u32 [cap]       interned source_agent code
+// Host: ids (16 B per row), id -> row hash map, mirrors of meta/agent.
+#include <algorithm>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace cx {
+
+static thread_local char g_err[512];
+char *err_buf() { return g_err; }
+int set_err(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+struct IdKey {
+    uint64_t a, b;
+    bool operator==(const IdKey &o) const { return a == o.a && b == o.b; }
+};
+struct IdHash {
+    size_t operator()(const IdKey &k) const {
+        uint64_t h = k.a * 0x9E3779B97F4A7C15ull ^ (k.b + 0xC2B2AE3D27D4EB4Full + (k.a << 6) + (k.a >> 2));
+        h ^= h >> 29;
+        h *= 0xBF58476D1CE4E5B9ull;
+        return (size_t)(h ^ (h >> 32));
+    }
+};
+static inline IdKey id_key(const uint8_t *id) {
+    IdKey k;
+    memcpy(&k.a, id, 8);
+    memcpy(&k.b, id + 8, 8);
+    return k;
+}
+
+template <typename T>
+static int ensure_dev(T *&p, size_t &cap, size_t need) {
+    if (need <= cap) return CX_OK;
+    size_t ncap = std::max(need, cap * 2);
+    if (p) CX_HIP(hipFree(p));
+    p = nullptr;
+    cap = 0;
+    CX_HIP(hipMalloc((void **)&p, ncap * sizeof(T)));
+    cap = ncap;
+    return CX_OK;
+}
+template <typename T>
+static int ensure_pinned(T *&p, size_t &cap, size_t need) {
+    if (need <= cap) return CX_OK;
+    size_t ncap = std::max(need, cap * 2);
+    if (p) CX_HIP(hipHostFree(p));
+    p = nullptr;
+    cap = 0;
+    CX_HIP(hipHostMalloc((void **)&p, ncap * sizeof(T), hipHostMallocDefault));
+    cap = ncap;
+    return CX_OK;
+}
+
+// Per-call scratch.  Host-API calls take one from the pool for the duration
+// of the call (re-entrancy under the callers' read lock); *_dev calls get the
+// one bound to their stream, so back-to-back calls on a stream reuse it in
+// stream order.
+struct Ctx {
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    float *d_query = nullptr; size_t q_cap = 0;
+    uint64_t *d_part_keys = nullptr; size_t pk_cap = 0;
+    float *d_part_sims = nullptr; size_t ps_cap = 0;
+    uint32_t *d_out_rows = nullptr; size_t or_cap = 0;
+    float *d_out_scores = nullptr; size_t os_cap = 0;
+    float *d_out_dists = nullptr; size_t od_cap = 0;
+    uint32_t *d_out_counts = nullptr; size_t oc_cap = 0;
+    uint32_t *d_excl = nullptr; size_t ex_cap = 0;
+    uint32_t *d_kinds = nullptr; size_t kd_cap = 0;
+    uint64_t *d_keys = nullptr; size_t k1_cap = 0;
+    uint64_t *d_keys2 = nullptr; size_t k2_cap = 0;
+    float *d_sims = nullptr; size_t s1_cap = 0;
+    float *d_sims2 = nullptr; size_t s2_cap = 0;
+    char *d_temp = nullptr; size_t tmp_cap = 0;
+    float *h_query = nullptr; size_t hq_cap = 0;
+    uint32_t *h_rows = nullptr; size_t hr_cap = 0;
+    float *h_scores = nullptr; size_t hs_cap = 0;
+    float *h_dists = nullptr; size_t hd_cap = 0;
+    uint32_t *h_counts = nullptr; size_t hc_cap = 0;
+
+    ~Ctx() {
+        (void)hipFree(d_query); (void)hipFree(d_part_keys); (void)hipFree(d_part_sims); (void)hipFree(d_out_rows);
+        (void)hipFree(d_out_scores); (void)hipFree(d_out_dists); (void)hipFree(d_out_counts); (void)hipFree(d_excl);
+        (void)hipFree(d_kinds); (void)hipFree(d_keys); (void)hipFree(d_keys2); (void)hipFree(d_sims); (void)hipFree(d_sims2);
+        (void)hipFree(d_temp);
+        (void)hipHostFree(h_query); (void)hipHostFree(h_rows); (void)hipHostFree(h_scores); (void)hipHostFree(h_dists);
+        (void)hipHostFree(h_counts);
+        if (own_stream && stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+}  // namespace cx
+
+using namespace cx;
+
+struct cx_index {
+    uint32_t dim = 0;
+    int device = 0;
+    float *d_rows = nullptr;
+    uint32_t *d_meta = nullptr;
+    uint32_t *d_agent = nullptr;
+    uint64_t cap = 0;
+    uint64_t n_rows = 0;
+    uint64_t n_alive = 0;
+    uint64_t n_removed = 0;
+    std::vector<uint8_t> ids;
+    std::vector<uint32_t> h_meta, h_agent;
+    std::unordered_map<IdKey, uint32_t, IdHash> map;
+    std::unordered_map<std::string, uint32_t> interned;
+    hipStream_t up_stream = nullptr;
+    mutable std::mutex mu;
+    mutable std::vector<Ctx *> pool;
+    mutable std::unordered_map<void *, Ctx *> by_stream;
+    // measurement (cx_profile_*): event pairs around the scan kernel
+    bool profiling = false;
+    mutable std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    double prof_ms = 0.0;
+    uint64_t prof_n = 0;
+};
+
+namespace {
+
+int use_device(const cx_index *ix) {
+    CX_HIP(hipSetDevice(ix->device));
+    return CX_OK;
+}
+
+Ctx *acquire_ctx(const cx_index *ix) {
+    {
+        std::lock_guard<std::mutex> g(ix->mu);
+        if (!ix->pool.empty()) {
+            Ctx *c = ix->pool.back();
+            ix->pool.pop_back();
+            return c;
+        }
+    }
+    Ctx *c = new Ctx();
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        set_err(CX_ERR_DEVICE, "hipStreamCreate failed");
+        return nullptr;
+    }
+    c->own_stream = true;
+    return c;
+}
+void release_ctx(const cx_index *ix, Ctx *c) {
+    std::lock_guard<std::mutex> g(ix->mu);
+    ix->pool.push_back(c);
+}
+Ctx *ctx_for_stream(const cx_index *ix, hipStream_t s) {
+    std::lock_guard<std::mutex> g(ix->mu);
+    auto it = ix->by_stream.find((void *)s);
+    if (it != ix->by_stream.end()) return it->second;
+    Ctx *c = new Ctx();
+    c->stream = s;
+    c->own_stream = false;
+    ix->by_stream[(void *)s] = c;
+    return c;
+}
+
+int grow_rows(cx_index *ix, uint64_t need) {
+    if (need <= ix->cap) return CX_OK;
+    if (need >= 0xFFFFFFF0ull) return set_err(CX_ERR_VALIDATION, "row store limited to 2^32-16 rows per shard");
+    uint64_t ncap = std::max<uint64_t>(need, std::max<uint64_t>(ix->cap * 2, 1024));
+    float *nr = nullptr;
+    uint32_t *nm = nullptr, *na = nullptr;
+    CX_HIP(hipMalloc((void **)&nr, ncap * ix->dim * sizeof(float) + 64));
+    CX_HIP(hipMalloc((void **)&nm, ncap * sizeof(uint32_t)));
+    CX_HIP(hipMalloc((void **)&na, ncap * sizeof(uint32_t)));
+    CX_HIP(hipMemsetAsync(nm, 0, ncap * sizeof(uint32_t), ix->up_stream));
+    CX_HIP(hipMemsetAsync(na, 0, ncap * sizeof(uint32_t), ix->up_stream));
+    if (ix->n_rows) {
+        CX_HIP(hipMemcpyAsync(nr, ix->d_rows, ix->n_rows * ix->dim * sizeof(float), hipMemcpyDeviceToDevice, ix->up_stream));
+        CX_HIP(hipMemcpyAsync(nm, ix->d_meta, ix->n_rows * sizeof(uint32_t), hipMemcpyDeviceToDevice, ix->up_stream));
+        CX_HIP(hipMemcpyAsync(na, ix->d_agent, ix->n_rows * sizeof(uint32_t), hipMemcpyDeviceToDevice, ix->up_stream));
+    }
+    CX_HIP(hipStreamSynchronize(ix->up_stream));
+    if (ix->d_rows) CX_HIP(hipFree(ix->d_rows));
+    if (ix->d_meta) CX_HIP(hipFree(ix->d_meta));
+    if (ix->d_agent) CX_HIP(hipFree(ix->d_agent));
+    ix->d_rows = nr;
+    ix->d_meta = nm;
+    ix->d_agent = na;
+    ix->cap = ncap;
+    return CX_OK;
+}
+
+int push_meta(cx_index *ix, uint32_t row) {
+    CX_HIP(hipMemcpyAsync(ix->d_meta + row, &ix->h_meta[row], 4, hipMemcpyHostToDevice, ix->up_stream));
+    CX_HIP(hipMemcpyAsync(ix->d_agent + row, &ix->h_agent[row], 4, hipMemcpyHostToDevice, ix->up_stream));
+    CX_HIP(hipStreamSynchronize(ix->up_stream));
+    return CX_OK;
+}
+
+// vector/index.rs:298-314 for n rows.  Runs of fresh ids land in consecutive
+// rows and move with one copy each.
+int upsert_impl(cx_index *ix, uint64_t n, const uint8_t *ids, const float *embs, uint64_t len, bool on_device) {
+    if (!ix) return set_err(CX_ERR_VALIDATION, "null index");
+    if (len != ix->dim)
+        return set_err(CX_ERR_VALIDATION, "Embedding dimension mismatch: expected %u, got %llu", ix->dim,
+                       (unsigned long long)len);
+    if (!n) return CX_OK;
+    if (!ids || !embs) return set_err(CX_ERR_VALIDATION, "null ids/embeddings");
+    if (int rc = use_device(ix)) return rc;
+    if (int rc = grow_rows(ix, ix->n_rows + n)) return rc;
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    const size_t row_bytes = (size_t)ix->dim * sizeof(float);
+    uint64_t i = 0;
+    while (i < n) {
+        const IdKey key = id_key(ids + 16 * i);
+        auto it = ix->map.find(key);
+        if (it != ix->map.end()) {  // replace in place, row position kept
+            if (row_bytes)
+                CX_HIP(hipMemcpyAsync(ix->d_rows + (size_t)it->second * ix->dim, embs + i * len, row_bytes, kind, ix->up_stream));
+            i++;
+            continue;
+        }
+        // extend a run of fresh ids (stop at a known id or a repeat inside the run)
+        const uint64_t run_start = i;
+        const uint64_t first_row = ix->n_rows;
+        while (i < n) {
+            const IdKey kk = id_key(ids + 16 * i);
+            if (ix->map.find(kk) != ix->map.end()) break;
+            ix->map.emplace(kk, (uint32_t)ix->n_rows);
+            ix->ids.insert(ix->ids.end(), ids + 16 * i, ids + 16 * i + 16);
+            ix->h_meta.push_back(0);
+            ix->h_agent.push_back(0);
+            ix->n_rows++;
+            ix->n_alive++;
+            i++;
+        }
+        if (row_bytes)
+            CX_HIP(hipMemcpyAsync(ix->d_rows + (size_t)first_row * ix->dim, embs + run_start * len,
+                                  (i - run_start) * row_bytes, kind, ix->up_stream));
+    }
+    CX_HIP(hipStreamSynchronize(ix->up_stream));
+    return CX_OK;
+}
+
+struct FilterUpload {
+    DevFilter f;
+    bool needs_sync = false;
+};
+
+// VectorFilter -> device view.  Exclude ids that are not in the index cannot
+// match any row and are dropped.
+int build_filter(const cx_index *ix, Ctx *c, const cx_filter *filter, hipStream_t s, FilterUpload &out) {
+    DevFilter &f = out.f;
+    memset(&f, 0, sizeof f);
+    f.meta = ix->d_meta;
+    f.agent = ix->d_agent;
+    if (!filter) return CX_OK;
+    if (filter->has_exclude && filter->n_exclude) {
+        if (!filter->exclude_ids) return set_err(CX_ERR_VALIDATION, "filter: exclude_ids is null");
+        std::vector<uint32_t> rows;
+        rows.reserve(filter->n_exclude);
+        for (uint64_t i = 0; i < filter->n_exclude; i++) {
+            auto it = ix->map.find(id_key(filter->exclude_ids + 16 * i));
+            if (it != ix->map.end()) rows.push_back(it->second);
+        }
+        std::sort(rows.begin(), rows.end());
+        if (!rows.empty()) {
+            if (int rc = ensure_dev(c->d_excl, c->ex_cap, rows.size())) return rc;
+            CX_HIP(hipMemcpyAsync(c->d_excl, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, s));
+            CX_HIP(hipStreamSynchronize(s));  // rows is a local; the copy must finish before it dies
+            f.exclude_rows = c->d_excl;
+            f.n_exclude = (uint32_t)rows.size();
+        }
+    }
+    if (filter->has_kinds) {
+        f.has_kinds = 1;
+        f.n_kinds = (uint32_t)filter->n_kinds;
+        if (filter->n_kinds) {
+            if (!filter->kind_codes) return set_err(CX_ERR_VALIDATION, "filter: kind_codes is null");
+            if (int rc = ensure_dev(c->d_kinds, c->kd_cap, (size_t)filter->n_kinds)) return rc;
+            CX_HIP(hipMemcpyAsync(c->d_kinds, filter->kind_codes, filter->n_kinds * 4, hipMemcpyHostToDevice, s));
+            CX_HIP(hipStreamSynchronize(s));
+            f.kind_codes = c->d_kinds;
+        }
+    }
+    if (filter->has_agent) {
+        f.has_agent = 1;
+        f.agent_code = filter->agent_code;
+    }
+    return CX_OK;
+}
+
+bool use_nontemporal(const cx_index *ix) {
+    static int forced = -1;
+    if (forced == -1) {
+        const char *e = getenv("CX_SCAN_NT");
+        forced = e ? (atoi(e) ? 1 : 0) : 2;
+    }
+    if (forced != 2) return forced == 1;
+    // rows larger than the 256 MiB Infinity Cache cannot stay resident between queries
+    return (uint64_t)ix->n_rows * ix->dim * sizeof(float) > (256ull << 20);
+}
+
+// nq single-query scans enqueued on s; query i's results at [i*k_out, ...).
+// threshold searches (has_thr) and k > TOPK_MAX take the dense+sort path.
+int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float *tails, uint64_t nq, uint32_t k_eff,
+                const DevFilter &flt, float thr, bool has_thr, uint32_t *d_rows, float *d_scores, float *d_dists,
+                uint32_t *d_counts, hipStream_t s) {
+    const uint32_t n = (uint32_t)ix->n_rows;
+    const bool nt = use_nontemporal(ix);
+    const bool topk_path = !has_thr && k_eff <= TOPK_MAX;
+    uint32_t grid = 0;
+    if (topk_path) {
+        grid = scan_grid_blocks(n, ix->dim);
+        if (int rc = ensure_dev(c->d_part_keys, c->pk_cap, (size_t)grid * std::max(k_eff, 1u))) return rc;
+        if (int rc = ensure_dev(c->d_part_sims, c->ps_cap, (size_t)grid * std::max(k_eff, 1u))) return rc;
+    } else {
+        if (int rc = ensure_dev(c->d_keys, c->k1_cap, n)) return rc;
+        if (int rc = ensure_dev(c->d_keys2, c->k2_cap, n)) return rc;
+        if (int rc = ensure_dev(c->d_sims, c->s1_cap, n)) return rc;
+        if (int rc = ensure_dev(c->d_sims2, c->s2_cap, n)) return rc;
+        if (int rc = ensure_dev(c->d_temp, c->tmp_cap, sort_temp_bytes(n))) return rc;
+    }
+    for (uint64_t i = 0; i < nq; i++) {
+        ScanArgs a;
+        memset(&a, 0, sizeof a);
+        a.rows = ix->d_rows;
+        a.query = d_queries + i * ix->dim;
+        a.q_tail_sumsq = tails ? tails[i] : 0.0f;
+        a.n_rows = n;
+        a.dim = ix->dim;
+        a.k = k_eff;
+        a.flt = flt;
+        if (topk_path) {
+            if (k_eff == 0) {
+                CX_HIP(hipMemsetAsync(d_counts + i, 0, 4, s));
+                continue;
+            }
+            a.part_keys = c->d_part_keys;
+            a.part_sims = c->d_part_sims;
+            MergeArgs m;
+            m.part_keys = c->d_part_keys;
+            m.part_sims = c->d_part_sims;
+            m.n_lists = grid;
+            m.k = k_eff;
+            m.out_rows = d_rows + i * k_eff;
+            m.out_scores = d_scores + i * k_eff;
+            m.out_dists = d_dists + i * k_eff;
+            m.out_count = d_counts + i;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (ix->profiling) {
+                CX_HIP(hipEventCreate(&e0));
+                CX_HIP(hipEventCreate(&e1));
+                std::lock_guard<std::mutex> g(ix->mu);
+                ix->prof_events.emplace_back(e0, e1);
+            }
+            if (int rc = launch_scan_topk(a, m, nt, s, e0, e1)) return rc;
+        } else {
+            a.dense_keys = c->d_keys;
+            a.dense_sims = c->d_sims;
+            a.threshold = thr;
+            a.has_threshold = has_thr ? 1u : 0u;
+            if (int rc = launch_scan_dense(a, nt, s)) return rc;
+            if (int rc = launch_sort_select(c->d_keys, c->d_sims, c->d_keys2, c->d_sims2, n, k_eff, c->d_temp,
+                                            c->tmp_cap, d_rows + i * k_eff, d_scores + i * k_eff,
+                                            d_dists + i * k_eff, d_counts + i, s))
+                return rc;
+        }
+    }
+    return CX_OK;
+}
+
+// Host queries -> pinned staging, zero-padded / truncated to dim; the sum of
+// squares of any elements beyond dim still belongs to |q| (the reference
+// zips for the dot but takes the norm over the whole query, index.rs:172-173).
+int stage_queries(const cx_index *ix, Ctx *c, uint64_t nq, const float *queries, uint64_t len, std::vector<float> &tails) {
+    const uint32_t dim = ix->dim;
+    if (int rc = ensure_pinned(c->h_query, c->hq_cap, (size_t)nq * std::max(dim, 1u))) return rc;
+    if (int rc = ensure_dev(c->d_query, c->q_cap, (size_t)nq * std::max(dim, 1u) + 4)) return rc;
+    tails.assign(nq, 0.0f);
+    for (uint64_t i = 0; i < nq; i++) {
+        const float *q = queries + i * len;
+        float *dst = c->h_query + i * dim;
+        const uint64_t m = std::min<uint64_t>(len, dim);
+        memcpy(dst, q, m * sizeof(float));
+        for (uint64_t j = m; j < dim; j++) dst[j] = 0.0f;
+        float t = 0.0f;
+        for (uint64_t j = dim; j < len; j++) t += q[j] * q[j];
+        tails[i] = t;
+    }
+    if (dim) CX_HIP(hipMemcpyAsync(c->d_query, c->h_query, (size_t)nq * dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    return CX_OK;
+}
+
+int ensure_out(Ctx *c, size_t entries, size_t nq) {
+    entries = std::max<size_t>(entries, 1);
+    if (int rc = ensure_dev(c->d_out_rows, c->or_cap, entries)) return rc;
+    if (int rc = ensure_dev(c->d_out_scores, c->os_cap, entries)) return rc;
+    if (int rc = ensure_dev(c->d_out_dists, c->od_cap, entries)) return rc;
+    if (int rc = ensure_dev(c->d_out_counts, c->oc_cap, std::max<size_t>(nq, 1))) return rc;
+    if (int rc = ensure_pinned(c->h_counts, c->hc_cap, std::max<size_t>(nq, 1))) return rc;
+    return CX_OK;
+}
+
+int fetch_results(Ctx *c, size_t entries) {
+    entries = std::max<size_t>(entries, 1);
+    if (int rc = ensure_pinned(c->h_rows, c->hr_cap, entries)) return rc;
+    if (int rc = ensure_pinned(c->h_scores, c->hs_cap, entries)) return rc;
+    if (int rc = ensure_pinned(c->h_dists, c->hd_cap, entries)) return rc;
+    CX_HIP(hipMemcpyAsync(c->h_rows, c->d_out_rows, entries * 4, hipMemcpyDeviceToHost, c->stream));
+    CX_HIP(hipMemcpyAsync(c->h_scores, c->d_out_scores, entries * 4, hipMemcpyDeviceToHost, c->stream));
+    CX_HIP(hipMemcpyAsync(c->h_dists, c->d_out_dists, entries * 4, hipMemcpyDeviceToHost, c->stream));
+    CX_HIP(hipStreamSynchronize(c->stream));
+    return CX_OK;
+}
+
+struct CtxLease {
+    const cx_index *ix;
+    Ctx *c;
+    CtxLease(const cx_index *i) : ix(i), c(acquire_ctx(i)) {}
+    ~CtxLease() { if (c) release_ctx(ix, c); }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char *cx_last_error(void) { return err_buf(); }
+
+int cx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+cx_index *cx_create(uint32_t dimension, int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_err(CX_ERR_DEVICE, "no HIP device available (%s); libcortex_hip has no CPU fallback",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return nullptr;
+    }
+    if (device < 0 || device >= n) {
+        set_err(CX_ERR_VALIDATION, "device %d out of range (0..%d)", device, n - 1);
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        set_err(CX_ERR_DEVICE, "hipSetDevice(%d) failed", device);
+        return nullptr;
+    }
+    cx_index *ix = new cx_index();
+    ix->dim = dimension;
+    ix->device = device;
+    if (hipStreamCreateWithFlags(&ix->up_stream, hipStreamNonBlocking) != hipSuccess) {
+        set_err(CX_ERR_DEVICE, "hipStreamCreate failed");
+        delete ix;
+        return nullptr;
+    }
+    return ix;
+}
+
+void cx_destroy(cx_index *ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    (void)hipDeviceSynchronize();
+    for (Ctx *c : ix->pool) delete c;
+    for (auto &kv : ix->by_stream) delete kv.second;
+    (void)hipFree(ix->d_rows);
+    (void)hipFree(ix->d_meta);
+    (void)hipFree(ix->d_agent);
+    if (ix->up_stream) (void)hipStreamDestroy(ix->up_stream);
+    delete ix;
+}
+
+int cx_reserve(cx_index *ix, uint64_t rows) {
+    if (!ix) return set_err(CX_ERR_VALIDATION, "null index");
+    if (int rc = use_device(ix)) return rc;
+    return grow_rows(ix, rows);
+}
+
+int cx_upsert(cx_index *ix, const uint8_t id[16], const float *embedding, uint64_t len) {
+    return upsert_impl(ix, 1, id, embedding, len, false);
+}
+int cx_upsert_batch(cx_index *ix, uint64_t n, const uint8_t *ids, const float *embeddings, uint64_t len) {
+    return upsert_impl(ix, n, ids, embeddings, len, false);
+}
+int cx_upsert_batch_dev(cx_index *ix, uint64_t n, const uint8_t *ids, const float *d_embeddings, uint64_t len) {
+    return upsert_impl(ix, n, ids, d_embeddings, len, true);
+}
+
+int cx_remove(cx_index *ix, const uint8_t id[16]) {
+    if (!ix || !id) return set_err(CX_ERR_VALIDATION, "null argument");
+    auto it = ix->map.find(id_key(id));
+    if (it == ix->map.end()) return CX_OK;  // vector/index.rs:317 — HashMap::remove of a missing key
+    if (int rc = use_device(ix)) return rc;
+    const uint32_t row = it->second;
+    ix->map.erase(it);
+    ix->h_meta[row] = META_REMOVED;  // metadata goes with the vector (:318)
+    ix->h_agent[row] = 0;
+    ix->n_alive--;
+    ix->n_removed++;
+    return push_meta(ix, row);
+}
+
+int cx_set_metadata(cx_index *ix, const uint8_t id[16], uint32_t kind_code, uint32_t agent_code) {
+    if (!ix || !id) return set_err(CX_ERR_VALIDATION, "null argument");
+    if (kind_code >= (1u << 24)) return set_err(CX_ERR_VALIDATION, "kind code out of range");
+    auto it = ix->map.find(id_key(id));
+    // The reference keeps metadata in its own map and only consults it for ids
+    // that have a vector (:234); metadata for an unknown id has no effect.
+    if (it == ix->map.end()) return CX_OK;
+    if (int rc = use_device(ix)) return rc;
+    const uint32_t row = it->second;
+    ix->h_meta[row] = META_HAS | (kind_code << 8);
+    ix->h_agent[row] = agent_code;
+    return push_meta(ix, row);
+}
+
+uint32_t cx_intern(cx_index *ix, const char *utf8, uint64_t len) {
+    if (!ix || (!utf8 && len)) return 0;
+    std::string s(utf8 ? utf8 : "", (size_t)len);
+    auto it = ix->interned.find(s);
+    if (it != ix->interned.end()) return it->second;
+    const uint32_t code = (uint32_t)ix->interned.size() + 1;
+    ix->interned.emplace(std::move(s), code);
+    return code;
+}
+
+int cx_rebuild(cx_index *ix) {
+    if (!ix) return set_err(CX_ERR_VALIDATION, "null index");
+    if (!ix->n_removed) return CX_OK;
+    if (int rc = use_device(ix)) return rc;
+    std::vector<uint32_t> keep;
+    keep.reserve(ix->n_alive);
+    for (uint64_t r = 0; r < ix->n_rows; r++)
+        if (!(ix->h_meta[r] & META_REMOVED)) keep.push_back((uint32_t)r);
+    const uint64_t n_new = keep.size();
+    const uint64_t ncap = std::max<uint64_t>(n_new, 1024);
+    float *nr = nullptr;
+    uint32_t *nm = nullptr, *na = nullptr, *d_keep = nullptr;
+    CX_HIP(hipMalloc((void **)&nr, ncap * ix->dim * sizeof(float) + 64));
+    CX_HIP(hipMalloc((void **)&nm, ncap * sizeof(uint32_t)));
+    CX_HIP(hipMalloc((void **)&na, ncap * sizeof(uint32_t)));
+    CX_HIP(hipMemsetAsync(nm, 0, ncap * sizeof(uint32_t), ix->up_stream));
+    CX_HIP(hipMemsetAsync(na, 0, ncap * sizeof(uint32_t), ix->up_stream));
+    std::vector<uint8_t> nids(n_new * 16);
+    std::vector<uint32_t> nmeta(n_new), nagent(n_new);
+    ix->map.clear();
+    for (uint64_t i = 0; i < n_new; i++) {
+        const uint32_t r = keep[i];
+        memcpy(&nids[16 * i], &ix->ids[16 * (size_t)r], 16);
+        nmeta[i] = ix->h_meta[r];
+        nagent[i] = ix->h_agent[r];
+        ix->map.emplace(id_key(&nids[16 * i]), (uint32_t)i);
+    }
+    if (n_new) {
+        CX_HIP(hipMalloc((void **)&d_keep, n_new * 4));
+        CX_HIP(hipMemcpyAsync(d_keep, keep.data(), n_new * 4, hipMemcpyHostToDevice, ix->up_stream));
+        if (ix->dim)
+            if (int rc = launch_gather_rows(ix->d_rows, nr, d_keep, (uint32_t)n_new, ix->dim, ix->up_stream)) return rc;
+        CX_HIP(hipMemcpyAsync(nm, nmeta.data(), n_new * 4, hipMemcpyHostToDevice, ix->up_stream));
+        CX_HIP(hipMemcpyAsync(na, nagent.data(), n_new * 4, hipMemcpyHostToDevice, ix->up_stream));
+    }
+    CX_HIP(hipStreamSynchronize(ix->up_stream));
+    if (d_keep) CX_HIP(hipFree(d_keep));
+    CX_HIP(hipFree(ix->d_rows));
+    CX_HIP(hipFree(ix->d_meta));
+    CX_HIP(hipFree(ix->d_agent));
+    ix->d_rows = nr;
+    ix->d_meta = nm;
+    ix->d_agent = na;
+    ix->cap = ncap;
+    ix->ids.swap(nids);
+    ix->h_meta.swap(nmeta);
+    ix->h_agent.swap(nagent);
+    ix->n_rows = n_new;
+    ix->n_alive = n_new;
+    ix->n_removed = 0;
+    return CX_OK;
+}
+
+int cx_profile_enable(cx_index *ix, int on) {
+    if (!ix) return set_err(CX_ERR_VALIDATION, "null index");
+    ix->profiling = on != 0;
+    return CX_OK;
+}
+
+int cx_profile_read(cx_index *ix, double *kernel_ms_sum, uint64_t *launches, int reset) {
+    if (!ix || !kernel_ms_sum || !launches) return set_err(CX_ERR_VALIDATION, "null argument");
+    if (int rc = use_device(ix)) return rc;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
+    {
+        std::lock_guard<std::mutex> g(ix->mu);
+        evs.swap(ix->prof_events);
+    }
+    for (auto &p : evs) {
+        float ms = 0.0f;
+        CX_HIP(hipEventSynchronize(p.second));
+        CX_HIP(hipEventElapsedTime(&ms, p.first, p.second));
+        ix->prof_ms += ms;
+        ix->prof_n++;
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    *kernel_ms_sum = ix->prof_ms;
+    *launches = ix->prof_n;
+    if (reset) {
+        ix->prof_ms = 0.0;
+        ix->prof_n = 0;
+    }
+    return CX_OK;
+}
+
+uint64_t cx_len(const cx_index *ix) { return ix ? ix->n_alive : 0; }
+uint32_t cx_dimension(const cx_index *ix) { return ix ? ix->dim : 0; }
+uint64_t cx_row_count(const cx_index *ix) { return ix ? ix->n_rows : 0; }
+const float *cx_device_rows(const cx_index *ix) { return ix ? ix->d_rows : nullptr; }
+
+int cx_row_id(const cx_index *ix, uint64_t row, uint8_t out_id[16]) {
+    if (!ix || !out_id) return set_err(CX_ERR_VALIDATION, "null argument");
+    if (row >= ix->n_rows) return set_err(CX_ERR_VALIDATION, "row %llu out of range", (unsigned long long)row);
+    memcpy(out_id, &ix->ids[16 * (size_t)row], 16);
+    return CX_OK;
+}
+
+int cx_search_batch(const cx_index *ix, uint64_t nq, const float *queries, uint64_t len, uint64_t k,
+                    const cx_filter *filter, uint8_t *out_ids, float *out_scores, float *out_distances,
+                    uint64_t *out_counts) {
+    if (!ix) return set_err(CX_ERR_VALIDATION, "null index");
+    if (nq && (!queries || !out_counts)) return set_err(CX_ERR_VALIDATION, "null queries/out_counts");
+    for (uint64_t i = 0; i < nq; i++) out_counts[i] = 0;
+    if (!nq || ix->n_alive == 0 || k == 0) return CX_OK;  // vector/index.rs:331-333
+    if (!out_ids || !out_scores || !out_distances) return set_err(CX_ERR_VALIDATION, "null output buffer");
+    if (int rc = use_device(ix)) return rc;
+    CtxLease lease(ix);
+    Ctx *c = lease.c;
+    if (!c) return CX_ERR_DEVICE;
+    const uint32_t k_eff = (uint32_t)std::min<uint64_t>(k, ix->n_rows);
+    std::vector<float> tails;
+    if (int rc = stage_queries(ix, c, nq, queries, len, tails)) return rc;
+    FilterUpload fu;
+    if (int rc = build_filter(ix, c, filter, c->stream, fu)) return rc;
+    const size_t entries = (size_t)nq * k_eff;
+    if (int rc = ensure_out(c, entries, nq)) return rc;
+    if (int rc = search_core(ix, c, c->d_query, tails.data(), nq, k_eff, fu.f, 0.0f, false, c->d_out_rows,
+                             c->d_out_scores, c->d_out_dists, c->d_out_counts, c->stream))
+        return rc;
+    CX_HIP(hipMemcpyAsync(c->h_counts, c->d_out_counts, nq * 4, hipMemcpyDeviceToHost, c->stream));
+    if (int rc = fetch_results(c, entries)) return rc;
+    for (uint64_t i = 0; i < nq; i++) {
+        const uint32_t cnt = c->h_counts[i];
+        out_counts[i] = cnt;
+        for (uint32_t j = 0; j < cnt; j++) {
+            const size_t src = (size_t)i * k_eff + j, dst = (size_t)i * k + j;
+            memcpy(out_ids + 16 * dst, &ix->ids[16 * (size_t)c->h_rows[src]], 16);
+            out_scores[dst] = c->h_scores[src];
+            out_distances[dst] = c->h_dists[src];
+        }
+    }
+    return CX_OK;
+}
+
+int cx_search(const cx_index *ix, const float *query, uint64_t len, uint64_t k, const cx_filter *filter,
+              uint8_t *out_ids, float *out_scores, float *out_distances, uint64_t *n_out) {
+    if (!n_out) return set_err(CX_ERR_VALIDATION, "null n_out");
+    return cx_search_batch(ix, 1, query, len, k, filter, out_ids, out_scores, out_distances, n_out);
+}
+
+int cx_search_threshold(const cx_index *ix, const float *query, uint64_t len, float threshold,
+                        const cx_filter *filter, uint64_t cap, uint8_t *out_ids, float *out_scores,
+                        float *out_distances, uint64_t *n_out, uint64_t *n_needed) {
+    if (!ix || !query || !n_out) return set_err(CX_ERR_VALIDATION, "null argument");
+    *n_out = 0;
+    if (n_needed) *n_needed = 0;
+    if (ix->n_alive == 0) return CX_OK;
+    if (int rc = use_device(ix)) return rc;
+    CtxLease lease(ix);
+    Ctx *c = lease.c;
+    if (!c) return CX_ERR_DEVICE;
+    const uint32_t n = (uint32_t)ix->n_rows;
+    std::vector<float> tails;
+    if (int rc = stage_queries(ix, c, 1, query, len, tails)) return rc;
+    FilterUpload fu;
+    if (int rc = build_filter(ix, c, filter, c->stream, fu)) return rc;
+    if (int rc = ensure_out(c, n, 1)) return rc;
+    if (int rc = search_core(ix, c, c->d_query, tails.data(), 1, n, fu.f, threshold, true, c->d_out_rows,
+                             c->d_out_scores, c->d_out_dists, c->d_out_counts, c->stream))
+        return rc;
+    CX_HIP(hipMemcpyAsync(c->h_counts, c->d_out_counts, 4, hipMemcpyDeviceToHost, c->stream));
+    CX_HIP(hipStreamSynchronize(c->stream));
+    const uint64_t total = c->h_counts[0];
+    if (n_needed) *n_needed = total;
+    const uint64_t take = std::min<uint64_t>(total, cap);
+    if (take) {
+        if (!out_ids || !out_scores || !out_distances) return set_err(CX_ERR_VALIDATION, "null output buffer");
+        if (int rc = fetch_results(c, take)) return rc;
+        for (uint64_t j = 0; j < take; j++) {
+            memcpy(out_ids + 16 * j, &ix->ids[16 * (size_t)c->h_rows[j]], 16);
+            out_scores[j] = c->h_scores[j];
+            out_distances[j] = c->h_dists[j];
+        }
+    }
+    *n_out = take;
+    if (total > cap)
+        return set_err(CX_ERR_CAPACITY, "search_threshold: %llu results, buffer holds %llu",
+                       (unsigned long long)total, (unsigned long long)cap);
+    return CX_OK;
+}
+
+int cx_search_batch_dev(const cx_index *ix, uint64_t nq, const float *d_queries, uint64_t k,
+                        const cx_filter *filter, uint32_t *d_rows, float *d_scores, float *d_distances,
+                        uint32_t *d_counts, void *stream) {
+    if (!ix) return set_err(CX_ERR_VALIDATION, "null index");
+    if (!nq) return CX_OK;
+    if (!d_queries || !d_counts) return set_err(CX_ERR_VALIDATION, "null device pointer");
+    if (int rc = use_device(ix)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (ix->n_rows == 0 || k == 0) {
+        CX_HIP(hipMemsetAsync(d_counts, 0, nq * 4, s));
+        return CX_OK;
+    }
+    if (!d_rows || !d_scores || !d_distances) return set_err(CX_ERR_VALIDATION, "null device output");
+    if (k > ix->n_rows) return set_err(CX_ERR_VALIDATION, "k=%llu exceeds the %llu rows of this shard; clamp it",
+                                        (unsigned long long)k, (unsigned long long)ix->n_rows);
+    Ctx *c = ctx_for_stream(ix, s);
+    FilterUpload fu;
+    if (int rc = build_filter(ix, c, filter, s, fu)) return rc;
+    return search_core(ix, c, d_queries, nullptr, nq, (uint32_t)k, fu.f, 0.0f, false, d_rows, d_scores,
+                       d_distances, d_counts, s);
+}
+
+int cx_search_dev(const cx_index *ix, const float *d_query, uint64_t k, const cx_filter *filter, uint32_t *d_rows,
+                  float *d_scores, float *d_distances, uint32_t *d_count, void *stream) {
+    return cx_search_batch_dev(ix, 1, d_query, k, filter, d_rows, d_scores, d_distances, d_count, stream);
+}
+
+int cx_merge_topk_dev(int device, uint64_t n_parts, uint64_t nq, uint64_t k, uint64_t part_stride, const uint64_t *part_base,
+                      const uint32_t *d_rows, const float *d_scores, const float *d_distances,
+                      const uint32_t *d_counts, uint64_t *d_out_rows, float *d_out_scores,
+                      float *d_out_distances, uint32_t *d_out_counts, void *stream) {
+    if (!part_base || !d_rows || !d_scores || !d_distances || !d_counts || !d_out_rows || !d_out_scores ||
+        !d_out_distances || !d_out_counts)
+        return set_err(CX_ERR_VALIDATION, "null argument");
+    if (n_parts > MAX_PARTS) return set_err(CX_ERR_VALIDATION, "merge: at most %u parts", MAX_PARTS);
+    CX_HIP(hipSetDevice(device));
+    PartBase pb;
+    memset(&pb, 0, sizeof pb);
+    for (uint64_t p = 0; p < n_parts; p++) pb.base[p] = part_base[p];
+    return launch_merge_parts((uint32_t)n_parts, (uint32_t)nq, (uint32_t)k, part_stride, pb, d_rows, d_scores, d_distances,
+                              d_counts, d_out_rows, d_out_scores, d_out_distances, d_out_counts,
+                              (hipStream_t)stream);
+}
+
+}  // extern "C"

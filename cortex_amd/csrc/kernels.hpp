@@ -1,0 +1,68 @@
+// kernels.hpp — host-callable launchers of the HIP kernels (internal API).
+#pragma once
+
+#include "common.hpp"
+
+namespace cx {
+
+constexpr uint32_t TOPK_MAX = 256;  // largest k served by the in-register top-k lists
+
+// One single-query scan over the row store.
+struct ScanArgs {
+    const float *rows;     // [n_rows][dim] f32 row-major, 16-byte aligned when dim % 4 == 0
+    const float *query;    // [dim] f32 in HBM
+    float q_tail_sumsq;    // sum of squares of query elements beyond dim (host queries longer than dim)
+    uint32_t n_rows;
+    uint32_t dim;
+    uint32_t k;
+    DevFilter flt;
+    // MODE 0: per-block partial lists [grid][k]
+    uint64_t *part_keys;
+    float *part_sims;
+    // MODE 1: dense per-row keys/sims [n_rows] (0 = filtered out / below threshold)
+    uint64_t *dense_keys;
+    float *dense_sims;
+    float threshold;
+    uint32_t has_threshold;
+};
+
+struct MergeArgs {
+    const uint64_t *part_keys;  // [n_lists][k]
+    const float *part_sims;
+    uint32_t n_lists;
+    uint32_t k;
+    uint32_t *out_rows;   // [k]
+    float *out_scores;    // [k]
+    float *out_dists;     // [k]
+    uint32_t *out_count;  // [1]
+};
+
+// number of blocks launch_scan_topk will use for this shape (scratch sizing)
+uint32_t scan_grid_blocks(uint32_t n_rows, uint32_t dim);
+// k <= TOPK_MAX.  scan + merge, results sorted best-first.
+// ev0/ev1 (optional) are recorded on the stream right before / after the scan kernel.
+int launch_scan_topk(const ScanArgs &a, const MergeArgs &m, bool nontemporal, hipStream_t stream,
+                     hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+// dense keys for the sort path (large k, threshold search)
+int launch_scan_dense(const ScanArgs &a, bool nontemporal, hipStream_t stream);
+
+// sort path: sorts n (key, sim) pairs best-first, counts non-empty keys, and
+// writes the first min(count, k) as rows/scores/dists.
+size_t sort_temp_bytes(uint32_t n);
+int launch_sort_select(uint64_t *keys_in, float *sims_in, uint64_t *keys_tmp, float *sims_tmp, uint32_t n,
+                       uint32_t k, void *temp, size_t temp_bytes, uint32_t *out_rows, float *out_scores,
+                       float *out_dists, uint32_t *out_count, hipStream_t stream);
+
+// cross-shard merge of [n_parts][nq][k] partial lists
+constexpr uint32_t MAX_PARTS = 64;
+struct PartBase { uint64_t base[MAX_PARTS]; };  // by-value kernel argument: first global row of each shard
+int launch_merge_parts(uint32_t n_parts, uint32_t nq, uint32_t k, uint64_t part_stride, const PartBase &part_base,
+                       const uint32_t *d_rows, const float *d_scores, const float *d_dists,
+                       const uint32_t *d_counts, uint64_t *out_rows, float *out_scores, float *out_dists,
+                       uint32_t *out_counts, hipStream_t stream);
+
+// row maintenance
+int launch_gather_rows(const float *src, float *dst, const uint32_t *d_src_rows, uint32_t n_dst, uint32_t dim,
+                       hipStream_t stream);
+
+}  // namespace cx

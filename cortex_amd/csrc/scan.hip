@@ -1,0 +1,458 @@
+// scan.hip — the single-query cosine top-k scan (BASELINE config 2 / headline).
+//
+// Replaces HnswIndex::brute_force_search (vector/index.rs:259-294) and the
+// per-pair EmbeddingPoint::distance (:169-179).  HBM-bound: the only traffic
+// that matters is one pass over the f32 row store, N*dim*4 bytes per query.
+//
+// Shape of the kernel (gfx950, wave64):
+//  - G lanes cooperate on one row (G = 64 for dim % 256 == 0, 32 for
+//    dim % 128 == 0, 16 for dim % 64 == 0); every lane issues 16-byte loads
+//    and a wave-level load instruction covers 64/G rows x G*16 contiguous
+//    bytes each, so every 128-byte line is fetched whole and once.
+//  - R row groups are loaded back to back before any arithmetic: R*dim/(4G)
+//    independent 16-byte loads in flight per lane; with 8-16 waves per CU
+//    that is far more than the ~32 KiB per CU the HBM latency needs.
+//  - the query slice a lane needs never changes, so it sits in registers
+//    (dim/(4G) float4s), read once from HBM; the row's sum of squares is
+//    accumulated next to the dot product (the reference recomputes it per
+//    pair too), so no norm array is read.
+//  - dot / norms are reduced over the G lanes by a butterfly, the
+//    reference's epilogue is applied one IEEE op at a time, and the score is
+//    offered to the wave's register top-k list (topk.hpp).
+//  - rows beyond 256 MiB are streamed with non-temporal loads: they cannot
+//    stay in the 256 MiB Infinity Cache between queries anyway.
+//  - per-block lists are merged by a second, tiny kernel (merge_kernel).
+#include "kernels.hpp"
+#include "topk.hpp"
+
+namespace cx {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <bool NT>
+__device__ inline f32x4 ld4(const f32x4 *p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+
+template <int G>
+__device__ inline float group_sum(float v) {
+#pragma unroll
+    for (int off = G / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Shared tail: merge the block's 4 wave lists into wave 0 and write the
+// block's partial list.
+template <int KS>
+__device__ inline void block_merge_store(WaveTopK<KS> &top, uint32_t k, uint64_t *part_keys, float *part_sims) {
+    __shared__ uint64_t sk[3][64 * KS];
+    __shared__ float ss[3][64 * KS];
+    const int wave = (int)(threadIdx.x >> 6);
+    if (wave > 0) top.store(sk[wave - 1], ss[wave - 1], k);
+    __syncthreads();
+    if (wave == 0) {
+        const uint32_t lane = (uint32_t)lane_id();
+        for (int w = 0; w < 3; w++) {
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+                const uint32_t i = (uint32_t)s * 64u + lane;
+                const uint64_t kg = i < k ? sk[w][i] : 0ull;
+                const float sg = i < k ? ss[w][i] : 0.0f;
+                top.offer_lanes(kg, sg, [](uint32_t) { return true; });
+            }
+        }
+        top.store(part_keys + (size_t)blockIdx.x * k, part_sims + (size_t)blockIdx.x * k, k);
+    }
+}
+
+// MODE 0: top-k partial lists.  MODE 1: dense keys.
+template <int D, int G, int R, int KS, bool NT, int MODE>
+__global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a) {
+    constexpr int GPW = 64 / G;        // rows per wave-level load instruction
+    constexpr int NJ = D / (4 * G);    // 16-byte loads per lane per row
+    constexpr int RPW = R * GPW;       // rows per wave iteration
+    static_assert(D % (4 * G) == 0, "dim must be a multiple of 4*G");
+    const int lane = lane_id();
+    const int wave = (int)(threadIdx.x >> 6);
+    const int lig = lane % G;
+    const int grp = lane / G;
+
+    // query slice -> registers; |q|^2 with the same lane split
+    f32x4 q[NJ];
+    const f32x4 *q4 = reinterpret_cast<const f32x4 *>(a.query);
+    float qq = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        q[j] = q4[j * G + lig];
+        qq += q[j].x * q[j].x + q[j].y * q[j].y + q[j].z * q[j].z + q[j].w * q[j].w;
+    }
+    qq = group_sum<G>(qq) + a.q_tail_sumsq;
+
+    WaveTopK<KS> top;
+    if constexpr (MODE == 0) top.init(a.k);
+
+    const uint32_t n_rows = a.n_rows;
+    const uint32_t n_tiles = (n_rows + RPW - 1) / RPW;
+    const uint32_t stride = gridDim.x * 4u;
+    for (uint32_t t = blockIdx.x * 4u + (uint32_t)wave; t < n_tiles; t += stride) {
+        const uint32_t base = t * RPW;
+        f32x4 v[R][NJ];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            uint32_t row = base + (uint32_t)(r * GPW + grp);
+            row = row < n_rows ? row : n_rows - 1;  // clamp: tail lanes re-read the last row
+            const f32x4 *p = reinterpret_cast<const f32x4 *>(a.rows + (size_t)row * D) + lig;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) v[r][j] = ld4<NT>(p + j * G);
+        }
+        float dot[R], rr[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            float d0 = 0.0f, n0 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                d0 += v[r][j].x * q[j].x + v[r][j].y * q[j].y + v[r][j].z * q[j].z + v[r][j].w * q[j].w;
+                n0 += v[r][j].x * v[r][j].x + v[r][j].y * v[r][j].y + v[r][j].z * v[r][j].z + v[r][j].w * v[r][j].w;
+            }
+            dot[r] = d0;
+            rr[r] = n0;
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            dot[r] = group_sum<G>(dot[r]);
+            rr[r] = group_sum<G>(rr[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t row = base + (uint32_t)(r * GPW + grp);
+            const float sim = cosine_from_sums(dot[r], qq, rr[r]);
+            const float score = score_of(distance_of(sim));
+            if constexpr (MODE == 0) {
+                // one candidate per row group: lanes with lig == 0 carry it
+                const uint64_t key = (row < n_rows && lig == 0) ? make_key(score, row) : 0ull;
+                const DevFilter &f = a.flt;
+                top.offer_lanes(key, sim, [&f](uint32_t rw) { return row_passes(f, rw); });
+            } else {
+                if (row < n_rows && lig == 0) {
+                    bool ok = row_passes(a.flt, row);
+                    if (a.has_threshold) ok = ok && (score >= a.threshold);
+                    a.dense_keys[row] = ok ? make_key(score, row) : 0ull;
+                    a.dense_sims[row] = sim;
+                }
+            }
+        }
+    }
+    if constexpr (MODE == 0) block_merge_store<KS>(top, a.k, a.part_keys, a.part_sims);
+}
+
+// Any dimension (the reference's own tests use dim = 3): one wave per row,
+// lane l takes elements l, l+64, ...; scalar loads.  Correctness path only.
+template <int KS, int MODE>
+__global__ __launch_bounds__(256) void scan_generic_kernel(const ScanArgs a) {
+    const int lane = lane_id();
+    const int wave = (int)(threadIdx.x >> 6);
+    const uint32_t dim = a.dim;
+    float qq = 0.0f;
+    for (uint32_t j = (uint32_t)lane; j < dim; j += 64u) qq += a.query[j] * a.query[j];
+    qq = group_sum<64>(qq) + a.q_tail_sumsq;
+
+    WaveTopK<KS> top;
+    if constexpr (MODE == 0) top.init(a.k);
+    const uint32_t stride = gridDim.x * 4u;
+    for (uint32_t row = blockIdx.x * 4u + (uint32_t)wave; row < a.n_rows; row += stride) {
+        const float *p = a.rows + (size_t)row * dim;
+        float d0 = 0.0f, n0 = 0.0f;
+        for (uint32_t j = (uint32_t)lane; j < dim; j += 64u) {
+            const float x = p[j];
+            d0 += x * a.query[j];
+            n0 += x * x;
+        }
+        d0 = group_sum<64>(d0);
+        n0 = group_sum<64>(n0);
+        const float sim = cosine_from_sums(d0, qq, n0);
+        const float score = score_of(distance_of(sim));
+        if constexpr (MODE == 0) {
+            const uint64_t key = lane == 0 ? make_key(score, row) : 0ull;
+            const DevFilter &f = a.flt;
+            top.offer_lanes(key, sim, [&f](uint32_t rw) { return row_passes(f, rw); });
+        } else if (lane == 0) {
+            bool ok = row_passes(a.flt, row);
+            if (a.has_threshold) ok = ok && (score >= a.threshold);
+            a.dense_keys[row] = ok ? make_key(score, row) : 0ull;
+            a.dense_sims[row] = sim;
+        }
+    }
+    if constexpr (MODE == 0) block_merge_store<KS>(top, a.k, a.part_keys, a.part_sims);
+}
+
+// Second stage: one block folds [n_lists][k] partial lists into the final,
+// sorted top-k.  16 waves each sweep a strided share with coalesced loads,
+// then wave 0 folds the 15 other lists and ranks the k survivors.
+template <int KS>
+__global__ __launch_bounds__(1024) void merge_kernel(const MergeArgs m) {
+    __shared__ uint64_t sk[16][64 * KS];
+    __shared__ float ss[16][64 * KS];
+    __shared__ uint32_t s_count;
+    const uint32_t lane = (uint32_t)lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t k = m.k;
+    const uint32_t total = m.n_lists * k;
+    WaveTopK<KS> top;
+    top.init(k);
+    for (uint32_t i0 = wave * 64u; i0 < total; i0 += 16u * 64u) {
+        const uint32_t i = i0 + lane;
+        const uint64_t kg = i < total ? m.part_keys[i] : 0ull;
+        const float sg = i < total ? m.part_sims[i] : 0.0f;
+        top.offer_lanes(kg, sg, [](uint32_t) { return true; });
+    }
+    top.store(sk[wave], ss[wave], k);
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 1; w < 16; w++) {
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+                const uint32_t i = (uint32_t)s * 64u + lane;
+                const uint64_t kg = i < k ? sk[w][i] : 0ull;
+                const float sg = i < k ? ss[w][i] : 0.0f;
+                top.offer_lanes(kg, sg, [](uint32_t) { return true; });
+            }
+        }
+        top.store(sk[0], ss[0], k);
+    }
+    __syncthreads();
+    // rank = number of strictly better keys; keys are unique except empties (0)
+    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
+        const uint64_t ki = sk[0][i];
+        if (ki == 0ull) continue;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < k; j++) rank += (sk[0][j] > ki) ? 1u : 0u;
+        const float sim = ss[0][i];
+        const float dist = distance_of(sim);
+        m.out_rows[rank] = key_row(ki);
+        m.out_dists[rank] = dist;
+        m.out_scores[rank] = score_of(dist);
+        atomicAdd(&s_count, 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *m.out_count = s_count;
+}
+
+// ------------------------------------------------------------------ host
+
+static int g_num_cus = 0;
+static int num_cus() {
+    if (!g_num_cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
+            g_num_cus = p.multiProcessorCount;
+        if (g_num_cus <= 0) g_num_cus = 256;
+    }
+    return g_num_cus;
+}
+
+static uint32_t blocks_per_cu() {
+    static int v = 0;
+    if (!v) {
+        const char *e = getenv("CX_SCAN_BLOCKS_PER_CU");
+        v = e ? atoi(e) : 4;
+        if (v < 1) v = 1;
+        if (v > 8) v = 8;
+    }
+    return (uint32_t)v;
+}
+
+uint32_t scan_grid_blocks(uint32_t n_rows, uint32_t dim) {
+    (void)dim;
+    uint32_t want = (n_rows + 3u) / 4u;  // at least one row per wave
+    uint32_t cap = (uint32_t)num_cus() * blocks_per_cu();
+    if (want < 1u) want = 1u;
+    return want < cap ? want : cap;
+}
+
+template <int D, int G, int R, int MODE>
+static void launch_fixed(const ScanArgs &a, uint32_t grid, int ks, bool nt, hipStream_t s) {
+#define CX_LAUNCH(KS_)                                                                        \
+    do {                                                                                       \
+        if (nt) hipLaunchKernelGGL((scan_kernel<D, G, R, KS_, true, MODE>), dim3(grid), dim3(256), 0, s, a);  \
+        else hipLaunchKernelGGL((scan_kernel<D, G, R, KS_, false, MODE>), dim3(grid), dim3(256), 0, s, a);    \
+    } while (0)
+    if constexpr (MODE == 1) { CX_LAUNCH(1); }
+    else {
+        if (ks == 1) CX_LAUNCH(1);
+        else if (ks == 2) CX_LAUNCH(2);
+        else CX_LAUNCH(4);
+    }
+#undef CX_LAUNCH
+}
+
+template <int MODE>
+static void launch_generic(const ScanArgs &a, uint32_t grid, int ks, hipStream_t s) {
+    if constexpr (MODE == 1) {
+        hipLaunchKernelGGL((scan_generic_kernel<1, 1>), dim3(grid), dim3(256), 0, s, a);
+    } else {
+        if (ks == 1) hipLaunchKernelGGL((scan_generic_kernel<1, 0>), dim3(grid), dim3(256), 0, s, a);
+        else if (ks == 2) hipLaunchKernelGGL((scan_generic_kernel<2, 0>), dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((scan_generic_kernel<4, 0>), dim3(grid), dim3(256), 0, s, a);
+    }
+}
+
+template <int MODE>
+static void dispatch_scan(const ScanArgs &a, uint32_t grid, int ks, bool nt, hipStream_t s) {
+    const bool aligned = ((reinterpret_cast<uintptr_t>(a.rows) | reinterpret_cast<uintptr_t>(a.query)) & 15u) == 0;
+    if (aligned) {
+        switch (a.dim) {
+            case 128: return launch_fixed<128, 32, 4, MODE>(a, grid, ks, nt, s);
+            case 256: return launch_fixed<256, 64, 8, MODE>(a, grid, ks, nt, s);
+            case 384: return launch_fixed<384, 32, 4, MODE>(a, grid, ks, nt, s);
+            case 512: return launch_fixed<512, 64, 4, MODE>(a, grid, ks, nt, s);
+            case 768: return launch_fixed<768, 64, 4, MODE>(a, grid, ks, nt, s);
+            case 1024: return launch_fixed<1024, 64, 2, MODE>(a, grid, ks, nt, s);
+            case 1536: return launch_fixed<1536, 64, 2, MODE>(a, grid, ks, nt, s);
+            default: break;
+        }
+    }
+    launch_generic<MODE>(a, grid, ks, s);
+}
+
+int launch_scan_topk(const ScanArgs &a, const MergeArgs &m, bool nontemporal, hipStream_t stream, hipEvent_t ev0,
+                     hipEvent_t ev1) {
+    if (a.k > TOPK_MAX) return set_err(CX_ERR_VALIDATION, "launch_scan_topk: k=%u exceeds %u", a.k, TOPK_MAX);
+    const int ks = a.k <= 64 ? 1 : (a.k <= 128 ? 2 : 4);
+    const uint32_t grid = scan_grid_blocks(a.n_rows, a.dim);
+    if (m.n_lists != grid) return set_err(CX_ERR_VALIDATION, "launch_scan_topk: scratch sized for %u lists, grid is %u", m.n_lists, grid);
+    if (ev0) CX_HIP(hipEventRecord(ev0, stream));
+    dispatch_scan<0>(a, grid, ks, nontemporal, stream);
+    if (ev1) CX_HIP(hipEventRecord(ev1, stream));
+    if (ks == 1) hipLaunchKernelGGL((merge_kernel<1>), dim3(1), dim3(1024), 0, stream, m);
+    else if (ks == 2) hipLaunchKernelGGL((merge_kernel<2>), dim3(1), dim3(1024), 0, stream, m);
+    else hipLaunchKernelGGL((merge_kernel<4>), dim3(1), dim3(1024), 0, stream, m);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+
+int launch_scan_dense(const ScanArgs &a, bool nontemporal, hipStream_t stream) {
+    const uint32_t grid = scan_grid_blocks(a.n_rows, a.dim);
+    dispatch_scan<1>(a, grid, 1, nontemporal, stream);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+
+// ------------------------------------------------ cross-shard merge (§8e)
+
+// One block per query: fold n_parts lists of k (already sorted per shard, but
+// order is not relied on) into the global top-k.  Keys are rebuilt with the
+// global row so ties resolve by global insertion order.
+template <int KS>
+__global__ __launch_bounds__(256) void merge_parts_kernel(uint32_t n_parts, uint32_t nq, uint32_t k, uint64_t lstride, uint64_t cstride,
+                                                          const PartBase part_base, const uint32_t *rows,
+                                                          const float *scores, const float *dists,
+                                                          const uint32_t *counts, uint64_t *out_rows,
+                                                          float *out_scores, float *out_dists,
+                                                          uint32_t *out_counts) {
+    // a 64-bit global row does not fit the 32-bit row field of a key, so the
+    // key's row field holds the candidate's index (part*k + slot): parts are
+    // ordered by row range and slots by row within equal scores, hence the
+    // index order equals the global row order among ties.
+    __shared__ uint64_t sk[4][64 * KS];
+    __shared__ float ss[4][64 * KS];
+    __shared__ uint32_t s_count;
+    const uint32_t qi = blockIdx.x;
+    const uint32_t lane = (uint32_t)lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t total = n_parts * k;
+    WaveTopK<KS> top;
+    top.init(k);
+    for (uint32_t i0 = wave * 64u; i0 < total; i0 += 4u * 64u) {
+        const uint32_t i = i0 + lane;
+        uint64_t kg = 0ull;
+        float sg = 0.0f;
+        if (i < total) {
+            const uint32_t p = i / k, slot = i % k;
+            if (slot < counts[(size_t)p * cstride + qi]) {
+                const size_t src = (size_t)p * lstride + (size_t)qi * k + slot;
+                kg = make_key(scores[src], i);
+                sg = dists[src];  // payload: the shard's distance, carried through unchanged
+            }
+        }
+        top.offer_lanes(kg, sg, [](uint32_t) { return true; });
+    }
+    top.store(sk[wave], ss[wave], k);
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 1; w < 4; w++) {
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+                const uint32_t i = (uint32_t)s * 64u + lane;
+                const uint64_t kg = i < k ? sk[w][i] : 0ull;
+                const float sg = i < k ? ss[w][i] : 0.0f;
+                top.offer_lanes(kg, sg, [](uint32_t) { return true; });
+            }
+        }
+        top.store(sk[0], ss[0], k);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
+        const uint64_t ki = sk[0][i];
+        if (ki == 0ull) continue;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < k; j++) rank += (sk[0][j] > ki) ? 1u : 0u;
+        const uint32_t idx = key_row(ki);
+        const uint32_t p = idx / k, slot = idx % k;
+        const size_t src = (size_t)p * lstride + (size_t)qi * k + slot;
+        out_rows[(size_t)qi * k + rank] = part_base.base[p] + rows[src];
+        out_scores[(size_t)qi * k + rank] = scores[src];
+        out_dists[(size_t)qi * k + rank] = ss[0][i];
+        atomicAdd(&s_count, 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) out_counts[qi] = s_count;
+}
+
+int launch_merge_parts(uint32_t n_parts, uint32_t nq, uint32_t k, uint64_t part_stride, const PartBase &part_base,
+                       const uint32_t *d_rows, const float *d_scores, const float *d_dists,
+                       const uint32_t *d_counts, uint64_t *out_rows, float *out_scores, float *out_dists,
+                       uint32_t *out_counts, hipStream_t stream) {
+    if (k > TOPK_MAX) return set_err(CX_ERR_VALIDATION, "merge: k=%u exceeds %u", k, TOPK_MAX);
+    if (nq == 0 || k == 0) return CX_OK;
+    const uint64_t lstride = part_stride ? part_stride : (uint64_t)nq * k;
+    const uint64_t cstride = part_stride ? part_stride : (uint64_t)nq;
+#define CX_MP(KS_) hipLaunchKernelGGL((merge_parts_kernel<KS_>), dim3(nq), dim3(256), 0, stream, n_parts, nq, k, lstride, cstride, \
+                                      part_base, d_rows, d_scores, d_dists, d_counts, out_rows, out_scores,       \
+                                      out_dists, out_counts)
+    if (k <= 64) CX_MP(1);
+    else if (k <= 128) CX_MP(2);
+    else CX_MP(4);
+#undef CX_MP
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+
+// ------------------------------------------------------- row maintenance
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float *src, float *dst, const uint32_t *src_rows,
+                                                          uint32_t n_dst, uint32_t dim) {
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t r = wave; r < n_dst; r += n_waves) {
+        const float *s = src + (size_t)src_rows[r] * dim;
+        float *d = dst + (size_t)r * dim;
+        for (uint32_t j = lane; j < dim; j += 64u) d[j] = s[j];
+    }
+}
+
+int launch_gather_rows(const float *src, float *dst, const uint32_t *d_src_rows, uint32_t n_dst, uint32_t dim,
+                       hipStream_t stream) {
+    if (!n_dst) return CX_OK;
+    uint32_t grid = (n_dst + 3u) / 4u;
+    if (grid > 4096u) grid = 4096u;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, stream, src, dst, d_src_rows, n_dst, dim);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+
+}  // namespace cx

@@ -1,0 +1,285 @@
+"""Host-side mirror of the reference's vector-layer interface over the C ABI.
+
+Same names, argument meaning and error behaviour as
+crates/cortex-core/src/vector/index.rs (trait VectorIndex :50-99, HnswIndex
+:182-473, VectorFilter :18-47, SimilarityResult :11-15), so the parity tests
+read like the reference's own.  All arithmetic happens in libcortex_hip.so on
+the GPU; this module only marshals arguments.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import uuid
+from dataclasses import dataclass
+from typing import Dict, Iterable, List, NamedTuple, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import _lib
+
+NodeId = Union[uuid.UUID, bytes]
+
+
+class CortexError(Exception):
+    """CortexError (error.rs:7-50)."""
+
+
+class ValidationError(CortexError):
+    """CortexError::Validation(String) — the only kind the vector layer raises."""
+
+
+def _id16(i: NodeId) -> bytes:
+    if isinstance(i, uuid.UUID):
+        return i.bytes
+    b = bytes(i)
+    if len(b) != 16:
+        raise ValidationError(f"node id must be 16 bytes, got {len(b)}")
+    return b
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class SimilarityResult(NamedTuple):
+    """vector/index.rs:11-15."""
+    node_id: uuid.UUID
+    score: float
+    distance: float
+
+
+@dataclass
+class VectorFilter:
+    """vector/index.rs:18-47 (None = Option::None)."""
+    kinds: Optional[List[str]] = None
+    exclude: Optional[List[NodeId]] = None
+    source_agent: Optional[str] = None
+
+    @staticmethod
+    def new() -> "VectorFilter":
+        return VectorFilter()
+
+    def with_kinds(self, kinds: Sequence[str]) -> "VectorFilter":
+        self.kinds = list(kinds)
+        return self
+
+    def excluding(self, ids: Sequence[NodeId]) -> "VectorFilter":
+        self.exclude = list(ids)
+        return self
+
+    def with_source_agent(self, agent: str) -> "VectorFilter":
+        self.source_agent = agent
+        return self
+
+
+class HipIndex:
+    """Drop-in for HnswIndex (vector/index.rs:182-473) on one MI355X.
+
+    Exact search: inserts are visible to the next search and `rebuild()` is
+    never needed for correctness."""
+
+    def __init__(self, dimension: int, device: int = 0):
+        self._L = _lib.load()
+        self._h = self._L.cx_create(dimension, device)
+        if not self._h:
+            raise CortexError(self._err())
+        self.dimension = dimension
+        self.device = device
+
+    @classmethod
+    def new(cls, dimension: int, device: int = 0) -> "HipIndex":
+        return cls(dimension, device)
+
+    @classmethod
+    def with_metadata(cls, dimension: int, device: int = 0) -> "HipIndex":
+        """vector/index.rs:214-216."""
+        return cls(dimension, device)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._L.cx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers ---------------------------------------------------------
+    def _err(self) -> str:
+        return (self._L.cx_last_error() or b"").decode(errors="replace")
+
+    def _check(self, rc: int) -> None:
+        if rc == 0:
+            return
+        msg = self._err()
+        if rc == 1:
+            raise ValidationError(msg)
+        raise CortexError(msg)
+
+    def _filter(self, f: Optional[VectorFilter]):
+        if f is None:
+            return None, None
+        cf = _lib.cx_filter()
+        keep = []
+        if f.exclude is not None:
+            buf = b"".join(_id16(e) for e in f.exclude)
+            cb = C.create_string_buffer(buf, max(1, len(buf)))
+            keep.append(cb)
+            cf.has_exclude, cf.n_exclude, cf.exclude_ids = 1, len(f.exclude), C.cast(cb, C.c_void_p)
+        if f.kinds is not None:
+            codes = np.array([self.intern(k) for k in f.kinds], dtype=np.uint32)
+            keep.append(codes)
+            cf.has_kinds, cf.n_kinds, cf.kind_codes = 1, len(f.kinds), codes.ctypes.data
+        if f.source_agent is not None:
+            cf.has_agent, cf.agent_code = 1, self.intern(f.source_agent)
+        return cf, keep
+
+    def intern(self, s: str) -> int:
+        b = s.encode()
+        return self._L.cx_intern(self._h, b, len(b))
+
+    # -- VectorIndex: mutation --------------------------------------------
+    def insert(self, node_id: NodeId, embedding) -> None:
+        e = _f32(embedding).reshape(-1)
+        self._check(self._L.cx_upsert(self._h, _id16(node_id), e.ctypes.data, e.size))
+
+    def insert_batch(self, ids: np.ndarray, embeddings: np.ndarray) -> None:
+        """n inserts in one call: ids uint8 [n,16], embeddings f32 [n,len]."""
+        e = _f32(embeddings)
+        i = np.ascontiguousarray(ids, dtype=np.uint8)
+        if e.ndim != 2 or i.shape != (e.shape[0], 16):
+            raise ValidationError("insert_batch: ids must be [n,16] and embeddings [n,len]")
+        self._check(self._L.cx_upsert_batch(self._h, e.shape[0], i.ctypes.data, e.ctypes.data, e.shape[1]))
+
+    def insert_batch_dev(self, ids: np.ndarray, d_ptr: int, n: int, length: int) -> None:
+        """Rows already resident in HBM on this device (row-major f32)."""
+        i = np.ascontiguousarray(ids, dtype=np.uint8)
+        if i.shape != (n, 16):
+            raise ValidationError("insert_batch_dev: ids must be [n,16]")
+        self._check(self._L.cx_upsert_batch_dev(self._h, n, i.ctypes.data, d_ptr, length))
+
+    def remove(self, node_id: NodeId) -> None:
+        self._check(self._L.cx_remove(self._h, _id16(node_id)))
+
+    def set_metadata(self, node_id: NodeId, kind: str, source_agent: str) -> None:
+        self._check(self._L.cx_set_metadata(self._h, _id16(node_id), self.intern(kind), self.intern(source_agent)))
+
+    def rebuild(self) -> None:
+        self._check(self._L.cx_rebuild(self._h))
+
+    def reserve(self, rows: int) -> None:
+        self._check(self._L.cx_reserve(self._h, rows))
+
+    # -- VectorIndex: queries ----------------------------------------------
+    def __len__(self) -> int:
+        return int(self._L.cx_len(self._h))
+
+    def len(self) -> int:
+        return len(self)
+
+    def is_empty(self) -> bool:
+        return len(self) == 0
+
+    def row_count(self) -> int:
+        return int(self._L.cx_row_count(self._h))
+
+    def row_id(self, row: int) -> uuid.UUID:
+        out = (C.c_uint8 * 16)()
+        self._check(self._L.cx_row_id(self._h, row, out))
+        return uuid.UUID(bytes=bytes(out))
+
+    def device_rows_ptr(self) -> int:
+        return int(self._L.cx_device_rows(self._h) or 0)
+
+    def search_arrays(self, query, k: int, filter: Optional[VectorFilter] = None
+                      ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """search() returning (ids uint8 [n,16], scores f32 [n], distances f32 [n])."""
+        q = _f32(query).reshape(-1)
+        kk = max(1, min(int(k), max(1, self.row_count())))
+        ids = np.zeros((kk, 16), dtype=np.uint8)
+        scores = np.zeros(kk, dtype=np.float32)
+        dists = np.zeros(kk, dtype=np.float32)
+        n = C.c_uint64(0)
+        cf, keep = self._filter(filter)
+        self._check(self._L.cx_search(self._h, q.ctypes.data, q.size, int(k), C.byref(cf) if cf else None,
+                                      ids.ctypes.data, scores.ctypes.data, dists.ctypes.data, C.byref(n)))
+        return ids[:n.value], scores[:n.value], dists[:n.value]
+
+    def search(self, query, k: int, filter: Optional[VectorFilter] = None) -> List[SimilarityResult]:
+        ids, s, d = self.search_arrays(query, k, filter)
+        return [SimilarityResult(uuid.UUID(bytes=ids[i].tobytes()), float(s[i]), float(d[i])) for i in range(len(s))]
+
+    def search_threshold_arrays(self, query, threshold: float, filter: Optional[VectorFilter] = None
+                                ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        q = _f32(query).reshape(-1)
+        cf, keep = self._filter(filter)
+        cap = 1024
+        while True:
+            ids = np.zeros((cap, 16), dtype=np.uint8)
+            scores = np.zeros(cap, dtype=np.float32)
+            dists = np.zeros(cap, dtype=np.float32)
+            n, need = C.c_uint64(0), C.c_uint64(0)
+            rc = self._L.cx_search_threshold(self._h, q.ctypes.data, q.size, float(threshold),
+                                             C.byref(cf) if cf else None, cap, ids.ctypes.data,
+                                             scores.ctypes.data, dists.ctypes.data, C.byref(n), C.byref(need))
+            if rc == 4:  # CX_ERR_CAPACITY: count-then-fill
+                cap = int(need.value)
+                continue
+            self._check(rc)
+            return ids[:n.value], scores[:n.value], dists[:n.value]
+
+    def search_threshold(self, query, threshold: float, filter: Optional[VectorFilter] = None
+                         ) -> List[SimilarityResult]:
+        ids, s, d = self.search_threshold_arrays(query, threshold, filter)
+        return [SimilarityResult(uuid.UUID(bytes=ids[i].tobytes()), float(s[i]), float(d[i])) for i in range(len(s))]
+
+    def search_batch_arrays(self, queries, k: int, filter: Optional[VectorFilter] = None):
+        """queries f32 [nq,len] -> (ids [nq,k,16], scores [nq,k], distances [nq,k], counts [nq])."""
+        qs = _f32(queries)
+        if qs.ndim != 2:
+            raise ValidationError("search_batch: queries must be [nq,len]")
+        nq = qs.shape[0]
+        kk = max(1, int(k))
+        ids = np.zeros((nq, kk, 16), dtype=np.uint8)
+        scores = np.zeros((nq, kk), dtype=np.float32)
+        dists = np.zeros((nq, kk), dtype=np.float32)
+        counts = np.zeros(nq, dtype=np.uint64)
+        cf, keep = self._filter(filter)
+        self._check(self._L.cx_search_batch(self._h, nq, qs.ctypes.data, qs.shape[1], int(k),
+                                            C.byref(cf) if cf else None, ids.ctypes.data, scores.ctypes.data,
+                                            dists.ctypes.data, counts.ctypes.data))
+        return ids, scores, dists, counts
+
+    def search_batch(self, queries: Iterable[Tuple[NodeId, Sequence[float]]], k: int,
+                     filter: Optional[VectorFilter] = None) -> Dict[uuid.UUID, List[SimilarityResult]]:
+        """vector/index.rs:390-410: &[(NodeId, Embedding)] -> HashMap<NodeId, Vec<SimilarityResult>>."""
+        queries = list(queries)
+        if not queries:
+            return {}
+        qs = np.stack([_f32(e).reshape(-1) for _, e in queries])
+        ids, s, d, cnt = self.search_batch_arrays(qs, k, filter)
+        out: Dict[uuid.UUID, List[SimilarityResult]] = {}
+        for qi, (qid, _) in enumerate(queries):
+            key = qid if isinstance(qid, uuid.UUID) else uuid.UUID(bytes=_id16(qid))
+            out[key] = [SimilarityResult(uuid.UUID(bytes=ids[qi, j].tobytes()), float(s[qi, j]), float(d[qi, j]))
+                        for j in range(int(cnt[qi]))]
+        return out
+
+    # -- measurement ---------------------------------------------------------
+    def profile_enable(self, on: bool = True) -> None:
+        self._check(self._L.cx_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self, reset: bool = True) -> Tuple[float, int]:
+        """(sum of scan-kernel durations in ms, number of launches) since the last reset."""
+        ms, n = C.c_double(0.0), C.c_uint64(0)
+        self._check(self._L.cx_profile_read(self._h, C.byref(ms), C.byref(n), 1 if reset else 0))
+        return ms.value, n.value
+
+    # -- HBM-resident variants ---------------------------------------------
+    def search_batch_dev(self, d_queries: int, nq: int, k: int, d_rows: int, d_scores: int, d_dists: int,
+                         d_counts: int, stream: int = 0, filter: Optional[VectorFilter] = None) -> None:
+        cf, keep = self._filter(filter)
+        self._check(self._L.cx_search_batch_dev(self._h, nq, d_queries, int(k), C.byref(cf) if cf else None,
+                                                d_rows, d_scores, d_dists, d_counts, stream))

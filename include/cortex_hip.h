@@ -1,0 +1,175 @@
+/*
+ * cortex_hip.h — C ABI of the MI355X-native similarity engine that replaces
+ * cortex-core's vector layer (L2+L1 in SURVEY.md §1) behind the reference's
+ * own seam, `trait VectorIndex` (crates/cortex-core/src/vector/index.rs:50-99).
+ *
+ * Every entry point names the reference interface it replaces (file:line,
+ * relative to /root/reference/crates/cortex-core/src/).  The binding a
+ * maintainer adds on the Rust side (`impl VectorIndex for HipIndex`) is shown
+ * in INTEGRATION.md.
+ *
+ * Conventions
+ *  - Plain C: pointers and sizes only, no C++/torch types.
+ *  - Status return: 0 = ok, non-zero = CX_ERR_*; the message is read with
+ *    cx_last_error() (thread-local) and maps to CortexError::Validation(msg)
+ *    (error.rs:7-50), the only error kind the reference's vector layer
+ *    produces.  Nothing aborts or unwinds across the boundary.
+ *  - Ownership: inputs are borrowed for the call; outputs are written into
+ *    caller-allocated buffers; the engine never returns memory to free.
+ *  - Ids are the reference's NodeId = Uuid (types.rs:9): 16 raw bytes.
+ *  - Threading mirrors `Send + Sync` under the callers' RwLock
+ *    (RwLockVectorIndex, vector/index.rs:104-163): functions taking
+ *    `const cx_index*` (&self) are re-entrant and may run concurrently from
+ *    many threads; functions taking `cx_index*` (&mut self) need exclusive
+ *    access, which the caller's write lock already provides.
+ *  - Order of results where the reference leaves it open (HashMap iteration
+ *    into a stable sort, vector/index.rs:266-292): score descending, ties by
+ *    insertion row ascending, NaN scores last.
+ *  - There is no CPU fallback: without a usable gfx950 device cx_create
+ *    fails with CX_ERR_DEVICE.
+ */
+#ifndef CORTEX_HIP_H
+#define CORTEX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CX_OK 0
+#define CX_ERR_VALIDATION 1 /* bad argument, dimension mismatch */
+#define CX_ERR_DEVICE 2     /* no device / HIP runtime failure */
+#define CX_ERR_IO 3         /* save/load file errors */
+#define CX_ERR_CAPACITY 4   /* caller buffer too small; see n_needed */
+
+typedef struct cx_index cx_index;
+
+/* VectorFilter (vector/index.rs:18-47).  has_* = Option::Some.  Kinds and
+ * agents are interned strings (cx_intern). */
+typedef struct cx_filter {
+    int32_t has_exclude;
+    uint64_t n_exclude;
+    const uint8_t *exclude_ids; /* n_exclude * 16 bytes */
+    int32_t has_kinds;
+    uint64_t n_kinds;
+    const uint32_t *kind_codes;
+    int32_t has_agent;
+    uint32_t agent_code;
+} cx_filter;
+
+/* thread-local message of the last failing call on this thread */
+const char *cx_last_error(void);
+/* number of visible HIP devices (0 when none; never fails) */
+int cx_device_count(void);
+
+/* ---- lifecycle ------------------------------------------------------- */
+
+/* HnswIndex::new(dimension) / with_metadata — vector/index.rs:204-216.
+ * device: HIP device ordinal this shard lives on.  NULL on failure. */
+cx_index *cx_create(uint32_t dimension, int device);
+void cx_destroy(cx_index *ix);
+/* pre-size the HBM row store (rows, not bytes); optional */
+int cx_reserve(cx_index *ix, uint64_t rows);
+
+/* ---- mutation: &mut self --------------------------------------------- */
+
+/* VectorIndex::insert — vector/index.rs:298-314.  len != dimension ->
+ * CX_ERR_VALIDATION "Embedding dimension mismatch: expected D, got L".
+ * Upsert: an existing id keeps its row, the vector is replaced.  Visible to
+ * the next search (the reference's exact-path semantics). */
+int cx_upsert(cx_index *ix, const uint8_t id[16], const float *embedding, uint64_t len);
+/* n inserts in one call: ids n*16 bytes, embeddings row-major n*len (host) */
+int cx_upsert_batch(cx_index *ix, uint64_t n, const uint8_t *ids, const float *embeddings, uint64_t len);
+/* same, embeddings already resident in HBM on the index's device */
+int cx_upsert_batch_dev(cx_index *ix, uint64_t n, const uint8_t *ids, const float *d_embeddings, uint64_t len);
+/* VectorIndex::remove — vector/index.rs:316-323; unknown id is not an error */
+int cx_remove(cx_index *ix, const uint8_t id[16]);
+/* HnswIndex::set_metadata — vector/index.rs:219-222 (kind, source_agent interned) */
+int cx_set_metadata(cx_index *ix, const uint8_t id[16], uint32_t kind_code, uint32_t agent_code);
+/* string -> stable code for cx_set_metadata / cx_filter (NodeKind / agent names) */
+uint32_t cx_intern(cx_index *ix, const char *utf8, uint64_t len);
+/* VectorIndex::rebuild — vector/index.rs:416-435.  The exact engine needs no
+ * graph: this compacts removed rows out of HBM (order preserved). Never
+ * required for correctness. */
+int cx_rebuild(cx_index *ix);
+
+/* ---- queries: &self --------------------------------------------------- */
+
+/* VectorIndex::len — vector/index.rs:412-414 */
+uint64_t cx_len(const cx_index *ix);
+uint32_t cx_dimension(const cx_index *ix);
+/* rows resident in HBM including removed-but-not-compacted ones */
+uint64_t cx_row_count(const cx_index *ix);
+/* id of a row (for callers that work with row indices); 0 ok */
+int cx_row_id(const cx_index *ix, uint64_t row, uint8_t out_id[16]);
+
+/* VectorIndex::search — vector/index.rs:325-374 on its exact path
+ * (:338-340 -> brute_force_search :259-294).  Writes n_out <= k results,
+ * best first: out_ids n*16 bytes, out_scores = clamp(1-distance,0,1),
+ * out_distances = 1 - cosine.  An empty index yields n_out = 0 (:331-333).
+ * len is the query length; like the reference (zip, :172) a query longer or
+ * shorter than the dimension is not an error. */
+int cx_search(const cx_index *ix, const float *query, uint64_t len, uint64_t k,
+              const cx_filter *filter, uint8_t *out_ids, float *out_scores,
+              float *out_distances, uint64_t *n_out);
+
+/* VectorIndex::search_threshold — vector/index.rs:376-388: every row with
+ * score >= threshold, best first.  Writes min(cap, n) results; *n_needed = n.
+ * Returns CX_ERR_CAPACITY when n > cap (call again with a larger buffer). */
+int cx_search_threshold(const cx_index *ix, const float *query, uint64_t len, float threshold,
+                        const cx_filter *filter, uint64_t cap, uint8_t *out_ids,
+                        float *out_scores, float *out_distances, uint64_t *n_out,
+                        uint64_t *n_needed);
+
+/* VectorIndex::search_batch — vector/index.rs:390-410.  queries row-major
+ * nq*len; out arrays hold nq*k entries, query i's results start at i*k and
+ * out_counts[i] of them are valid.  The corpus is read once per batch. */
+int cx_search_batch(const cx_index *ix, uint64_t nq, const float *queries, uint64_t len, uint64_t k,
+                    const cx_filter *filter, uint8_t *out_ids, float *out_scores,
+                    float *out_distances, uint64_t *out_counts);
+
+/* ---- HBM-resident variants (multi-GPU shards, benchmarking) ----------- */
+
+/* As cx_search / cx_search_batch with the queries (dimension floats each)
+ * and the results in HBM on the index's device.  d_rows are local row
+ * indices; d_counts[i] valid entries per query.  Enqueued on `stream` (a
+ * hipStream_t; NULL = the legacy default stream); returns without waiting. */
+int cx_search_dev(const cx_index *ix, const float *d_query, uint64_t k, const cx_filter *filter,
+                  uint32_t *d_rows, float *d_scores, float *d_distances, uint32_t *d_count,
+                  void *stream);
+int cx_search_batch_dev(const cx_index *ix, uint64_t nq, const float *d_queries, uint64_t k,
+                        const cx_filter *filter, uint32_t *d_rows, float *d_scores,
+                        float *d_distances, uint32_t *d_counts, void *stream);
+
+/* Merge per-shard partial top-k lists after the all-gather.
+ * Shard p's lists live at d_rows/d_scores/d_distances + p*part_stride, each
+ * [nq][k], and its counts at d_counts + p*part_stride, [nq] (part_stride in
+ * 4-byte elements: the size of one rank's packed all-gather chunk; 0 = dense
+ * arrays [n_parts][nq][k] and [n_parts][nq]).  Shard p's rows are offset by
+ * part_base[p] (host array) so ties resolve by global row.  Outputs [nq][k]
+ * global rows (u64), scores, distances, and counts [nq]. */
+int cx_merge_topk_dev(int device, uint64_t n_parts, uint64_t nq, uint64_t k, uint64_t part_stride,
+                      const uint64_t *part_base, const uint32_t *d_rows, const float *d_scores,
+                      const float *d_distances, const uint32_t *d_counts, uint64_t *d_out_rows,
+                      float *d_out_scores, float *d_out_distances, uint32_t *d_out_counts,
+                      void *stream);
+
+/* ---- measurement ------------------------------------------------------ */
+
+/* When on, every launch of the dominant scan kernel is bracketed by HIP
+ * events on the stream it runs on (bench.py's roofline leg). */
+int cx_profile_enable(cx_index *ix, int on);
+/* Sum of the bracketed kernel durations (ms) and their count since the last
+ * reset; waits for the recorded events. */
+int cx_profile_read(cx_index *ix, double *kernel_ms_sum, uint64_t *launches, int reset);
+
+/* raw device pointer to the f32 row store (row-major, cx_dimension floats per
+ * row) — read-only view for tools and tests */
+const float *cx_device_rows(const cx_index *ix);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CORTEX_HIP_H */

@@ -1,0 +1,30 @@
+/*
+ * cortex_hip_synth.h — benchmark/test support: deterministic synthetic
+ * embeddings generated directly in HBM, so multi-GB corpora
+ * are never shipped over PCIe.  Not part of the reference's interface; the
+ * reference has no data generator.  Bit-identical to its CPU twin in
+ * oracle/cortex_synth.c (tests/test_hip_synth.py).
+ */
+#ifndef CORTEX_HIP_SYNTH_H
+#define CORTEX_HIP_SYNTH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CX_SYNTH_DUPLICATES 1u /* rows r%1000==999 exact, ==998 near duplicates of an earlier row */
+#define CX_SYNTH_SCALED 2u     /* per-row scale in [0.5, 2): the un-normalised fixture */
+
+/* Writes rows [row_lo, row_lo + n_rows) of the synthetic corpus whose mixture
+ * has n_centres centres, row-major f32 [n_rows][dim], into d_out (HBM on
+ * `device`).  Synchronous.  0 = ok, else CX_ERR_* with cx_last_error(). */
+int cx_synth_fill_dev(int device, float *d_out, uint64_t seed_centres, uint64_t seed_rows,
+                      uint64_t seed_dup, uint64_t n_centres, uint64_t row_lo, uint64_t n_rows,
+                      uint32_t dim, uint32_t flags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

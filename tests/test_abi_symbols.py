@@ -1,0 +1,68 @@
+"""The C-ABI library loads here (no GPU) and exports every symbol include/cortex_hip.h declares;
+no compute call works without a device and none falls back to the CPU."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    names = []
+    for hdr in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        if not hdr.endswith(".h"):
+            continue
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names += re.findall(r"\b(cx_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol():
+    from cortex_amd import _lib
+    L = _lib.load()
+    names = declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/ but not exported"
+    assert set(names) == set(_lib.SIGNATURES), "ctypes table and header disagree"
+
+
+def test_no_cpu_fallback_without_device():
+    from cortex_amd import _lib
+    import cortex_amd
+    L = _lib.load()
+    if L.cx_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(cortex_amd.CortexError, match="no CPU fallback"):
+        cortex_amd.HipIndex(3)
+
+
+def test_product_never_imports_oracle():
+    """cortex_amd/ (the product) must not reference oracle/ in any way."""
+    bad = []
+    for dp, _, fs in os.walk(os.path.join(ROOT, "cortex_amd")):
+        for f in fs:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")) or f == "Makefile":
+                t = open(os.path.join(dp, f), errors="replace").read()
+                if re.search(r"\boracle\b|cxo_|cxs_", t):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, f"product files mention the oracle: {bad}"
+
+
+def test_similarity_config_mirror():  # vector/config.rs:93-135
+    import numpy as np
+    from cortex_amd import SimilarityConfig, ValidationError
+    c = SimilarityConfig.default()
+    assert (np.float32(c.auto_link_threshold), np.float32(c.dedup_threshold),
+            np.float32(c.contradiction_threshold), c.auto_link_k) == (np.float32(0.75), np.float32(0.92), np.float32(0.80), 20)
+    c.validate()
+    c = SimilarityConfig.new().with_auto_link_threshold(0.70).with_dedup_threshold(0.95).with_auto_link_k(30)
+    assert (np.float32(c.auto_link_threshold), np.float32(c.dedup_threshold), c.auto_link_k) == (np.float32(0.70), np.float32(0.95), 30)
+    bad = SimilarityConfig.new().with_auto_link_threshold(0.95).with_dedup_threshold(0.90)
+    with pytest.raises(ValidationError):
+        bad.validate()
+    c = SimilarityConfig.new().with_auto_link_threshold(1.5).with_dedup_threshold(-0.5)
+    assert c.auto_link_threshold == 1.0 and c.dedup_threshold == 0.0

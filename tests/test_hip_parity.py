@@ -1,0 +1,258 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the golden fixtures.
+
+Bar (north_star): row ids bit-exact under the declared order (score desc, row asc, NaN last)
+except among near-ties closer than SCORE_TOL; scores/distances within SCORE_TOL = 5e-5 absolute
+(conftest.py explains the bound)."""
+import glob
+import os
+import uuid
+
+import numpy as np
+import pytest
+
+from conftest import SCORE_TOL, assert_topk_parity, ids_for
+
+pytestmark = pytest.mark.gpu
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+def rows_of(index_ids: np.ndarray, got_ids: np.ndarray) -> np.ndarray:
+    """map returned 16-byte ids back to insertion rows"""
+    lut = {index_ids[i].tobytes(): i for i in range(len(index_ids))}
+    return np.array([lut[g.tobytes()] for g in got_ids], dtype=np.int64)
+
+
+def build_both(hip, oracle, rows, ids=None):
+    ids = ids_for(len(rows)) if ids is None else ids
+    h = hip.HipIndex(rows.shape[1])
+    h.insert_batch(ids, rows)
+    o = oracle.OracleIndex(rows.shape[1])
+    o.insert_batch(ids, rows)
+    return h, o, ids
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_golden_fixtures(hip, path):
+    g = np.load(path)
+    rows, qs, k = g["rows"], g["queries"], int(g["k"])
+    ids = ids_for(len(rows))
+    h = hip.HipIndex(rows.shape[1])
+    h.insert_batch(ids, rows)
+    for i, q in enumerate(qs):
+        gi, gs, gd = h.search_arrays(q, k)
+        n = len(gs)
+        assert_topk_parity(rows_of(ids, gi), gs, g["exp_rows"][i][:n], g["exp_scores"][i][:n], what=f"{path} q{i}")
+        exp_d = g["exp_dists"][i][:n]
+        pos = {int(r): j for j, r in enumerate(g["exp_rows"][i][:n])}
+        for j, r in enumerate(rows_of(ids, gi)):
+            if int(r) in pos:
+                e = exp_d[pos[int(r)]]
+                assert (np.isnan(e) and np.isnan(gd[j])) or abs(e - gd[j]) <= SCORE_TOL
+    # batch entry point gives the same lists
+    bi, bs, bd, bc = h.search_batch_arrays(qs, k)
+    for i in range(len(qs)):
+        gi, gs, gd = h.search_arrays(qs[i], k)
+        assert bc[i] == len(gs)
+        assert np.array_equal(bi[i, :len(gs)], gi) and np.array_equal(bs[i, :len(gs)], gs, equal_nan=True)
+
+
+@pytest.mark.parametrize("n,d,k", [
+    (1000, 384, 5),      # BASELINE config 1 shape, reduced rows
+    (5000, 768, 10),     # headline dim
+    (3000, 1024, 10),    # config 5 dim
+    (2000, 128, 100),    # k = 100 (auto-linker's k), G=32 kernel
+    (777, 256, 200),     # k in the 4-slot lists, ragged tail
+    (513, 100, 10),      # dim with no fast kernel -> generic path
+    (300, 7, 3),         # tiny odd dim
+    (64, 1536, 64),      # k == n
+])
+def test_search_matches_oracle(hip, oracle, n, d, k):
+    rows = oracle.synth_rows(n, d)
+    qs = oracle.synth_queries(n, d, 6)
+    h, o, ids = build_both(hip, oracle, rows)
+    for i, q in enumerate(qs):
+        gi, gs, gd = h.search_arrays(q, k)
+        e = o.search(q, k)
+        assert_topk_parity(rows_of(ids, gi), gs, e["row"], e["score"], what=f"n={n} d={d} k={k} q{i}")
+        assert np.all(np.abs(gd - (1.0 - (1.0 - gd))) < 1e-6)  # distance finite and consistent
+        assert np.all(np.diff(gs) <= 0), "scores not sorted descending"
+
+
+def test_unnormalised_rows_and_queries(hip, oracle):
+    rows = oracle.synth_rows(1500, 384, flags=3)  # norms in [0.5, 2)
+    qs = oracle.synth_queries(1500, 384, 4) * np.float32(3.25)
+    h, o, ids = build_both(hip, oracle, rows)
+    for q in qs:
+        gi, gs, gd = h.search_arrays(q, 10)
+        e = o.search(q, 10)
+        assert_topk_parity(rows_of(ids, gi), gs, e["row"], e["score"], what="unnormalised")
+
+
+def test_exact_duplicates_resolve_by_insertion_row(hip, oracle):
+    rows = oracle.synth_rows(3000, 256)            # rows 999, 1999, 2999 duplicate earlier rows
+    h, o, ids = build_both(hip, oracle, rows)
+    for r in (999, 1999, 2999):
+        gi, gs, gd = h.search_arrays(rows[r], 4)
+        e = o.search(rows[r], 4)
+        got = rows_of(ids, gi)
+        assert list(got[:2]) == list(e["row"][:2]), "duplicate pair must come back in insertion order"
+        assert got[0] < got[1] and gs[0] == gs[1]
+
+
+def test_large_k_and_threshold_paths(hip, oracle):
+    rows = oracle.synth_rows(1200, 384)
+    q = oracle.synth_queries(1200, 384, 1)[0]
+    h, o, ids = build_both(hip, oracle, rows)
+    # k > 256 -> sort path; k > len -> everything
+    for k in (300, 1200, 5000):
+        gi, gs, gd = h.search_arrays(q, k)
+        e = o.search(q, k)
+        assert_topk_parity(rows_of(ids, gi), gs, e["row"], e["score"], what=f"k={k}")
+    for thr in (0.92, 0.75, 0.3, 0.0, -1.0, 1.5):
+        gi, gs, gd = h.search_threshold_arrays(q, thr)
+        e = o.search_threshold(q, thr)
+        # rows whose oracle score is within tol of thr may fall either side
+        edge = np.abs(o.search(q, 1200)["score"].astype(np.float64) - thr) <= SCORE_TOL
+        assert abs(len(gs) - len(e)) <= edge.sum(), f"thr={thr}: {len(gs)} vs {len(e)}"
+        if len(gs) == len(e):
+            assert_topk_parity(rows_of(ids, gi), gs, e["row"], e["score"], what=f"thr={thr}")
+        assert np.all(gs >= np.float32(thr))
+
+
+def test_filters_match_oracle(hip, oracle):
+    n, d = 900, 128
+    rows = oracle.synth_rows(n, d)
+    q = oracle.synth_queries(n, d, 1)[0]
+    h, o, ids = build_both(hip, oracle, rows)
+    kinds = ["fact", "decision", "event"]
+    agents = ["kai", "test"]
+    for r in range(0, n, 2):           # only even rows get metadata: "no metadata => passes" (Q3)
+        k, a = kinds[r % 3], agents[(r // 2) % 2]
+        h.set_metadata(ids[r].tobytes(), k, a)
+        o.set_metadata(ids[r].tobytes(), k, a)
+    top = o.search(q, 5)
+    excl = [bytes(x["node_id"]) for x in top[:3]] + [uuid.uuid4().bytes]  # plus an id that is not indexed
+    cases = [
+        (hip.VectorFilter(kinds=["decision"]), oracle.Filter(kinds=["decision"])),
+        (hip.VectorFilter(kinds=[]), oracle.Filter(kinds=[])),
+        (hip.VectorFilter(kinds=["fact", "event"], source_agent="kai"), oracle.Filter(kinds=["fact", "event"], source_agent="kai")),
+        (hip.VectorFilter(exclude=excl), oracle.Filter(exclude=excl)),
+        (hip.VectorFilter(exclude=excl, kinds=["event"], source_agent="nobody"), oracle.Filter(exclude=excl, kinds=["event"], source_agent="nobody")),
+    ]
+    for hf, of in cases:
+        for k in (7, 600):
+            gi, gs, gd = h.search_arrays(q, k, hf)
+            e = o.search(q, k, of)
+            assert_topk_parity(rows_of(ids, gi), gs, e["row"], e["score"], what=f"filter {hf} k={k}")
+        gi, gs, gd = h.search_threshold_arrays(q, 0.5, hf)
+        e = o.search_threshold(q, 0.5, of)
+        assert abs(len(gs) - len(e)) <= 1
+
+
+def test_upsert_remove_rebuild_semantics(hip, oracle):
+    n, d = 400, 64
+    rows = oracle.synth_rows(n, d)
+    q = rows[10]
+    h, o, ids = build_both(hip, oracle, rows)
+    # upsert replaces in place, visible immediately
+    new = oracle.synth_queries(n, d, 1)[0]
+    h.insert(ids[10].tobytes(), new)
+    o.insert(ids[10].tobytes(), new)
+    assert len(h) == len(o) == n
+    for k in (5, n):
+        gi, gs, _ = h.search_arrays(q, k)
+        e = o.search(q, k)
+        assert_topk_parity(rows_of(ids, gi), gs, e["row"], e["score"], what="after upsert")
+    # remove: gone from results at once; len drops
+    victims = [int(x) for x in o.search(q, 3)["row"]]
+    for v in victims:
+        h.remove(ids[v].tobytes())
+        o.remove(ids[v].tobytes())
+    h.remove(uuid.uuid4().bytes)  # unknown id: not an error (index.rs:316-323)
+    assert len(h) == len(o) == n - 3
+    gi, gs, _ = h.search_arrays(q, 10)
+    e = o.search(q, 10)
+    assert not set(victims) & set(rows_of(ids, gi))
+    assert_topk_parity(rows_of(ids, gi), gs, e["row"], e["score"], what="after remove")
+    # rebuild compacts; results unchanged; re-insert of a removed id lands at the end
+    h.rebuild()
+    assert h.row_count() == n - 3
+    gi2, gs2, _ = h.search_arrays(q, 10)
+    assert np.array_equal(gi, gi2) and np.array_equal(gs, gs2)
+    h.insert(ids[victims[0]].tobytes(), rows[victims[0]])
+    o.insert(ids[victims[0]].tobytes(), rows[victims[0]])
+    gi, gs, _ = h.search_arrays(rows[victims[0]], 2)
+    assert gi[0].tobytes() == ids[victims[0]].tobytes() and gs[0] > 0.9999
+    assert h.row_id(h.row_count() - 1).bytes == ids[victims[0]].tobytes()
+
+
+def test_query_length_mismatch_is_not_an_error(hip, oracle):
+    """The reference zips (index.rs:172): a longer/shorter query still searches."""
+    from oracle import np_twin as T
+    rows = oracle.synth_rows(200, 64)
+    ids = ids_for(200)
+    h = hip.HipIndex(64)
+    h.insert_batch(ids, rows)
+    rng = np.random.default_rng(5)
+    for qlen in (40, 100):
+        q = rng.standard_normal(qlen).astype(np.float32)
+        gi, gs, gd = h.search_arrays(q, 5)
+        m = min(qlen, 64)
+        dot = np.array([np.cumsum(r[:m] * q[:m], dtype=np.float32)[-1] for r in rows])
+        nr = np.sqrt(np.array([np.cumsum(r * r, dtype=np.float32)[-1] for r in rows]))
+        nq = np.sqrt(np.cumsum(q * q, dtype=np.float32)[-1])
+        s = np.clip(1 - (1 - dot / (nq * nr)), 0, 1)
+        order = np.argsort(-s, kind="stable")[:5]
+        assert_topk_parity(rows_of(ids, gi), gs, order, s[order], what=f"qlen={qlen}")
+
+
+def test_zero_norm_rows_and_query_give_nan_last(hip, oracle):
+    rows = oracle.synth_rows(50, 32).copy()
+    rows[7] = 0.0
+    h, o, ids = build_both(hip, oracle, rows)
+    gi, gs, gd = h.search_arrays(rows[3], 50)
+    e = o.search(rows[3], 50)
+    assert np.isnan(gs[-1]) and rows_of(ids, gi)[-1] == 7
+    assert_topk_parity(rows_of(ids, gi), gs, e["row"], e["score"], what="zero row")
+    gi, gs, gd = h.search_arrays(np.zeros(32, np.float32), 5)   # zero query: all NaN, row order
+    assert np.all(np.isnan(gs)) and list(rows_of(ids, gi)) == [0, 1, 2, 3, 4]
+    assert len(h.search_threshold_arrays(np.zeros(32, np.float32), 0.0)[1]) == 0  # NaN >= t is false
+
+
+def test_incremental_inserts_visible_without_rebuild(hip, oracle):
+    d = 384
+    rows = oracle.synth_rows(600, d)
+    ids = ids_for(600)
+    h = hip.HipIndex(d)
+    o = oracle.OracleIndex(d)
+    q = oracle.synth_queries(600, d, 1)[0]
+    for lo in range(0, 600, 150):   # four batches, a search after each, never a rebuild (Q1)
+        h.insert_batch(ids[lo:lo + 150], rows[lo:lo + 150])
+        o.insert_batch(ids[lo:lo + 150], rows[lo:lo + 150])
+        gi, gs, _ = h.search_arrays(q, 10)
+        e = o.search(q, 10)
+        assert_topk_parity(rows_of(ids, gi), gs, e["row"], e["score"], what=f"after {lo + 150} rows")
+
+
+def test_concurrent_readers(hip, oracle):
+    """&self methods are re-entrant: many threads search at once (RwLock read side)."""
+    import threading
+    rows = oracle.synth_rows(4000, 384)
+    qs = oracle.synth_queries(4000, 384, 16)
+    h, o, ids = build_both(hip, oracle, rows)
+    want = [o.search(q, 10) for q in qs]
+    errs = []
+
+    def work(t):
+        try:
+            for rep in range(5):
+                for i in range(t, len(qs), 4):
+                    gi, gs, _ = h.search_arrays(qs[i], 10)
+                    assert_topk_parity(rows_of(ids, gi), gs, want[i]["row"], want[i]["score"], what=f"thread {t}")
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs[0]
