@@ -62,6 +62,15 @@ def load() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(cortex_amd has no CPU fallback)")
+        # torch ships its own libamdhip64.so.7 / libhsa-runtime64; two HIP runtimes in one process
+        # cannot both own the GPU ("No HIP GPUs are available").  Loading torch first makes our
+        # DT_NEEDED libamdhip64.so.7 resolve to the copy torch already mapped, so the library, torch
+        # tensors and RCCL share one runtime, one set of streams and one address space.  Without torch
+        # (a non-Python host) the RUNPATH picks /opt/rocm/lib.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the header and the library disagree

@@ -76,11 +76,16 @@ __device__ inline bool row_passes(const DevFilter &f, uint32_t row) {
 }
 
 // The reference's epilogue, one IEEE operation per step
-// (vector/index.rs:173-177 and :254-256).
+// (vector/index.rs:173-177 and :254-256).  sqrtf and '/' are correctly rounded
+// in HIP device code (-fhip-fp32-correctly-rounded-divide-sqrt, the default);
+// the __fsqrt_rn/__fdiv_rn "intrinsics" of this toolchain are NOT (native
+// approximations), so they are not used anywhere.
 __device__ inline float cosine_from_sums(float dot, float qq, float rr) {
-    const float norm_a = __fsqrt_rn(qq);
-    const float norm_b = __fsqrt_rn(rr);
-    return __fdiv_rn(dot, __fmul_rn(norm_a, norm_b));
+#pragma clang fp contract(off)
+    const float norm_a = sqrtf(qq);
+    const float norm_b = sqrtf(rr);
+    const float den = norm_a * norm_b;
+    return dot / den;
 }
 __host__ __device__ inline float distance_of(float sim) { return 1.0f - sim; }
 __host__ __device__ inline float score_of(float distance) {

@@ -7,6 +7,10 @@
 #include "common.hpp"
 #include "../../include/cortex_hip_synth.h"
 
+// every float op below must be a single IEEE operation: no FMA contraction, correctly rounded
+// sqrtf and divide (the default for HIP device code)
+#pragma clang fp contract(off)
+
 namespace cx {
 
 __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
@@ -27,21 +31,21 @@ __device__ inline float gauss(uint64_t seed, uint64_t idx, uint32_t stream) {
     uint32_t x[4];
     philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), stream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
     const int32_t s = (int32_t)((x[0] >> 8) + (x[1] >> 8) + (x[2] >> 8) + (x[3] >> 8)) - 33554430;
-    return __fmul_rn((float)s, 1.0323829e-07f);
+    return (float)s * 1.0323829e-07f;
 }
 
 // fold the 64 lane partials in the twin's order; the total ends up in every lane
 __device__ inline float fold64(float part) {
 #pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) part = __fadd_rn(part, __shfl_down(part, s, 64));
+    for (int s = 32; s >= 1; s >>= 1) part = part + __shfl_down(part, s, 64);
     return __shfl(part, 0, 64);
 }
 
 __device__ inline void normalise_row(float *row, uint32_t d, uint32_t lane) {
     float a = 0.0f;
-    for (uint32_t j = lane; j < d; j += 64u) a = __fadd_rn(a, __fmul_rn(row[j], row[j]));
-    const float n = __fsqrt_rn(fold64(a));
-    for (uint32_t j = lane; j < d; j += 64u) row[j] = __fdiv_rn(row[j], n);
+    for (uint32_t j = lane; j < d; j += 64u) { const float p = row[j] * row[j]; a = a + p; }
+    const float n = sqrtf(fold64(a));
+    for (uint32_t j = lane; j < d; j += 64u) row[j] = row[j] / n;
 }
 
 __global__ __launch_bounds__(256) void synth_centres_kernel(float *centres, uint64_t seed, uint64_t n_centres, uint32_t d) {
@@ -77,20 +81,22 @@ __global__ __launch_bounds__(256) void synth_rows_kernel(float *out, const float
     uint32_t xb[4];
     philox4x32_10((uint32_t)src, (uint32_t)(src >> 32), 1u, 0u, (uint32_t)seed_rows, (uint32_t)(seed_rows >> 32), xb);
     const float *centre = centres + (uint64_t)(xb[0] % n_centres) * d;
-    const float inv_sqrt_d = __fdiv_rn(1.0f, __fsqrt_rn((float)d));
-    const float amp = __fmul_rn(sigma_of(xb[1]), inv_sqrt_d);
+    const float inv_sqrt_d = 1.0f / sqrtf((float)d);
+    const float amp = sigma_of(xb[1]) * inv_sqrt_d;
     for (uint32_t j = lane; j < d; j += 64u)
-        row[j] = __fadd_rn(centre[j], __fmul_rn(amp, gauss(seed_rows, src * (uint64_t)d + j, 2u)));
+        { const float t = amp * gauss(seed_rows, src * (uint64_t)d + j, 2u); row[j] = centre[j] + t; }
     normalise_row(row, d, lane);
     if (dup && m == 998u) {
-        const float amp2 = __fmul_rn(0.045f, inv_sqrt_d);
+        const float amp2 = 0.045f * inv_sqrt_d;
         for (uint32_t j = lane; j < d; j += 64u)
-            row[j] = __fadd_rn(row[j], __fmul_rn(amp2, gauss(seed_dup, r * (uint64_t)d + j, 3u)));
+            { const float t = amp2 * gauss(seed_dup, r * (uint64_t)d + j, 3u); row[j] = row[j] + t; }
         normalise_row(row, d, lane);
     }
     if (flags & 2u) {
-        const float s = __fadd_rn(0.5f, __fmul_rn(1.5f, __fmul_rn((float)(x[3] >> 8), 5.9604645e-08f)));
-        for (uint32_t j = lane; j < d; j += 64u) row[j] = __fmul_rn(row[j], s);
+        const float u = (float)(x[3] >> 8) * 5.9604645e-08f;
+        const float s15 = 1.5f * u;
+        const float s = 0.5f + s15;
+        for (uint32_t j = lane; j < d; j += 64u) row[j] = row[j] * s;
     }
 }
 
