@@ -190,7 +190,8 @@ def cpu_baseline(ix, gen: torch.Tensor, queries: torch.Tensor, n: int, d: int, k
                 hits += 1
         max_ds = max(max_ds, float(np.max(np.abs(gs.astype(np.float64) - e["score"].astype(np.float64)))))
     # all host cores across queries: the reference's search_batch (rayon par_iter, :390-410)
-    cores = os.cpu_count() or 1
+    # the GPU box's CPU share is 16 hardware threads per GPU (os.cpu_count() reports the whole host)
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
     nb = min(2 * cores, 64)
     t2 = time.perf_counter()
     o.search_batch(qs_h[:nb], k, n_threads=cores)

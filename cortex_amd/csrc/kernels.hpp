@@ -7,6 +7,17 @@ namespace cx {
 
 constexpr uint32_t TOPK_MAX = 256;  // largest k served by the in-register top-k lists
 
+struct MergeArgs {
+    const uint64_t *part_keys;  // [n_lists][k]
+    const float *part_sims;
+    uint32_t n_lists;
+    uint32_t k;
+    uint32_t *out_rows;   // [k]
+    float *out_scores;    // [k]
+    float *out_dists;     // [k]
+    uint32_t *out_count;  // [1]
+};
+
 // One single-query scan over the row store.
 struct ScanArgs {
     const float *rows;     // [n_rows][dim] f32 row-major, 16-byte aligned when dim % 4 == 0
@@ -24,17 +35,6 @@ struct ScanArgs {
     float *dense_sims;
     float threshold;
     uint32_t has_threshold;
-};
-
-struct MergeArgs {
-    const uint64_t *part_keys;  // [n_lists][k]
-    const float *part_sims;
-    uint32_t n_lists;
-    uint32_t k;
-    uint32_t *out_rows;   // [k]
-    float *out_scores;    // [k]
-    float *out_dists;     // [k]
-    uint32_t *out_count;  // [1]
 };
 
 // number of blocks launch_scan_topk will use for this shape (scratch sizing)

@@ -49,7 +49,7 @@ __device__ inline void block_merge_store(WaveTopK<KS> &top, uint32_t k, uint64_t
     __shared__ uint64_t sk[3][64 * KS];
     __shared__ float ss[3][64 * KS];
     const int wave = (int)(threadIdx.x >> 6);
-    if (wave > 0) top.store(sk[wave - 1], ss[wave - 1], k);
+    if (wave > 0) top.store(sk[wave - 1], ss[wave - 1]);
     __syncthreads();
     if (wave == 0) {
         const uint32_t lane = (uint32_t)lane_id();
@@ -62,7 +62,7 @@ __device__ inline void block_merge_store(WaveTopK<KS> &top, uint32_t k, uint64_t
                 top.offer_lanes(kg, sg, [](uint32_t) { return true; });
             }
         }
-        top.store(part_keys + (size_t)blockIdx.x * k, part_sims + (size_t)blockIdx.x * k, k);
+        top.store(part_keys + (size_t)blockIdx.x * k, part_sims + (size_t)blockIdx.x * k);
     }
 }
 
@@ -193,7 +193,6 @@ template <int KS>
 __global__ __launch_bounds__(1024) void merge_kernel(const MergeArgs m) {
     __shared__ uint64_t sk[16][64 * KS];
     __shared__ float ss[16][64 * KS];
-    __shared__ uint32_t s_count;
     const uint32_t lane = (uint32_t)lane_id();
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t k = m.k;
@@ -206,8 +205,7 @@ __global__ __launch_bounds__(1024) void merge_kernel(const MergeArgs m) {
         const float sg = i < total ? m.part_sims[i] : 0.0f;
         top.offer_lanes(kg, sg, [](uint32_t) { return true; });
     }
-    top.store(sk[wave], ss[wave], k);
-    if (threadIdx.x == 0) s_count = 0;
+    if (wave > 0) top.store(sk[wave], ss[wave]);
     __syncthreads();
     if (wave == 0) {
         for (int w = 1; w < 16; w++) {
@@ -219,25 +217,105 @@ __global__ __launch_bounds__(1024) void merge_kernel(const MergeArgs m) {
                 top.offer_lanes(kg, sg, [](uint32_t) { return true; });
             }
         }
-        top.store(sk[0], ss[0], k);
+        // the list is sorted best-first: rank = position
+        uint32_t count = 0;
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            const uint32_t i = (uint32_t)s * 64u + lane;
+            const uint64_t ki = top.key[s];
+            const bool valid = i < k && ki != 0ull;
+            if (valid) {
+                const float dist = distance_of(top.sim[s]);
+                m.out_rows[i] = key_row(ki);
+                m.out_dists[i] = dist;
+                m.out_scores[i] = score_of(dist);
+            }
+            count += (uint32_t)__popcll(__ballot(valid));
+        }
+        if (lane == 0) *m.out_count = count;
     }
-    __syncthreads();
-    // rank = number of strictly better keys; keys are unique except empties (0)
-    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
-        const uint64_t ki = sk[0][i];
-        if (ki == 0ull) continue;
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < k; j++) rank += (sk[0][j] > ki) ? 1u : 0u;
-        const float sim = ss[0][i];
-        const float dist = distance_of(sim);
-        m.out_rows[rank] = key_row(ki);
-        m.out_dists[rank] = dist;
-        m.out_scores[rank] = score_of(dist);
-        atomicAdd(&s_count, 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) *m.out_count = s_count;
 }
+
+// Second stage for k <= 32 (the interactive searches: k = 5, 10, 30): no serial
+// fold.  Every partial list is sorted best-first, so its head is its best key.
+//  P0 heads -> LDS.
+//  P1 t0 = k-th largest of a 64-head sample (rank counting inside wave 0 with
+//     v_readlane broadcasts).  At least k real candidates are >= t0, so it is a
+//     valid lower bound on the answer's k-th key.
+//  P2 heads >= t0 are compacted (typically ~ n*k/64 of them);
+//  P3 rank counting among those gives tau = the exact k-th largest head.
+//     Keys are unique, so exactly k lists have a head >= tau, each holding at
+//     most k entries: <= k*k <= 1024 survivors.
+//  P4 every (list, slot) pair is looked at once, in parallel: entries >= tau
+//     of lists whose head is >= tau are appended to LDS.
+//  P5 every survivor counts the survivors that beat it; rank < k -> out[rank].
+// NT = threads in the block (a multiple of 64, <= 1024); n_lists <= 2048.
+constexpr uint32_t MERGE_SMALL_MAX_LISTS = 2048;
+template <int NT>
+__device__ inline void merge_small_body(const MergeArgs &m) {
+    __shared__ uint64_t heads[MERGE_SMALL_MAX_LISTS];
+    __shared__ uint64_t hsurv[MERGE_SMALL_MAX_LISTS];
+    __shared__ uint64_t surv_k[1024];
+    __shared__ float surv_s[1024];
+    __shared__ uint32_t s_nh, s_n;
+    __shared__ uint64_t s_t0, s_tau;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t k = m.k, n = m.n_lists;
+    for (uint32_t i = tid; i < n; i += NT) heads[i] = m.part_keys[(size_t)i * k];
+    if (tid == 0) { s_nh = 0; s_n = 0; s_t0 = 0ull; s_tau = 0ull; }
+    __syncthreads();
+    if (wave == 0) {
+        const uint32_t step = n >= 64u ? n / 64u : 1u;
+        const uint32_t i = lane * step;
+        const uint64_t mine = i < n ? heads[i] : 0ull;
+        uint32_t rank = 0;
+        for (int l = 0; l < 64; l++) {
+            const uint64_t o = readlane_u64(mine, l);
+            rank += (o > mine || (o == mine && (uint32_t)l < lane)) ? 1u : 0u;  // zeros tie: order by lane
+        }
+        if (rank == k - 1u) s_t0 = mine;
+    }
+    __syncthreads();
+    const uint64_t t0 = s_t0;
+    for (uint32_t i = tid; i < n; i += NT) {
+        const uint64_t h = heads[i];
+        if (h != 0ull && h >= t0) hsurv[atomicAdd(&s_nh, 1u)] = h;
+    }
+    __syncthreads();
+    const uint32_t SH = s_nh;
+    for (uint32_t i = tid; i < SH; i += NT) {
+        const uint64_t hi = hsurv[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < SH; j++) rank += hsurv[j] > hi ? 1u : 0u;
+        if (rank == k - 1u) s_tau = hi;  // stays 0 when fewer than k lists are non-empty
+    }
+    __syncthreads();
+    const uint64_t tau = s_tau;
+    for (uint32_t e = tid; e < n * k; e += NT) {
+        const uint64_t h = heads[e / k];
+        if (h == 0ull || h < tau) continue;
+        const uint64_t kg = m.part_keys[e];
+        if (kg == 0ull || kg < tau) continue;
+        const uint32_t pos = atomicAdd(&s_n, 1u);
+        if (pos < 1024u) { surv_k[pos] = kg; surv_s[pos] = m.part_sims[e]; }
+    }
+    __syncthreads();
+    const uint32_t S = s_n < 1024u ? s_n : 1024u;
+    for (uint32_t i = tid; i < S; i += NT) {
+        const uint64_t ki = surv_k[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < S; j++) rank += surv_k[j] > ki ? 1u : 0u;
+        if (rank < k) {
+            const float dist = distance_of(surv_s[i]);
+            m.out_rows[rank] = key_row(ki);
+            m.out_dists[rank] = dist;
+            m.out_scores[rank] = score_of(dist);
+        }
+    }
+    if (tid == 0) *m.out_count = S < k ? S : k;
+}
+
+__global__ __launch_bounds__(1024) void merge_small_kernel(const MergeArgs m) { merge_small_body<1024>(m); }
 
 // ------------------------------------------------------------------ host
 
@@ -257,7 +335,7 @@ static uint32_t blocks_per_cu() {
     static int v = 0;
     if (!v) {
         const char *e = getenv("CX_SCAN_BLOCKS_PER_CU");
-        v = e ? atoi(e) : 4;
+        v = e ? atoi(e) : 2;  // 8 waves x 12 KiB of loads in flight per CU measured best (profiles/r01)
         if (v < 1) v = 1;
         if (v > 8) v = 8;
     }
@@ -308,7 +386,12 @@ static void dispatch_scan(const ScanArgs &a, uint32_t grid, int ks, bool nt, hip
             case 256: return launch_fixed<256, 64, 8, MODE>(a, grid, ks, nt, s);
             case 384: return launch_fixed<384, 32, 4, MODE>(a, grid, ks, nt, s);
             case 512: return launch_fixed<512, 64, 4, MODE>(a, grid, ks, nt, s);
-            case 768: return launch_fixed<768, 64, 4, MODE>(a, grid, ks, nt, s);
+            case 768: {
+                static const int r768 = getenv("CX_SCAN_R") ? atoi(getenv("CX_SCAN_R")) : 4;  // tuning knob
+                if (r768 == 2) return launch_fixed<768, 64, 2, MODE>(a, grid, ks, nt, s);
+                if (r768 == 8) return launch_fixed<768, 64, 8, MODE>(a, grid, ks, nt, s);
+                return launch_fixed<768, 64, 4, MODE>(a, grid, ks, nt, s);
+            }
             case 1024: return launch_fixed<1024, 64, 2, MODE>(a, grid, ks, nt, s);
             case 1536: return launch_fixed<1536, 64, 2, MODE>(a, grid, ks, nt, s);
             default: break;
@@ -326,7 +409,8 @@ int launch_scan_topk(const ScanArgs &a, const MergeArgs &m, bool nontemporal, hi
     if (ev0) CX_HIP(hipEventRecord(ev0, stream));
     dispatch_scan<0>(a, grid, ks, nontemporal, stream);
     if (ev1) CX_HIP(hipEventRecord(ev1, stream));
-    if (ks == 1) hipLaunchKernelGGL((merge_kernel<1>), dim3(1), dim3(1024), 0, stream, m);
+    if (a.k <= 32 && grid <= MERGE_SMALL_MAX_LISTS) hipLaunchKernelGGL(merge_small_kernel, dim3(1), dim3(1024), 0, stream, m);
+    else if (ks == 1) hipLaunchKernelGGL((merge_kernel<1>), dim3(1), dim3(1024), 0, stream, m);
     else if (ks == 2) hipLaunchKernelGGL((merge_kernel<2>), dim3(1), dim3(1024), 0, stream, m);
     else hipLaunchKernelGGL((merge_kernel<4>), dim3(1), dim3(1024), 0, stream, m);
     CX_HIP(hipGetLastError());
@@ -358,7 +442,6 @@ __global__ __launch_bounds__(256) void merge_parts_kernel(uint32_t n_parts, uint
     // index order equals the global row order among ties.
     __shared__ uint64_t sk[4][64 * KS];
     __shared__ float ss[4][64 * KS];
-    __shared__ uint32_t s_count;
     const uint32_t qi = blockIdx.x;
     const uint32_t lane = (uint32_t)lane_id();
     const uint32_t wave = threadIdx.x >> 6;
@@ -379,8 +462,7 @@ __global__ __launch_bounds__(256) void merge_parts_kernel(uint32_t n_parts, uint
         }
         top.offer_lanes(kg, sg, [](uint32_t) { return true; });
     }
-    top.store(sk[wave], ss[wave], k);
-    if (threadIdx.x == 0) s_count = 0;
+    if (wave > 0) top.store(sk[wave], ss[wave]);
     __syncthreads();
     if (wave == 0) {
         for (int w = 1; w < 4; w++) {
@@ -392,24 +474,24 @@ __global__ __launch_bounds__(256) void merge_parts_kernel(uint32_t n_parts, uint
                 top.offer_lanes(kg, sg, [](uint32_t) { return true; });
             }
         }
-        top.store(sk[0], ss[0], k);
+        uint32_t count = 0;
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            const uint32_t i = (uint32_t)s * 64u + lane;
+            const uint64_t ki = top.key[s];
+            const bool valid = i < k && ki != 0ull;
+            if (valid) {
+                const uint32_t idx = key_row(ki);
+                const uint32_t p = idx / k, slot = idx % k;
+                const size_t src = (size_t)p * lstride + (size_t)qi * k + slot;
+                out_rows[(size_t)qi * k + i] = part_base.base[p] + rows[src];
+                out_scores[(size_t)qi * k + i] = scores[src];
+                out_dists[(size_t)qi * k + i] = top.sim[s];
+            }
+            count += (uint32_t)__popcll(__ballot(valid));
+        }
+        if (lane == 0) out_counts[qi] = count;
     }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
-        const uint64_t ki = sk[0][i];
-        if (ki == 0ull) continue;
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < k; j++) rank += (sk[0][j] > ki) ? 1u : 0u;
-        const uint32_t idx = key_row(ki);
-        const uint32_t p = idx / k, slot = idx % k;
-        const size_t src = (size_t)p * lstride + (size_t)qi * k + slot;
-        out_rows[(size_t)qi * k + rank] = part_base.base[p] + rows[src];
-        out_scores[(size_t)qi * k + rank] = scores[src];
-        out_dists[(size_t)qi * k + rank] = ss[0][i];
-        atomicAdd(&s_count, 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) out_counts[qi] = s_count;
 }
 
 int launch_merge_parts(uint32_t n_parts, uint32_t nq, uint32_t k, uint64_t part_stride, const PartBase &part_base,

@@ -1,12 +1,17 @@
 // topk.hpp — wavefront-level top-k list kept in registers (gfx950, wave64).
 //
-// A wave owns up to 64*KS slots, slot (s, lane) enabled when s*64+lane < k.
-// Keys are the 64-bit order keys of common.hpp (larger = better, 0 = empty).
-// `tau` is the smallest enabled key and is wave-uniform: a candidate is
+// A wave holds 64*KS entries sorted best-first across its lanes: rank
+// r = s*64 + lane lives in (key[s], sim[s]) of that lane.  Keys are the 64-bit
+// order keys of common.hpp (larger = better, 0 = empty, so empties sit at the
+// tail).  `tau` is the key at rank k-1 and is wave-uniform: a candidate is
 // worth inserting only if its key exceeds tau, so after warm-up almost every
-// row is rejected by one scalar compare.  Insertion replaces the slot holding
-// tau and recomputes tau with a 6-step butterfly — rare, so its cost does not
-// matter next to the HBM stream.
+// row is rejected by one scalar compare.
+//
+// Insertion is a sorted insert: one ballot per slot gives the position
+// (entries better than the newcomer form a prefix), every worse entry moves
+// one rank down with a single DPP wave shift (wave_shr:1 — VALU rate, no LDS
+// crossbar round trip), the newcomer drops into the hole and tau is re-read
+// with v_readlane.  ~20 instructions, no dependent shuffle chain.
 #pragma once
 
 #include "common.hpp"
@@ -14,15 +19,6 @@
 namespace cx {
 
 __device__ inline int lane_id() { return (int)(threadIdx.x & 63u); }
-
-__device__ inline uint64_t wave_min_u64(uint64_t v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const uint64_t o = __shfl_xor(v, off, 64);
-        v = o < v ? o : v;
-    }
-    return v;
-}
 
 __device__ inline uint64_t readlane_u64(uint64_t v, int src) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
@@ -33,43 +29,58 @@ __device__ inline float readlane_f32(float v, int src) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
 
+// lane i <- v of lane i-1; lane 0 <- carry (DPP wave_shr:1, bound_ctrl off keeps `old`)
+__device__ inline uint32_t wave_shr1(uint32_t carry, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)v, 0x138, 0xf, 0xf, false);
+}
+
 template <int KS>
 struct WaveTopK {
     uint64_t key[KS];
     float sim[KS];
     uint64_t tau;
+    uint32_t k;
 
-    __device__ void init(uint32_t k) {
-        const uint32_t lane = (uint32_t)lane_id();
+    __device__ void init(uint32_t k_) {
 #pragma unroll
         for (int s = 0; s < KS; s++) {
-            key[s] = ((uint32_t)s * 64u + lane < k) ? 0ull : ~0ull;  // ~0 = disabled slot
+            key[s] = 0ull;
             sim[s] = 0.0f;
         }
-        tau = k ? 0ull : ~0ull;
+        k = k_;
+        tau = k_ ? 0ull : ~0ull;
     }
 
-    // kn, sn wave-uniform; requires kn > tau
+    // kn, sn wave-uniform; requires kn > tau (hence its rank is < k)
     __device__ void insert(uint64_t kn, float sn) {
-        const int lane = lane_id();
-        bool done = false;
+        const uint32_t lane = (uint32_t)lane_id();
+        uint32_t pos = 0;
+#pragma unroll
+        for (int s = 0; s < KS; s++) pos += (uint32_t)__popcll(__ballot(key[s] > kn));
+        const uint32_t kn_lo = (uint32_t)kn, kn_hi = (uint32_t)(kn >> 32), sn_b = __float_as_uint(sn);
+        uint32_t c_lo = 0, c_hi = 0, c_s = 0;  // what enters lane 0 of the current slot
 #pragma unroll
         for (int s = 0; s < KS; s++) {
-            const uint64_t m = __ballot(key[s] == tau);
-            if (!done && m) {
-                const int src = __ffsll((unsigned long long)m) - 1;
-                if (lane == src) { key[s] = kn; sim[s] = sn; }
-                done = true;
-            }
+            uint32_t lo = (uint32_t)key[s], hi = (uint32_t)(key[s] >> 32), sb = __float_as_uint(sim[s]);
+            const uint32_t n_lo = (uint32_t)__builtin_amdgcn_readlane((int)lo, 63);
+            const uint32_t n_hi = (uint32_t)__builtin_amdgcn_readlane((int)hi, 63);
+            const uint32_t n_s = (uint32_t)__builtin_amdgcn_readlane((int)sb, 63);
+            const uint32_t sh_lo = wave_shr1(c_lo, lo), sh_hi = wave_shr1(c_hi, hi), sh_s = wave_shr1(c_s, sb);
+            const uint32_t r = (uint32_t)s * 64u + lane;
+            if (r > pos) { lo = sh_lo; hi = sh_hi; sb = sh_s; }
+            else if (r == pos) { lo = kn_lo; hi = kn_hi; sb = sn_b; }
+            key[s] = ((uint64_t)hi << 32) | lo;
+            sim[s] = __uint_as_float(sb);
+            c_lo = n_lo; c_hi = n_hi; c_s = n_s;
         }
-        uint64_t loc = key[0];
+        const uint32_t last = k - 1u;
 #pragma unroll
-        for (int s = 1; s < KS; s++) loc = key[s] < loc ? key[s] : loc;
-        tau = wave_min_u64(loc);
+        for (int s = 0; s < KS; s++)
+            if ((last >> 6) == (uint32_t)s) tau = readlane_u64(key[s], (int)(last & 63u));
     }
 
-    // offer the (per-lane) candidates of a whole wave: lanes with key > tau
-    // are inserted one by one (uniform loop over the ballot mask)
+    // offer the (per-lane) candidates of a whole wave: lanes whose key beats
+    // tau are inserted one by one (uniform loop over the ballot mask)
     template <typename Pred>
     __device__ void offer_lanes(uint64_t kg, float sg, Pred pass) {
         uint64_t m = __ballot(kg > tau);
@@ -81,8 +92,8 @@ struct WaveTopK {
         }
     }
 
-    // slot i = s*64 + lane of the list, written to dst[i] for i < k (0 for empty)
-    __device__ void store(uint64_t *dk, float *ds, uint32_t k) const {
+    // rank i = s*64 + lane of the list, written to dst[i] for i < k (0 for empty)
+    __device__ void store(uint64_t *dk, float *ds) const {
         const uint32_t lane = (uint32_t)lane_id();
 #pragma unroll
         for (int s = 0; s < KS; s++) {

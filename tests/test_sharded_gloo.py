@@ -1,0 +1,95 @@
+"""N > 1 path on CPU: world_size-2 gloo run of cortex_amd.sharded.ShardedKnn.
+
+The row-range sharding, the packed all-gather layout, the shard row bases and the merge order are
+product code (cortex_amd/sharded.py); the local searcher is injected — here the CPU oracle, on the GPU
+the HIP index — so the collective plumbing is exercised without a GPU.  The HIP merge kernel itself is
+checked against the same reference merge in tests/test_hip_sharded.py."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank: int, world: int, port: int, n_total: int, d: int, k: int, nq: int, ragged: bool, out_q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O
+        from cortex_amd.sharded import ShardedKnn, reference_merge
+        from conftest import ids_for
+        # ragged: shard sizes differ and one shard is smaller than k
+        if ragged:
+            sizes = [n_total - 3, 3][:world] if world == 2 else [n_total // world] * world
+        else:
+            sizes = [n_total // world] * world
+        bases = np.concatenate([[0], np.cumsum(sizes)[:-1]]).tolist()
+        rows = O.synth_rows(n_total, d)
+        qs = O.synth_queries(n_total, d, nq)
+        lo, hi = bases[rank], bases[rank] + sizes[rank]
+        local = O.OracleIndex(d)
+        local.insert_batch(ids_for(n_total)[lo:hi], rows[lo:hi])
+
+        def local_fn(queries, nq_, s):
+            r, sc, di, cnt = s.chunk_views(s.local)
+            for qi in range(nq_):
+                e = local.search(queries[qi], s.k)
+                m = len(e)
+                cnt[qi] = m
+                r[qi, :m] = torch.from_numpy(e["row"].astype(np.int32))
+                sc[qi, :m] = torch.from_numpy(e["score"].copy())
+                di[qi, :m] = torch.from_numpy(e["distance"].copy())
+
+        knn = ShardedKnn(rank, world, bases, nq, k, torch.device("cpu"), local_fn, merge_fn=reference_merge)
+        knn.search(qs)
+        # every rank holds the same merged answer; compare with one oracle over the whole corpus
+        full = O.OracleIndex(d)
+        full.insert_batch(ids_for(n_total), rows)
+        ok = True
+        for qi in range(nq):
+            e = full.search(qs[qi], k)
+            m = int(knn.out_counts[qi])
+            ok &= m == len(e)
+            ok &= np.array_equal(knn.out_rows[qi, :m].numpy(), e["row"].astype(np.int64))
+            ok &= np.array_equal(knn.out_scores[qi, :m].numpy(), e["score"])
+            ok &= np.array_equal(knn.out_dists[qi, :m].numpy(), e["distance"])
+        out_q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total,d,k,nq,ragged", [(400, 64, 10, 3, False), (120, 32, 7, 2, True)])
+def test_two_rank_gloo_sharded_search_equals_single_index(n_total, d, k, nq, ragged):
+    from oracle import oracle as O
+    O.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, d, k, nq, ragged, q)) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    got = sorted(q.get(timeout=5) for _ in range(2))
+    assert got == [(0, True), (1, True)]
+
+
+def test_packed_layout():
+    from cortex_amd.sharded import packed_words
+    assert packed_words(1, 10) == 32 and packed_words(64, 10) % 4 == 0 and packed_words(64, 10) >= 3 * 640 + 64
