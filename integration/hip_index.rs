@@ -1,0 +1,173 @@
+//! hip_index.rs — the reference-side binding: `impl VectorIndex for HipIndex` over libcortex_hip.so.
+//!
+//! Drop this file into crates/cortex-core/src/vector/ (mod hip_index; pub use hip_index::HipIndex;)
+//! and swap `HnswIndex` for `HipIndex` at the construction sites listed in INTEGRATION.md.
+//! NOT COMPILED in this repository's image (no Rust toolchain); every semantic decision lives on the
+//! C side, this file only marshals.  The identical ABI is exercised by cortex_amd/index.py + tests/.
+use crate::error::{CortexError, Result};
+use crate::types::{Embedding, NodeId, NodeKind};
+use crate::vector::{SimilarityResult, VectorFilter, VectorIndex};
+use std::collections::HashMap;
+use std::ffi::CStr;
+use std::os::raw::{c_char, c_int, c_void};
+use std::path::Path;
+
+#[repr(C)]
+struct CxFilter {
+    has_exclude: i32,
+    n_exclude: u64,
+    exclude_ids: *const u8,
+    has_kinds: i32,
+    n_kinds: u64,
+    kind_codes: *const u32,
+    has_agent: i32,
+    agent_code: u32,
+}
+
+#[link(name = "cortex_hip")]
+extern "C" {
+    fn cx_last_error() -> *const c_char;
+    fn cx_create(dimension: u32, device: c_int) -> *mut c_void;
+    fn cx_destroy(ix: *mut c_void);
+    fn cx_upsert(ix: *mut c_void, id: *const u8, emb: *const f32, len: u64) -> c_int;
+    fn cx_remove(ix: *mut c_void, id: *const u8) -> c_int;
+    fn cx_set_metadata(ix: *mut c_void, id: *const u8, kind: u32, agent: u32) -> c_int;
+    fn cx_intern(ix: *mut c_void, s: *const c_char, len: u64) -> u32;
+    fn cx_rebuild(ix: *mut c_void) -> c_int;
+    fn cx_len(ix: *const c_void) -> u64;
+    fn cx_row_count(ix: *const c_void) -> u64;
+    fn cx_search(ix: *const c_void, q: *const f32, len: u64, k: u64, f: *const CxFilter,
+                 ids: *mut u8, scores: *mut f32, dists: *mut f32, n_out: *mut u64) -> c_int;
+    fn cx_search_threshold(ix: *const c_void, q: *const f32, len: u64, thr: f32, f: *const CxFilter,
+                           cap: u64, ids: *mut u8, scores: *mut f32, dists: *mut f32,
+                           n_out: *mut u64, n_needed: *mut u64) -> c_int;
+    fn cx_search_batch(ix: *const c_void, nq: u64, qs: *const f32, len: u64, k: u64, f: *const CxFilter,
+                       ids: *mut u8, scores: *mut f32, dists: *mut f32, counts: *mut u64) -> c_int;
+    fn cx_save(ix: *const c_void, path: *const c_char) -> c_int;
+    fn cx_load(path: *const c_char, device: c_int) -> *mut c_void;
+}
+
+const CX_ERR_CAPACITY: c_int = 4;
+
+fn last_error() -> CortexError {
+    // the vector layer only ever produces CortexError::Validation(String) (index.rs:299-305, :438-459)
+    let msg = unsafe { CStr::from_ptr(cx_last_error()) }.to_string_lossy().into_owned();
+    CortexError::Validation(msg)
+}
+fn check(rc: c_int) -> Result<()> { if rc == 0 { Ok(()) } else { Err(last_error()) } }
+
+/// Exact cosine index resident in the HBM of one MI355X.
+pub struct HipIndex { h: *mut c_void, dimension: usize }
+// &self entry points are re-entrant in the library; &mut self ones need exclusivity,
+// which Arc<RwLock<HipIndex>> at every call site already provides.
+unsafe impl Send for HipIndex {}
+unsafe impl Sync for HipIndex {}
+impl Drop for HipIndex { fn drop(&mut self) { unsafe { cx_destroy(self.h) } } }
+
+/// Owns the marshalled arrays a CxFilter points into.
+struct FilterBuf { ex: Vec<u8>, kinds: Vec<u32>, c: CxFilter }
+
+impl HipIndex {
+    pub fn new(dimension: usize) -> Self { Self::on_device(dimension, 0).expect("no MI355X available") }
+    pub fn with_metadata(dimension: usize) -> Self { Self::new(dimension) }
+    pub fn on_device(dimension: usize, device: i32) -> Result<Self> {
+        let h = unsafe { cx_create(dimension as u32, device) };
+        if h.is_null() { Err(last_error()) } else { Ok(Self { h, dimension }) }
+    }
+    fn intern(&self, s: &str) -> u32 { unsafe { cx_intern(self.h, s.as_ptr() as *const c_char, s.len() as u64) } }
+    pub fn set_metadata(&mut self, id: NodeId, kind: NodeKind, source_agent: String) {
+        let (k, a) = (self.intern(kind.as_str()), self.intern(&source_agent));
+        unsafe { cx_set_metadata(self.h, id.as_bytes().as_ptr(), k, a) };
+    }
+    fn filter(&self, f: Option<&VectorFilter>) -> Option<Box<FilterBuf>> {
+        let f = f?;
+        let mut b = Box::new(FilterBuf { ex: Vec::new(), kinds: Vec::new(), c: unsafe { std::mem::zeroed() } });
+        if let Some(ex) = &f.exclude {
+            for id in ex { b.ex.extend_from_slice(id.as_bytes()); }
+            b.c.has_exclude = 1; b.c.n_exclude = ex.len() as u64; b.c.exclude_ids = b.ex.as_ptr();
+        }
+        if let Some(kinds) = &f.kinds {
+            b.kinds = kinds.iter().map(|k| self.intern(k.as_str())).collect();
+            b.c.has_kinds = 1; b.c.n_kinds = kinds.len() as u64; b.c.kind_codes = b.kinds.as_ptr();
+        }
+        if let Some(agent) = &f.source_agent { b.c.has_agent = 1; b.c.agent_code = self.intern(agent); }
+        Some(b)
+    }
+    fn collect(ids: &[u8], scores: &[f32], dists: &[f32], n: usize) -> Vec<SimilarityResult> {
+        (0..n).map(|i| SimilarityResult {
+            node_id: NodeId::from_slice(&ids[16 * i..16 * i + 16]).unwrap(),
+            score: scores[i], distance: dists[i],
+        }).collect()
+    }
+}
+
+impl VectorIndex for HipIndex {
+    fn insert(&mut self, id: NodeId, embedding: &Embedding) -> Result<()> {
+        check(unsafe { cx_upsert(self.h, id.as_bytes().as_ptr(), embedding.as_ptr(), embedding.len() as u64) })
+    }
+    fn remove(&mut self, id: NodeId) -> Result<()> { check(unsafe { cx_remove(self.h, id.as_bytes().as_ptr()) }) }
+
+    fn search(&self, query: &Embedding, k: usize, filter: Option<&VectorFilter>) -> Result<Vec<SimilarityResult>> {
+        let cap = k.min(unsafe { cx_row_count(self.h) } as usize).max(1);
+        let (mut ids, mut sc, mut di) = (vec![0u8; 16 * cap], vec![0f32; cap], vec![0f32; cap]);
+        let mut n = 0u64;
+        let fb = self.filter(filter);
+        let fp = fb.as_ref().map_or(std::ptr::null(), |b| &b.c as *const CxFilter);
+        check(unsafe { cx_search(self.h, query.as_ptr(), query.len() as u64, k as u64, fp,
+                                 ids.as_mut_ptr(), sc.as_mut_ptr(), di.as_mut_ptr(), &mut n) })?;
+        Ok(Self::collect(&ids, &sc, &di, n as usize))
+    }
+
+    fn search_threshold(&self, query: &Embedding, threshold: f32, filter: Option<&VectorFilter>)
+        -> Result<Vec<SimilarityResult>> {
+        let fb = self.filter(filter);
+        let fp = fb.as_ref().map_or(std::ptr::null(), |b| &b.c as *const CxFilter);
+        let mut cap = 256usize;
+        loop { // count-then-fill: CX_ERR_CAPACITY reports the size needed
+            let (mut ids, mut sc, mut di) = (vec![0u8; 16 * cap], vec![0f32; cap], vec![0f32; cap]);
+            let (mut n, mut need) = (0u64, 0u64);
+            let rc = unsafe { cx_search_threshold(self.h, query.as_ptr(), query.len() as u64, threshold, fp,
+                                                  cap as u64, ids.as_mut_ptr(), sc.as_mut_ptr(), di.as_mut_ptr(),
+                                                  &mut n, &mut need) };
+            if rc == CX_ERR_CAPACITY { cap = need as usize; continue; }
+            check(rc)?;
+            return Ok(Self::collect(&ids, &sc, &di, n as usize));
+        }
+    }
+
+    fn search_batch(&self, queries: &[(NodeId, Embedding)], k: usize, filter: Option<&VectorFilter>)
+        -> Result<HashMap<NodeId, Vec<SimilarityResult>>> {
+        let nq = queries.len();
+        if nq == 0 { return Ok(HashMap::new()); }
+        let len = queries[0].1.len();
+        let mut flat = Vec::with_capacity(nq * len);
+        for (_, e) in queries { flat.extend_from_slice(e); } // one upload, corpus read once per batch
+        let kk = k.max(1);
+        let (mut ids, mut sc, mut di) = (vec![0u8; 16 * nq * kk], vec![0f32; nq * kk], vec![0f32; nq * kk]);
+        let mut counts = vec![0u64; nq];
+        let fb = self.filter(filter);
+        let fp = fb.as_ref().map_or(std::ptr::null(), |b| &b.c as *const CxFilter);
+        check(unsafe { cx_search_batch(self.h, nq as u64, flat.as_ptr(), len as u64, k as u64, fp,
+                                       ids.as_mut_ptr(), sc.as_mut_ptr(), di.as_mut_ptr(), counts.as_mut_ptr()) })?;
+        let mut map = HashMap::with_capacity(nq);
+        for (i, (qid, _)) in queries.iter().enumerate() {
+            let o = i * kk;
+            map.insert(*qid, Self::collect(&ids[16 * o..], &sc[o..], &di[o..], counts[i] as usize));
+        }
+        Ok(map)
+    }
+
+    fn len(&self) -> usize { unsafe { cx_len(self.h) as usize } }
+    fn rebuild(&mut self) -> Result<()> { check(unsafe { cx_rebuild(self.h) }) }
+
+    fn save(&self, path: &Path) -> Result<()> {
+        let p = std::ffi::CString::new(path.to_string_lossy().as_bytes()).map_err(|e| CortexError::Validation(e.to_string()))?;
+        check(unsafe { cx_save(self.h, p.as_ptr()) })
+    }
+    fn load(path: &Path) -> Result<Self> {
+        let p = std::ffi::CString::new(path.to_string_lossy().as_bytes()).map_err(|e| CortexError::Validation(e.to_string()))?;
+        let h = unsafe { cx_load(p.as_ptr(), 0) };
+        if h.is_null() { return Err(last_error()); }
+        Ok(Self { h, dimension: 0 })
+    }
+}
