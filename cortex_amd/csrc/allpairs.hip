@@ -1,0 +1,347 @@
+// allpairs.hip — the auto-linker's similarity pass as one dense contraction
+// (BASELINE config 3).
+//
+// Replaces the per-node loop of AutoLinker::run_cycle (linker/auto_linker.rs:
+// 215-264: one search(emb, 100) per scanned node, each an O(N*d) scan) and
+// DedupScanner::scan (linker/dedup.rs:65-127: one search_threshold per node).
+// Over n_scan x N pairs that is a Q x C^T GEMM — the one place on this path
+// where MFMA is the right unit:
+//
+//  1. build_shadow_kernel   rows -> L2-normalised bf16 shadow [rows][dim]
+//  2. pair_filter_kernel    bf16 MFMA 32x32x16 GEMM over 128x128 tiles whose
+//                           epilogue never writes the score matrix: it only
+//                           appends column j to row i's candidate list when
+//                           approx_cos >= thr - eps.  eps bounds the bf16 error
+//                           rigorously (|x^.y^ - cos| <= 2u(1+u) + f32 sum slack,
+//                           u = 2^-8), so no pair with exact score >= thr is lost.
+//  3. rescore_kernel        exact f32 cosine of the sparse survivors with the
+//                           scan kernel's arithmetic, exact threshold, ordered
+//                           top-k per scanned row (register top-k lists).
+//  4. link_count/emit       the reference's walk over each ordered list: skip
+//                           self, skip storage-deleted neighbours, score >= thr
+//                           -> edge, stop at max_edges_per_node.
+//
+// MFMA-bound: 2*n_scan*N*dim flops; the bf16 shadow (154 MB at 100k x 768) sits
+// in the 256 MiB Infinity Cache, tiles are ordered so that an XCD's L2 holds
+// the 8+8 panels its concurrent blocks share.
+#include "kernels.hpp"
+#include "topk.hpp"
+
+namespace cx {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ inline uint16_t f32_to_bf16_rne(float x) {  // finite inputs only
+    uint32_t u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------- 1. shadow
+
+__global__ __launch_bounds__(256) void build_shadow_kernel(const float *rows, uint16_t *shadow, uint32_t row_lo,
+                                                           uint32_t row_hi, uint32_t dim) {
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t r = row_lo + wave; r < row_hi; r += n_waves) {
+        const float *p = rows + (size_t)r * dim;
+        float ss = 0.0f;
+        for (uint32_t j = lane; j < dim; j += 64u) ss += p[j] * p[j];
+        ss = wave_sum(ss);
+        const float inv = ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f;  // zero rows -> zero shadow (never a candidate)
+        uint16_t *o = shadow + (size_t)r * dim;
+        for (uint32_t j = lane; j < dim; j += 64u) {
+            const float v = p[j] * inv;
+            o[j] = (v == v && fabsf(v) <= 3.0e38f) ? f32_to_bf16_rne(v) : (uint16_t)0;
+        }
+    }
+}
+
+int launch_build_shadow(const float *rows, uint16_t *shadow, uint32_t row_lo, uint32_t row_hi, uint32_t dim,
+                        hipStream_t stream) {
+    if (row_hi <= row_lo) return CX_OK;
+    uint32_t grid = (row_hi - row_lo + 3u) / 4u;
+    if (grid > 8192u) grid = 8192u;
+    hipLaunchKernelGGL(build_shadow_kernel, dim3(grid), dim3(256), 0, stream, rows, shadow, row_lo, row_hi, dim);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+
+// ---------------------------------------------------------------- 2. filter GEMM
+
+constexpr int BM = 128, BN = 128, BK = 64;          // block tile; BK bf16 = 128 B per row
+constexpr int TILE_BYTES = BM * BK * 2;             // 16 KiB per operand per stage
+constexpr int LDS_BYTES = 2 * 2 * TILE_BYTES;       // 2 stages x (A + B) = 64 KiB
+
+// LDS image of an operand tile: 128 rows x 128 B; the 16-byte piece p of row r
+// sits at piece position p ^ ((r >> 1) & 7), so the 16 rows a ds_read_b128 lane
+// group touches at one logical piece fall on 16 different 16-byte bank groups.
+// global_load_lds writes linearly (base + lane*16), so the permutation is
+// applied to the per-lane SOURCE address and again on the read.
+__device__ inline uint32_t lds_off(uint32_t r, uint32_t p) { return r * 128u + ((p ^ ((r >> 1) & 7u)) << 4); }
+
+__global__ __launch_bounds__(256) void pair_filter_kernel(const PairFilterArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t wm = wave >> 1, wn = wave & 1u;
+
+    // tile order: XCD-contiguous chunks (blocks b, b+8, ... share an XCD), inside a
+    // chunk walk 8 I-panels per J-panel so concurrent blocks share panels in L2
+    const uint32_t tiles_i = (a.n_scan + BM - 1) / BM, tiles_j = (a.n_rows + BN - 1) / BN;
+    const uint32_t T = tiles_i * tiles_j;
+    uint32_t b = blockIdx.x;
+    {
+        const uint32_t q = T / 8u, r = T % 8u, xcd = b % 8u;
+        b = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + b / 8u;
+    }
+    const uint32_t GS = 8u;
+    const uint32_t per_group = GS * tiles_j;
+    const uint32_t group = b / per_group, first_i = group * GS;
+    const uint32_t gsz = (tiles_i - first_i) < GS ? (tiles_i - first_i) : GS;
+    const uint32_t ti = first_i + (b % per_group) % gsz, tj = (b % per_group) / gsz;
+    const uint32_t i0 = ti * BM, j0 = tj * BN;
+
+    // loader: each wave-level LDS-DMA moves 8 rows x 128 B; 16 per operand tile, 4 per wave
+    const uint32_t lrow = lane >> 3, lslot = lane & 7u;
+    const uint16_t *srcA[4], *srcB[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t r = (wave * 4u + (uint32_t)q) * 8u + lrow;      // row inside the tile
+        const uint32_t piece = lslot ^ ((r >> 1) & 7u);
+        uint32_t gi = i0 + r;
+        gi = gi < a.n_scan ? gi : a.n_scan - 1u;
+        const uint32_t ga = a.scan_rows ? a.scan_rows[gi] : gi;
+        uint32_t gb = j0 + r;
+        gb = gb < a.n_rows ? gb : a.n_rows - 1u;
+        srcA[q] = a.shadow + (size_t)ga * a.dim + piece * 8u;
+        srcB[q] = a.shadow + (size_t)gb * a.dim + piece * 8u;
+    }
+    auto stage = [&](uint32_t buf, uint32_t kt) {
+        char *A = smem + buf * 2 * TILE_BYTES, *B = A + TILE_BYTES;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t off = (wave * 4u + (uint32_t)q) * 1024u;  // wave-uniform LDS base of this DMA
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcA[q] + kt * BK),
+                                             (__attribute__((address_space(3))) void *)(A + off), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcB[q] + kt * BK),
+                                             (__attribute__((address_space(3))) void *)(B + off), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[m][n][e] = 0.0f;
+
+    const uint32_t KT = a.dim / BK;
+    const uint32_t fr = lane & 31u, fh = lane >> 5;
+    stage(0, 0);
+    __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and makes it visible to all waves
+    for (uint32_t kt = 0; kt < KT; kt++) {
+        const uint32_t buf = kt & 1u;
+        if (kt + 1 < KT) stage(buf ^ 1u, kt + 1);
+        const char *A = smem + buf * 2 * TILE_BYTES, *B = A + TILE_BYTES;
+#pragma unroll
+        for (uint32_t ks = 0; ks < 4; ks++) {
+            bf16x8 af[2], bf[2];
+#pragma unroll
+            for (uint32_t m = 0; m < 2; m++)
+                af[m] = *reinterpret_cast<const bf16x8 *>(A + lds_off(wm * 64u + m * 32u + fr, 2u * ks + fh));
+#pragma unroll
+            for (uint32_t n = 0; n < 2; n++)
+                bf[n] = *reinterpret_cast<const bf16x8 *>(B + lds_off(wn * 64u + n * 32u + fr, 2u * ks + fh));
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int n = 0; n < 2; n++)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bf[n], acc[m][n], 0, 0, 0);
+        }
+        __syncthreads();  // next stage landed; everyone is done reading this one
+    }
+
+    // epilogue: C[row][col], col = lane & 31 (j), row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5) (i)
+#pragma unroll
+    for (uint32_t m = 0; m < 2; m++)
+#pragma unroll
+        for (uint32_t n = 0; n < 2; n++) {
+            const uint32_t j = j0 + wn * 64u + n * 32u + fr;
+#pragma unroll
+            for (uint32_t e = 0; e < 16; e++) {
+                const float c = acc[m][n][e];
+                if (c >= a.thr_lo) {
+                    const uint32_t i = i0 + wm * 64u + m * 32u + (e & 3u) + 8u * (e >> 2) + 4u * fh;
+                    if (i < a.n_scan && j < a.n_rows) {
+                        const uint32_t slot = atomicAdd(a.cand_cnt + i, 1u);
+                        if (slot < a.cap) a.cand[(size_t)i * a.cap + slot] = j;
+                    }
+                }
+            }
+        }
+}
+
+int launch_pair_filter(const PairFilterArgs &a, hipStream_t stream) {
+    if (a.dim % BK != 0 || a.dim == 0) return set_err(CX_ERR_VALIDATION, "pair filter needs dim %% 64 == 0 (got %u)", a.dim);
+    if (!a.n_scan || !a.n_rows) return CX_OK;
+    const uint64_t tiles = (uint64_t)((a.n_scan + BM - 1) / BM) * ((a.n_rows + BN - 1) / BN);
+    if (tiles > 0x7FFFFFFFull) return set_err(CX_ERR_VALIDATION, "pair filter: too many tiles");
+    static bool attr_set = false;
+    if (!attr_set) {
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_filter_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(pair_filter_kernel, dim3((uint32_t)tiles), dim3(256), LDS_BYTES, stream, a);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+
+// ---------------------------------------------------------------- 3. rescore
+
+// One wave per scanned row: exact cosine (the scan kernel's arithmetic: lane-
+// strided f32 partials + butterfly, reference epilogue) of every candidate,
+// exact threshold, ordered top-k.  Rows whose candidate list overflowed are
+// flagged and redone by the caller on the exact scan path.
+template <int KS>
+__global__ __launch_bounds__(256) void rescore_kernel(const RescoreArgs a) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t dim = a.dim;
+    const bool vec4 = (dim & 3u) == 0;
+    for (uint32_t i = wave; i < a.n_scan; i += n_waves) {
+        const uint32_t qrow = a.scan_rows ? a.scan_rows[i] : i;
+        const float *q = a.rows + (size_t)qrow * dim;
+        const uint32_t total = a.cand_cnt[i];
+        const uint32_t cnt = total < a.cap ? total : a.cap;
+        if (lane == 0) a.overflow[i] = total > a.cap ? 1u : 0u;
+        float qq = 0.0f;
+        if (vec4) {
+            const f32x4 *q4 = reinterpret_cast<const f32x4 *>(q);
+            for (uint32_t j = lane; j < dim / 4u; j += 64u) {
+                const f32x4 x = q4[j];
+                qq += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+            }
+        } else {
+            for (uint32_t j = lane; j < dim; j += 64u) qq += q[j] * q[j];
+        }
+        qq = wave_sum(qq);
+        WaveTopK<KS> top;
+        top.init(a.topk);
+        for (uint32_t c = 0; c < cnt; c++) {
+            const uint32_t jrow = a.cand[(size_t)i * a.cap + c];
+            const float *p = a.rows + (size_t)jrow * dim;
+            float d0 = 0.0f, n0 = 0.0f;
+            if (vec4) {
+                const f32x4 *p4 = reinterpret_cast<const f32x4 *>(p);
+                const f32x4 *q4 = reinterpret_cast<const f32x4 *>(q);
+                for (uint32_t j = lane; j < dim / 4u; j += 64u) {
+                    const f32x4 x = p4[j], y = q4[j];
+                    d0 += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+                    n0 += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+                }
+            } else {
+                for (uint32_t j = lane; j < dim; j += 64u) {
+                    const float x = p[j];
+                    d0 += x * q[j];
+                    n0 += x * x;
+                }
+            }
+            d0 = wave_sum(d0);
+            n0 = wave_sum(n0);
+            const float sim = cosine_from_sums(d0, qq, n0);
+            const float score = score_of(distance_of(sim));
+            if (!(score >= a.threshold)) continue;              // rules.rs:50 / index.rs:386 (NaN fails)
+            if (a.meta[jrow] & META_REMOVED) continue;          // removed from the index
+            const uint64_t key = make_key(score, jrow);
+            if (key > top.tau) top.insert(key, sim);
+        }
+        // ordered list out
+        uint32_t n_out = 0;
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            const uint32_t r = (uint32_t)s * 64u + lane;
+            const bool valid = r < a.topk && top.key[s] != 0ull;
+            if (valid) {
+                a.out_rows[(size_t)i * a.topk + r] = key_row(top.key[s]);
+                a.out_scores[(size_t)i * a.topk + r] = score_of(distance_of(top.sim[s]));
+            }
+            n_out += (uint32_t)__popcll(__ballot(valid));
+        }
+        if (lane == 0) a.out_cnt[i] = n_out;
+    }
+}
+
+int launch_rescore(const RescoreArgs &a, hipStream_t stream) {
+    if (!a.n_scan) return CX_OK;
+    if (a.topk > TOPK_MAX) return set_err(CX_ERR_VALIDATION, "rescore: topk=%u exceeds %u", a.topk, TOPK_MAX);
+    uint32_t grid = (a.n_scan + 3u) / 4u;
+    if (grid > 16384u) grid = 16384u;
+    if (a.topk <= 64) hipLaunchKernelGGL((rescore_kernel<1>), dim3(grid), dim3(256), 0, stream, a);
+    else if (a.topk <= 128) hipLaunchKernelGGL((rescore_kernel<2>), dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((rescore_kernel<4>), dim3(grid), dim3(256), 0, stream, a);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+
+// ---------------------------------------------------------------- 4. link rules
+
+// linker/auto_linker.rs:233-264 with SimilarityLinkRule (rules.rs:42-62) as the
+// only rule: walk the ordered list; skip self (:235-237); skip neighbours the
+// storage has tombstoned (:240-243); score >= threshold -> edge (weight =
+// score); stop once max_edges_per_node edges were proposed (:261-263).
+// With a.dedup the same walk emits DedupScanner::scan's pairs instead (dedup.rs:65-127).
+// MODE 0 counts, MODE 1 writes at the exclusive-scan offsets.
+template <int MODE>
+__global__ __launch_bounds__(256) void link_rules_kernel(const LinkArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_scan) return;
+    const uint32_t self = a.scan_rows ? a.scan_rows[i] : i;
+    const uint32_t cnt = a.list_cnt[i];
+    uint32_t n = 0;
+    const uint64_t base = MODE == 1 ? a.offsets[i] : 0ull;
+    for (uint32_t r = 0; r < cnt && n < a.max_edges; r++) {
+        const uint32_t j = a.list_rows[(size_t)i * a.topk + r];
+        if (j == self) continue;
+        if (a.dedup) {
+            // linker/dedup.rs:93-102: a pair is reported by whichever of its nodes is scanned first
+            // (row order here); cosine is symmetric, so (i, j) was already seen iff j was scanned
+            // before i, i.e. j < i and j is not storage-deleted (deleted nodes are never scanned, :72-74)
+            if (j < self && !(a.deleted && a.deleted[j])) continue;
+        } else if (a.deleted && a.deleted[j]) {
+            continue;
+        }
+        const float s = a.list_scores[(size_t)i * a.topk + r];
+        if (s >= a.threshold) {
+            if (MODE == 1) {
+                a.out_from[base + n] = self;
+                a.out_to[base + n] = j;
+                a.out_weight[base + n] = s;
+            }
+            n++;
+        }
+    }
+    if (MODE == 0) a.counts[i] = n;
+}
+
+int launch_link_rules(const LinkArgs &a, bool emit, hipStream_t stream) {
+    if (!a.n_scan) return CX_OK;
+    const uint32_t grid = (a.n_scan + 255u) / 256u;
+    if (emit) hipLaunchKernelGGL((link_rules_kernel<1>), dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((link_rules_kernel<0>), dim3(grid), dim3(256), 0, stream, a);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+
+}  // namespace cx

@@ -1,0 +1,317 @@
+// autolink.cpp — C ABI of the auto-linker's batched similarity pass and the dedup scan.
+// Orchestrates allpairs.hip: shadow -> MFMA filter -> exact rescore -> link rules.
+#include "internal.hpp"
+
+namespace {
+
+using namespace cx;
+
+constexpr uint32_t CHUNK_ROWS = 131072;  // scanned rows per filter launch (bounds the candidate scratch)
+
+uint32_t cand_cap() {  // candidate slots per scanned row; rows that overflow are redone on the exact scan path
+    const char *e = getenv("CX_PAIR_CAND_CAP");
+    int v = e ? atoi(e) : 512;
+    return (uint32_t)(v < 16 ? 16 : v);
+}
+
+// bf16 error bound of the filter: both operands are rounded to bf16 (unit roundoff u = 2^-8), so
+// |x^.y^ - cos| <= (2u + u^2) * sum|x_i y_i| <= 2u + u^2 for unit rows; plus f32 accumulation slack.
+constexpr float FILTER_EPS = 2.0f / 256.0f + 1.0f / 65536.0f + 1.0e-4f;
+
+int ensure_shadow(const cx_index *ix, hipStream_t s) {
+    std::lock_guard<std::mutex> g(ix->shadow_mu);
+    const uint64_t n = ix->n_rows;
+    if (ix->shadow_cap < n) {
+        if (ix->d_shadow) CX_HIP(hipFree(ix->d_shadow));
+        ix->d_shadow = nullptr;
+        ix->shadow_cap = 0;
+        const uint64_t cap = std::max<uint64_t>(n, ix->cap);
+        CX_HIP(hipMalloc((void **)&ix->d_shadow, cap * ix->dim * sizeof(uint16_t) + 64));
+        ix->shadow_cap = cap;
+        ix->shadow_rows = 0;
+        ix->shadow_stale.clear();
+    }
+    for (uint32_t r : ix->shadow_stale)
+        if (r < ix->shadow_rows)
+            if (int rc = launch_build_shadow(ix->d_rows, ix->d_shadow, r, r + 1, ix->dim, s)) return rc;
+    ix->shadow_stale.clear();
+    if (ix->shadow_rows < n) {
+        if (int rc = launch_build_shadow(ix->d_rows, ix->d_shadow, (uint32_t)ix->shadow_rows, (uint32_t)n, ix->dim, s)) return rc;
+        ix->shadow_rows = n;
+    }
+    CX_HIP(hipStreamSynchronize(s));
+    return CX_OK;
+}
+
+struct PassScratch {
+    uint32_t *d_scan = nullptr, *d_cand_cnt = nullptr, *d_cand = nullptr, *d_overflow = nullptr;
+    uint32_t *d_list_rows = nullptr, *d_list_cnt = nullptr, *d_counts = nullptr;
+    float *d_list_scores = nullptr, *d_list_dists = nullptr;
+    uint64_t *d_offsets = nullptr;
+    uint8_t *d_deleted = nullptr;
+    char *d_temp = nullptr;
+    uint32_t *d_from = nullptr, *d_to = nullptr;
+    float *d_w = nullptr;
+    ~PassScratch() {
+        (void)hipFree(d_scan); (void)hipFree(d_cand_cnt); (void)hipFree(d_cand); (void)hipFree(d_overflow);
+        (void)hipFree(d_list_rows); (void)hipFree(d_list_cnt); (void)hipFree(d_counts);
+        (void)hipFree(d_list_scores); (void)hipFree(d_list_dists); (void)hipFree(d_offsets);
+        (void)hipFree(d_deleted); (void)hipFree(d_temp); (void)hipFree(d_from); (void)hipFree(d_to); (void)hipFree(d_w);
+    }
+};
+
+// Runs the pass and leaves the edges in ps.d_from/d_to/d_w (total of them in *total).
+int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, const uint32_t *scan_rows,
+              uint32_t topk, float threshold, uint32_t max_edges, const uint8_t *deleted, bool dedup,
+              uint64_t *total, double *phase_ms /* optional [4] */) {
+    const uint32_t n_rows = (uint32_t)ix->n_rows;
+    const uint32_t n_scan = (uint32_t)n_scan64;
+    hipStream_t s = c->stream;
+    *total = 0;
+    if (!n_scan || !n_rows) return CX_OK;
+    if (topk == 0 || topk > TOPK_MAX) return set_err(CX_ERR_VALIDATION, "autolink: topk must be in 1..%u", TOPK_MAX);
+    for (uint32_t i = 0; scan_rows && i < n_scan; i++)
+        if (scan_rows[i] >= n_rows) return set_err(CX_ERR_VALIDATION, "autolink: scan row %u out of range", scan_rows[i]);
+    const uint32_t cap = cand_cap();
+    const bool mfma_path = ix->dim % 64 == 0 && ix->dim > 0;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (phase_ms) for (auto &e : ev) CX_HIP(hipEventCreate(&e));
+
+    if (scan_rows) {
+        CX_HIP(hipMalloc((void **)&ps.d_scan, (size_t)n_scan * 4));
+        CX_HIP(hipMemcpyAsync(ps.d_scan, scan_rows, (size_t)n_scan * 4, hipMemcpyHostToDevice, s));
+    }
+    if (deleted) {
+        CX_HIP(hipMalloc((void **)&ps.d_deleted, n_rows));
+        CX_HIP(hipMemcpyAsync(ps.d_deleted, deleted, n_rows, hipMemcpyHostToDevice, s));
+    }
+    CX_HIP(hipMalloc((void **)&ps.d_list_rows, (size_t)n_scan * topk * 4));
+    CX_HIP(hipMalloc((void **)&ps.d_list_scores, (size_t)n_scan * topk * 4));
+    CX_HIP(hipMalloc((void **)&ps.d_list_cnt, (size_t)n_scan * 4));
+    CX_HIP(hipMalloc((void **)&ps.d_overflow, (size_t)n_scan * 4));
+    CX_HIP(hipMemsetAsync(ps.d_overflow, 0, (size_t)n_scan * 4, s));
+    if (phase_ms) CX_HIP(hipEventRecord(ev[0], s));
+
+    std::vector<uint32_t> redo;  // scanned positions that must take the exact scan path
+    if (mfma_path) {
+        if (int rc = ensure_shadow(ix, s)) return rc;
+        if (phase_ms) CX_HIP(hipEventRecord(ev[1], s));
+        const uint32_t chunk = std::min<uint32_t>(n_scan, CHUNK_ROWS);
+        CX_HIP(hipMalloc((void **)&ps.d_cand_cnt, (size_t)chunk * 4));
+        CX_HIP(hipMalloc((void **)&ps.d_cand, (size_t)chunk * cap * 4));
+        // phases are timed over all chunks: filter launches first would need all scratch at once, so
+        // filter+rescore alternate per chunk and the two event pairs bracket their sums approximately
+        for (uint32_t lo = 0; lo < n_scan; lo += chunk) {
+            const uint32_t m = std::min<uint32_t>(chunk, n_scan - lo);
+            CX_HIP(hipMemsetAsync(ps.d_cand_cnt, 0, (size_t)m * 4, s));
+            PairFilterArgs f;
+            f.shadow = ix->d_shadow;
+            f.scan_rows = ps.d_scan ? ps.d_scan + lo : nullptr;
+            f.n_scan = m;
+            f.n_rows = n_rows;
+            f.dim = ix->dim;
+            f.thr_lo = threshold - FILTER_EPS;
+            f.cand_cnt = ps.d_cand_cnt;
+            f.cand = ps.d_cand;
+            f.cap = cap;
+            // identity scan rows of a later chunk still need their global row: materialise them
+            uint32_t *d_ident = nullptr;
+            if (!ps.d_scan && lo > 0) {
+                std::vector<uint32_t> ident(m);
+                for (uint32_t i = 0; i < m; i++) ident[i] = lo + i;
+                CX_HIP(hipMalloc((void **)&d_ident, (size_t)m * 4));
+                CX_HIP(hipMemcpyAsync(d_ident, ident.data(), (size_t)m * 4, hipMemcpyHostToDevice, s));
+                CX_HIP(hipStreamSynchronize(s));
+                f.scan_rows = d_ident;
+            }
+            if (int rc = launch_pair_filter(f, s)) return rc;
+            if (phase_ms && lo == 0) CX_HIP(hipEventRecord(ev[2], s));
+            RescoreArgs r;
+            r.rows = ix->d_rows;
+            r.meta = ix->d_meta;
+            r.scan_rows = f.scan_rows;
+            r.cand_cnt = ps.d_cand_cnt;
+            r.cand = ps.d_cand;
+            r.n_scan = m;
+            r.dim = ix->dim;
+            r.cap = cap;
+            r.topk = topk;
+            r.threshold = threshold;
+            r.out_rows = ps.d_list_rows + (size_t)lo * topk;
+            r.out_scores = ps.d_list_scores + (size_t)lo * topk;
+            r.out_cnt = ps.d_list_cnt + lo;
+            r.overflow = ps.d_overflow + lo;
+            if (int rc = launch_rescore(r, s)) return rc;
+            if (d_ident) {
+                CX_HIP(hipStreamSynchronize(s));
+                CX_HIP(hipFree(d_ident));
+            }
+        }
+        if (phase_ms && n_scan > chunk) CX_HIP(hipEventRecord(ev[2], s));  // multi-chunk: only the total is meaningful
+        if (phase_ms) CX_HIP(hipEventRecord(ev[3], s));
+        std::vector<uint32_t> of(n_scan);
+        CX_HIP(hipMemcpyAsync(of.data(), ps.d_overflow, (size_t)n_scan * 4, hipMemcpyDeviceToHost, s));
+        CX_HIP(hipStreamSynchronize(s));
+        for (uint32_t i = 0; i < n_scan; i++)
+            if (of[i]) redo.push_back(i);
+    } else {
+        if (phase_ms) { CX_HIP(hipEventRecord(ev[1], s)); CX_HIP(hipEventRecord(ev[2], s)); CX_HIP(hipEventRecord(ev[3], s)); }
+        redo.resize(n_scan);
+        for (uint32_t i = 0; i < n_scan; i++) redo[i] = i;
+    }
+
+    // exact scan path for rows the filter could not serve (candidate overflow, dim % 64 != 0):
+    // search(emb_i, topk) with the row itself as the query, straight into the list arrays
+    if (!redo.empty()) {
+        CX_HIP(hipMalloc((void **)&ps.d_list_dists, (size_t)topk * 4));
+        DevFilter flt;
+        memset(&flt, 0, sizeof flt);
+        flt.meta = ix->d_meta;
+        flt.agent = ix->d_agent;
+        const uint32_t k_eff = std::min<uint32_t>(topk, n_rows);
+        for (uint32_t i : redo) {
+            const uint32_t row = scan_rows ? scan_rows[i] : i;
+            if (int rc = search_core(ix, c, ix->d_rows + (size_t)row * ix->dim, nullptr, 1, k_eff, flt, 0.0f, false,
+                                     ps.d_list_rows + (size_t)i * topk, ps.d_list_scores + (size_t)i * topk,
+                                     ps.d_list_dists, ps.d_list_cnt + i, s))
+                return rc;
+        }
+    }
+
+    // link rules: count, exclusive scan, emit
+    CX_HIP(hipMalloc((void **)&ps.d_counts, (size_t)n_scan * 4));
+    CX_HIP(hipMalloc((void **)&ps.d_offsets, (size_t)n_scan * 8));
+    const size_t tb = scan_temp_bytes(n_scan);
+    CX_HIP(hipMalloc((void **)&ps.d_temp, tb));
+    LinkArgs l;
+    memset(&l, 0, sizeof l);
+    l.scan_rows = ps.d_scan;
+    l.list_rows = ps.d_list_rows;
+    l.list_scores = ps.d_list_scores;
+    l.list_cnt = ps.d_list_cnt;
+    l.deleted = ps.d_deleted;
+    l.n_scan = n_scan;
+    l.topk = topk;
+    l.max_edges = dedup ? 0xFFFFFFFFu : max_edges;
+    l.dedup = dedup ? 1u : 0u;
+    l.threshold = threshold;
+    l.counts = ps.d_counts;
+    if (int rc = launch_link_rules(l, false, s)) return rc;
+    if (int rc = launch_exclusive_scan(ps.d_counts, ps.d_offsets, n_scan, ps.d_temp, tb, s)) return rc;
+    uint64_t last_off = 0;
+    uint32_t last_cnt = 0;
+    CX_HIP(hipMemcpyAsync(&last_off, ps.d_offsets + (n_scan - 1), 8, hipMemcpyDeviceToHost, s));
+    CX_HIP(hipMemcpyAsync(&last_cnt, ps.d_counts + (n_scan - 1), 4, hipMemcpyDeviceToHost, s));
+    CX_HIP(hipStreamSynchronize(s));
+    const uint64_t n_edges = last_off + last_cnt;
+    if (n_edges) {
+        CX_HIP(hipMalloc((void **)&ps.d_from, n_edges * 4));
+        CX_HIP(hipMalloc((void **)&ps.d_to, n_edges * 4));
+        CX_HIP(hipMalloc((void **)&ps.d_w, n_edges * 4));
+        l.offsets = ps.d_offsets;
+        l.out_from = ps.d_from;
+        l.out_to = ps.d_to;
+        l.out_weight = ps.d_w;
+        if (int rc = launch_link_rules(l, true, s)) return rc;
+    }
+    if (phase_ms) CX_HIP(hipEventRecord(ev[4], s));
+    CX_HIP(hipStreamSynchronize(s));
+    if (dedup) {
+        // search_threshold has no k: a list that is full at topk may hide further neighbours above the threshold
+        std::vector<uint32_t> cnt(n_scan);
+        CX_HIP(hipMemcpy(cnt.data(), ps.d_list_cnt, (size_t)n_scan * 4, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n_scan; i++) {
+            if (cnt[i] < topk) continue;
+            float last = 0.0f;  // lists from the exact path are not thresholded: full only matters if the tail still passes
+            CX_HIP(hipMemcpy(&last, ps.d_list_scores + (size_t)i * topk + (topk - 1), 4, hipMemcpyDeviceToHost));
+            if (last >= threshold)
+                return set_err(CX_ERR_CAPACITY, "dedup: row %u has %u or more neighbours above the threshold; "
+                               "scan it with cx_search_threshold", scan_rows ? scan_rows[i] : i, topk);
+        }
+    }
+    if (phase_ms) {
+        for (int p = 0; p < 4; p++) {
+            float ms = 0.0f;
+            CX_HIP(hipEventElapsedTime(&ms, ev[p], ev[p + 1]));
+            phase_ms[p] = ms;
+        }
+        for (auto &e : ev) (void)hipEventDestroy(e);
+    }
+    *total = n_edges;
+    return CX_OK;
+}
+
+int copy_edges_rows(Ctx *c, PassScratch &ps, uint64_t total, uint64_t cap, uint32_t *out_from, uint32_t *out_to,
+                    float *out_w, uint64_t *n_out, uint64_t *n_needed) {
+    if (n_needed) *n_needed = total;
+    const uint64_t take = std::min(total, cap);
+    if (take) {
+        if (!out_from || !out_to || !out_w) return set_err(CX_ERR_VALIDATION, "null output buffer");
+        CX_HIP(hipMemcpyAsync(out_from, ps.d_from, take * 4, hipMemcpyDeviceToHost, c->stream));
+        CX_HIP(hipMemcpyAsync(out_to, ps.d_to, take * 4, hipMemcpyDeviceToHost, c->stream));
+        CX_HIP(hipMemcpyAsync(out_w, ps.d_w, take * 4, hipMemcpyDeviceToHost, c->stream));
+        CX_HIP(hipStreamSynchronize(c->stream));
+    }
+    *n_out = take;
+    if (total > cap) return set_err(CX_ERR_CAPACITY, "%llu edges, buffer holds %llu", (unsigned long long)total, (unsigned long long)cap);
+    return CX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cx_autolink_pass_rows(const cx_index *ix, uint64_t n_scan, const uint32_t *scan_rows, uint64_t topk,
+                          float threshold, uint64_t max_edges_per_node, const uint8_t *deleted, uint64_t cap,
+                          uint32_t *out_from, uint32_t *out_to, float *out_weight, uint64_t *n_out,
+                          uint64_t *n_needed) {
+    if (!ix || !n_out) return set_err(CX_ERR_VALIDATION, "null argument");
+    *n_out = 0;
+    if (n_needed) *n_needed = 0;
+    if (!scan_rows) n_scan = ix->n_rows;
+    if (n_scan > 0xFFFFFFF0ull) return set_err(CX_ERR_VALIDATION, "too many scanned rows");
+    if (int rc = use_device(ix)) return rc;
+    CtxLease lease(ix);
+    if (!lease.c) return CX_ERR_DEVICE;
+    PassScratch ps;
+    uint64_t total = 0;
+    if (int rc = pass_core(ix, lease.c, ps, n_scan, scan_rows, (uint32_t)std::min<uint64_t>(topk, 0xFFFFFFFFull), threshold,
+                           (uint32_t)std::min<uint64_t>(max_edges_per_node, 0xFFFFFFFFull), deleted, false, &total, nullptr))
+        return rc;
+    return copy_edges_rows(lease.c, ps, total, cap, out_from, out_to, out_weight, n_out, n_needed);
+}
+
+int cx_dedup_scan_rows(const cx_index *ix, float dedup_threshold, const uint8_t *deleted, uint64_t cap,
+                       uint32_t *out_a, uint32_t *out_b, float *out_similarity, uint64_t *n_out,
+                       uint64_t *n_needed) {
+    if (!ix || !n_out) return set_err(CX_ERR_VALIDATION, "null argument");
+    *n_out = 0;
+    if (n_needed) *n_needed = 0;
+    if (int rc = use_device(ix)) return rc;
+    // scanned nodes: every row that is in the index and not storage-deleted (dedup.rs:70-81), in row order
+    std::vector<uint32_t> scan;
+    scan.reserve(ix->n_alive);
+    for (uint64_t r = 0; r < ix->n_rows; r++)
+        if (!(ix->h_meta[r] & META_REMOVED) && !(deleted && deleted[r])) scan.push_back((uint32_t)r);
+    CtxLease lease(ix);
+    if (!lease.c) return CX_ERR_DEVICE;
+    PassScratch ps;
+    uint64_t total = 0;
+    if (int rc = pass_core(ix, lease.c, ps, scan.size(), scan.data(), TOPK_MAX, dedup_threshold, 0, deleted, true, &total, nullptr))
+        return rc;
+    return copy_edges_rows(lease.c, ps, total, cap, out_a, out_b, out_similarity, n_out, n_needed);
+}
+
+int cx_autolink_pass_timed(const cx_index *ix, uint64_t n_scan, const uint32_t *scan_rows, uint64_t topk,
+                           float threshold, uint64_t max_edges_per_node, uint64_t *n_edges, double *phase_ms) {
+    if (!ix || !n_edges || !phase_ms) return set_err(CX_ERR_VALIDATION, "null argument");
+    if (!scan_rows) n_scan = ix->n_rows;
+    if (int rc = use_device(ix)) return rc;
+    CtxLease lease(ix);
+    if (!lease.c) return CX_ERR_DEVICE;
+    PassScratch ps;
+    return pass_core(ix, lease.c, ps, n_scan, scan_rows, (uint32_t)topk, threshold, (uint32_t)max_edges_per_node, nullptr,
+                     false, n_edges, phase_ms);
+}
+
+}  // extern "C"

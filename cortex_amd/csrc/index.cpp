@@ -9,13 +9,7 @@
 //   d_meta  u32 [cap]       bit0 removed, bit1 has-metadata, bits 8.. kind code
 //   d_agent u32 [cap]       interned source_agent code
 // Host: ids (16 B per row), id -> row hash map, mirrors of meta/agent.
-#include <algorithm>
-#include <mutex>
-#include <string>
-#include <unordered_map>
-#include <vector>
-
-#include "kernels.hpp"
+#include "internal.hpp"
 
 namespace cx {
 
@@ -29,116 +23,11 @@ int set_err(int code, const char *fmt, ...) {
     return code;
 }
 
-struct IdKey {
-    uint64_t a, b;
-    bool operator==(const IdKey &o) const { return a == o.a && b == o.b; }
-};
-struct IdHash {
-    size_t operator()(const IdKey &k) const {
-        uint64_t h = k.a * 0x9E3779B97F4A7C15ull ^ (k.b + 0xC2B2AE3D27D4EB4Full + (k.a << 6) + (k.a >> 2));
-        h ^= h >> 29;
-        h *= 0xBF58476D1CE4E5B9ull;
-        return (size_t)(h ^ (h >> 32));
-    }
-};
-static inline IdKey id_key(const uint8_t *id) {
-    IdKey k;
-    memcpy(&k.a, id, 8);
-    memcpy(&k.b, id + 8, 8);
-    return k;
-}
-
-template <typename T>
-static int ensure_dev(T *&p, size_t &cap, size_t need) {
-    if (need <= cap) return CX_OK;
-    size_t ncap = std::max(need, cap * 2);
-    if (p) CX_HIP(hipFree(p));
-    p = nullptr;
-    cap = 0;
-    CX_HIP(hipMalloc((void **)&p, ncap * sizeof(T)));
-    cap = ncap;
-    return CX_OK;
-}
-template <typename T>
-static int ensure_pinned(T *&p, size_t &cap, size_t need) {
-    if (need <= cap) return CX_OK;
-    size_t ncap = std::max(need, cap * 2);
-    if (p) CX_HIP(hipHostFree(p));
-    p = nullptr;
-    cap = 0;
-    CX_HIP(hipHostMalloc((void **)&p, ncap * sizeof(T), hipHostMallocDefault));
-    cap = ncap;
-    return CX_OK;
-}
-
-// Per-call scratch.  Host-API calls take one from the pool for the duration
-// of the call (re-entrancy under the callers' read lock); *_dev calls get the
-// one bound to their stream, so back-to-back calls on a stream reuse it in
-// stream order.
-struct Ctx {
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    float *d_query = nullptr; size_t q_cap = 0;
-    uint64_t *d_part_keys = nullptr; size_t pk_cap = 0;
-    float *d_part_sims = nullptr; size_t ps_cap = 0;
-    uint32_t *d_out_rows = nullptr; size_t or_cap = 0;
-    float *d_out_scores = nullptr; size_t os_cap = 0;
-    float *d_out_dists = nullptr; size_t od_cap = 0;
-    uint32_t *d_out_counts = nullptr; size_t oc_cap = 0;
-    uint32_t *d_excl = nullptr; size_t ex_cap = 0;
-    uint32_t *d_kinds = nullptr; size_t kd_cap = 0;
-    uint64_t *d_keys = nullptr; size_t k1_cap = 0;
-    uint64_t *d_keys2 = nullptr; size_t k2_cap = 0;
-    float *d_sims = nullptr; size_t s1_cap = 0;
-    float *d_sims2 = nullptr; size_t s2_cap = 0;
-    char *d_temp = nullptr; size_t tmp_cap = 0;
-    float *h_query = nullptr; size_t hq_cap = 0;
-    uint32_t *h_rows = nullptr; size_t hr_cap = 0;
-    float *h_scores = nullptr; size_t hs_cap = 0;
-    float *h_dists = nullptr; size_t hd_cap = 0;
-    uint32_t *h_counts = nullptr; size_t hc_cap = 0;
-
-    ~Ctx() {
-        (void)hipFree(d_query); (void)hipFree(d_part_keys); (void)hipFree(d_part_sims); (void)hipFree(d_out_rows);
-        (void)hipFree(d_out_scores); (void)hipFree(d_out_dists); (void)hipFree(d_out_counts); (void)hipFree(d_excl);
-        (void)hipFree(d_kinds); (void)hipFree(d_keys); (void)hipFree(d_keys2); (void)hipFree(d_sims); (void)hipFree(d_sims2);
-        (void)hipFree(d_temp);
-        (void)hipHostFree(h_query); (void)hipHostFree(h_rows); (void)hipHostFree(h_scores); (void)hipHostFree(h_dists);
-        (void)hipHostFree(h_counts);
-        if (own_stream && stream) (void)hipStreamDestroy(stream);
-    }
-};
-
 }  // namespace cx
 
 using namespace cx;
 
-struct cx_index {
-    uint32_t dim = 0;
-    int device = 0;
-    float *d_rows = nullptr;
-    uint32_t *d_meta = nullptr;
-    uint32_t *d_agent = nullptr;
-    uint64_t cap = 0;
-    uint64_t n_rows = 0;
-    uint64_t n_alive = 0;
-    uint64_t n_removed = 0;
-    std::vector<uint8_t> ids;
-    std::vector<uint32_t> h_meta, h_agent;
-    std::unordered_map<IdKey, uint32_t, IdHash> map;
-    std::unordered_map<std::string, uint32_t> interned;
-    hipStream_t up_stream = nullptr;
-    mutable std::mutex mu;
-    mutable std::vector<Ctx *> pool;
-    mutable std::unordered_map<void *, Ctx *> by_stream;
-    // measurement (cx_profile_*): event pairs around the scan kernel
-    bool profiling = false;
-    mutable std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
-    double prof_ms = 0.0;
-    uint64_t prof_n = 0;
-};
-
-namespace {
+namespace cx {
 
 int use_device(const cx_index *ix) {
     CX_HIP(hipSetDevice(ix->device));
@@ -167,6 +56,10 @@ void release_ctx(const cx_index *ix, Ctx *c) {
     std::lock_guard<std::mutex> g(ix->mu);
     ix->pool.push_back(c);
 }
+}  // namespace cx
+
+namespace {
+
 Ctx *ctx_for_stream(const cx_index *ix, hipStream_t s) {
     std::lock_guard<std::mutex> g(ix->mu);
     auto it = ix->by_stream.find((void *)s);
@@ -230,6 +123,7 @@ int upsert_impl(cx_index *ix, uint64_t n, const uint8_t *ids, const float *embs,
         const IdKey key = id_key(ids + 16 * i);
         auto it = ix->map.find(key);
         if (it != ix->map.end()) {  // replace in place, row position kept
+            if (it->second < ix->shadow_rows) ix->shadow_stale.push_back(it->second);
             if (row_bytes)
                 CX_HIP(hipMemcpyAsync(ix->d_rows + (size_t)it->second * ix->dim, embs + i * len, row_bytes, kind, ix->up_stream));
             i++;
@@ -305,6 +199,8 @@ int build_filter(const cx_index *ix, Ctx *c, const cx_filter *filter, hipStream_
     return CX_OK;
 }
 
+}  // namespace
+namespace cx {
 bool use_nontemporal(const cx_index *ix) {
     static int forced = -1;
     if (forced == -1) {
@@ -315,7 +211,11 @@ bool use_nontemporal(const cx_index *ix) {
     // rows larger than the 256 MiB Infinity Cache cannot stay resident between queries
     return (uint64_t)ix->n_rows * ix->dim * sizeof(float) > (256ull << 20);
 }
+}  // namespace cx
+namespace {
 
+}  // namespace
+namespace cx {
 // nq single-query scans enqueued on s; query i's results at [i*k_out, ...).
 // threshold searches (has_thr) and k > TOPK_MAX take the dense+sort path.
 int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float *tails, uint64_t nq, uint32_t k_eff,
@@ -385,6 +285,9 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
     return CX_OK;
 }
 
+}  // namespace cx
+namespace {
+
 // Host queries -> pinned staging, zero-padded / truncated to dim; the sum of
 // squares of any elements beyond dim still belongs to |q| (the reference
 // zips for the dot but takes the norm over the whole query, index.rs:172-173).
@@ -429,12 +332,6 @@ int fetch_results(Ctx *c, size_t entries) {
     return CX_OK;
 }
 
-struct CtxLease {
-    const cx_index *ix;
-    Ctx *c;
-    CtxLease(const cx_index *i) : ix(i), c(acquire_ctx(i)) {}
-    ~CtxLease() { if (c) release_ctx(ix, c); }
-};
 
 }  // namespace
 
@@ -484,6 +381,7 @@ void cx_destroy(cx_index *ix) {
     (void)hipFree(ix->d_rows);
     (void)hipFree(ix->d_meta);
     (void)hipFree(ix->d_agent);
+    (void)hipFree(ix->d_shadow);
     if (ix->up_stream) (void)hipStreamDestroy(ix->up_stream);
     delete ix;
 }
@@ -592,6 +490,8 @@ int cx_rebuild(cx_index *ix) {
     ix->n_rows = n_new;
     ix->n_alive = n_new;
     ix->n_removed = 0;
+    ix->shadow_rows = 0;  // rows moved: the bf16 shadow is rebuilt on next use
+    ix->shadow_stale.clear();
     return CX_OK;
 }
 

@@ -1,0 +1,148 @@
+// internal.hpp — host-side structures shared by the C-ABI translation units (not installed).
+#pragma once
+
+#include <algorithm>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace cx {
+
+struct IdKey {
+    uint64_t a, b;
+    bool operator==(const IdKey &o) const { return a == o.a && b == o.b; }
+};
+struct IdHash {
+    size_t operator()(const IdKey &k) const {
+        uint64_t h = k.a * 0x9E3779B97F4A7C15ull ^ (k.b + 0xC2B2AE3D27D4EB4Full + (k.a << 6) + (k.a >> 2));
+        h ^= h >> 29;
+        h *= 0xBF58476D1CE4E5B9ull;
+        return (size_t)(h ^ (h >> 32));
+    }
+};
+inline IdKey id_key(const uint8_t *id) {
+    IdKey k;
+    memcpy(&k.a, id, 8);
+    memcpy(&k.b, id + 8, 8);
+    return k;
+}
+
+template <typename T>
+inline int ensure_dev(T *&p, size_t &cap, size_t need) {
+    if (need <= cap) return CX_OK;
+    size_t ncap = std::max(need, cap * 2);
+    if (p) CX_HIP(hipFree(p));
+    p = nullptr;
+    cap = 0;
+    CX_HIP(hipMalloc((void **)&p, ncap * sizeof(T)));
+    cap = ncap;
+    return CX_OK;
+}
+template <typename T>
+inline int ensure_pinned(T *&p, size_t &cap, size_t need) {
+    if (need <= cap) return CX_OK;
+    size_t ncap = std::max(need, cap * 2);
+    if (p) CX_HIP(hipHostFree(p));
+    p = nullptr;
+    cap = 0;
+    CX_HIP(hipHostMalloc((void **)&p, ncap * sizeof(T), hipHostMallocDefault));
+    cap = ncap;
+    return CX_OK;
+}
+
+// Per-call scratch.  Host-API calls take one from the pool for the duration
+// of the call (re-entrancy under the callers' read lock); *_dev calls get the
+// one bound to their stream, so back-to-back calls on a stream reuse it in
+// stream order.
+struct Ctx {
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    float *d_query = nullptr; size_t q_cap = 0;
+    uint64_t *d_part_keys = nullptr; size_t pk_cap = 0;
+    float *d_part_sims = nullptr; size_t ps_cap = 0;
+    uint32_t *d_out_rows = nullptr; size_t or_cap = 0;
+    float *d_out_scores = nullptr; size_t os_cap = 0;
+    float *d_out_dists = nullptr; size_t od_cap = 0;
+    uint32_t *d_out_counts = nullptr; size_t oc_cap = 0;
+    uint32_t *d_excl = nullptr; size_t ex_cap = 0;
+    uint32_t *d_kinds = nullptr; size_t kd_cap = 0;
+    uint64_t *d_keys = nullptr; size_t k1_cap = 0;
+    uint64_t *d_keys2 = nullptr; size_t k2_cap = 0;
+    float *d_sims = nullptr; size_t s1_cap = 0;
+    float *d_sims2 = nullptr; size_t s2_cap = 0;
+    char *d_temp = nullptr; size_t tmp_cap = 0;
+    float *h_query = nullptr; size_t hq_cap = 0;
+    uint32_t *h_rows = nullptr; size_t hr_cap = 0;
+    float *h_scores = nullptr; size_t hs_cap = 0;
+    float *h_dists = nullptr; size_t hd_cap = 0;
+    uint32_t *h_counts = nullptr; size_t hc_cap = 0;
+
+    ~Ctx() {
+        (void)hipFree(d_query); (void)hipFree(d_part_keys); (void)hipFree(d_part_sims); (void)hipFree(d_out_rows);
+        (void)hipFree(d_out_scores); (void)hipFree(d_out_dists); (void)hipFree(d_out_counts); (void)hipFree(d_excl);
+        (void)hipFree(d_kinds); (void)hipFree(d_keys); (void)hipFree(d_keys2); (void)hipFree(d_sims); (void)hipFree(d_sims2);
+        (void)hipFree(d_temp);
+        (void)hipHostFree(h_query); (void)hipHostFree(h_rows); (void)hipHostFree(h_scores); (void)hipHostFree(h_dists);
+        (void)hipHostFree(h_counts);
+        if (own_stream && stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+}  // namespace cx
+
+using namespace cx;
+
+struct cx_index {
+    uint32_t dim = 0;
+    int device = 0;
+    float *d_rows = nullptr;
+    uint32_t *d_meta = nullptr;
+    uint32_t *d_agent = nullptr;
+    uint64_t cap = 0;
+    uint64_t n_rows = 0;
+    uint64_t n_alive = 0;
+    uint64_t n_removed = 0;
+    std::vector<uint8_t> ids;
+    std::vector<uint32_t> h_meta, h_agent;
+    std::unordered_map<IdKey, uint32_t, IdHash> map;
+    std::unordered_map<std::string, uint32_t> interned;
+    hipStream_t up_stream = nullptr;
+    mutable std::mutex mu;
+    mutable std::vector<Ctx *> pool;
+    mutable std::unordered_map<void *, Ctx *> by_stream;
+    // bf16 L2-normalised shadow of the rows for the all-pairs pass (allpairs.hip); built lazily
+    // under shadow_mu, rows [0, shadow_rows) valid, in-place upserts listed in shadow_stale
+    mutable std::mutex shadow_mu;
+    mutable uint16_t *d_shadow = nullptr;
+    mutable uint64_t shadow_cap = 0;
+    mutable uint64_t shadow_rows = 0;
+    mutable std::vector<uint32_t> shadow_stale;
+    // measurement (cx_profile_*): event pairs around the scan kernel
+    bool profiling = false;
+    mutable std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    double prof_ms = 0.0;
+    uint64_t prof_n = 0;
+};
+
+
+namespace cx {
+int use_device(const cx_index *ix);
+Ctx *acquire_ctx(const cx_index *ix);
+void release_ctx(const cx_index *ix, Ctx *c);
+struct CtxLease {
+    const cx_index *ix;
+    Ctx *c;
+    explicit CtxLease(const cx_index *i) : ix(i), c(acquire_ctx(i)) {}
+    ~CtxLease() { if (c) release_ctx(ix, c); }
+    CtxLease(const CtxLease &) = delete;
+    CtxLease &operator=(const CtxLease &) = delete;
+};
+bool use_nontemporal(const cx_index *ix);
+// nq single-query scans (query i = d_queries + i*dim) enqueued on s; results at [i*k_eff, ...)
+int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float *tails, uint64_t nq, uint32_t k_eff,
+                const DevFilter &flt, float thr, bool has_thr, uint32_t *d_rows, float *d_scores, float *d_dists,
+                uint32_t *d_counts, hipStream_t s);
+}  // namespace cx

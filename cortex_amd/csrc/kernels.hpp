@@ -61,6 +61,56 @@ int launch_merge_parts(uint32_t n_parts, uint32_t nq, uint32_t k, uint64_t part_
                        const uint32_t *d_counts, uint64_t *out_rows, float *out_scores, float *out_dists,
                        uint32_t *out_counts, hipStream_t stream);
 
+// ---- all-pairs auto-link pass (allpairs.hip) ----
+int launch_build_shadow(const float *rows, uint16_t *shadow, uint32_t row_lo, uint32_t row_hi, uint32_t dim,
+                        hipStream_t stream);
+
+struct PairFilterArgs {
+    const uint16_t *shadow;     // [n_rows][dim] bf16, L2-normalised rows
+    const uint32_t *scan_rows;  // [n_scan] row of each scanned node, or null = identity
+    uint32_t n_scan, n_rows, dim;
+    float thr_lo;               // threshold - eps (bf16 error bound)
+    uint32_t *cand_cnt;         // [n_scan], zeroed by the caller
+    uint32_t *cand;             // [n_scan][cap]
+    uint32_t cap;
+};
+int launch_pair_filter(const PairFilterArgs &a, hipStream_t stream);
+
+struct RescoreArgs {
+    const float *rows;
+    const uint32_t *meta;
+    const uint32_t *scan_rows;
+    const uint32_t *cand_cnt;
+    const uint32_t *cand;
+    uint32_t n_scan, dim, cap, topk;
+    float threshold;
+    uint32_t *out_rows;    // [n_scan][topk] ordered best-first
+    float *out_scores;     // [n_scan][topk]
+    uint32_t *out_cnt;     // [n_scan]
+    uint32_t *overflow;    // [n_scan] 1 = candidate list overflowed, redo on the exact path
+};
+int launch_rescore(const RescoreArgs &a, hipStream_t stream);
+
+struct LinkArgs {
+    const uint32_t *scan_rows;
+    const uint32_t *list_rows;
+    const float *list_scores;
+    const uint32_t *list_cnt;
+    const uint8_t *deleted;   // [n_rows] storage tombstones (quirk Q2) or null
+    uint32_t n_scan, topk, max_edges, dedup;
+    float threshold;
+    uint32_t *counts;         // [n_scan]  (count pass)
+    const uint64_t *offsets;  // [n_scan]  (emit pass)
+    uint32_t *out_from, *out_to;
+    float *out_weight;
+};
+int launch_link_rules(const LinkArgs &a, bool emit, hipStream_t stream);
+
+// exclusive prefix sum u32 -> u64 (edge offsets); temp sized by scan_temp_bytes
+size_t scan_temp_bytes(uint32_t n);
+int launch_exclusive_scan(const uint32_t *in, uint64_t *out, uint32_t n, void *temp, size_t temp_bytes,
+                          hipStream_t stream);
+
 // row maintenance
 int launch_gather_rows(const float *src, float *dst, const uint32_t *d_src_rows, uint32_t n_dst, uint32_t dim,
                        hipStream_t stream);

@@ -9,6 +9,8 @@
 #include <string.h>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "kernels.hpp"
 
@@ -51,6 +53,27 @@ int launch_sort_select(uint64_t *keys_in, float *sims_in, uint64_t *keys_tmp, fl
     hipLaunchKernelGGL(emit_sorted_kernel, dim3((lim + 255u) / 256u), dim3(256), 0, stream, keys_tmp, sims_tmp, lim,
                        out_rows, out_scores, out_dists, out_count);
     CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+
+
+struct U32ToU64 {
+    __host__ __device__ uint64_t operator()(uint32_t v) const { return (uint64_t)v; }
+};
+
+size_t scan_temp_bytes(uint32_t n) {
+    size_t bytes = 0;
+    auto it = rocprim::make_transform_iterator((const uint32_t *)nullptr, U32ToU64());
+    (void)rocprim::exclusive_scan(nullptr, bytes, it, (uint64_t *)nullptr, (uint64_t)0, (size_t)n,
+                                  rocprim::plus<uint64_t>(), (hipStream_t)0);
+    return bytes ? bytes : 16;
+}
+
+int launch_exclusive_scan(const uint32_t *in, uint64_t *out, uint32_t n, void *temp, size_t temp_bytes,
+                          hipStream_t stream) {
+    if (!n) return CX_OK;
+    auto it = rocprim::make_transform_iterator(in, U32ToU64());
+    CX_HIP(rocprim::exclusive_scan(temp, temp_bytes, it, out, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), stream));
     return CX_OK;
 }
 

@@ -267,6 +267,58 @@ class HipIndex:
                         for j in range(int(cnt[qi]))]
         return out
 
+    # -- the auto-linker's similarity pass, batched ---------------------------
+    def autolink_pass_rows(self, scan_rows, topk: int, threshold: float, max_edges_per_node: int,
+                           deleted: Optional[np.ndarray] = None):
+        """cx_autolink_pass_rows: (from_rows u32, to_rows u32, weights f32), scan order then score order.
+        scan_rows=None scans every row."""
+        sr = None if scan_rows is None else np.ascontiguousarray(scan_rows, dtype=np.uint32)
+        n_scan = self.row_count() if sr is None else sr.size
+        dl = None if deleted is None else np.ascontiguousarray(deleted, dtype=np.uint8)
+        if dl is not None and dl.size != self.row_count():
+            raise ValidationError("deleted must have one flag per row")
+        cap = max(1024, n_scan * 4)
+        while True:
+            fr, to = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+            w = np.zeros(cap, np.float32)
+            n, need = C.c_uint64(0), C.c_uint64(0)
+            rc = self._L.cx_autolink_pass_rows(self._h, n_scan, sr.ctypes.data if sr is not None else None, int(topk),
+                                               float(threshold), int(max_edges_per_node),
+                                               dl.ctypes.data if dl is not None else None, cap, fr.ctypes.data,
+                                               to.ctypes.data, w.ctypes.data, C.byref(n), C.byref(need))
+            if rc == 4 and need.value > cap:
+                cap = int(need.value)
+                continue
+            self._check(rc)
+            return fr[:n.value], to[:n.value], w[:n.value]
+
+    def dedup_scan_rows(self, dedup_threshold: float, deleted: Optional[np.ndarray] = None):
+        """cx_dedup_scan_rows: (a_rows, b_rows, similarity) — DedupScanner::scan's pairs (dedup.rs:65-127)."""
+        dl = None if deleted is None else np.ascontiguousarray(deleted, dtype=np.uint8)
+        cap = max(1024, self.row_count())
+        while True:
+            a, b = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+            s = np.zeros(cap, np.float32)
+            n, need = C.c_uint64(0), C.c_uint64(0)
+            rc = self._L.cx_dedup_scan_rows(self._h, float(dedup_threshold), dl.ctypes.data if dl is not None else None,
+                                            cap, a.ctypes.data, b.ctypes.data, s.ctypes.data, C.byref(n), C.byref(need))
+            if rc == 4 and need.value > cap:
+                cap = int(need.value)
+                continue
+            self._check(rc)
+            return a[:n.value], b[:n.value], s[:n.value]
+
+    def autolink_pass_timed(self, topk: int, threshold: float, max_edges_per_node: int, scan_rows=None):
+        """(n_edges, [shadow_ms, filter_ms, rescore_ms, rules_ms]) with the edges left in HBM."""
+        sr = None if scan_rows is None else np.ascontiguousarray(scan_rows, dtype=np.uint32)
+        n_scan = self.row_count() if sr is None else sr.size
+        ne = C.c_uint64(0)
+        ph = (C.c_double * 4)()
+        self._check(self._L.cx_autolink_pass_timed(self._h, n_scan, sr.ctypes.data if sr is not None else None,
+                                                   int(topk), float(threshold), int(max_edges_per_node),
+                                                   C.byref(ne), ph))
+        return ne.value, list(ph)
+
     # -- measurement ---------------------------------------------------------
     def profile_enable(self, on: bool = True) -> None:
         self._check(self._L.cx_profile_enable(self._h, 1 if on else 0))

@@ -130,6 +130,41 @@ int cx_search_batch(const cx_index *ix, uint64_t nq, const float *queries, uint6
                     const cx_filter *filter, uint8_t *out_ids, float *out_scores,
                     float *out_distances, uint64_t *out_counts);
 
+/* ---- the auto-linker's similarity pass, batched -------------------------- */
+
+/* AutoLinker::run_cycle's per-node kNN loop (linker/auto_linker.rs:215-264) with
+ * SimilarityLinkRule (linker/rules.rs:42-62) as the only rule, for n_scan nodes
+ * in one pass: for each scanned node, in scan order, take its `topk` nearest
+ * rows in score order (search(emb, topk), self included in the ranks), skip
+ * self, skip rows flagged in `deleted` (nodes the storage has tombstoned but
+ * that are still indexed), propose an edge for score >=
+ * threshold with weight = score, stop after max_edges_per_node.  scan_rows =
+ * row index of each scanned node (NULL = every row, n_scan ignored);
+ * deleted = cx_row_count() flags or NULL.  Rows are insertion rows
+ * (cx_row_id maps them to ids).  Edges come out in scan order, then score
+ * order.  Writes min(cap, n) edges, *n_needed = n; CX_ERR_CAPACITY if n > cap.
+ * topk <= 256.  Structural / config rules stay on the host: they need the
+ * ordered neighbour lists only (cx_search_batch with k = 100). */
+int cx_autolink_pass_rows(const cx_index *ix, uint64_t n_scan, const uint32_t *scan_rows, uint64_t topk,
+                          float threshold, uint64_t max_edges_per_node, const uint8_t *deleted,
+                          uint64_t cap, uint32_t *out_from, uint32_t *out_to, float *out_weight,
+                          uint64_t *n_out, uint64_t *n_needed);
+
+/* DedupScanner::scan's pair emission (linker/dedup.rs:65-127): every indexed,
+ * non-deleted node in row order, its neighbours with score >= dedup_threshold
+ * in score order, self skipped, each unordered pair reported once by the node
+ * scanned first.  out_a = scanned row, out_b = other row. */
+int cx_dedup_scan_rows(const cx_index *ix, float dedup_threshold, const uint8_t *deleted, uint64_t cap,
+                       uint32_t *out_a, uint32_t *out_b, float *out_similarity, uint64_t *n_out,
+                       uint64_t *n_needed);
+
+/* cx_autolink_pass_rows without the copy-out: edges stay in HBM, only their
+ * number and the device time of the four phases (ms: shadow refresh, MFMA
+ * filter, exact rescore, link rules) are returned.  bench.py's auto-link leg. */
+int cx_autolink_pass_timed(const cx_index *ix, uint64_t n_scan, const uint32_t *scan_rows, uint64_t topk,
+                           float threshold, uint64_t max_edges_per_node, uint64_t *n_edges,
+                           double *phase_ms);
+
 /* ---- HBM-resident variants (multi-GPU shards, benchmarking) ----------- */
 
 /* As cx_search / cx_search_batch with the queries (dimension floats each)
