@@ -77,7 +77,7 @@ int grow_rows(cx_index *ix, uint64_t need) {
     uint64_t ncap = std::max<uint64_t>(need, std::max<uint64_t>(ix->cap * 2, 1024));
     float *nr = nullptr;
     uint32_t *nm = nullptr, *na = nullptr;
-    CX_HIP(hipMalloc((void **)&nr, ncap * ix->dim * sizeof(float) + 64));
+    CX_HIP(hipMalloc((void **)&nr, (ncap + 16) * ix->dim * sizeof(float) + 64));  // + one batch tile of padding (batch.hip)
     CX_HIP(hipMalloc((void **)&nm, ncap * sizeof(uint32_t)));
     CX_HIP(hipMalloc((void **)&na, ncap * sizeof(uint32_t)));
     CX_HIP(hipMemsetAsync(nm, 0, ncap * sizeof(uint32_t), ix->up_stream));
@@ -235,6 +235,50 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
         if (int rc = ensure_dev(c->d_sims, c->s1_cap, n)) return rc;
         if (int rc = ensure_dev(c->d_sims2, c->s2_cap, n)) return rc;
         if (int rc = ensure_dev(c->d_temp, c->tmp_cap, sort_temp_bytes(n))) return rc;
+    }
+    // batched pass: the row store is read once per <= 64 queries (batch.hip)
+    bool no_tails = true;
+    for (uint64_t i = 0; tails && i < nq; i++) no_tails = no_tails && tails[i] == 0.0f;
+    static const int batch_min = getenv("CX_BATCH_MIN") ? atoi(getenv("CX_BATCH_MIN")) : 3;
+    if (topk_path && no_tails && nq >= (uint64_t)batch_min && k_eff >= 1 && batch_supported(ix->dim, k_eff)) {
+        const uint32_t bgrid = batch_grid_blocks(n);
+        if (int rc = ensure_dev(c->d_part_keys, c->pk_cap, (size_t)64 * bgrid * k_eff)) return rc;
+        if (int rc = ensure_dev(c->d_part_sims, c->ps_cap, (size_t)64 * bgrid * k_eff)) return rc;
+        for (uint64_t q0 = 0; q0 < nq; q0 += 64) {
+            const uint32_t m = (uint32_t)std::min<uint64_t>(64, nq - q0);
+            BatchArgs b;
+            memset(&b, 0, sizeof b);
+            b.rows = ix->d_rows;
+            b.queries = d_queries + q0 * ix->dim;
+            b.n_rows = n;
+            b.nq = m;
+            b.dim = ix->dim;
+            b.k = k_eff;
+            b.flt = flt;
+            b.part_keys = c->d_part_keys;
+            b.part_sims = c->d_part_sims;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (ix->profiling) {
+                CX_HIP(hipEventCreate(&e0));
+                CX_HIP(hipEventCreate(&e1));
+                std::lock_guard<std::mutex> g(ix->mu);
+                ix->prof_events.emplace_back(e0, e1);
+                CX_HIP(hipEventRecord(e0, s));
+            }
+            if (int rc = launch_batch_scan(b, bgrid, s)) return rc;
+            if (e1) CX_HIP(hipEventRecord(e1, s));
+            MergeArgs mg;
+            mg.part_keys = c->d_part_keys;
+            mg.part_sims = c->d_part_sims;
+            mg.n_lists = bgrid;
+            mg.k = k_eff;
+            mg.out_rows = d_rows + q0 * k_eff;
+            mg.out_scores = d_scores + q0 * k_eff;
+            mg.out_dists = d_dists + q0 * k_eff;
+            mg.out_count = d_counts + q0;
+            if (int rc = launch_merge_batch(mg, m, s)) return rc;
+        }
+        return CX_OK;
     }
     for (uint64_t i = 0; i < nq; i++) {
         ScanArgs a;
@@ -452,7 +496,7 @@ int cx_rebuild(cx_index *ix) {
     const uint64_t ncap = std::max<uint64_t>(n_new, 1024);
     float *nr = nullptr;
     uint32_t *nm = nullptr, *na = nullptr, *d_keep = nullptr;
-    CX_HIP(hipMalloc((void **)&nr, ncap * ix->dim * sizeof(float) + 64));
+    CX_HIP(hipMalloc((void **)&nr, (ncap + 16) * ix->dim * sizeof(float) + 64));  // + one batch tile of padding (batch.hip)
     CX_HIP(hipMalloc((void **)&nm, ncap * sizeof(uint32_t)));
     CX_HIP(hipMalloc((void **)&na, ncap * sizeof(uint32_t)));
     CX_HIP(hipMemsetAsync(nm, 0, ncap * sizeof(uint32_t), ix->up_stream));

@@ -61,6 +61,23 @@ int launch_merge_parts(uint32_t n_parts, uint32_t nq, uint32_t k, uint64_t part_
                        const uint32_t *d_counts, uint64_t *out_rows, float *out_scores, float *out_dists,
                        uint32_t *out_counts, hipStream_t stream);
 
+// ---- batched search (batch.hip) ----
+struct BatchArgs {
+    const float *rows;      // [n_rows][dim]
+    const float *queries;   // [nq][dim] in HBM
+    uint32_t n_rows, nq, dim, k, capq;
+    DevFilter flt;
+    uint64_t *part_keys;    // [nq][grid][k]
+    float *part_sims;
+    unsigned long long *diag;  // diagnostic build only (CX_BATCH_DIAG=1): [grid*4 waves][5] cycle sums
+};
+bool batch_supported(uint32_t dim, uint32_t k);
+uint32_t batch_grid_blocks(uint32_t n_rows);
+// one pass of <= 64 queries; per-block lists, to be folded by launch_merge_batch
+int launch_batch_scan(BatchArgs a, uint32_t grid, hipStream_t stream);
+// second stage for nq queries at once: query q's lists are part[q*n_lists*k ...], outputs at [q*k]
+int launch_merge_batch(const MergeArgs &m, uint32_t nq, hipStream_t stream);
+
 // ---- all-pairs auto-link pass (allpairs.hip) ----
 int launch_build_shadow(const float *rows, uint16_t *shadow, uint32_t row_lo, uint32_t row_hi, uint32_t dim,
                         hipStream_t stream);

@@ -190,7 +190,14 @@ __global__ __launch_bounds__(256) void scan_generic_kernel(const ScanArgs a) {
 // sorted top-k.  16 waves each sweep a strided share with coalesced loads,
 // then wave 0 folds the 15 other lists and ranks the k survivors.
 template <int KS>
-__global__ __launch_bounds__(1024) void merge_kernel(const MergeArgs m) {
+__global__ __launch_bounds__(1024) void merge_kernel(const MergeArgs m0) {
+    MergeArgs m = m0;  // one block per query
+    m.part_keys += (size_t)blockIdx.x * m0.n_lists * m0.k;
+    m.part_sims += (size_t)blockIdx.x * m0.n_lists * m0.k;
+    m.out_rows += (size_t)blockIdx.x * m0.k;
+    m.out_scores += (size_t)blockIdx.x * m0.k;
+    m.out_dists += (size_t)blockIdx.x * m0.k;
+    m.out_count += blockIdx.x;
     __shared__ uint64_t sk[16][64 * KS];
     __shared__ float ss[16][64 * KS];
     const uint32_t lane = (uint32_t)lane_id();
@@ -252,7 +259,15 @@ __global__ __launch_bounds__(1024) void merge_kernel(const MergeArgs m) {
 // NT = threads in the block (a multiple of 64, <= 1024); n_lists <= 2048.
 constexpr uint32_t MERGE_SMALL_MAX_LISTS = 2048;
 template <int NT>
-__device__ inline void merge_small_body(const MergeArgs &m) {
+__device__ inline void merge_small_body(const MergeArgs &m0) {
+    // one block per query: query q's lists start at q*n_lists*k, its outputs at q*k
+    MergeArgs m = m0;
+    m.part_keys += (size_t)blockIdx.x * m0.n_lists * m0.k;
+    m.part_sims += (size_t)blockIdx.x * m0.n_lists * m0.k;
+    m.out_rows += (size_t)blockIdx.x * m0.k;
+    m.out_scores += (size_t)blockIdx.x * m0.k;
+    m.out_dists += (size_t)blockIdx.x * m0.k;
+    m.out_count += blockIdx.x;
     __shared__ uint64_t heads[MERGE_SMALL_MAX_LISTS];
     __shared__ uint64_t hsurv[MERGE_SMALL_MAX_LISTS];
     __shared__ uint64_t surv_k[1024];
@@ -413,6 +428,16 @@ int launch_scan_topk(const ScanArgs &a, const MergeArgs &m, bool nontemporal, hi
     else if (ks == 1) hipLaunchKernelGGL((merge_kernel<1>), dim3(1), dim3(1024), 0, stream, m);
     else if (ks == 2) hipLaunchKernelGGL((merge_kernel<2>), dim3(1), dim3(1024), 0, stream, m);
     else hipLaunchKernelGGL((merge_kernel<4>), dim3(1), dim3(1024), 0, stream, m);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+
+int launch_merge_batch(const MergeArgs &m, uint32_t nq, hipStream_t stream) {
+    if (!nq || !m.k) return CX_OK;
+    if (m.k <= 32 && m.n_lists <= MERGE_SMALL_MAX_LISTS) hipLaunchKernelGGL(merge_small_kernel, dim3(nq), dim3(1024), 0, stream, m);
+    else if (m.k <= 64) hipLaunchKernelGGL((merge_kernel<1>), dim3(nq), dim3(1024), 0, stream, m);
+    else if (m.k <= 128) hipLaunchKernelGGL((merge_kernel<2>), dim3(nq), dim3(1024), 0, stream, m);
+    else hipLaunchKernelGGL((merge_kernel<4>), dim3(nq), dim3(1024), 0, stream, m);
     CX_HIP(hipGetLastError());
     return CX_OK;
 }

@@ -48,12 +48,13 @@ def test_golden_fixtures(hip, path):
             if int(r) in pos:
                 e = exp_d[pos[int(r)]]
                 assert (np.isnan(e) and np.isnan(gd[j])) or abs(e - gd[j]) <= SCORE_TOL
-    # batch entry point gives the same lists
+    # the batch entry point (MFMA path for 384/768-d, k <= 32) meets the same bar; its summation order
+    # differs from the single-query kernel's, so scores may differ from it in the last ulp
     bi, bs, bd, bc = h.search_batch_arrays(qs, k)
     for i in range(len(qs)):
-        gi, gs, gd = h.search_arrays(qs[i], k)
-        assert bc[i] == len(gs)
-        assert np.array_equal(bi[i, :len(gs)], gi) and np.array_equal(bs[i, :len(gs)], gs, equal_nan=True)
+        n = int(bc[i])
+        assert_topk_parity(rows_of(ids, bi[i, :n]), bs[i, :n], g["exp_rows"][i][:n], g["exp_scores"][i][:n],
+                           what=f"{path} batch q{i}")
 
 
 @pytest.mark.parametrize("n,d,k", [
@@ -256,3 +257,45 @@ def test_concurrent_readers(hip, oracle):
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errs, errs[0]
+
+
+@pytest.mark.parametrize("n,d,k,nq", [
+    (5000, 768, 10, 64),     # BASELINE config 4's inner loop: batch-64, k=10
+    (3001, 384, 5, 100),     # two passes (64 + 36), ragged last tile
+    (777, 768, 32, 7),       # k = 32 (largest fused k), fewer queries than one wave's share
+    (40, 384, 10, 3),        # fewer rows than blocks
+    (2000, 768, 100, 5),     # k > 32: falls back to one scan per query
+])
+def test_search_batch_matches_oracle(hip, oracle, n, d, k, nq):
+    rows = oracle.synth_rows(n, d)
+    qs = oracle.synth_queries(n, d, nq)
+    h, o, ids = build_both(hip, oracle, rows)
+    bi, bs, bd, bc = h.search_batch_arrays(qs, k)
+    for i in range(nq):
+        e = o.search(qs[i], k)
+        m = int(bc[i])
+        assert_topk_parity(rows_of(ids, bi[i, :m]), bs[i, :m], e["row"], e["score"], what=f"batch n={n} d={d} k={k} q{i}")
+        assert np.all(np.diff(bs[i, :m]) <= 0)
+        pos = {int(r): j for j, r in enumerate(e["row"])}
+        for jj, r in enumerate(rows_of(ids, bi[i, :m])):
+            if int(r) in pos:
+                assert abs(bd[i, jj] - e["distance"][pos[int(r)]]) <= SCORE_TOL
+
+
+def test_search_batch_with_filter_and_tombstones(hip, oracle):
+    n, d = 1500, 768
+    rows = oracle.synth_rows(n, d)
+    qs = oracle.synth_queries(n, d, 20)
+    h, o, ids = build_both(hip, oracle, rows)
+    for r in range(0, n, 3):
+        h.set_metadata(ids[r].tobytes(), "fact" if r % 2 else "event", "kai")
+        o.set_metadata(ids[r].tobytes(), "fact" if r % 2 else "event", "kai")
+    for r in (10, 11, 500):
+        h.remove(ids[r].tobytes()); o.remove(ids[r].tobytes())
+    excl = [ids[i].tobytes() for i in (1, 2, 3)]
+    hf, of = hip.VectorFilter(kinds=["fact"], exclude=excl), oracle.Filter(kinds=["fact"], exclude=excl)
+    bi, bs, bd, bc = h.search_batch_arrays(qs, 10, hf)
+    for i in range(len(qs)):
+        e = o.search(qs[i], 10, of)
+        m = int(bc[i])
+        assert_topk_parity(rows_of(ids, bi[i, :m]), bs[i, :m], e["row"], e["score"], what=f"batch filter q{i}")
