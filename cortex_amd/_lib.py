@@ -34,6 +34,8 @@ SIGNATURES = {
     "cx_set_metadata": (C.c_int, [_P, _P, _U32, _U32]),
     "cx_intern": (_U32, [_P, C.c_char_p, _U64]),
     "cx_rebuild": (C.c_int, [_P]),
+    "cx_save": (C.c_int, [_P, C.c_char_p]),
+    "cx_load": (_P, [C.c_char_p, C.c_int]),
     "cx_len": (_U64, [_P]),
     "cx_dimension": (_U32, [_P]),
     "cx_row_count": (_U64, [_P]),

@@ -172,6 +172,23 @@ class HipIndex:
     def reserve(self, rows: int) -> None:
         self._check(self._L.cx_reserve(self._h, rows))
 
+    def save(self, path) -> None:
+        """vector/index.rs:437-445 — the reference's bincode file format."""
+        self._check(self._L.cx_save(self._h, str(path).encode()))
+
+    @classmethod
+    def load(cls, path, device: int = 0) -> "HipIndex":
+        """vector/index.rs:447-473."""
+        L = _lib.load()
+        h = L.cx_load(str(path).encode(), device)
+        if not h:
+            msg = (L.cx_last_error() or b"").decode(errors="replace")
+            raise ValidationError(msg)
+        self = cls.__new__(cls)
+        self._L, self._h, self.device = L, h, device
+        self.dimension = int(L.cx_dimension(h))
+        return self
+
     # -- VectorIndex: queries ----------------------------------------------
     def __len__(self) -> int:
         return int(self._L.cx_len(self._h))

@@ -95,6 +95,14 @@ uint32_t cx_intern(cx_index *ix, const char *utf8, uint64_t len);
  * required for correctness. */
 int cx_rebuild(cx_index *ix);
 
+/* VectorIndex::save / load — vector/index.rs:437-473, same file format: bincode of
+ * (HashMap<Uuid, Vec<f32>>, HashMap<Uuid, NodeMetadata>, usize), so files written by
+ * HnswIndex::save load here and vice versa.  Errors carry the reference's messages
+ * ("Failed to write index file: ...", "Failed to read index file: ...",
+ * "Failed to deserialize index: ...").  cx_load returns NULL on failure. */
+int cx_save(const cx_index *ix, const char *path);
+cx_index *cx_load(const char *path, int device);
+
 /* ---- queries: &self --------------------------------------------------- */
 
 /* VectorIndex::len — vector/index.rs:412-414 */
