@@ -1,0 +1,179 @@
+// cortex_hip.hpp — C++ host-side mirror of the reference's vector-layer interface over the C ABI
+// (header only).  Same names, argument meaning and error behaviour as
+// crates/cortex-core/src/vector/index.rs: trait VectorIndex (:50-99), HnswIndex (:182-473),
+// VectorFilter (:18-47), SimilarityResult (:11-15); SimilarityConfig from vector/config.rs:3-87.
+// Result<T> becomes "returns T or throws CortexError" (the vector layer only produces
+// CortexError::Validation(String)).  Everything numeric happens in libcortex_hip.so.
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "cortex_hip.h"
+
+namespace cortex {
+
+using NodeId = std::array<uint8_t, 16>;  // types.rs:9 — Uuid
+using Embedding = std::vector<float>;    // types.rs:22
+
+struct CortexError : std::runtime_error {  // error.rs:7-50
+    int code;
+    CortexError(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+struct SimilarityResult {  // index.rs:11-15
+    NodeId node_id;
+    float score;
+    float distance;
+};
+
+struct VectorFilter {  // index.rs:18-47
+    std::optional<std::vector<std::string>> kinds;
+    std::optional<std::vector<NodeId>> exclude;
+    std::optional<std::string> source_agent;
+    static VectorFilter new_() { return {}; }
+    VectorFilter with_kinds(std::vector<std::string> k) && { kinds = std::move(k); return std::move(*this); }
+    VectorFilter excluding(std::vector<NodeId> ids) && { exclude = std::move(ids); return std::move(*this); }
+    VectorFilter with_source_agent(std::string a) && { source_agent = std::move(a); return std::move(*this); }
+};
+
+struct VectorIndex {  // index.rs:50-99
+    virtual ~VectorIndex() = default;
+    virtual void insert(const NodeId &id, const Embedding &embedding) = 0;
+    virtual void remove(const NodeId &id) = 0;
+    virtual std::vector<SimilarityResult> search(const Embedding &query, size_t k, const VectorFilter *filter = nullptr) const = 0;
+    virtual std::vector<SimilarityResult> search_threshold(const Embedding &query, float threshold, const VectorFilter *filter = nullptr) const = 0;
+    virtual std::map<NodeId, std::vector<SimilarityResult>> search_batch(const std::vector<std::pair<NodeId, Embedding>> &queries,
+                                                                        size_t k, const VectorFilter *filter = nullptr) const = 0;
+    virtual size_t len() const = 0;
+    bool is_empty() const { return len() == 0; }
+    virtual void rebuild() = 0;
+    virtual void save(const std::string &path) const = 0;
+};
+
+class HipIndex final : public VectorIndex {
+    cx_index *h_ = nullptr;
+    explicit HipIndex(cx_index *h) : h_(h) {}
+    static void check(int rc) {
+        if (rc != CX_OK) throw CortexError(rc, cx_last_error());
+    }
+    struct FilterBuf {
+        std::vector<uint8_t> ex;
+        std::vector<uint32_t> kinds;
+        cx_filter c{};
+    };
+    uint32_t intern(const std::string &s) const { return cx_intern(h_, s.data(), s.size()); }
+    bool marshal(const VectorFilter *f, FilterBuf &b) const {
+        if (!f) return false;
+        if (f->exclude) {
+            for (auto &id : *f->exclude) b.ex.insert(b.ex.end(), id.begin(), id.end());
+            b.c.has_exclude = 1; b.c.n_exclude = f->exclude->size(); b.c.exclude_ids = b.ex.data();
+        }
+        if (f->kinds) {
+            for (auto &k : *f->kinds) b.kinds.push_back(intern(k));
+            b.c.has_kinds = 1; b.c.n_kinds = f->kinds->size(); b.c.kind_codes = b.kinds.data();
+        }
+        if (f->source_agent) { b.c.has_agent = 1; b.c.agent_code = intern(*f->source_agent); }
+        return true;
+    }
+    static std::vector<SimilarityResult> collect(const uint8_t *ids, const float *s, const float *d, size_t n) {
+        std::vector<SimilarityResult> out(n);
+        for (size_t i = 0; i < n; i++) {
+            std::memcpy(out[i].node_id.data(), ids + 16 * i, 16);
+            out[i].score = s[i];
+            out[i].distance = d[i];
+        }
+        return out;
+    }
+
+public:
+    explicit HipIndex(size_t dimension, int device = 0) : h_(cx_create((uint32_t)dimension, device)) {  // index.rs:204
+        if (!h_) throw CortexError(CX_ERR_DEVICE, cx_last_error());
+    }
+    static HipIndex with_metadata(size_t dimension, int device = 0) { return HipIndex(dimension, device); }  // :214
+    HipIndex(HipIndex &&o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+    HipIndex(const HipIndex &) = delete;
+    ~HipIndex() override { if (h_) cx_destroy(h_); }
+
+    void set_metadata(const NodeId &id, const std::string &kind, const std::string &source_agent) {  // :219
+        check(cx_set_metadata(h_, id.data(), intern(kind), intern(source_agent)));
+    }
+    void insert(const NodeId &id, const Embedding &e) override { check(cx_upsert(h_, id.data(), e.data(), e.size())); }
+    void remove(const NodeId &id) override { check(cx_remove(h_, id.data())); }
+
+    std::vector<SimilarityResult> search(const Embedding &q, size_t k, const VectorFilter *filter = nullptr) const override {
+        const size_t cap = std::max<size_t>(1, std::min<size_t>(k, (size_t)cx_row_count(h_)));
+        std::vector<uint8_t> ids(16 * cap);
+        std::vector<float> s(cap), d(cap);
+        uint64_t n = 0;
+        FilterBuf b;
+        const bool has = marshal(filter, b);
+        check(cx_search(h_, q.data(), q.size(), k, has ? &b.c : nullptr, ids.data(), s.data(), d.data(), &n));
+        return collect(ids.data(), s.data(), d.data(), (size_t)n);
+    }
+    std::vector<SimilarityResult> search_threshold(const Embedding &q, float threshold, const VectorFilter *filter = nullptr) const override {
+        FilterBuf b;
+        const bool has = marshal(filter, b);
+        size_t cap = 256;
+        for (;;) {
+            std::vector<uint8_t> ids(16 * cap);
+            std::vector<float> s(cap), d(cap);
+            uint64_t n = 0, need = 0;
+            const int rc = cx_search_threshold(h_, q.data(), q.size(), threshold, has ? &b.c : nullptr, cap, ids.data(),
+                                               s.data(), d.data(), &n, &need);
+            if (rc == CX_ERR_CAPACITY) { cap = (size_t)need; continue; }
+            check(rc);
+            return collect(ids.data(), s.data(), d.data(), (size_t)n);
+        }
+    }
+    std::map<NodeId, std::vector<SimilarityResult>> search_batch(const std::vector<std::pair<NodeId, Embedding>> &queries, size_t k,
+                                                                const VectorFilter *filter = nullptr) const override {
+        std::map<NodeId, std::vector<SimilarityResult>> out;
+        if (queries.empty()) return out;
+        const size_t nq = queries.size(), len = queries[0].second.size(), kk = std::max<size_t>(k, 1);
+        std::vector<float> flat;
+        for (auto &q : queries) flat.insert(flat.end(), q.second.begin(), q.second.end());
+        std::vector<uint8_t> ids(16 * nq * kk);
+        std::vector<float> s(nq * kk), d(nq * kk);
+        std::vector<uint64_t> counts(nq);
+        FilterBuf b;
+        const bool has = marshal(filter, b);
+        check(cx_search_batch(h_, nq, flat.data(), len, k, has ? &b.c : nullptr, ids.data(), s.data(), d.data(), counts.data()));
+        for (size_t i = 0; i < nq; i++)
+            out[queries[i].first] = collect(ids.data() + 16 * i * kk, s.data() + i * kk, d.data() + i * kk, (size_t)counts[i]);
+        return out;
+    }
+    size_t len() const override { return (size_t)cx_len(h_); }
+    void rebuild() override { check(cx_rebuild(h_)); }
+    void save(const std::string &path) const override { check(cx_save(h_, path.c_str())); }
+    static HipIndex load(const std::string &path, int device = 0) {  // :447-473
+        cx_index *h = cx_load(path.c_str(), device);
+        if (!h) throw CortexError(CX_ERR_VALIDATION, cx_last_error());
+        return HipIndex(h);
+    }
+    cx_index *raw() const { return h_; }
+};
+
+struct SimilarityConfig {  // vector/config.rs:3-87
+    float auto_link_threshold = 0.75f, dedup_threshold = 0.92f, contradiction_threshold = 0.80f;
+    size_t auto_link_k = 20;
+    static float clamp01(float t) { return t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t); }
+    SimilarityConfig &with_auto_link_threshold(float t) { auto_link_threshold = clamp01(t); return *this; }
+    SimilarityConfig &with_dedup_threshold(float t) { dedup_threshold = clamp01(t); return *this; }
+    SimilarityConfig &with_contradiction_threshold(float t) { contradiction_threshold = clamp01(t); return *this; }
+    SimilarityConfig &with_auto_link_k(size_t k) { auto_link_k = k; return *this; }
+    void validate() const {
+        if (auto_link_threshold >= dedup_threshold) throw CortexError(CX_ERR_VALIDATION, "auto_link_threshold must be less than dedup_threshold");
+        if (contradiction_threshold >= dedup_threshold) throw CortexError(CX_ERR_VALIDATION, "contradiction_threshold must be less than dedup_threshold");
+        if (auto_link_k == 0) throw CortexError(CX_ERR_VALIDATION, "auto_link_k must be greater than 0");
+    }
+};
+
+}  // namespace cortex

@@ -1,0 +1,166 @@
+// The reference's own vector-layer tests (crates/cortex-core/src/vector/index.rs:484-728 and
+// vector/config.rs:93-135), written against the C++ host mirror (include/cortex_hip.hpp).
+// Needs a GPU; run by tests/test_hip_cpp_mirror.py.
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <string>
+
+#include "cortex_hip.hpp"
+
+using namespace cortex;
+
+static int g_failed = 0, g_run = 0;
+#define CHECK(cond)                                                                  \
+    do {                                                                             \
+        if (!(cond)) { std::fprintf(stderr, "%s:%d: CHECK failed: %s\n", __FILE__, __LINE__, #cond); g_failed++; } \
+    } while (0)
+#define TEST(name) static void name(); static void run_##name() { g_run++; std::fprintf(stderr, "[ RUN ] %s\n", #name); name(); } static void name()
+
+static NodeId now_v7() {
+    static std::mt19937_64 rng(42);
+    NodeId id;
+    for (auto &b : id) b = (uint8_t)rng();
+    return id;
+}
+
+TEST(test_index_insert_and_search) {  // :484-510
+    HipIndex index(3);
+    auto id1 = now_v7(), id2 = now_v7(), id3 = now_v7();
+    index.insert(id1, {1.0f, 0.0f, 0.0f});
+    index.insert(id2, {0.9f, 0.1f, 0.0f});
+    index.insert(id3, {0.0f, 1.0f, 0.0f});
+    index.rebuild();
+    auto results = index.search({1.0f, 0.0f, 0.0f}, 2);
+    CHECK(results.size() == 2);
+    CHECK(results[0].node_id == id1);
+}
+TEST(test_threshold_search) {  // :513-535
+    HipIndex index(3);
+    auto id1 = now_v7(), id2 = now_v7();
+    index.insert(id1, {1.0f, 0.0f, 0.0f});
+    index.insert(id2, {0.0f, 1.0f, 0.0f});
+    index.rebuild();
+    auto results = index.search_threshold({1.0f, 0.0f, 0.0f}, 0.95f);
+    CHECK(results.size() == 1);
+    CHECK(results[0].node_id == id1);
+}
+TEST(test_index_persistence) {  // :538-566
+    const std::string path = std::string(std::getenv("TMPDIR") ? std::getenv("TMPDIR") : "/tmp") + "/cx_cpp_test.hnsw";
+    HipIndex index(3);
+    auto id1 = now_v7();
+    index.insert(id1, {1.0f, 0.0f, 0.0f});
+    index.rebuild();
+    index.save(path);
+    HipIndex loaded = HipIndex::load(path);
+    CHECK(loaded.len() == 1);
+    auto results = loaded.search({1.0f, 0.0f, 0.0f}, 1);
+    CHECK(results.size() == 1 && results[0].node_id == id1);
+    std::remove(path.c_str());
+}
+TEST(test_dimension_mismatch_rejected) {  // :579-583
+    HipIndex index(3);
+    bool threw = false;
+    try { index.insert(now_v7(), {1.0f, 2.0f}); }
+    catch (const CortexError &e) { threw = std::string(e.what()) == "Embedding dimension mismatch: expected 3, got 2"; }
+    CHECK(threw);
+}
+TEST(test_empty_index_search) {  // :586-590
+    HipIndex index(3);
+    CHECK(index.search({1.0f, 0.0f, 0.0f}, 5).empty());
+}
+TEST(test_brute_force_fallback) {  // :593-606
+    HipIndex index(3);
+    auto id1 = now_v7(), id2 = now_v7();
+    index.insert(id1, {1.0f, 0.0f, 0.0f});
+    index.insert(id2, {0.0f, 1.0f, 0.0f});
+    auto results = index.search({1.0f, 0.0f, 0.0f}, 2);  // no rebuild
+    CHECK(results.size() == 2 && results[0].node_id == id1);
+}
+TEST(test_filter_by_kind) {  // :609-627
+    HipIndex index(3);
+    auto id1 = now_v7(), id2 = now_v7();
+    index.insert(id1, {1.0f, 0.0f, 0.0f});
+    index.set_metadata(id1, "fact", "test");
+    index.insert(id2, {0.9f, 0.1f, 0.0f});
+    index.set_metadata(id2, "decision", "test");
+    index.rebuild();
+    auto filter = VectorFilter::new_().with_kinds({"decision"});
+    auto results = index.search({1.0f, 0.0f, 0.0f}, 5, &filter);
+    CHECK(results.size() == 1 && results[0].node_id == id2);
+}
+TEST(test_filter_exclude) {  // :630-646
+    HipIndex index(3);
+    auto id1 = now_v7(), id2 = now_v7();
+    index.insert(id1, {1.0f, 0.0f, 0.0f});
+    index.insert(id2, {0.9f, 0.1f, 0.0f});
+    index.rebuild();
+    auto filter = VectorFilter::new_().excluding({id1});
+    auto results = index.search({1.0f, 0.0f, 0.0f}, 5, &filter);
+    CHECK(results.size() == 1 && results[0].node_id == id2);
+}
+TEST(test_remove_doesnt_crash_search) {  // :649-664
+    HipIndex index(3);
+    auto id1 = now_v7(), id2 = now_v7();
+    index.insert(id1, {1.0f, 0.0f, 0.0f});
+    index.insert(id2, {0.0f, 1.0f, 0.0f});
+    index.rebuild();
+    index.remove(id1);
+    CHECK(index.len() == 1);
+    CHECK(!index.search({1.0f, 0.0f, 0.0f}, 5).empty());
+}
+TEST(test_search_batch) {  // :667-684
+    HipIndex index(3);
+    auto id1 = now_v7(), id2 = now_v7(), id3 = now_v7();
+    index.insert(id1, {1.0f, 0.0f, 0.0f});
+    index.insert(id2, {0.0f, 1.0f, 0.0f});
+    index.insert(id3, {0.0f, 0.0f, 1.0f});
+    index.rebuild();
+    auto results = index.search_batch({{id1, {1.0f, 0.0f, 0.0f}}, {id2, {0.0f, 1.0f, 0.0f}}}, 1);
+    CHECK(results.size() == 2);
+    CHECK(results[id1][0].node_id == id1);
+    CHECK(results[id2][0].node_id == id2);
+}
+TEST(test_similarity_score_range) {  // :687-708
+    HipIndex index(3);
+    index.insert(now_v7(), {1.0f, 0.0f, 0.0f});
+    index.insert(now_v7(), {-1.0f, 0.0f, 0.0f});
+    index.rebuild();
+    auto results = index.search({1.0f, 0.0f, 0.0f}, 2);
+    for (auto &r : results) CHECK(r.score >= 0.0f && r.score <= 1.0f);
+    CHECK(results[0].score > 0.99f);
+}
+TEST(test_threshold_returns_only_above) {  // :711-728
+    HipIndex index(3);
+    auto id_close = now_v7(), id_far = now_v7();
+    index.insert(id_close, {1.0f, 0.0f, 0.0f});
+    index.insert(id_far, {0.0f, 0.0f, 1.0f});
+    index.rebuild();
+    auto results = index.search_threshold({1.0f, 0.0f, 0.0f}, 0.5f);
+    bool all_above = true, any_close = false;
+    for (auto &r : results) { all_above &= r.score >= 0.5f; any_close |= r.node_id == id_close; }
+    CHECK(all_above && any_close);
+}
+TEST(test_config) {  // vector/config.rs:93-135
+    SimilarityConfig c;
+    CHECK(c.auto_link_threshold == 0.75f && c.dedup_threshold == 0.92f && c.contradiction_threshold == 0.80f && c.auto_link_k == 20);
+    c.validate();
+    SimilarityConfig bad;
+    bad.with_auto_link_threshold(0.95f).with_dedup_threshold(0.90f);
+    bool threw = false;
+    try { bad.validate(); } catch (const CortexError &) { threw = true; }
+    CHECK(threw);
+    SimilarityConfig cl;
+    cl.with_auto_link_threshold(1.5f).with_dedup_threshold(-0.5f);
+    CHECK(cl.auto_link_threshold == 1.0f && cl.dedup_threshold == 0.0f);
+}
+
+int main() {
+    if (cx_device_count() <= 0) { std::fprintf(stderr, "no HIP device: %s\n", "this test needs a GPU"); return 2; }
+    run_test_index_insert_and_search(); run_test_threshold_search(); run_test_index_persistence();
+    run_test_dimension_mismatch_rejected(); run_test_empty_index_search(); run_test_brute_force_fallback();
+    run_test_filter_by_kind(); run_test_filter_exclude(); run_test_remove_doesnt_crash_search(); run_test_search_batch();
+    run_test_similarity_score_range(); run_test_threshold_returns_only_above(); run_test_config();
+    std::printf("%d tests run, %d checks failed\n", g_run, g_failed);
+    return g_failed ? 1 : 0;
+}
