@@ -89,6 +89,9 @@ constexpr int LDS_BYTES = 2 * 2 * TILE_BYTES;       // 2 stages x (A + B) = 64 K
 // applied to the per-lane SOURCE address and again on the read.
 __device__ inline uint32_t lds_off(uint32_t r, uint32_t p) { return r * 128u + ((p ^ ((r >> 1) & 7u)) << 4); }
 
+// SHAPE 32: mfma_f32_32x32x16_bf16 (2x2 tiles per wave).  SHAPE 16: mfma_f32_16x16x32_bf16 (4x4 tiles per
+// wave) — same flops per LDS byte; the chip holds a higher clock on it (MI355X_MICROARCH.md, DVFS item 7).
+template <int SHAPE>
 __global__ __launch_bounds__(256) void pair_filter_kernel(const PairFilterArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -97,17 +100,25 @@ __global__ __launch_bounds__(256) void pair_filter_kernel(const PairFilterArgs a
     // tile order: XCD-contiguous chunks (blocks b, b+8, ... share an XCD), inside a
     // chunk walk 8 I-panels per J-panel so concurrent blocks share panels in L2
     const uint32_t tiles_i = (a.n_scan + BM - 1) / BM, tiles_j = (a.n_rows + BN - 1) / BN;
-    const uint32_t T = tiles_i * tiles_j;
+    const uint32_t T = a.symmetric ? a.n_tiles : tiles_i * tiles_j;
     uint32_t b = blockIdx.x;
     {
         const uint32_t q = T / 8u, r = T % 8u, xcd = b % 8u;
         b = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + b / 8u;
     }
-    const uint32_t GS = 8u;
-    const uint32_t per_group = GS * tiles_j;
-    const uint32_t group = b / per_group, first_i = group * GS;
-    const uint32_t gsz = (tiles_i - first_i) < GS ? (tiles_i - first_i) : GS;
-    const uint32_t ti = first_i + (b % per_group) % gsz, tj = (b % per_group) / gsz;
+    uint32_t ti, tj;
+    if (a.symmetric) {  // cosine is symmetric: only tiles with tj >= ti exist, each emits both directions
+        const uint32_t t = a.tile_list[b];
+        ti = t >> 16;
+        tj = t & 0xFFFFu;
+    } else {
+        const uint32_t GS = 8u;
+        const uint32_t per_group = GS * tiles_j;
+        const uint32_t group = b / per_group, first_i = group * GS;
+        const uint32_t gsz = (tiles_i - first_i) < GS ? (tiles_i - first_i) : GS;
+        ti = first_i + (b % per_group) % gsz;
+        tj = (b % per_group) / gsz;
+    }
     const uint32_t i0 = ti * BM, j0 = tj * BN;
 
     // loader: each wave-level LDS-DMA moves 8 rows x 128 B; 16 per operand tile, 4 per wave
@@ -137,72 +148,139 @@ __global__ __launch_bounds__(256) void pair_filter_kernel(const PairFilterArgs a
         }
     };
 
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; m++)
-#pragma unroll
-        for (int n = 0; n < 2; n++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[m][n][e] = 0.0f;
-
     const uint32_t KT = a.dim / BK;
-    const uint32_t fr = lane & 31u, fh = lane >> 5;
-    stage(0, 0);
-    __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and makes it visible to all waves
-    for (uint32_t kt = 0; kt < KT; kt++) {
-        const uint32_t buf = kt & 1u;
-        if (kt + 1 < KT) stage(buf ^ 1u, kt + 1);
-        const char *A = smem + buf * 2 * TILE_BYTES, *B = A + TILE_BYTES;
-#pragma unroll
-        for (uint32_t ks = 0; ks < 4; ks++) {
-            bf16x8 af[2], bf[2];
-#pragma unroll
-            for (uint32_t m = 0; m < 2; m++)
-                af[m] = *reinterpret_cast<const bf16x8 *>(A + lds_off(wm * 64u + m * 32u + fr, 2u * ks + fh));
-#pragma unroll
-            for (uint32_t n = 0; n < 2; n++)
-                bf[n] = *reinterpret_cast<const bf16x8 *>(B + lds_off(wn * 64u + n * 32u + fr, 2u * ks + fh));
-#pragma unroll
-            for (int m = 0; m < 2; m++)
-#pragma unroll
-                for (int n = 0; n < 2; n++)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bf[n], acc[m][n], 0, 0, 0);
+    auto emit = [&](uint32_t i, uint32_t j) {
+        if (i < a.n_scan && j < a.n_rows) {
+            const uint32_t slot = atomicAdd(a.cand_cnt + i, 1u);
+            if (slot < a.cap) a.cand[(size_t)i * a.cap + slot] = j;
         }
-        __syncthreads();  // next stage landed; everyone is done reading this one
-    }
+    };
+    const bool mirror = a.symmetric && ti != tj;
 
-    // epilogue: C[row][col], col = lane & 31 (j), row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5) (i)
+    if constexpr (SHAPE == 32) {
+        f32x16 acc[2][2];
 #pragma unroll
-    for (uint32_t m = 0; m < 2; m++)
+        for (int m = 0; m < 2; m++)
 #pragma unroll
-        for (uint32_t n = 0; n < 2; n++) {
-            const uint32_t j = j0 + wn * 64u + n * 32u + fr;
+            for (int n = 0; n < 2; n++)
 #pragma unroll
-            for (uint32_t e = 0; e < 16; e++) {
-                const float c = acc[m][n][e];
-                if (c >= a.thr_lo) {
-                    const uint32_t i = i0 + wm * 64u + m * 32u + (e & 3u) + 8u * (e >> 2) + 4u * fh;
-                    if (i < a.n_scan && j < a.n_rows) {
-                        const uint32_t slot = atomicAdd(a.cand_cnt + i, 1u);
-                        if (slot < a.cap) a.cand[(size_t)i * a.cap + slot] = j;
+                for (int e = 0; e < 16; e++) acc[m][n][e] = 0.0f;
+        const uint32_t fr = lane & 31u, fh = lane >> 5;
+        stage(0, 0);
+        __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and makes it visible to all waves
+        for (uint32_t kt = 0; kt < KT; kt++) {
+            const uint32_t buf = kt & 1u;
+            if (kt + 1 < KT) stage(buf ^ 1u, kt + 1);
+            const char *A = smem + buf * 2 * TILE_BYTES, *B = A + TILE_BYTES;
+#pragma unroll
+            for (uint32_t ks = 0; ks < 4; ks++) {
+                bf16x8 af[2], bf[2];
+#pragma unroll
+                for (uint32_t m = 0; m < 2; m++)
+                    af[m] = *reinterpret_cast<const bf16x8 *>(A + lds_off(wm * 64u + m * 32u + fr, 2u * ks + fh));
+#pragma unroll
+                for (uint32_t n = 0; n < 2; n++)
+                    bf[n] = *reinterpret_cast<const bf16x8 *>(B + lds_off(wn * 64u + n * 32u + fr, 2u * ks + fh));
+#pragma unroll
+                for (int m = 0; m < 2; m++)
+#pragma unroll
+                    for (int n = 0; n < 2; n++)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bf[n], acc[m][n], 0, 0, 0);
+            }
+            __syncthreads();  // next stage landed; everyone is done reading this one
+        }
+        // C[row][col], col = lane & 31 (j), row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5) (i)
+#pragma unroll
+        for (uint32_t m = 0; m < 2; m++)
+#pragma unroll
+            for (uint32_t n = 0; n < 2; n++) {
+                const uint32_t j = j0 + wn * 64u + n * 32u + fr;
+#pragma unroll
+                for (uint32_t e = 0; e < 16; e++) {
+                    if (acc[m][n][e] >= a.thr_lo) {
+                        const uint32_t i = i0 + wm * 64u + m * 32u + (e & 3u) + 8u * (e >> 2) + 4u * fh;
+                        emit(i, j);
+                        if (mirror) emit(j, i);
                     }
                 }
             }
+    } else {
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int n = 0; n < 4; n++) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const uint32_t fr = lane & 15u, fq = lane >> 4;   // A/B: row fr of the 16-row block, k quarter fq (8 bf16)
+        stage(0, 0);
+        __syncthreads();
+        for (uint32_t kt = 0; kt < KT; kt++) {
+            const uint32_t buf = kt & 1u;
+            if (kt + 1 < KT) stage(buf ^ 1u, kt + 1);
+            const char *A = smem + buf * 2 * TILE_BYTES, *B = A + TILE_BYTES;
+#pragma unroll
+            for (uint32_t ks = 0; ks < 2; ks++) {       // two 32-deep k-steps per 64-deep stage
+                bf16x8 af[4], bf[4];
+#pragma unroll
+                for (uint32_t m = 0; m < 4; m++)
+                    af[m] = *reinterpret_cast<const bf16x8 *>(A + lds_off(wm * 64u + m * 16u + fr, 4u * ks + fq));
+#pragma unroll
+                for (uint32_t n = 0; n < 4; n++)
+                    bf[n] = *reinterpret_cast<const bf16x8 *>(B + lds_off(wn * 64u + n * 16u + fr, 4u * ks + fq));
+#pragma unroll
+                for (int m = 0; m < 4; m++)
+#pragma unroll
+                    for (int n = 0; n < 4; n++)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bf[n], acc[m][n], 0, 0, 0);
+            }
+            __syncthreads();
         }
+        // C[row][col], col = lane & 15 (j), row = 4*(lane >> 4) + e (i)
+#pragma unroll
+        for (uint32_t m = 0; m < 4; m++)
+#pragma unroll
+            for (uint32_t n = 0; n < 4; n++) {
+                const uint32_t j = j0 + wn * 64u + n * 16u + fr;
+#pragma unroll
+                for (uint32_t e = 0; e < 4; e++) {
+                    if (acc[m][n][e] >= a.thr_lo) {
+                        const uint32_t i = i0 + wm * 64u + m * 16u + 4u * fq + e;
+                        emit(i, j);
+                        if (mirror) emit(j, i);
+                    }
+                }
+            }
+    }
+}
+
+void pair_filter_tile_list(uint32_t n_rows, std::vector<uint32_t> &out) {
+    const uint32_t tiles = (n_rows + BM - 1) / BM, GS = 8;
+    out.clear();
+    out.reserve((size_t)tiles * (tiles + 1) / 2);
+    for (uint32_t g0 = 0; g0 < tiles; g0 += GS) {          // 8 I-panels at a time ...
+        const uint32_t g1 = g0 + GS < tiles ? g0 + GS : tiles;
+        for (uint32_t tj = g0; tj < tiles; tj++)            // ... walking the J-panels to their right
+            for (uint32_t ti = g0; ti < g1 && ti <= tj; ti++) out.push_back((ti << 16) | tj);
+    }
 }
 
 int launch_pair_filter(const PairFilterArgs &a, hipStream_t stream) {
+    if (a.symmetric && (!a.tile_list || (a.n_rows + BM - 1) / BM > 0xFFFFu))
+        return set_err(CX_ERR_VALIDATION, "pair filter: symmetric pass needs a tile list and < 65536 tiles per side");
     if (a.dim % BK != 0 || a.dim == 0) return set_err(CX_ERR_VALIDATION, "pair filter needs dim %% 64 == 0 (got %u)", a.dim);
     if (!a.n_scan || !a.n_rows) return CX_OK;
-    const uint64_t tiles = (uint64_t)((a.n_scan + BM - 1) / BM) * ((a.n_rows + BN - 1) / BN);
+    const uint64_t tiles = a.symmetric ? a.n_tiles : (uint64_t)((a.n_scan + BM - 1) / BM) * ((a.n_rows + BN - 1) / BN);
     if (tiles > 0x7FFFFFFFull) return set_err(CX_ERR_VALIDATION, "pair filter: too many tiles");
     static bool attr_set = false;
     if (!attr_set) {
-        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_filter_kernel),
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_filter_kernel<32>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_filter_kernel<16>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL(pair_filter_kernel, dim3((uint32_t)tiles), dim3(256), LDS_BYTES, stream, a);
+    static const int shape = getenv("CX_PAIR_MFMA") ? atoi(getenv("CX_PAIR_MFMA")) : 16;  // +5 % over 32x32x16 (profiles/r01)
+    if (shape == 16) hipLaunchKernelGGL(pair_filter_kernel<16>, dim3((uint32_t)tiles), dim3(256), LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL(pair_filter_kernel<32>, dim3((uint32_t)tiles), dim3(256), LDS_BYTES, stream, a);
     CX_HIP(hipGetLastError());
     return CX_OK;
 }

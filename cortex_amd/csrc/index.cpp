@@ -426,6 +426,7 @@ void cx_destroy(cx_index *ix) {
     (void)hipFree(ix->d_meta);
     (void)hipFree(ix->d_agent);
     (void)hipFree(ix->d_shadow);
+    (void)hipFree(ix->d_tile_list);
     if (ix->up_stream) (void)hipStreamDestroy(ix->up_stream);
     delete ix;
 }

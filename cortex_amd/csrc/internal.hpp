@@ -79,8 +79,11 @@ struct Ctx {
     float *h_scores = nullptr; size_t hs_cap = 0;
     float *h_dists = nullptr; size_t hd_cap = 0;
     uint32_t *h_counts = nullptr; size_t hc_cap = 0;
+    void *pass_scratch = nullptr;              // autolink.cpp's PassScratch (grow-only), freed through the hook
+    void (*pass_scratch_free)(void *) = nullptr;
 
     ~Ctx() {
+        if (pass_scratch && pass_scratch_free) pass_scratch_free(pass_scratch);
         (void)hipFree(d_query); (void)hipFree(d_part_keys); (void)hipFree(d_part_sims); (void)hipFree(d_out_rows);
         (void)hipFree(d_out_scores); (void)hipFree(d_out_dists); (void)hipFree(d_out_counts); (void)hipFree(d_excl);
         (void)hipFree(d_kinds); (void)hipFree(d_keys); (void)hipFree(d_keys2); (void)hipFree(d_sims); (void)hipFree(d_sims2);
@@ -120,6 +123,8 @@ struct cx_index {
     mutable uint64_t shadow_cap = 0;
     mutable uint64_t shadow_rows = 0;
     mutable std::vector<uint32_t> shadow_stale;
+    mutable uint32_t *d_tile_list = nullptr;   // live tiles of the symmetric all-pairs pass, cached per row count
+    mutable uint32_t tile_list_rows = 0, tile_list_n = 0;
     // measurement (cx_profile_*): event pairs around the scan kernel
     bool profiling = false;
     mutable std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;

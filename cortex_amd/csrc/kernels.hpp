@@ -1,6 +1,8 @@
 // kernels.hpp — host-callable launchers of the HIP kernels (internal API).
 #pragma once
 
+#include <vector>
+
 #include "common.hpp"
 
 namespace cx {
@@ -90,7 +92,12 @@ struct PairFilterArgs {
     uint32_t *cand_cnt;         // [n_scan], zeroed by the caller
     uint32_t *cand;             // [n_scan][cap]
     uint32_t cap;
+    uint32_t symmetric;         // scan set == all rows in order: compute tiles tj >= ti only, emit (i,j) and (j,i)
+    const uint32_t *tile_list;  // symmetric only: (ti << 16) | tj of every live tile, in launch order
+    uint32_t n_tiles;           // entries in tile_list
 };
+// live tiles of the symmetric pass in L2-friendly order (host side); tile = 128 rows
+void pair_filter_tile_list(uint32_t n_rows, std::vector<uint32_t> &out);
 int launch_pair_filter(const PairFilterArgs &a, hipStream_t stream);
 
 struct RescoreArgs {
