@@ -235,14 +235,21 @@ def autolink_leg(L, device: int, d: int, skip_cpu: bool, n: int = 100_000, thr: 
         if rep and (best is None or wall < best[0]):
             best = (wall, ph, ne)
     wall, ph, ne = best
-    flops = 2.0 * n * n * d
+    flops = 2.0 * n * n * d           # the full ordered matrix, no symmetry credit
+    tiles = -(-n // 128)
+    executed = 2.0 * 128 * 128 * d * (tiles * (tiles + 1) // 2)   # what the MFMAs actually ran: tiles tj >= ti only
     res = {
         "workload": f"auto-link all-pairs {n} x {d}, threshold {thr}, top-100, 50 edges/node, similarity rule only",
         "pairs_per_s": n * float(n) / wall, "wall_ms": wall * 1e3, "edges": ne,
         "phase_ms": {"shadow_refresh": ph[0], "mfma_filter_gemm": ph[1], "exact_rescore": ph[2], "link_rules": ph[3]},
         "roofline": {"bound": "mfma", "achieved": flops / (ph[1] * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                      "frac": flops / (ph[1] * 1e-3) / 2.5e15, "kernel": "cx::pair_filter_kernel",
-                     "algorithmic_flops_per_launch": flops, "dtype": "bf16 in, f32 accumulate"},
+                     "algorithmic_flops_per_launch": flops, "dtype": "bf16 in, f32 accumulate",
+                     "executed_flops_per_launch": executed, "executed_tflops": executed / (ph[1] * 1e-3) / 1e12,
+                     "executed_frac": executed / (ph[1] * 1e-3) / 2.5e15,
+                     "note": "cosine is symmetric: only tiles with tj >= ti are computed and each emits both directions, so the "
+                             "algorithmic rate (the contract's figure) is ~2x the executed MFMA rate; profiles/r01 holds the "
+                             "PMC MFMA-busy measurement of the kernel"},
     }
     if not skip_cpu:
         from oracle import oracle as O
