@@ -64,11 +64,17 @@ def main() -> None:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         args.gpus = world
+    # one rank per GPU; CX_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the N > 1 path
+    backend = os.environ.get("CX_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import cortex_amd
     from cortex_amd import _lib
@@ -99,10 +105,12 @@ def main() -> None:
     qptr = queries.data_ptr()
 
     def step(i: int) -> None:
-        knn.search(qptr + ((i * B) % (nq_pool - B + 1)) * d * 4)
+        # stream of queries: the all-gather of query i is hidden under the scan of query i+1 (N > 1)
+        knn.submit(qptr + ((i * B) % (nq_pool - B + 1)) * d * 4)
 
     for i in range(args.warmup):
         step(i)
+    knn.flush()
     torch.cuda.synchronize()
     ix.profile_read(reset=True)
     ix.profile_enable(True)
@@ -112,6 +120,7 @@ def main() -> None:
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    knn.flush()                      # every query's merged result is complete inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -127,7 +136,13 @@ def main() -> None:
     algo_bytes = float(n) * d * 4.0  # N*d*sizeof(f32) per query per shard; norms recomputed in-scan
     avg_ms = kern_ms / max(1, kern_n)
     achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    traffic = os.environ.get("CX_BENCH_TRAFFIC_BYTES")  # filled from a separate rocprofv3 --pmc pass
+    # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; gfx950 x2 read
+    # correction) whose summary is committed under profiles/; reported only for the shape it was taken on
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r01", "knn_1Mx768_pmc_v1.json")
+    if B == 1 and n == 1_000_000 and d == 768 and os.path.exists(pmc):
+        traffic = json.load(open(pmc)).get("scan_kernel_hbm_bytes_per_launch")
+        traffic_src = "profiles/r01/knn_1Mx768_pmc_v1.json"
     out = {
         "metric": "knn_queries_per_sec_1Mx768",
         "value": value,
@@ -149,7 +164,7 @@ def main() -> None:
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": float(traffic) if traffic else None,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": float(traffic) if traffic else None, "traffic_source": traffic_src,
             "kernel": "cx::scan_kernel" if B < 3 else "cx::batch_scan_kernel", "avg_kernel_ms": avg_ms, "launches": kern_n,
             "algorithmic_bytes_per_launch": algo_bytes,
         },
@@ -196,6 +211,12 @@ def cpu_baseline(ix, gen: torch.Tensor, queries: torch.Tensor, n: int, d: int, k
             if r in set(int(x) for x in e["row"]) or abs(float(s) - kth) <= 5e-5:
                 hits += 1
         max_ds = max(max_ds, float(np.max(np.abs(gs.astype(np.float64) - e["score"].astype(np.float64)))))
+    # the boundary as the reference calls it: host query in, host results out (3 KB H2D + k results D2H + sync)
+    t4 = time.perf_counter()
+    reps = 200
+    for i in range(reps):
+        ix.search_arrays(qs_h[i % len(qs_h)], k)
+    host_api_qps = reps / (time.perf_counter() - t4)
     # all host cores across queries: the reference's search_batch (rayon par_iter, :390-410)
     # the GPU box's CPU share is 16 hardware threads per GPU (os.cpu_count() reports the whole host)
     cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
@@ -209,6 +230,7 @@ def cpu_baseline(ix, gen: torch.Tensor, queries: torch.Tensor, n: int, d: int, k
     }
     extra = {
         "recall_at_k_vs_exact": hits / max(1, tot), "max_abs_score_diff_vs_oracle": max_ds,
+        "host_api_pcie_inclusive_qps": host_api_qps,
         "cpu_all_cores": {"value": nb / t3, "unit": "queries/s", "cores": cores,
                           "sample": f"{nb} queries in one search_batch, {cores} threads"},
     }

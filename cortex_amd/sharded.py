@@ -41,8 +41,12 @@ class ShardedKnn:
         self.device = device
         self.group = group
         self.words = packed_words(nq, k)
-        self.local = torch.zeros(self.words, dtype=torch.int32, device=device)
-        self.gathered = torch.zeros(world * self.words, dtype=torch.int32, device=device)
+        # two sets of exchange buffers: submit() pipelines the all-gather of batch i under the scan of batch i+1
+        self._locals = [torch.zeros(self.words, dtype=torch.int32, device=device) for _ in range(2)]
+        self._gathered = [torch.zeros(world * self.words, dtype=torch.int32, device=device) for _ in range(2)]
+        self.local, self.gathered = self._locals[0], self._gathered[0]
+        self._pending = None   # (work handle, buffer index) of the all-gather still in flight
+        self._seq = 0
         self.out_rows = torch.zeros((nq, k), dtype=torch.int64, device=device)
         self.out_scores = torch.zeros((nq, k), dtype=torch.float32, device=device)
         self.out_dists = torch.zeros((nq, k), dtype=torch.float32, device=device)
@@ -70,6 +74,44 @@ class ShardedKnn:
         else:
             self.gathered.copy_(self.local)
         self.merge_fn(self)
+
+
+    # -- pipelined stream of batches ------------------------------------------------------------
+    def submit(self, queries) -> None:
+        """Like search(), for a stream of batches: the all-gather of this batch is left in flight (async_op)
+        and its merge is enqueued by the NEXT submit()/flush(), after that call's local scan — so the
+        exchange latency hides under the next scan.  Results of a batch are complete after the following
+        submit() or flush(); out_* always hold the most recently merged batch."""
+        i = self._seq & 1
+        self.local, self.gathered = self._locals[i], self._gathered[i]
+        self.local_fn(queries, self.nq, self)
+        prev = self._pending
+        if self.world > 1:
+            work = dist.all_gather_into_tensor(self._gathered[i], self._locals[i], group=self.group, async_op=True)
+        else:
+            work = None
+            if self.merge_fn is not _hip_merge:
+                self._gathered[i].copy_(self._locals[i])
+        self._pending = (work, i)
+        self._seq += 1
+        if prev is not None:
+            self._finish(prev)
+
+    def flush(self) -> None:
+        if self._pending is not None:
+            self._finish(self._pending)
+            self._pending = None
+
+    def _finish(self, pending) -> None:
+        work, i = pending
+        if work is not None:
+            work.wait()   # the current stream waits for the collective; the host does not block
+        if self.world == 1 and self.merge_fn is _hip_merge:
+            return
+        keep = self.local, self.gathered
+        self.local, self.gathered = self._locals[i], self._gathered[i]
+        self.merge_fn(self)
+        self.local, self.gathered = keep
 
 
 def hip_local_fn(index) -> Callable:

@@ -25,7 +25,7 @@ def _free_port() -> int:
     return p
 
 
-def _worker(rank: int, world: int, port: int, n_total: int, d: int, k: int, nq: int, ragged: bool, out_q):
+def _worker(rank: int, world: int, port: int, n_total: int, d: int, k: int, nq: int, ragged: bool, pipelined: bool, out_q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -58,7 +58,14 @@ def _worker(rank: int, world: int, port: int, n_total: int, d: int, k: int, nq: 
                 di[qi, :m] = torch.from_numpy(e["distance"].copy())
 
         knn = ShardedKnn(rank, world, bases, nq, k, torch.device("cpu"), local_fn, merge_fn=reference_merge)
-        knn.search(qs)
+        if pipelined:
+            # stream of three batches; the answer checked below is the last one's
+            knn.submit(O.synth_queries(n_total, d, nq) * np.float32(-1.0))
+            knn.submit(qs[::-1].copy())
+            knn.submit(qs)
+            knn.flush()
+        else:
+            knn.search(qs)
         # every rank holds the same merged answer; compare with one oracle over the whole corpus
         full = O.OracleIndex(d)
         full.insert_batch(ids_for(n_total), rows)
@@ -75,14 +82,15 @@ def _worker(rank: int, world: int, port: int, n_total: int, d: int, k: int, nq: 
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_total,d,k,nq,ragged", [(400, 64, 10, 3, False), (120, 32, 7, 2, True)])
-def test_two_rank_gloo_sharded_search_equals_single_index(n_total, d, k, nq, ragged):
+@pytest.mark.parametrize("n_total,d,k,nq,ragged,pipelined", [(400, 64, 10, 3, False, False), (120, 32, 7, 2, True, False),
+                                                             (300, 64, 10, 2, False, True)])
+def test_two_rank_gloo_sharded_search_equals_single_index(n_total, d, k, nq, ragged, pipelined):
     from oracle import oracle as O
     O.build()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, d, k, nq, ragged, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, d, k, nq, ragged, pipelined, q)) for r in range(2)]
     [p.start() for p in procs]
     [p.join(120) for p in procs]
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
