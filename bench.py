@@ -174,6 +174,8 @@ def main() -> None:
         out["cpu_baseline"], extra = cpu_baseline(ix, gen, queries, n, d, k, args.cpu_seconds)
         out["extra"] = extra
     del gen
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out.setdefault("extra", {})["config1_10k_x_384_k5"] = config1_leg(L, local_rank)
     if rank == 0 and world == 1 and not args.no_autolink:
         out.setdefault("extra", {})["autolink_allpairs"] = autolink_leg(L, local_rank, d, args.no_cpu_baseline)
     if rank == 0:
@@ -235,6 +237,43 @@ def cpu_baseline(ix, gen: torch.Tensor, queries: torch.Tensor, n: int, d: int, k
                           "sample": f"{nb} queries in one search_batch, {cores} threads"},
     }
     return base, extra
+
+
+def config1_leg(L, device: int, n: int = 10_000, d: int = 384, k: int = 5, nq: int = 200):
+    """BASELINE config 1 (10k x 384, Cortex::search k=5): the GPU engine through the host API next to the
+    CPU paths the reference can take — exact brute force (the oracle) and HNSW (from-the-paper restatement of
+    instant-distance 0.6.1 with M=32, M0=64, ef_construction=100, ef_search=100; parity unpinned)."""
+    import cortex_amd
+    from oracle import oracle as O
+    rows = O.synth_rows(n, d)
+    qs = O.synth_queries(n, d, nq)
+    ids = synth_ids(0, n)
+    ix = cortex_amd.HipIndex(d, device=device)
+    ix.insert_batch(ids, rows)
+    ix.search_arrays(qs[0], k)
+    t0 = time.perf_counter()
+    got = [ix.search_arrays(q, k) for q in qs]
+    t_gpu = time.perf_counter() - t0
+    o = O.OracleIndex(d)
+    o.insert_batch(ids, rows)
+    t0 = time.perf_counter()
+    exact = [o.search(q, k) for q in qs[:50]]
+    t_bf = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    h = O.HnswBaseline(rows)
+    t_build = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ann = [h.search(q, k, 100) for q in qs]
+    t_ann = time.perf_counter() - t0
+    rec_h = sum(len(set(ann[i][0].tolist()) & set(exact[i]["row"].tolist())) for i in range(50)) / (50.0 * k)
+    g_rows = [g[0][:, 8:].copy().view(">u8").reshape(-1).astype(np.int64) for g in got[:50]]
+    rec_g = sum(len(set(g_rows[i].tolist()) & set(exact[i]["row"].tolist())) for i in range(50)) / (50.0 * k)
+    ix.close()
+    return {"gpu_host_api_qps": nq / t_gpu, "gpu_recall_at_5_vs_exact": rec_g,
+            "cpu_brute_force_qps_1thread": 50 / t_bf,
+            "cpu_hnsw_restatement": {"qps_1thread": nq / t_ann, "recall_at_5_vs_exact": rec_h, "build_s": t_build,
+                                     "params": "M=32 M0=64 ef_construction=100 ef_search=100",
+                                     "note": "restatement of instant-distance 0.6.1 from the HNSW paper; parity unpinned"}}
 
 
 def autolink_leg(L, device: int, d: int, skip_cpu: bool, n: int = 100_000, thr: float = 0.85):

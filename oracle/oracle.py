@@ -19,7 +19,7 @@ _LIB_PATH = os.path.join(_HERE, "libcortex_oracle.so")
 
 def build(force: bool = False) -> str:
     """Compile the C restatement with the flags in oracle/Makefile."""
-    srcs = [os.path.join(_HERE, f) for f in ("cortex_oracle.c", "cortex_synth.c", "cortex_oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("cortex_oracle.c", "cortex_synth.c", "cortex_hnsw.c", "cortex_oracle.h", "Makefile")]
     stale = force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
     if stale:
@@ -97,6 +97,13 @@ def lib():
         L.cxs_fill.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
                                C.c_size_t, C.c_uint32, C.c_void_p]
         L.cxs_centre.argtypes = [C.c_uint64, C.c_uint64, C.c_size_t, C.c_void_p]
+        L.cxo_hnsw_build.restype = C.c_void_p
+        L.cxo_hnsw_build.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_uint64]
+        L.cxo_hnsw_search.restype = C.c_size_t
+        L.cxo_hnsw_search.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+        L.cxo_hnsw_dist_evals.restype = C.c_uint64
+        L.cxo_hnsw_dist_evals.argtypes = [C.c_void_p]
+        L.cxo_hnsw_free.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -289,3 +296,26 @@ def synth_rows(n_total: int, d: int, row_lo: int = 0, n_rows: Optional[int] = No
 def synth_queries(n_total: int, d: int, nq: int, *, seed_centres: int = SEED_CORPUS) -> np.ndarray:
     """Held-out queries: same centres as the n_total-row corpus, fresh noise, no duplicates."""
     return synth_rows(n_total, d, 0, nq, flags=0, seed_rows=SEED_QUERIES, seed_centres=seed_centres)
+
+
+class HnswBaseline:
+    """CPU HNSW restatement (oracle/cortex_hnsw.c): a REPORTED BASELINE for the reference's approximate path
+    (instant-distance 0.6.1, not in /root/reference).  Parity unpinned — never used as a checker."""
+
+    def __init__(self, rows: np.ndarray, M: int = 32, M0: int = 64, ef_construction: int = 100, seed: int = 1):
+        self._L = lib()
+        self.rows = _f32(rows)
+        self._h = self._L.cxo_hnsw_build(self.rows.ctypes.data, self.rows.shape[0], self.rows.shape[1], M, M0,
+                                         ef_construction, seed)
+
+    def search(self, query, k: int, ef_search: int = 100):
+        q = _f32(query)
+        rows = np.zeros(max(1, k), dtype=np.uint32)
+        dist = np.zeros(max(1, k), dtype=np.float32)
+        n = self._L.cxo_hnsw_search(self._h, q.ctypes.data, k, ef_search, rows.ctypes.data, dist.ctypes.data)
+        return rows[:n], dist[:n]
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.cxo_hnsw_free(self._h)
+            self._h = None

@@ -86,3 +86,20 @@ def test_dedup_scan_and_autolink_semantics(oracle):
     edges = ix.autolink_pass([0, 3], 100, 0.75, 1, deleted)
     # per-node cap 1 (auto_linker.rs:261-263); deleted neighbour skipped (:240-243)
     assert [(int(e["from_row"]), int(e["to_row"])) for e in edges] == [(0, 2)]
+
+
+def test_hnsw_baseline_restatement_has_high_recall(oracle):
+    """The CPU HNSW baseline is only a reported number (parity unpinned); this checks it is a working ANN."""
+    n, d, k = 3000, 64, 10
+    rows = oracle.synth_rows(n, d)
+    qs = oracle.synth_queries(n, d, 20)
+    ix = oracle.OracleIndex(d)
+    ix.insert_batch(ids_for(n), rows)
+    h = oracle.HnswBaseline(rows)
+    hits = 0
+    for q in qs:
+        r, dist = h.search(q, k)
+        e = ix.search(q, k)
+        hits += len(set(r.tolist()) & set(e["row"].tolist()))
+        assert np.all(np.diff(dist) >= 0)
+    assert hits / (len(qs) * k) > 0.9
