@@ -139,10 +139,10 @@ def main() -> None:
     # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; gfx950 x2 read
     # correction) whose summary is committed under profiles/; reported only for the shape it was taken on
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r01", "knn_1Mx768_pmc_v1.json")
+    pmc = os.path.join(ROOT, "profiles", "r01", "knn_1Mx768_pmc_final.json")
     if B == 1 and n == 1_000_000 and d == 768 and os.path.exists(pmc):
         traffic = json.load(open(pmc)).get("scan_kernel_hbm_bytes_per_launch")
-        traffic_src = "profiles/r01/knn_1Mx768_pmc_v1.json"
+        traffic_src = "profiles/r01/knn_1Mx768_pmc_final.json"
     out = {
         "metric": "knn_queries_per_sec_1Mx768",
         "value": value,

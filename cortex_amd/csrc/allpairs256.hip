@@ -1,0 +1,218 @@
+// allpairs256.hip — the filter GEMM of the all-pairs pass for large scan sets: 256x256 tiles on a
+// 4-slot LDS ring with counted waits.
+//
+// Same contract as pair_filter_kernel (allpairs.hip): bf16 shadow rows in, candidate columns out, no score
+// matrix.  What changes is the pipeline (cdna_hip_programming.md §5 "Pipelining across barriers", T3+T4):
+//  - 256x256 block tile, BK = 32 (one mfma_f32_16x16x32_bf16 k-step), 8 waves as 2(M) x 4(N), each wave a
+//    128x64 sub-tile = 8x4 MFMA tiles (128 accumulator registers), two waves per SIMD;
+//  - per K-step a wave issues 4 LDS-DMA instructions (2 A + 2 B, 1 KiB each), 12 ds_read_b128 and 32 MFMAs:
+//    twice the MFMAs per DMA and 1.3x per LDS read of the 128^2 kernel;
+//  - LDS = ring of 4 slots x (A 16 KiB + B 16 KiB) = 128 KiB.  In step t a wave issues the DMA of step t+3 and
+//    the fragment reads of step t+1 (double-buffered registers), then the MFMAs of step t; the wait at the end
+//    of a step is `s_waitcnt vmcnt(4)` — this wave's part of step t+2 has landed, step t+3 stays in flight —
+//    followed by a RAW s_barrier (a __syncthreads() would drain vmcnt(0)).  All LDS is one array and there
+//    are no ordinary global loads in the loop, so hipcc adds no vmcnt(0) of its own (checked in the ISA).
+//  - RAW: slot t+2 is read (in step t+1) one barrier after the wait that retired it.  WAR: slot (t+3)%4 was
+//    last read in step t-2; those ds_reads retired before the MFMAs of step t-1 that consumed them.
+//  - 16-byte pieces of a 64-byte row are stored at piece ^ ((row >> 3 & 1) << 1): with rows at a 64-byte
+//    stride this makes every ds_read_b128 lane group hit 16 different bank groups.
+#include "kernels.hpp"
+
+namespace cx {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace p256 {
+constexpr int BM = 256, BN = 256, BK = 32, NS = 4;
+constexpr int OP_BYTES = BM * BK * 2;          // 16 KiB per operand per slot
+constexpr int SLOT_BYTES = 2 * OP_BYTES;       // 32 KiB
+constexpr int LDS_BYTES = NS * SLOT_BYTES;     // 128 KiB
+__device__ inline uint32_t off(uint32_t row, uint32_t piece) { return row * 64u + ((piece ^ (((row >> 3) & 1u) << 1)) << 4); }
+}  // namespace p256
+
+__global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArgs a) {
+    using namespace p256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t wm = wave >> 2, wn = wave & 3u;   // 2 x 4 waves: rows wm*128.., cols wn*64..
+
+    const uint32_t tiles_i = (a.n_scan + BM - 1) / BM, tiles_j = (a.n_rows + BN - 1) / BN;
+    const uint32_t T = a.symmetric ? a.n_tiles : tiles_i * tiles_j;
+    uint32_t b = blockIdx.x;
+    {
+        const uint32_t q = T / 8u, r = T % 8u, xcd = b % 8u;
+        b = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + b / 8u;
+    }
+    uint32_t ti, tj;
+    if (a.symmetric) {
+        const uint32_t t = a.tile_list[b];
+        ti = t >> 16;
+        tj = t & 0xFFFFu;
+    } else {
+        const uint32_t GS = 4u, per_group = GS * tiles_j;
+        const uint32_t group = b / per_group, first_i = group * GS;
+        const uint32_t gsz = (tiles_i - first_i) < GS ? (tiles_i - first_i) : GS;
+        ti = first_i + (b % per_group) % gsz;
+        tj = (b % per_group) / gsz;
+    }
+    const uint32_t i0 = ti * BM, j0 = tj * BN;
+
+    // loader: one LDS-DMA = 16 rows x 64 B; 16 per operand per slot, 2 per wave
+    const uint32_t lrow = lane >> 2, lpos = lane & 3u;
+    const uint16_t *srcA[2], *srcB[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const uint32_t r = (wave * 2u + (uint32_t)q) * 16u + lrow;
+        const uint32_t piece = lpos ^ (((r >> 3) & 1u) << 1);
+        uint32_t gi = i0 + r;
+        gi = gi < a.n_scan ? gi : a.n_scan - 1u;
+        const uint32_t ga = a.scan_rows ? a.scan_rows[gi] : gi;
+        uint32_t gb = j0 + r;
+        gb = gb < a.n_rows ? gb : a.n_rows - 1u;
+        srcA[q] = a.shadow + (size_t)ga * a.dim + piece * 8u;
+        srcB[q] = a.shadow + (size_t)gb * a.dim + piece * 8u;
+    }
+    auto stage = [&](uint32_t slot, uint32_t kt) {
+        char *A = smem + slot * SLOT_BYTES, *B = A + OP_BYTES;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const uint32_t o = (wave * 2u + (uint32_t)q) * 1024u;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcA[q] + kt * BK),
+                                             (__attribute__((address_space(3))) void *)(A + o), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcB[q] + kt * BK),
+                                             (__attribute__((address_space(3))) void *)(B + o), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int m = 0; m < 8; m++)
+#pragma unroll
+        for (int n = 0; n < 4; n++) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const uint32_t KT = a.dim / BK;
+    const uint32_t fr = lane & 15u, fq = lane >> 4;
+    // fragment read offsets inside an operand image (loop invariant)
+    uint32_t offA[8], offB[4];
+#pragma unroll
+    for (uint32_t m = 0; m < 8; m++) offA[m] = off(wm * 128u + m * 16u + fr, fq);
+#pragma unroll
+    for (uint32_t n = 0; n < 4; n++) offB[n] = OP_BYTES + off(wn * 64u + n * 16u + fr, fq);
+
+    // Software pipeline.  Fragment registers are double buffered (statically indexed: the K loop is unrolled
+    // by two): in step kt a wave first issues the DMA of step kt+3 and the ds_reads of step kt+1, then the 32
+    // MFMAs of step kt, whose operands were read during step kt-1.  Both waves of a SIMD run the same program
+    // in lockstep (one block per CU), so a stream that loads, then computes, then waits leaves the matrix pipe
+    // idle while both load; a stream whose loads sit under its own MFMAs keeps it fed.
+    bf16x8 fa0[8], fb0[4], fa1[8], fb1[4];
+    auto read_frags = [&](uint32_t kt, bf16x8 *fa, bf16x8 *fb) {
+        const char *S = smem + (kt & 3u) * SLOT_BYTES;
+#pragma unroll
+        for (int n = 0; n < 4; n++) fb[n] = *reinterpret_cast<const bf16x8 *>(S + offB[n]);
+#pragma unroll
+        for (int m = 0; m < 8; m++) fa[m] = *reinterpret_cast<const bf16x8 *>(S + offA[m]);
+    };
+    // FULL = steady state (steps kt+1 and kt+3 exist): no branches in the body, so hipcc keeps counted
+    // lgkmcnt waits; with the conditions inside it joins control flow and falls back to lgkmcnt(0) right
+    // after issuing the prefetch reads.
+    auto mfmas = [&](const bf16x8 *fa, const bf16x8 *fb) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int m = 0; m < 8; m++)
+#pragma unroll
+            for (int n = 0; n < 4; n++)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m], fb[n], acc[m][n], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto step_full = [&](uint32_t kt, const bf16x8 *fa, const bf16x8 *fb, bf16x8 *na, bf16x8 *nb) {
+        stage((kt + 3) & 3u, kt + 3);   // slot (kt-1)&3: its last ds_read was issued in step kt-2
+        read_frags(kt + 1, na, nb);      // landed: waited for before the barrier of step kt-1
+        mfmas(fa, fb);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // step kt+2 landed (read next step); kt+3 stays in flight
+        __builtin_amdgcn_s_barrier();
+    };
+    auto step_tail = [&](uint32_t kt, const bf16x8 *fa, const bf16x8 *fb, bf16x8 *na, bf16x8 *nb) {
+        if (kt + 3 < KT) stage((kt + 3) & 3u, kt + 3);
+        if (kt + 1 < KT) read_frags(kt + 1, na, nb);
+        mfmas(fa, fb);
+        if (kt + 3 < KT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    // prologue: steps 0..2 in flight; 0 and 1 must land (0 is read now, 1 during step 0)
+    stage(0, 0);
+    if (KT > 1) stage(1, 1);
+    if (KT > 2) stage(2, 2);
+    if (KT > 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, fa0, fb0);
+    uint32_t kt = 0;
+    for (; kt + 5 <= KT; kt += 2) {          // both steps of the pair have their kt+3 inside the K range
+        step_full(kt, fa0, fb0, fa1, fb1);
+        step_full(kt + 1, fa1, fb1, fa0, fb0);
+    }
+    for (; kt < KT; kt += 2) {
+        step_tail(kt, fa0, fb0, fa1, fb1);
+        if (kt + 1 < KT) step_tail(kt + 1, fa1, fb1, fa0, fb0);
+    }
+
+    // epilogue: C[row][col], col = lane & 15 (j), row = 4*(lane >> 4) + e (i)
+    const bool mirror = a.symmetric && ti != tj;
+    auto emit = [&](uint32_t i, uint32_t j) {
+        if (i < a.n_scan && j < a.n_rows) {
+            const uint32_t slot = atomicAdd(a.cand_cnt + i, 1u);
+            if (slot < a.cap) a.cand[(size_t)i * a.cap + slot] = j;
+        }
+    };
+#pragma unroll
+    for (uint32_t m = 0; m < 8; m++)
+#pragma unroll
+        for (uint32_t n = 0; n < 4; n++) {
+            const uint32_t j = j0 + wn * 64u + n * 16u + fr;
+#pragma unroll
+            for (uint32_t e = 0; e < 4; e++) {
+                if (acc[m][n][e] >= a.thr_lo) {
+                    const uint32_t i = i0 + wm * 128u + m * 16u + 4u * fq + e;
+                    emit(i, j);
+                    if (mirror) emit(j, i);
+                }
+            }
+        }
+}
+
+void pair_filter256_tile_list(uint32_t n_rows, std::vector<uint32_t> &out) {
+    const uint32_t tiles = (n_rows + p256::BM - 1) / p256::BM, GS = 4;
+    out.clear();
+    out.reserve((size_t)tiles * (tiles + 1) / 2);
+    for (uint32_t g0 = 0; g0 < tiles; g0 += GS) {
+        const uint32_t g1 = g0 + GS < tiles ? g0 + GS : tiles;
+        for (uint32_t tj = g0; tj < tiles; tj++)
+            for (uint32_t ti = g0; ti < g1 && ti <= tj; ti++) out.push_back((ti << 16) | tj);
+    }
+}
+
+int launch_pair_filter256(const PairFilterArgs &a, hipStream_t stream) {
+    using namespace p256;
+    if (a.dim % BK != 0 || a.dim == 0) return set_err(CX_ERR_VALIDATION, "pair filter 256 needs dim %% 32 == 0 (got %u)", a.dim);
+    if (!a.n_scan || !a.n_rows) return CX_OK;
+    if (a.symmetric && (!a.tile_list || (a.n_rows + BM - 1) / BM > 0xFFFFu))
+        return set_err(CX_ERR_VALIDATION, "pair filter 256: symmetric pass needs a tile list");
+    const uint64_t tiles = a.symmetric ? a.n_tiles : (uint64_t)((a.n_scan + BM - 1) / BM) * ((a.n_rows + BN - 1) / BN);
+    if (tiles > 0x7FFFFFFFull) return set_err(CX_ERR_VALIDATION, "pair filter 256: too many tiles");
+    static bool attr_set = false;
+    if (!attr_set) {
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_filter256_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(pair_filter256_kernel, dim3((uint32_t)tiles), dim3(512), LDS_BYTES, stream, a);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+
+}  // namespace cx

@@ -6,7 +6,7 @@ namespace {
 
 using namespace cx;
 
-constexpr uint32_t CHUNK_ROWS = 131072;  // scanned rows per filter launch (bounds the candidate scratch)
+constexpr uint32_t CHUNK_ROWS = 1u << 20;  // scanned rows per filter launch (bounds the candidate scratch: 2 GiB at cap 512)
 
 uint32_t cand_cap() {  // candidate slots per scanned row; rows that overflow are redone on the exact scan path
     const char *e = getenv("CX_PAIR_CAND_CAP");
@@ -131,15 +131,21 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
             f.cand_cnt = ps.d_cand_cnt;
             f.cand = ps.d_cand;
             f.cap = cap;
+            // large scan sets: 256x256 tiles on the 4-slot ring (allpairs256.hip); small ones (streaming ingest) keep
+            // the 128x128 kernel, where a mostly empty 256-row tile would waste MFMAs
+            static const int big_min = getenv("CX_PAIR_256_MIN") ? atoi(getenv("CX_PAIR_256_MIN")) : 1024;
+            const bool big = ix->dim % 32 == 0 && (int64_t)m >= big_min;
             static const int sym_ok = getenv("CX_PAIR_SYMMETRIC") ? atoi(getenv("CX_PAIR_SYMMETRIC")) : 1;
             f.symmetric = (sym_ok && !scan_rows && lo == 0 && m == n_rows && (n_rows + 127u) / 128u <= 0xFFFFu) ? 1u : 0u;
             f.tile_list = nullptr;
             f.n_tiles = 0;
             if (f.symmetric) {
                 std::lock_guard<std::mutex> g(ix->shadow_mu);
-                if (ix->tile_list_rows != n_rows || !ix->d_tile_list) {
+                if (ix->tile_list_rows != n_rows || !ix->d_tile_list || ix->tile_list_big != (big ? 1u : 0u)) {
                     std::vector<uint32_t> tl;
-                    pair_filter_tile_list(n_rows, tl);
+                    if (big) pair_filter256_tile_list(n_rows, tl);
+                    else pair_filter_tile_list(n_rows, tl);
+                    ix->tile_list_big = big ? 1u : 0u;
                     if (ix->d_tile_list) CX_HIP(hipFree(ix->d_tile_list));
                     ix->d_tile_list = nullptr;
                     CX_HIP(hipMalloc((void **)&ix->d_tile_list, tl.size() * 4));
@@ -160,7 +166,7 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
                 CX_HIP(hipStreamSynchronize(s));
                 f.scan_rows = ps.d_ident;
             }
-            if (int rc = launch_pair_filter(f, s)) return rc;
+            if (int rc = big ? launch_pair_filter256(f, s) : launch_pair_filter(f, s)) return rc;
             if (phase_ms && lo == 0) CX_HIP(hipEventRecord(ev[2], s));
             RescoreArgs r;
             r.rows = ix->d_rows;

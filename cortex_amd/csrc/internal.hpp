@@ -124,7 +124,7 @@ struct cx_index {
     mutable uint64_t shadow_rows = 0;
     mutable std::vector<uint32_t> shadow_stale;
     mutable uint32_t *d_tile_list = nullptr;   // live tiles of the symmetric all-pairs pass, cached per row count
-    mutable uint32_t tile_list_rows = 0, tile_list_n = 0;
+    mutable uint32_t tile_list_rows = 0, tile_list_n = 0, tile_list_big = 0;
     // measurement (cx_profile_*): event pairs around the scan kernel
     bool profiling = false;
     mutable std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;

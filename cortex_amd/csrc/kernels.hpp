@@ -98,6 +98,9 @@ struct PairFilterArgs {
 };
 // live tiles of the symmetric pass in L2-friendly order (host side); tile = 128 rows
 void pair_filter_tile_list(uint32_t n_rows, std::vector<uint32_t> &out);
+// 256x256-tile variant for large scan sets (allpairs256.hip); tile list with 256-row tiles
+void pair_filter256_tile_list(uint32_t n_rows, std::vector<uint32_t> &out);
+int launch_pair_filter256(const PairFilterArgs &a, hipStream_t stream);
 int launch_pair_filter(const PairFilterArgs &a, hipStream_t stream);
 
 struct RescoreArgs {
