@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256, 1) void batch_scan_kernel(const BatchArgs a) {
 
     if constexpr (DIAG) {
         if (lane == 0) {
-            unsigned long long *o = a.diag + ((size_t)blockIdx.x * 4 + wave) * 5;
+            unsigned long long *o = a.diag + ((size_t)blockIdx.x * 8 + wave) * 8;
             o[0] = t_stage; o[1] = t_mfma; o[2] = t_epi; o[3] = t_bar; o[4] = (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
         }
     }
@@ -266,6 +266,329 @@ __global__ __launch_bounds__(256, 1) void batch_scan_kernel(const BatchArgs a) {
     for (uint32_t l = 0; l < 16u; l++) compact(wave * 16u + l, readlane_f32(qq, (int)l));
     for (uint32_t l = 0; l < 16u; l++) {
         const uint32_t qs = wave * 16u + l;
+        if (qs >= a.nq) break;
+        const uint32_t n = c_cnt[qs];
+        const size_t base = ((size_t)qs * gridDim.x + blockIdx.x) * k;
+        const float qq_l = readlane_f32(qq, (int)l);
+        if (lane < k) {
+            const bool valid = lane < n;
+            const uint32_t row = valid ? c_rows[qs * capq + lane] : 0u;
+            const float sim = valid ? cosine_from_sums(c_dots[qs * capq + lane], qq_l, c_rrs[qs * capq + lane]) : 0.0f;
+            a.part_keys[base + lane] = valid ? cand_key(row, sim) : 0ull;
+            a.part_sims[base + lane] = sim;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// batch2: the same pass on bf16 split-precision MFMAs (the default).
+//
+// What the f32-MFMA kernel above taught (in-kernel stamps, profiles/r01/tuning.md): with one wave per SIMD
+// every phase serialises, an LDS-DMA costs ~180 cycles to issue, and the f32 MFMA alone needs 6.1k cycles
+// per 16-row tile.  Here
+//  - every f32 value is split once into bf16 hi + bf16 lo (hi = bf16(a), lo = bf16(a - hi): 16 mantissa
+//    bits) and a product is the four bf16 MFMAs hi*hi + hi*lo + lo*hi + lo*lo accumulated in f32
+//    (mfma_f32_16x16x32_bf16): 4 x 16 cycles per 32-deep step instead of 8 x 32 — a quarter of the matrix
+//    time.  Error per dot product <= 2^-16 * sum|a_i b_i| (residuals of the two splits), ~1e-6 in practice,
+//    inside the 5e-5 parity tolerance;
+//  - rows travel global -> VGPR (plain 16-byte loads, ~8 issue cycles each) -> split -> LDS as two bf16
+//    images (hi, lo), by the wave that loaded them: the conversion and the row norms are done once, and
+//    the MFMA loop is ds_read_b128 + MFMA only;
+//  - the queries live in registers already split (dim/4 VGPRs, as before).
+template <int D>
+struct Batch2Cfg {
+    static constexpr int ROW_BYTES = D * 2;                  // one bf16 image row
+    static constexpr int IMG_BYTES = BT_ROWS * ROW_BYTES;    // hi or lo image of a tile
+    static constexpr int TILE_BYTES = 2 * IMG_BYTES;         // = 16 rows x D x 4 B
+    static constexpr int LOADS = BT_ROWS * D * 4 / 1024 / 4; // 1 KiB wave loads per wave per tile (4 waves)
+    static constexpr int SEGS = D / 256;                     // 1 KiB segments per row
+    static_assert(D % 256 == 0 || D == 384, "dim must be 384 or a multiple of 256");
+};
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ inline void split4(const f32x4 v, bf16x4_t &hi, bf16x4_t &lo) {
+    hi = __builtin_convertvector(v, bf16x4_t);                       // round to nearest even, NaN stays NaN
+    const f32x4 back = __builtin_convertvector(hi, f32x4);
+    lo = __builtin_convertvector(v - back, bf16x4_t);
+}
+
+// byte offset of the 8-byte half `half` of 16-byte piece p of row i inside a bf16 image (XOR swizzle
+// inside each 256-byte segment, same involution as the f32 kernel)
+template <int D>
+__device__ inline uint32_t img_off(uint32_t i, uint32_t p, uint32_t half) {
+    return i * Batch2Cfg<D>::ROW_BYTES + (((p & ~15u) | ((p ^ i) & 15u)) << 4) + half * 8u;
+}
+
+// sum over the 64 lanes, result in every lane: four DPP steps inside each 16-lane row (VALU rate), then
+// two cross-row exchanges
+__device__ inline float wave_sum_dpp(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));  // row_mirror
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+template <int D, bool DIAG>
+__global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
+    using C = Batch2Cfg<D>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // LDS: [2 tiles: hi image | lo image][rr: 2 x 16 f32][cand rows | dots | rrs: 64 x capq][tau][cnt][tsq]
+    char *tiles = smem;
+    float *c_rr = reinterpret_cast<float *>(smem + 2 * C::TILE_BYTES);
+    const uint32_t capq = a.capq;
+    uint32_t *c_rows = reinterpret_cast<uint32_t *>(c_rr + 2 * BT_ROWS);
+    float *c_dots = reinterpret_cast<float *>(c_rows + BT_Q * capq);
+    float *c_rrs = c_dots + BT_Q * capq;
+    uint64_t *c_tau = reinterpret_cast<uint64_t *>(c_rrs + BT_Q * capq);
+    uint32_t *c_cnt = reinterpret_cast<uint32_t *>(c_tau + BT_Q);
+    float *c_tsq = reinterpret_cast<float *>(c_cnt + BT_Q);
+
+    // Wave roles: waves 0-3 are CONSUMERS (16 queries each in registers: MFMA loop, epilogue, candidate
+    // buffers), waves 4-7 are PRODUCERS (bring the next tile: global loads, bf16 split, row norms, LDS
+    // writes).  A consumer and a producer share each SIMD, so the producer's VALU/LDS work for tile t+1 runs
+    // under the consumer's MFMAs for tile t instead of after them (one wave per SIMD serialised every phase:
+    // profiles/r01/tuning.md).  One block barrier per tile hands the tile over.
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const bool consumer = __builtin_amdgcn_readfirstlane(wave) < 4u;
+    const uint32_t pw = wave & 3u;                 // consumer: query group; producer: row group of the tile
+    const uint32_t k = a.k, n_rows = a.n_rows;
+    const uint32_t n_tiles = (n_rows + BT_ROWS - 1) / BT_ROWS;
+    if (tid < BT_Q) { c_cnt[tid] = 0; c_tau[tid] = 0ull; c_tsq[tid] = -1.0f; }
+
+    unsigned long long t_stage = 0, t_mfma = 0, t_epi = 0, t_bar = 0, t_prev = 0, t_wait = 0, t_write = 0;
+    auto stamp = [&](unsigned long long &acc) {
+        if constexpr (DIAG) {
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            acc += t - t_prev;
+            t_prev = t;
+        }
+    };
+    auto stamp0 = [&]() {
+        if constexpr (DIAG) { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); t_prev = t; }
+    };
+
+    if (!consumer) {
+        // ------------------------------------------------------------------ producer
+        f32x4 ld[C::LOADS];
+        auto issue_loads = [&](uint32_t tile) {
+            const f32x4 *base = reinterpret_cast<const f32x4 *>(a.rows + ((size_t)tile * BT_ROWS + pw * 4u) * D);
+#pragma unroll
+            for (int e = 0; e < C::LOADS; e++) ld[e] = __builtin_nontemporal_load(base + e * 64 + lane);
+        };
+        auto write_tile = [&](uint32_t buf) {
+            char *hi_img = tiles + buf * C::TILE_BYTES, *lo_img = hi_img + C::IMG_BYTES;
+            float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int e = 0; e < C::LOADS; e++) {
+                // float index of the load inside the wave's 4 rows = e*256 + 4*lane: for dim % 256 == 0 the row
+                // is a compile-time constant and the column needs no division
+                const uint32_t base_r = (uint32_t)(e * 256) / D, base_c = (uint32_t)(e * 256) % D;
+                uint32_t r, col;
+                if (base_c + 256u <= (uint32_t)D) { r = base_r; col = base_c + lane * 4u; }
+                else { const uint32_t c2 = base_c + lane * 4u; r = base_r + (c2 >= (uint32_t)D ? 1u : 0u); col = c2 >= (uint32_t)D ? c2 - D : c2; }
+                const f32x4 v = ld[e];
+                bf16x4_t h, l;
+                split4(v, h, l);
+                const float s2 = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+                if (base_c + 256u <= (uint32_t)D) part[base_r] += s2;
+                else {
+#pragma unroll
+                    for (uint32_t rr_ = 0; rr_ < 4; rr_++) part[rr_] += (r == rr_) ? s2 : 0.0f;
+                }
+                const uint32_t o = img_off<D>(pw * 4u + r, col >> 3, (col >> 2) & 1u);
+                *reinterpret_cast<bf16x4_t *>(hi_img + o) = h;
+                *reinterpret_cast<bf16x4_t *>(lo_img + o) = l;
+            }
+            float sums[4];
+#pragma unroll
+            for (uint32_t rr_ = 0; rr_ < 4; rr_++) sums[rr_] = wave_sum_dpp(part[rr_]);
+            if (lane == 0) *reinterpret_cast<f32x4 *>(c_rr + buf * BT_ROWS + pw * 4u) = f32x4{sums[0], sums[1], sums[2], sums[3]};
+        };
+        uint32_t tile = blockIdx.x;
+        if (tile < n_tiles) { issue_loads(tile); write_tile(0); }
+        if (tile + gridDim.x < n_tiles) issue_loads(tile + gridDim.x);
+        __syncthreads();
+        stamp0();
+        uint32_t buf = 0;
+        for (; tile < n_tiles; tile += gridDim.x) {
+            const uint32_t next = tile + gridDim.x;
+            if (next < n_tiles) {
+                if constexpr (DIAG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(t_wait); }
+                write_tile(buf ^ 1u);     // buffer last read one tile ago, behind that tile's barrier
+                stamp(t_write);
+                if (next + gridDim.x < n_tiles) issue_loads(next + gridDim.x);
+            }
+            __syncthreads();
+            stamp(t_bar);
+            buf ^= 1u;
+        }
+        if constexpr (DIAG) {
+            if (lane == 0) {
+                unsigned long long *o = a.diag + ((size_t)blockIdx.x * 8 + wave) * 8;
+                o[3] = t_bar; o[5] = t_wait; o[6] = t_write;
+            }
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumer
+    // consumers are the critical path (producers wait >4k cycles per tile at the barrier): they win the
+    // VALU-issue arbitration on the SIMD they share with a producer
+    __builtin_amdgcn_s_setprio(2);
+    const uint32_t j = lane & 15u, kq = lane >> 4;
+    const uint32_t qslot = pw * 16u + j;
+    // queries -> split registers: step ks covers k = 32 ks .. 32 ks + 31; lane (j, kq) holds q_j[32 ks + 8 kq + e]
+    constexpr int KS = D / 32;
+    s16x8 qh[KS], ql[KS];
+    float qq = 0.0f;
+    {
+        const bool live = qslot < a.nq;
+        const f32x4 *q4 = reinterpret_cast<const f32x4 *>(a.queries + (size_t)(live ? qslot : 0) * D);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            f32x4 v0 = q4[8 * ks + 2 * kq], v1 = q4[8 * ks + 2 * kq + 1];
+            if (!live) { v0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; v1 = v0; }
+            qq += v0.x * v0.x + v0.y * v0.y + v0.z * v0.z + v0.w * v0.w + v1.x * v1.x + v1.y * v1.y + v1.z * v1.z + v1.w * v1.w;
+            bf16x4_t h0, l0, h1, l1;
+            split4(v0, h0, l0);
+            split4(v1, h1, l1);
+            const bf16x8_t H = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+            const bf16x8_t L = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+            qh[ks] = __builtin_bit_cast(s16x8, H);
+            ql[ks] = __builtin_bit_cast(s16x8, L);
+        }
+    }
+    qq += __shfl_xor(qq, 16, 64);
+    qq += __shfl_xor(qq, 32, 64);
+
+    // A-operand read offsets (hi image; lo image = + IMG_BYTES): lane (i = j, kq) reads piece 4 ks + kq of row i
+    uint32_t a_off[4];
+#pragma unroll
+    for (uint32_t ksl = 0; ksl < 4; ksl++) a_off[ksl] = j * C::ROW_BYTES + ((((4u * ksl + kq) ^ j) & 15u) << 4);
+
+    unsigned long long n_compact = 0, n_append_steps = 0;
+    auto compact = [&](uint32_t qs, float qq_of) {
+        if constexpr (DIAG) n_compact++;
+        const uint32_t n = c_cnt[qs] < capq ? c_cnt[qs] : capq;
+        uint32_t *rws = c_rows + qs * capq;
+        float *dts = c_dots + qs * capq, *rrs = c_rrs + qs * capq;
+        uint32_t r0 = 0, r1 = 0; float d0 = 0.0f, d1 = 0.0f, n0 = 1.0f, n1 = 1.0f; uint64_t k0 = 0ull, k1 = 0ull;
+        if (lane < n) { r0 = rws[lane]; d0 = dts[lane]; n0 = rrs[lane]; k0 = cand_key(r0, cosine_from_sums(d0, qq_of, n0)); }
+        if (lane + 64u < n) { r1 = rws[lane + 64u]; d1 = dts[lane + 64u]; n1 = rrs[lane + 64u]; k1 = cand_key(r1, cosine_from_sums(d1, qq_of, n1)); }
+        uint32_t rank0 = 0, rank1 = 0;
+        const uint32_t n_lo = n < 64u ? n : 64u;
+        for (uint32_t f = 0; f < n_lo; f++) {
+            const uint64_t kf = readlane_u64(k0, (int)f);
+            rank0 += kf > k0 ? 1u : 0u;
+            rank1 += kf > k1 ? 1u : 0u;
+        }
+        for (uint32_t f = 64u; f < n; f++) {
+            const uint64_t kf = readlane_u64(k1, (int)(f - 64u));
+            rank0 += kf > k0 ? 1u : 0u;
+            rank1 += kf > k1 ? 1u : 0u;
+        }
+        auto set_tau = [&](uint64_t kk, float dt, float nr) {
+            const float sm = cosine_from_sums(dt, qq_of, nr);
+            c_tau[qs] = kk;
+            c_tsq[qs] = sm > 0.0f ? sm * sm * (1.0f - 1.0e-4f) : -1.0f;
+        };
+        if (lane < n && rank0 < k) { rws[rank0] = r0; dts[rank0] = d0; rrs[rank0] = n0; if (rank0 == k - 1u) set_tau(k0, d0, n0); }
+        if (lane + 64u < n && rank1 < k) { rws[rank1] = r1; dts[rank1] = d1; rrs[rank1] = n1; if (rank1 == k - 1u) set_tau(k1, d1, n1); }
+        if (lane == 0) c_cnt[qs] = n < k ? n : k;
+    };
+
+    __syncthreads();   // tile 0 is in buffer 0
+    stamp0();
+    uint32_t buf = 0;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        {   // make room in the candidate buffers
+            uint64_t need = __ballot(kq == 0u && c_cnt[qslot] + 16u > capq);
+            while (need) {
+                const int l = __ffsll((unsigned long long)need) - 1;
+                need &= need - 1;
+                compact(pw * 16u + (uint32_t)l, readlane_f32(qq, l));
+            }
+        }
+        stamp(t_stage);
+        const char *Thi = tiles + buf * C::TILE_BYTES, *Tlo = Thi + C::IMG_BYTES;
+        // epilogue operands are read now, under the MFMA loop, not after it
+        const float tsq = c_tsq[qslot];
+        const f32x4 rr4 = *reinterpret_cast<const f32x4 *>(c_rr + buf * BT_ROWS + 4u * kq);
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        constexpr int CH = 2, NCH = KS / CH;
+        static_assert(KS % CH == 0, "dim/32 must be even");
+        auto rdh = [&](int ks) { return *reinterpret_cast<const s16x8 *>(Thi + a_off[ks & 3] + (uint32_t)(ks >> 2) * 256u); };
+        auto rdl = [&](int ks) { return *reinterpret_cast<const s16x8 *>(Tlo + a_off[ks & 3] + (uint32_t)(ks >> 2) * 256u); };
+        s16x8 ha[CH], la[CH], hb[CH], lb[CH];
+#pragma unroll
+        for (int u = 0; u < CH; u++) { ha[u] = rdh(u); la[u] = rdl(u); }
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            s16x8 *ch = (c & 1) ? hb : ha, *cl = (c & 1) ? lb : la, *nh = (c & 1) ? ha : hb, *nl = (c & 1) ? la : lb;
+            if (c + 1 < NCH) {
+#pragma unroll
+                for (int u = 0; u < CH; u++) { nh[u] = rdh((c + 1) * CH + u); nl[u] = rdl((c + 1) * CH + u); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < CH; u++) {
+                const int ks = c * CH + u;
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cl[u], ql[ks], acc, 0, 0, 0);   // small terms first
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cl[u], qh[ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ch[u], ql[ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ch[u], qh[ks], acc, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stamp(t_mfma);
+
+        // epilogue: lane (j, kq) holds rows 4 kq + r of query j.  All four tests first, one wave-level branch:
+        // after warm-up no lane has a survivor and the wave falls through
+        const uint32_t row0 = tile * BT_ROWS;
+        const float tq = tsq * qq;
+        const bool live = qslot < a.nq;
+        uint32_t mask = 0;
+#pragma unroll
+        for (uint32_t r = 0; r < 4; r++) {
+            const float rr = rr4[r], dot = acc[r];
+            const bool maybe = tsq < 0.0f || (dot > 0.0f && dot * dot >= tq * rr) || !(dot == dot) || !(rr == rr);
+            mask |= (maybe && live && row0 + 4u * kq + r < n_rows) ? (1u << r) : 0u;
+        }
+        if (__ballot(mask != 0u)) {
+            if constexpr (DIAG) n_append_steps++;
+#pragma unroll
+            for (uint32_t r = 0; r < 4; r++) {
+                const uint32_t row = row0 + 4u * kq + r;
+                if (((mask >> r) & 1u) && row_passes(a.flt, row)) {
+                    const uint32_t slot = atomicAdd(&c_cnt[qslot], 1u);
+                    if (slot < capq) { c_rows[qslot * capq + slot] = row; c_dots[qslot * capq + slot] = acc[r]; c_rrs[qslot * capq + slot] = rr4[r]; }
+                }
+            }
+        }
+        stamp(t_epi);
+        __syncthreads();
+        stamp(t_bar);
+        buf ^= 1u;
+    }
+    if constexpr (DIAG) {
+        if (lane == 0) {
+            unsigned long long *o = a.diag + ((size_t)blockIdx.x * 8 + wave) * 8;
+            o[0] = t_stage; o[1] = t_mfma; o[2] = t_epi; o[3] = t_bar; o[4] = (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+            o[5] = n_compact; o[6] = n_append_steps;
+        }
+    }
+    for (uint32_t l = 0; l < 16u; l++) compact(pw * 16u + l, readlane_f32(qq, (int)l));
+    for (uint32_t l = 0; l < 16u; l++) {
+        const uint32_t qs = pw * 16u + l;
         if (qs >= a.nq) break;
         const uint32_t n = c_cnt[qs];
         const size_t base = ((size_t)qs * gridDim.x + blockIdx.x) * k;
@@ -293,33 +616,43 @@ bool batch_supported(uint32_t dim, uint32_t k) { return (dim == 384 || dim == 76
 
 template <int D>
 static int launch_batch_d(BatchArgs a, uint32_t grid, hipStream_t stream) {
-    const size_t lds = 2 * (size_t)BatchCfg<D>::TILE_BYTES + (size_t)BT_Q * a.capq * 12 + BT_Q * 8 + BT_Q * 4 + BT_Q * 4;
+    static const int use_f32 = getenv("CX_BATCH_F32MFMA") ? atoi(getenv("CX_BATCH_F32MFMA")) : 0;
+    const size_t tail = (size_t)BT_Q * a.capq * 12 + BT_Q * 8 + BT_Q * 4 + BT_Q * 4;
+    const size_t lds = use_f32 ? 2 * (size_t)BatchCfg<D>::TILE_BYTES + tail
+                               : 2 * (size_t)Batch2Cfg<D>::TILE_BYTES + 2 * BT_ROWS * 4 + tail;
     static bool attr_set = false;
     if (!attr_set) {
-        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch_scan_kernel<D, false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch_scan_kernel<D, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch_scan_kernel<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch_scan_kernel<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch2_kernel<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch2_kernel<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     if (getenv("CX_BATCH_DIAG")) {  // diagnostic build: per-phase cycle shares on stderr, results still valid
-        const size_t n = (size_t)grid * 4 * 5;
+        const size_t n = (size_t)grid * 8 * 8;   // up to 8 waves x 8 slots per block
         CX_HIP(hipMalloc((void **)&a.diag, n * 8));
-        hipLaunchKernelGGL((batch_scan_kernel<D, true>), dim3(grid), dim3(256), lds, stream, a);
+        CX_HIP(hipMemset(a.diag, 0, n * 8));
+        if (use_f32) hipLaunchKernelGGL((batch_scan_kernel<D, true>), dim3(grid), dim3(256), lds, stream, a);
+        else hipLaunchKernelGGL((batch2_kernel<D, true>), dim3(grid), dim3(512), lds, stream, a);
         CX_HIP(hipStreamSynchronize(stream));
         std::vector<unsigned long long> h(n);
         CX_HIP(hipMemcpy(h.data(), a.diag, n * 8, hipMemcpyDeviceToHost));
         CX_HIP(hipFree(a.diag));
-        double s[4] = {0, 0, 0, 0}, tiles = 0;
-        for (size_t w = 0; w < (size_t)grid * 4; w++) {
-            for (int p = 0; p < 4; p++) s[p] += (double)h[w * 5 + p];
-            tiles += (double)h[w * 5 + 4];
+        double s[7] = {0, 0, 0, 0, 0, 0, 0}, tiles = 0;
+        double pbar = 0, ncomp = 0, nappend = 0;
+        for (size_t w = 0; w < (size_t)grid * 8; w++) {
+            const bool cons = use_f32 || (w % 8) < 4;
+            if (cons) { for (int p = 0; p < 4; p++) s[p] += (double)h[w * 8 + p]; tiles += (double)h[w * 8 + 4]; ncomp += (double)h[w * 8 + 5]; nappend += (double)h[w * 8 + 6]; }
+            else { pbar += (double)h[w * 8 + 3]; s[5] += (double)h[w * 8 + 5]; s[6] += (double)h[w * 8 + 6]; }
         }
-        fprintf(stderr, "[batch diag] cycles per tile per wave: stage+check %.0f  mfma-loop %.0f  epilogue %.0f  barrier %.0f\n",
-                s[0] / tiles, s[1] / tiles, s[2] / tiles, s[3] / tiles);
+        fprintf(stderr, "[batch diag] producer barrier wait per tile %.0f; per consumer wave-tile: compactions %.3f, tiles with appends %.3f\n", pbar / (tiles > 0 ? tiles : 1), ncomp / (tiles > 0 ? tiles : 1), nappend / (tiles > 0 ? tiles : 1));
+        fprintf(stderr, "[batch diag] cycles per tile per wave: stage+check %.0f  mfma-loop %.0f  epilogue %.0f  barrier %.0f"
+                        "  (load wait %.0f, split+write %.0f)\n",
+                s[0] / tiles, s[1] / tiles, s[2] / tiles, s[3] / tiles, s[5] / tiles, s[6] / tiles);
         return CX_OK;
     }
-    hipLaunchKernelGGL((batch_scan_kernel<D, false>), dim3(grid), dim3(256), lds, stream, a);
+    if (use_f32) hipLaunchKernelGGL((batch_scan_kernel<D, false>), dim3(grid), dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((batch2_kernel<D, false>), dim3(grid), dim3(512), lds, stream, a);
     CX_HIP(hipGetLastError());
     return CX_OK;
 }

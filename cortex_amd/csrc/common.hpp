@@ -53,12 +53,14 @@ struct DevFilter {
     uint32_t has_kinds;
     uint32_t has_agent;
     uint32_t agent_code;
+    uint32_t trivial;              // 1 = no filter and no removed rows: every row passes, skip the metadata read
 };
 
 constexpr uint32_t META_REMOVED = 1u;
 constexpr uint32_t META_HAS = 2u;
 
 __device__ inline bool row_passes(const DevFilter &f, uint32_t row) {
+    if (f.trivial) return true;
     const uint32_t m = f.meta[row];
     if (m & META_REMOVED) return false;
     for (uint32_t i = 0; i < f.n_exclude; i++)

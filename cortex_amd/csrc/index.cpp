@@ -163,6 +163,7 @@ int build_filter(const cx_index *ix, Ctx *c, const cx_filter *filter, hipStream_
     memset(&f, 0, sizeof f);
     f.meta = ix->d_meta;
     f.agent = ix->d_agent;
+    f.trivial = (!filter && ix->n_removed == 0) ? 1u : 0u;
     if (!filter) return CX_OK;
     if (filter->has_exclude && filter->n_exclude) {
         if (!filter->exclude_ids) return set_err(CX_ERR_VALIDATION, "filter: exclude_ids is null");
