@@ -46,6 +46,8 @@ SIGNATURES = {
     "cx_autolink_pass_rows": (C.c_int, [_P, _U64, _P, _U64, C.c_float, _U64, _P, _U64, _P, _P, _P, _P, _P]),
     "cx_dedup_scan_rows": (C.c_int, [_P, C.c_float, _P, _U64, _P, _P, _P, _P, _P]),
     "cx_autolink_pass_timed": (C.c_int, [_P, _U64, _P, _U64, C.c_float, _U64, _P, _P]),
+    "cx_autolink_lists_dev": (C.c_int, [_P, _U64, _P, _U64, C.c_float, _P, _P, _P, _P, _P]),
+    "cx_copy_rows_dev": (C.c_int, [_P, _U64, _U64, _P, _P]),
     "cx_search_dev": (C.c_int, [_P, _P, _U64, _P, _P, _P, _P, _P, _P]),
     "cx_search_batch_dev": (C.c_int, [_P, _U64, _P, _U64, _P, _P, _P, _P, _P, _P]),
     "cx_merge_topk_dev": (C.c_int, [C.c_int, _U64, _U64, _U64, _U64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

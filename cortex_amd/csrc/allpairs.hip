@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void pair_filter_kernel(const PairFilterArgs a
         const uint32_t ga = a.scan_rows ? a.scan_rows[gi] : gi;
         uint32_t gb = j0 + r;
         gb = gb < a.n_rows ? gb : a.n_rows - 1u;
-        srcA[q] = a.shadow + (size_t)ga * a.dim + piece * 8u;
+        srcA[q] = (a.shadow_q ? a.shadow_q : a.shadow) + (size_t)ga * a.dim + piece * 8u;
         srcB[q] = a.shadow + (size_t)gb * a.dim + piece * 8u;
     }
     auto stage = [&](uint32_t buf, uint32_t kt) {
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(const RescoreArgs a) {
     const bool vec4 = (dim & 3u) == 0;
     for (uint32_t i = wave; i < a.n_scan; i += n_waves) {
         const uint32_t qrow = a.scan_rows ? a.scan_rows[i] : i;
-        const float *q = a.rows + (size_t)qrow * dim;
+        const float *q = (a.q_rows ? a.q_rows : a.rows) + (size_t)qrow * dim;
         const uint32_t total = a.cand_cnt[i];
         const uint32_t cnt = total < a.cap ? total : a.cap;
         if (lane == 0) a.overflow[i] = total > a.cap ? 1u : 0u;
@@ -354,6 +354,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(const RescoreArgs a) {
             if (valid) {
                 a.out_rows[(size_t)i * a.topk + r] = key_row(top.key[s]);
                 a.out_scores[(size_t)i * a.topk + r] = score_of(distance_of(top.sim[s]));
+                if (a.out_dists) a.out_dists[(size_t)i * a.topk + r] = distance_of(top.sim[s]);
             }
             n_out += (uint32_t)__popcll(__ballot(valid));
         }

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArg
         const uint32_t ga = a.scan_rows ? a.scan_rows[gi] : gi;
         uint32_t gb = j0 + r;
         gb = gb < a.n_rows ? gb : a.n_rows - 1u;
-        srcA[q] = a.shadow + (size_t)ga * a.dim + piece * 8u;
+        srcA[q] = (a.shadow_q ? a.shadow_q : a.shadow) + (size_t)ga * a.dim + piece * 8u;
         srcB[q] = a.shadow + (size_t)gb * a.dim + piece * 8u;
     }
     auto stage = [&](uint32_t slot, uint32_t kt) {

@@ -122,6 +122,7 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
             const uint32_t m = std::min<uint32_t>(chunk, n_scan - lo);
             CX_HIP(hipMemsetAsync(ps.d_cand_cnt, 0, (size_t)m * 4, s));
             PairFilterArgs f;
+            memset(&f, 0, sizeof f);
             f.shadow = ix->d_shadow;
             f.scan_rows = d_scan ? d_scan + lo : nullptr;
             f.n_scan = m;
@@ -169,6 +170,7 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
             if (int rc = big ? launch_pair_filter256(f, s) : launch_pair_filter(f, s)) return rc;
             if (phase_ms && lo == 0) CX_HIP(hipEventRecord(ev[2], s));
             RescoreArgs r;
+            memset(&r, 0, sizeof r);
             r.rows = ix->d_rows;
             r.meta = ix->d_meta;
             r.scan_rows = f.scan_rows;
@@ -350,6 +352,104 @@ int cx_autolink_pass_timed(const cx_index *ix, uint64_t n_scan, const uint32_t *
     PassScratch &ps = scratch_of(lease.c);
     return pass_core(ix, lease.c, ps, n_scan, scan_rows, (uint32_t)topk, threshold, (uint32_t)max_edges_per_node, nullptr,
                      false, n_edges, phase_ms);
+}
+
+/* Ordered neighbour lists of nq external vectors against this shard (the multi-GPU building block of the
+ * all-pairs pass): bf16 shadow of the queries -> MFMA filter against the shard's shadow -> exact rescore.
+ * Lists that overflowed the candidate cap (and dims that are not a multiple of 64) are redone on the exact
+ * scan path; those lists are not thresholded (the rule walk applies the threshold anyway). */
+int cx_autolink_lists_dev(const cx_index *ix, uint64_t nq64, const float *d_queries, uint64_t topk64, float threshold,
+                          uint32_t *d_out_rows, float *d_out_scores, float *d_out_dists, uint32_t *d_out_counts,
+                          void *stream) {
+    if (!ix || !d_queries || !d_out_rows || !d_out_scores || !d_out_dists || !d_out_counts)
+        return set_err(CX_ERR_VALIDATION, "null argument");
+    if (topk64 == 0 || topk64 > TOPK_MAX) return set_err(CX_ERR_VALIDATION, "autolink lists: topk must be in 1..%u", TOPK_MAX);
+    if (nq64 > 0xFFFFFFF0ull) return set_err(CX_ERR_VALIDATION, "too many queries");
+    if (int rc = use_device(ix)) return rc;
+    const uint32_t nq = (uint32_t)nq64, topk = (uint32_t)topk64, n_rows = (uint32_t)ix->n_rows;
+    hipStream_t s = (hipStream_t)stream;
+    if (!nq) return CX_OK;
+    if (!n_rows) { CX_HIP(hipMemsetAsync(d_out_counts, 0, (size_t)nq * 4, s)); return CX_OK; }
+    CtxLease lease(ix);
+    if (!lease.c) return CX_ERR_DEVICE;
+    Ctx *c = lease.c;
+    PassScratch &ps = scratch_of(c);
+    const uint32_t cap = cand_cap();
+    std::vector<uint32_t> redo;
+    if (ix->dim % 64 == 0 && ix->dim > 0) {
+        if (int rc = ensure_shadow(ix, s)) return rc;
+        // query shadow lives in d_from scratch (uint32 words): nq*dim bf16 = nq*dim/2 words
+        if (int rc = ensure_dev(ps.d_from, ps.c_from, (size_t)nq * ix->dim / 2 + 16)) return rc;
+        uint16_t *d_qsh = reinterpret_cast<uint16_t *>(ps.d_from);
+        if (int rc = launch_build_shadow(d_queries, d_qsh, 0, nq, ix->dim, s)) return rc;
+        if (int rc = ensure_dev(ps.d_cand_cnt, ps.c_cand_cnt, (size_t)nq)) return rc;
+        if (int rc = ensure_dev(ps.d_cand, ps.c_cand, (size_t)nq * cap)) return rc;
+        if (int rc = ensure_dev(ps.d_overflow, ps.c_overflow, (size_t)nq)) return rc;
+        CX_HIP(hipMemsetAsync(ps.d_cand_cnt, 0, (size_t)nq * 4, s));
+        PairFilterArgs f;
+        memset(&f, 0, sizeof f);
+        f.shadow = ix->d_shadow;
+        f.shadow_q = d_qsh;
+        f.n_scan = nq;
+        f.n_rows = n_rows;
+        f.dim = ix->dim;
+        f.thr_lo = threshold - FILTER_EPS;
+        f.cand_cnt = ps.d_cand_cnt;
+        f.cand = ps.d_cand;
+        f.cap = cap;
+        static const int big_min = getenv("CX_PAIR_256_MIN") ? atoi(getenv("CX_PAIR_256_MIN")) : 1024;
+        if (int rc = ((int64_t)nq >= big_min) ? launch_pair_filter256(f, s) : launch_pair_filter(f, s)) return rc;
+        RescoreArgs r;
+        memset(&r, 0, sizeof r);
+        r.rows = ix->d_rows;
+        r.q_rows = d_queries;
+        r.meta = ix->d_meta;
+        r.cand_cnt = ps.d_cand_cnt;
+        r.cand = ps.d_cand;
+        r.n_scan = nq;
+        r.dim = ix->dim;
+        r.cap = cap;
+        r.topk = topk;
+        r.threshold = threshold;
+        r.out_rows = d_out_rows;
+        r.out_scores = d_out_scores;
+        r.out_dists = d_out_dists;
+        r.out_cnt = d_out_counts;
+        r.overflow = ps.d_overflow;
+        if (int rc = launch_rescore(r, s)) return rc;
+        std::vector<uint32_t> of(nq);
+        CX_HIP(hipMemcpyAsync(of.data(), ps.d_overflow, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+        CX_HIP(hipStreamSynchronize(s));
+        for (uint32_t i = 0; i < nq; i++)
+            if (of[i]) redo.push_back(i);
+    } else {
+        redo.resize(nq);
+        for (uint32_t i = 0; i < nq; i++) redo[i] = i;
+    }
+    if (!redo.empty()) {
+        DevFilter flt;
+        memset(&flt, 0, sizeof flt);
+        flt.meta = ix->d_meta;
+        flt.agent = ix->d_agent;
+        const uint32_t k_eff = std::min<uint32_t>(topk, n_rows);
+        for (uint32_t i : redo)
+            if (int rc = search_core(ix, c, d_queries + (size_t)i * ix->dim, nullptr, 1, k_eff, flt, 0.0f, false,
+                                     d_out_rows + (size_t)i * topk, d_out_scores + (size_t)i * topk,
+                                     d_out_dists + (size_t)i * topk, d_out_counts + i, s))
+                return rc;
+    }
+    CX_HIP(hipStreamSynchronize(s));   // the pooled scratch goes back with the lease
+    return CX_OK;
+}
+
+/* rows [row_lo, row_lo + n) of the shard copied to a caller buffer in HBM (e.g. to broadcast them to the other
+ * ranks as the scanned block of a sharded pass) */
+int cx_copy_rows_dev(const cx_index *ix, uint64_t row_lo, uint64_t n, float *d_dst, void *stream) {
+    if (!ix || !d_dst) return set_err(CX_ERR_VALIDATION, "null argument");
+    if (row_lo + n > ix->n_rows) return set_err(CX_ERR_VALIDATION, "rows [%llu, %llu) out of range", (unsigned long long)row_lo, (unsigned long long)(row_lo + n));
+    if (int rc = use_device(ix)) return rc;
+    if (n) CX_HIP(hipMemcpyAsync(d_dst, ix->d_rows + (size_t)row_lo * ix->dim, (size_t)n * ix->dim * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return CX_OK;
 }
 
 }  // extern "C"

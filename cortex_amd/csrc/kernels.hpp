@@ -85,7 +85,8 @@ int launch_build_shadow(const float *rows, uint16_t *shadow, uint32_t row_lo, ui
                         hipStream_t stream);
 
 struct PairFilterArgs {
-    const uint16_t *shadow;     // [n_rows][dim] bf16, L2-normalised rows
+    const uint16_t *shadow;     // [n_rows][dim] bf16, L2-normalised rows (the J operand)
+    const uint16_t *shadow_q;   // I operand if the scanned vectors are not rows of this shard ([n_scan][dim]); null = shadow
     const uint32_t *scan_rows;  // [n_scan] row of each scanned node, or null = identity
     uint32_t n_scan, n_rows, dim;
     float thr_lo;               // threshold - eps (bf16 error bound)
@@ -105,6 +106,8 @@ int launch_pair_filter(const PairFilterArgs &a, hipStream_t stream);
 
 struct RescoreArgs {
     const float *rows;
+    const float *q_rows;   // scanned vectors when they are not rows of this shard ([n_scan][dim]); null = rows
+    float *out_dists;      // optional [n_scan][topk]
     const uint32_t *meta;
     const uint32_t *scan_rows;
     const uint32_t *cand_cnt;

@@ -336,6 +336,15 @@ class HipIndex:
                                                    C.byref(ne), ph))
         return ne.value, list(ph)
 
+    def autolink_lists_dev(self, d_queries: int, nq: int, topk: int, threshold: float, d_rows: int, d_scores: int,
+                           d_dists: int, d_counts: int, stream: int = 0) -> None:
+        """cx_autolink_lists_dev: ordered neighbour lists of nq external vectors (HBM) against this shard."""
+        self._check(self._L.cx_autolink_lists_dev(self._h, nq, d_queries, int(topk), float(threshold), d_rows, d_scores,
+                                                  d_dists, d_counts, stream))
+
+    def copy_rows_dev(self, row_lo: int, n: int, d_dst: int, stream: int = 0) -> None:
+        self._check(self._L.cx_copy_rows_dev(self._h, row_lo, n, d_dst, stream))
+
     # -- measurement ---------------------------------------------------------
     def profile_enable(self, on: bool = True) -> None:
         self._check(self._L.cx_profile_enable(self._h, 1 if on else 0))

@@ -138,6 +138,86 @@ def _hip_merge(s: ShardedKnn) -> None:
         raise RuntimeError((L.cx_last_error() or b"").decode())
 
 
+class ShardedAutolink:
+    """The auto-linker's all-pairs similarity pass over row-range shards (SURVEY §8e): every rank owns a shard;
+    the scanned rows travel in blocks (the owner broadcasts a block of its f32 rows), every rank produces the
+    block's ordered neighbour lists against its own shard (cx_autolink_lists_dev: bf16 MFMA filter + exact
+    rescore), the lists are all-gathered and merged exactly like partial top-k lists (ShardedKnn), and the owner
+    walks the merged lists with the reference's rules (linker/auto_linker.rs:233-264, rules.rs:42-62).
+    Dedup needs no collective at all: each rank's threshold pairs are final (not built here).
+
+    lists_fn(queries, nq, knn) fills knn.local for a block; rows_fn(row_lo, n, tensor) copies own rows into the
+    block buffer.  Both are injectable (CPU gloo tests); hip_lists_fn / hip_rows_fn are the product paths."""
+
+    def __init__(self, rank: int, world: int, shard_rows: Sequence[int], dim: int, topk: int, device: torch.device,
+                 lists_fn: Callable, rows_fn: Callable, merge_fn=None, group=None, block: int = 2048):
+        self.rank, self.world, self.dim, self.topk, self.block = rank, world, dim, topk, block
+        self.shard_rows = [int(x) for x in shard_rows]
+        self.bases = np.concatenate([[0], np.cumsum(self.shard_rows)[:-1]]).astype(np.int64)
+        self.device, self.group = device, group
+        self.rows_fn = rows_fn
+        self.knn = ShardedKnn(rank, world, self.bases.tolist(), block, topk, device, lists_fn, merge_fn=merge_fn, group=group)
+        self.buf = torch.zeros((block, dim), dtype=torch.float32, device=device)
+
+    def run(self, threshold: float, max_edges_per_node: int, deleted: Optional[np.ndarray] = None):
+        """Edges proposed for the rows this rank owns: (from_global u64, to_global u64, weight f32), scan order then
+        score order.  deleted: optional flags over GLOBAL rows (storage tombstones, quirk Q2)."""
+        thr = np.float32(threshold)
+        out_f, out_t, out_w = [], [], []
+        for src in range(self.world):
+            n_src = self.shard_rows[src]
+            for lo in range(0, n_src, self.block):
+                m = min(self.block, n_src - lo)
+                if self.rank == src:
+                    self.buf.zero_()
+                    self.rows_fn(lo, m, self.buf)
+                if self.world > 1:
+                    dist.broadcast(self.buf, src, group=self.group)
+                self.knn.live = m
+                single = self.world == 1 and self.knn.merge_fn is _hip_merge
+                self.knn.search(self.buf)
+                if self.rank != src:
+                    continue
+                if single:   # one shard: the local lists are the answer
+                    if self.device.type == "cuda":
+                        torch.cuda.synchronize(self.device)
+                    r, sc, _, cnt = self.knn.chunk_views(self.knn.local)
+                    rows = (r[:m].cpu().numpy().astype(np.int64) & 0xFFFFFFFF)
+                    scores, counts = sc[:m].cpu().numpy(), cnt[:m].cpu().numpy()
+                else:
+                    if self.device.type == "cuda":
+                        torch.cuda.synchronize(self.device)
+                    rows = self.knn.out_rows[:m].cpu().numpy()
+                    scores, counts = self.knn.out_scores[:m].cpu().numpy(), self.knn.out_counts[:m].cpu().numpy()
+                self_g = self.bases[src] + lo + np.arange(m, dtype=np.int64)
+                valid = np.arange(self.topk)[None, :] < counts[:, None]
+                safe_rows = np.where(valid, rows, 0)
+                ok = valid & (rows != self_g[:, None]) & (scores >= thr)
+                if deleted is not None:
+                    ok &= ~deleted[safe_rows].astype(bool)
+                ok &= np.cumsum(ok, axis=1) <= max_edges_per_node
+                ii, jj = np.nonzero(ok)
+                out_f.append(self_g[ii]); out_t.append(rows[ii, jj]); out_w.append(scores[ii, jj])
+        cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt)
+        return cat(out_f, np.int64), cat(out_t, np.int64), cat(out_w, np.float32)
+
+
+def hip_lists_fn(index, threshold: float) -> Callable:
+    """lists_fn for a cortex_amd.HipIndex shard: queries = torch f32 [block, dim] on the device."""
+    def fn(queries: torch.Tensor, nq: int, s: ShardedKnn) -> None:
+        n = s.nq * s.k
+        base = s.local.data_ptr()
+        stream = torch.cuda.current_stream(s.device).cuda_stream
+        index.autolink_lists_dev(queries.data_ptr(), nq, s.k, threshold, base, base + 4 * n, base + 8 * n, base + 12 * n, stream)
+    return fn
+
+
+def hip_rows_fn(index) -> Callable:
+    def fn(row_lo: int, n: int, buf: torch.Tensor) -> None:
+        index.copy_rows_dev(row_lo, n, buf.data_ptr(), torch.cuda.current_stream(buf.device).cuda_stream)
+    return fn
+
+
 def reference_merge(s: ShardedKnn) -> None:
     """Plain torch/numpy statement of the merge (score desc, global row asc, NaN last) — used by the
     CPU gloo tests and as the checker of the HIP merge kernel in the GPU tests."""

@@ -173,6 +173,19 @@ int cx_autolink_pass_timed(const cx_index *ix, uint64_t n_scan, const uint32_t *
                            float threshold, uint64_t max_edges_per_node, uint64_t *n_edges,
                            double *phase_ms);
 
+/* Multi-GPU building block of the all-pairs pass: the ordered neighbour lists of nq
+ * EXTERNAL vectors (d_queries: nq x dimension f32 in HBM, e.g. a block of another shard's rows) against this
+ * shard: per query the rows with score >= threshold, best first, at most topk (<= 256).  Outputs in HBM:
+ * d_out_rows / d_out_scores / d_out_dists [nq][topk] (local row indices), d_out_counts [nq] — the layout
+ * cx_merge_topk_dev folds after the all-gather.  Lists that overflow the internal candidate cap come from
+ * the exact scan path and are not thresholded (the rule walk applies the threshold).  Synchronous. */
+int cx_autolink_lists_dev(const cx_index *ix, uint64_t nq, const float *d_queries, uint64_t topk, float threshold,
+                          uint32_t *d_out_rows, float *d_out_scores, float *d_out_dists,
+                          uint32_t *d_out_counts, void *stream);
+
+/* Copies rows [row_lo, row_lo + n) of the shard into a caller buffer in HBM (to broadcast a scanned block). */
+int cx_copy_rows_dev(const cx_index *ix, uint64_t row_lo, uint64_t n, float *d_dst, void *stream);
+
 /* ---- HBM-resident variants (multi-GPU shards, benchmarking) ----------- */
 
 /* As cx_search / cx_search_batch with the queries (dimension floats each)

@@ -87,3 +87,75 @@ def test_world_one_is_the_local_list(hip, oracle):
         e = o.search(qs[qi], 10)
         assert int(c[qi]) == 10
         assert_topk_parity(r[qi].cpu().numpy(), sc[qi].cpu().numpy(), e["row"], e["score"], what="world=1")
+
+
+@pytest.mark.parametrize("n,d,parts,thr,block", [(3000, 768, 3, 0.85, 1024), (2000, 384, 4, 0.75, 512), (900, 100, 2, 0.8, 400)])
+def test_sharded_autolink_equals_single_index_pass(hip, oracle, n, d, parts, thr, block):
+    """The all-pairs pass over row-range shards (external-query lists + all-gather layout + merge + rule walk)
+    proposes exactly the edges of the single-index pass; P shards live on the one GPU, the all-gather is
+    emulated by placing every shard's chunk where the collective would."""
+    from cortex_amd.sharded import ShardedAutolink, ShardedKnn, hip_lists_fn, hip_rows_fn, _hip_merge
+    dev = torch.device("cuda", 0)
+    rows = oracle.synth_rows(n, d)
+    ids = ids_for(n)
+    cuts = np.linspace(0, n, parts + 1).astype(int)
+    shards = []
+    for p in range(parts):
+        h = hip.HipIndex(d)
+        h.insert_batch(ids[cuts[p]:cuts[p + 1]], rows[cuts[p]:cuts[p + 1]])
+        shards.append(h)
+    whole = hip.HipIndex(d)
+    whole.insert_batch(ids, rows)
+    thr32 = float(np.float32(thr))
+    rng = np.random.default_rng(5)
+    deleted = (rng.random(n) < 0.05)
+    fr, to, w = whole.autolink_pass_rows(None, 100, thr32, 50, deleted.astype(np.uint8))
+    want = {}
+    for a, b, s in zip(fr, to, w):
+        want.setdefault(int(a), []).append((int(b), float(s)))
+
+    sizes = [int(cuts[p + 1] - cuts[p]) for p in range(parts)]
+    got = {}
+    # emulate the ranks: for every block, every "rank" computes its lists; rank `src` merges and walks the rules
+    drivers = [ShardedAutolink(p, parts, sizes, d, 100, dev, hip_lists_fn(shards[p], thr32), hip_rows_fn(shards[p]),
+                               block=block) for p in range(parts)]
+    bases = drivers[0].bases
+    for src in range(parts):
+        for lo in range(0, sizes[src], block):
+            m = min(block, sizes[src] - lo)
+            buf = drivers[src].buf
+            buf.zero_()
+            drivers[src].rows_fn(lo, m, buf)
+            owner = drivers[src].knn
+            for p in range(parts):
+                k = drivers[p].knn
+                k.local_fn(buf, block, k)
+                torch.cuda.synchronize()
+                owner.gathered[p * owner.words:(p + 1) * owner.words].copy_(k.local)
+            _hip_merge(owner)
+            torch.cuda.synchronize()
+            rws = owner.out_rows[:m].cpu().numpy(); sc = owner.out_scores[:m].cpu().numpy(); cnt = owner.out_counts[:m].cpu().numpy()
+            self_g = bases[src] + lo + np.arange(m)
+            valid = np.arange(100)[None, :] < cnt[:, None]
+            ok = valid & (rws != self_g[:, None]) & (sc >= np.float32(thr32)) & ~deleted[np.where(valid, rws, 0)]
+            ok &= np.cumsum(ok, axis=1) <= 50
+            for i, j in zip(*np.nonzero(ok)):
+                got.setdefault(int(self_g[i]), []).append((int(rws[i, j]), float(sc[i, j])))
+    assert got.keys() == want.keys()
+    for node in want:
+        assert [x[0] for x in got[node]] == [x[0] for x in want[node]], f"node {node}"
+        assert np.allclose([x[1] for x in got[node]], [x[1] for x in want[node]], atol=0, rtol=0)
+
+
+def test_sharded_autolink_world_one_run(hip, oracle):
+    from cortex_amd.sharded import ShardedAutolink, hip_lists_fn, hip_rows_fn
+    dev = torch.device("cuda", 0)
+    n, d = 1500, 768
+    rows = oracle.synth_rows(n, d)
+    h = hip.HipIndex(d)
+    h.insert_batch(ids_for(n), rows)
+    thr32 = float(np.float32(0.85))
+    sa = ShardedAutolink(0, 1, [n], d, 100, dev, hip_lists_fn(h, thr32), hip_rows_fn(h), block=512)
+    f, t, w = sa.run(thr32, 50)
+    fr, to, ww = h.autolink_pass_rows(None, 100, thr32, 50)
+    assert np.array_equal(f, fr.astype(np.int64)) and np.array_equal(t, to.astype(np.int64)) and np.array_equal(w, ww)

@@ -101,3 +101,65 @@ def test_two_rank_gloo_sharded_search_equals_single_index(n_total, d, k, nq, rag
 def test_packed_layout():
     from cortex_amd.sharded import packed_words
     assert packed_words(1, 10) == 32 and packed_words(64, 10) % 4 == 0 and packed_words(64, 10) >= 3 * 640 + 64
+
+
+def _autolink_worker(rank: int, world: int, port: int, n_total: int, d: int, thr: float, out_q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O
+        from cortex_amd.sharded import ShardedAutolink, reference_merge
+        from conftest import ids_for
+        sizes = [n_total - n_total // 3, n_total // 3]
+        bases = [0, sizes[0]]
+        rows = O.synth_rows(n_total, d)
+        lo, hi = bases[rank], bases[rank] + sizes[rank]
+        local = O.OracleIndex(d)
+        local.insert_batch(ids_for(n_total)[lo:hi], rows[lo:hi])
+        thr32 = float(np.float32(thr))
+        topk = 100
+
+        def lists_fn(queries, nq, s):  # the oracle stands in for cx_autolink_lists_dev
+            r, sc, di, cnt = s.chunk_views(s.local)
+            q = queries.numpy()
+            for qi in range(getattr(s, "live", nq)):
+                e = local.search_threshold(q[qi], thr32)[:topk]
+                m = len(e)
+                cnt[qi] = m
+                r[qi, :m] = torch.from_numpy(e["row"].astype(np.int32))
+                sc[qi, :m] = torch.from_numpy(e["score"].copy())
+                di[qi, :m] = torch.from_numpy(e["distance"].copy())
+            cnt[getattr(s, "live", nq):] = 0
+
+        def rows_fn(row_lo, n, buf):
+            buf[:n] = torch.from_numpy(rows[lo + row_lo:lo + row_lo + n])
+
+        sa = ShardedAutolink(rank, world, sizes, d, topk, torch.device("cpu"), lists_fn, rows_fn,
+                             merge_fn=reference_merge, block=64)
+        deleted = (np.arange(n_total) % 17 == 3)
+        f, t, w = sa.run(thr32, 50, deleted)
+        full = O.OracleIndex(d)
+        full.insert_batch(ids_for(n_total), rows)
+        e = full.autolink_pass(np.arange(lo, hi), topk, thr32, 50, deleted.astype(np.uint8))
+        ok = (np.array_equal(f, e["from_row"].astype(np.int64)) and np.array_equal(t, e["to_row"].astype(np.int64))
+              and np.array_equal(w, e["weight"]))
+        out_q.put((rank, bool(ok), len(f)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharded_autolink_equals_oracle_pass():
+    from oracle import oracle as O
+    O.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_autolink_worker, args=(r, 2, port, 300, 64, 0.75, q)) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(180) for p in procs]
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    got = sorted(q.get(timeout=5) for _ in range(2))
+    assert [g[:2] for g in got] == [(0, True), (1, True)] and all(g[2] > 0 for g in got)
