@@ -39,9 +39,15 @@ __device__ inline uint16_t f32_to_bf16_rne(float x) {  // finite inputs only
     return (uint16_t)(u >> 16);
 }
 
+// sum over the 64 lanes, result in every lane: four DPP steps inside each 16-lane row (VALU rate), then two
+// cross-row exchanges
 __device__ inline float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));  // row_mirror
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
     return v;
 }
 
@@ -309,41 +315,58 @@ __global__ __launch_bounds__(256) void rescore_kernel(const RescoreArgs a) {
             const f32x4 *q4 = reinterpret_cast<const f32x4 *>(q);
             for (uint32_t j = lane; j < dim / 4u; j += 64u) {
                 const f32x4 x = q4[j];
-                qq += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+                qq = fmaf(x.w, x.w, fmaf(x.z, x.z, fmaf(x.y, x.y, fmaf(x.x, x.x, qq))));
             }
         } else {
-            for (uint32_t j = lane; j < dim; j += 64u) qq += q[j] * q[j];
+            for (uint32_t j = lane; j < dim; j += 64u) qq = fmaf(q[j], q[j], qq);
         }
         qq = wave_sum(qq);
         WaveTopK<KS> top;
         top.init(a.topk);
-        for (uint32_t c = 0; c < cnt; c++) {
-            const uint32_t jrow = a.cand[(size_t)i * a.cap + c];
-            const float *p = a.rows + (size_t)jrow * dim;
-            float d0 = 0.0f, n0 = 0.0f;
+        // four candidates per step: their row loads and their reductions are independent, so the latency of
+        // one candidate's butterfly hides under the others' (one at a time the kernel was bound by 12 dependent
+        // cross-lane steps per candidate, not by the 13 TB/s of L2-served row reads)
+        for (uint32_t c0 = 0; c0 < cnt; c0 += 4) {
+            uint32_t jrow[4];
+            float d0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, n0[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int u = 0; u < 4; u++) jrow[u] = a.cand[(size_t)i * a.cap + (c0 + u < cnt ? c0 + u : cnt - 1u)];
             if (vec4) {
-                const f32x4 *p4 = reinterpret_cast<const f32x4 *>(p);
                 const f32x4 *q4 = reinterpret_cast<const f32x4 *>(q);
                 for (uint32_t j = lane; j < dim / 4u; j += 64u) {
-                    const f32x4 x = p4[j], y = q4[j];
-                    d0 += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
-                    n0 += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+                    const f32x4 y = q4[j];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const f32x4 x = reinterpret_cast<const f32x4 *>(a.rows + (size_t)jrow[u] * dim)[j];
+                        // explicit fixed-order FMA chains: a pair's score must not depend on which of the four
+                        // slots it landed in (left to the compiler, slots get different packed/scalar FMA trees)
+                        d0[u] = fmaf(x.w, y.w, fmaf(x.z, y.z, fmaf(x.y, y.y, fmaf(x.x, y.x, d0[u]))));
+                        n0[u] = fmaf(x.w, x.w, fmaf(x.z, x.z, fmaf(x.y, x.y, fmaf(x.x, x.x, n0[u]))));
+                    }
                 }
             } else {
                 for (uint32_t j = lane; j < dim; j += 64u) {
-                    const float x = p[j];
-                    d0 += x * q[j];
-                    n0 += x * x;
+                    const float y = q[j];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const float x = a.rows[(size_t)jrow[u] * dim + j];
+                        d0[u] = fmaf(x, y, d0[u]);
+                        n0[u] = fmaf(x, x, n0[u]);
+                    }
                 }
             }
-            d0 = wave_sum(d0);
-            n0 = wave_sum(n0);
-            const float sim = cosine_from_sums(d0, qq, n0);
-            const float score = score_of(distance_of(sim));
-            if (!(score >= a.threshold)) continue;              // rules.rs:50 / index.rs:386 (NaN fails)
-            if (a.meta[jrow] & META_REMOVED) continue;          // removed from the index
-            const uint64_t key = make_key(score, jrow);
-            if (key > top.tau) top.insert(key, sim);
+#pragma unroll
+            for (int u = 0; u < 4; u++) { d0[u] = wave_sum(d0[u]); n0[u] = wave_sum(n0[u]); }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (c0 + u >= cnt) break;
+                const float sim = cosine_from_sums(d0[u], qq, n0[u]);
+                const float score = score_of(distance_of(sim));
+                if (!(score >= a.threshold)) continue;              // rules.rs:50 / index.rs:386 (NaN fails)
+                if (a.meta[jrow[u]] & META_REMOVED) continue;       // removed from the index
+                const uint64_t key = make_key(score, jrow[u]);
+                if (key > top.tau) top.insert(key, sim);
+            }
         }
         // ordered list out
         uint32_t n_out = 0;
