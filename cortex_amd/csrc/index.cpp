@@ -355,28 +355,40 @@ int stage_queries(const cx_index *ix, Ctx *c, uint64_t nq, const float *queries,
     return CX_OK;
 }
 
-int ensure_out(Ctx *c, size_t entries, size_t nq) {
+// Results of a host-API call live in ONE device block [counts nq | pad][rows][scores][dists] mirrored by one
+// pinned host block, so they come back with a single D2H copy (four separate copies cost ~10 us of a ~40 us
+// small-corpus query).
+struct OutView {
+    uint32_t *counts, *rows;
+    float *scores, *dists;
+    size_t words;
+};
+OutView out_view(uint32_t *base, size_t entries, size_t nq) {
+    const size_t cpad = (nq + 3) / 4 * 4;
+    OutView v;
+    v.counts = base;
+    v.rows = base + cpad;
+    v.scores = reinterpret_cast<float *>(base + cpad + entries);
+    v.dists = reinterpret_cast<float *>(base + cpad + 2 * entries);
+    v.words = cpad + 3 * entries;
+    return v;
+}
+int ensure_out(Ctx *c, size_t entries, size_t nq, OutView &dev, OutView &host) {
     entries = std::max<size_t>(entries, 1);
-    if (int rc = ensure_dev(c->d_out_rows, c->or_cap, entries)) return rc;
-    if (int rc = ensure_dev(c->d_out_scores, c->os_cap, entries)) return rc;
-    if (int rc = ensure_dev(c->d_out_dists, c->od_cap, entries)) return rc;
-    if (int rc = ensure_dev(c->d_out_counts, c->oc_cap, std::max<size_t>(nq, 1))) return rc;
-    if (int rc = ensure_pinned(c->h_counts, c->hc_cap, std::max<size_t>(nq, 1))) return rc;
+    nq = std::max<size_t>(nq, 1);
+    const size_t words = (nq + 3) / 4 * 4 + 3 * entries;
+    if (int rc = ensure_dev(c->d_out_rows, c->or_cap, words)) return rc;
+    if (int rc = ensure_pinned(c->h_rows, c->hr_cap, words)) return rc;
+    dev = out_view(c->d_out_rows, entries, nq);
+    host = out_view(c->h_rows, entries, nq);
     return CX_OK;
 }
-
-int fetch_results(Ctx *c, size_t entries) {
-    entries = std::max<size_t>(entries, 1);
-    if (int rc = ensure_pinned(c->h_rows, c->hr_cap, entries)) return rc;
-    if (int rc = ensure_pinned(c->h_scores, c->hs_cap, entries)) return rc;
-    if (int rc = ensure_pinned(c->h_dists, c->hd_cap, entries)) return rc;
-    CX_HIP(hipMemcpyAsync(c->h_rows, c->d_out_rows, entries * 4, hipMemcpyDeviceToHost, c->stream));
-    CX_HIP(hipMemcpyAsync(c->h_scores, c->d_out_scores, entries * 4, hipMemcpyDeviceToHost, c->stream));
-    CX_HIP(hipMemcpyAsync(c->h_dists, c->d_out_dists, entries * 4, hipMemcpyDeviceToHost, c->stream));
+// counts + the first `entries_used` entries of each array would need gathers; the block is small, copy it whole
+int fetch_block(Ctx *c, const OutView &dev, const OutView &host) {
+    CX_HIP(hipMemcpyAsync(host.counts, dev.counts, dev.words * 4, hipMemcpyDeviceToHost, c->stream));
     CX_HIP(hipStreamSynchronize(c->stream));
     return CX_OK;
 }
-
 
 }  // namespace
 
@@ -603,20 +615,20 @@ int cx_search_batch(const cx_index *ix, uint64_t nq, const float *queries, uint6
     FilterUpload fu;
     if (int rc = build_filter(ix, c, filter, c->stream, fu)) return rc;
     const size_t entries = (size_t)nq * k_eff;
-    if (int rc = ensure_out(c, entries, nq)) return rc;
-    if (int rc = search_core(ix, c, c->d_query, tails.data(), nq, k_eff, fu.f, 0.0f, false, c->d_out_rows,
-                             c->d_out_scores, c->d_out_dists, c->d_out_counts, c->stream))
+    OutView dv, hv;
+    if (int rc = ensure_out(c, entries, nq, dv, hv)) return rc;
+    if (int rc = search_core(ix, c, c->d_query, tails.data(), nq, k_eff, fu.f, 0.0f, false, dv.rows, dv.scores, dv.dists,
+                             dv.counts, c->stream))
         return rc;
-    CX_HIP(hipMemcpyAsync(c->h_counts, c->d_out_counts, nq * 4, hipMemcpyDeviceToHost, c->stream));
-    if (int rc = fetch_results(c, entries)) return rc;
+    if (int rc = fetch_block(c, dv, hv)) return rc;
     for (uint64_t i = 0; i < nq; i++) {
-        const uint32_t cnt = c->h_counts[i];
+        const uint32_t cnt = hv.counts[i];
         out_counts[i] = cnt;
         for (uint32_t j = 0; j < cnt; j++) {
             const size_t src = (size_t)i * k_eff + j, dst = (size_t)i * k + j;
-            memcpy(out_ids + 16 * dst, &ix->ids[16 * (size_t)c->h_rows[src]], 16);
-            out_scores[dst] = c->h_scores[src];
-            out_distances[dst] = c->h_dists[src];
+            memcpy(out_ids + 16 * dst, &ix->ids[16 * (size_t)hv.rows[src]], 16);
+            out_scores[dst] = hv.scores[src];
+            out_distances[dst] = hv.dists[src];
         }
     }
     return CX_OK;
@@ -644,22 +656,26 @@ int cx_search_threshold(const cx_index *ix, const float *query, uint64_t len, fl
     if (int rc = stage_queries(ix, c, 1, query, len, tails)) return rc;
     FilterUpload fu;
     if (int rc = build_filter(ix, c, filter, c->stream, fu)) return rc;
-    if (int rc = ensure_out(c, n, 1)) return rc;
-    if (int rc = search_core(ix, c, c->d_query, tails.data(), 1, n, fu.f, threshold, true, c->d_out_rows,
-                             c->d_out_scores, c->d_out_dists, c->d_out_counts, c->stream))
+    OutView dv, hv;
+    if (int rc = ensure_out(c, n, 1, dv, hv)) return rc;
+    if (int rc = search_core(ix, c, c->d_query, tails.data(), 1, n, fu.f, threshold, true, dv.rows, dv.scores, dv.dists,
+                             dv.counts, c->stream))
         return rc;
-    CX_HIP(hipMemcpyAsync(c->h_counts, c->d_out_counts, 4, hipMemcpyDeviceToHost, c->stream));
+    CX_HIP(hipMemcpyAsync(hv.counts, dv.counts, 4, hipMemcpyDeviceToHost, c->stream));
     CX_HIP(hipStreamSynchronize(c->stream));
-    const uint64_t total = c->h_counts[0];
+    const uint64_t total = hv.counts[0];
     if (n_needed) *n_needed = total;
     const uint64_t take = std::min<uint64_t>(total, cap);
     if (take) {
         if (!out_ids || !out_scores || !out_distances) return set_err(CX_ERR_VALIDATION, "null output buffer");
-        if (int rc = fetch_results(c, take)) return rc;
+        CX_HIP(hipMemcpyAsync(hv.rows, dv.rows, take * 4, hipMemcpyDeviceToHost, c->stream));
+        CX_HIP(hipMemcpyAsync(hv.scores, dv.scores, take * 4, hipMemcpyDeviceToHost, c->stream));
+        CX_HIP(hipMemcpyAsync(hv.dists, dv.dists, take * 4, hipMemcpyDeviceToHost, c->stream));
+        CX_HIP(hipStreamSynchronize(c->stream));
         for (uint64_t j = 0; j < take; j++) {
-            memcpy(out_ids + 16 * j, &ix->ids[16 * (size_t)c->h_rows[j]], 16);
-            out_scores[j] = c->h_scores[j];
-            out_distances[j] = c->h_dists[j];
+            memcpy(out_ids + 16 * j, &ix->ids[16 * (size_t)hv.rows[j]], 16);
+            out_scores[j] = hv.scores[j];
+            out_distances[j] = hv.dists[j];
         }
     }
     *n_out = take;
