@@ -309,10 +309,20 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ inline void split4(const f32x4 v, bf16x4_t &hi, bf16x4_t &lo) {
-    hi = __builtin_convertvector(v, bf16x4_t);                       // round to nearest even, NaN stays NaN
-    const f32x4 back = __builtin_convertvector(hi, f32x4);
-    lo = __builtin_convertvector(v - back, bf16x4_t);
+    // hi = bf16(v) (round to nearest even, NaN stays NaN), lo = bf16(v - hi).  The packed conversion's result is
+    // unpacked with one shift / one mask per pair instead of being converted a second time element by element.
+    const uint32_t p01 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v.x, v.y}, bf16x2_t));
+    const uint32_t p23 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v.z, v.w}, bf16x2_t));
+    const float b0 = __uint_as_float(p01 << 16), b1 = __uint_as_float(p01 & 0xFFFF0000u);
+    const float b2 = __uint_as_float(p23 << 16), b3 = __uint_as_float(p23 & 0xFFFF0000u);
+    const uint32_t q01 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v.x - b0, v.y - b1}, bf16x2_t));
+    const uint32_t q23 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v.z - b2, v.w - b3}, bf16x2_t));
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    hi = __builtin_bit_cast(bf16x4_t, (u32x2){p01, p23});
+    lo = __builtin_bit_cast(bf16x4_t, (u32x2){q01, q23});
 }
 
 // byte offset of the 8-byte half `half` of 16-byte piece p of row i inside a bf16 image (XOR swizzle
@@ -338,7 +348,7 @@ template <int D, bool DIAG>
 __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
     using C = Batch2Cfg<D>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // LDS: [2 tiles: hi image | lo image][rr: 2 x 16 f32][cand rows | dots | rrs: 64 x capq][tau][cnt][tsq]
+    // LDS: [2 tiles: hi image | lo image][rr: 2 x 16 f32][cand rows | dots | rrs: 64 x capq][tau][cnt][tsq][pub][shr][qq]
     char *tiles = smem;
     float *c_rr = reinterpret_cast<float *>(smem + 2 * C::TILE_BYTES);
     const uint32_t capq = a.capq;
@@ -348,6 +358,9 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
     uint64_t *c_tau = reinterpret_cast<uint64_t *>(c_rrs + BT_Q * capq);
     uint32_t *c_cnt = reinterpret_cast<uint32_t *>(c_tau + BT_Q);
     float *c_tsq = reinterpret_cast<float *>(c_cnt + BT_Q);
+    uint32_t *c_pub = reinterpret_cast<uint32_t *>(c_tsq + BT_Q);   // entries of a list that are completely written
+    uint32_t *c_shr = c_pub + BT_Q;                                 // != 0: a producer compacted entries [0, c_shr) to [0, k)
+    float *c_qq = reinterpret_cast<float *>(c_shr + BT_Q);          // |q|^2 per query, for the producers
 
     // Wave roles: waves 0-3 are CONSUMERS (16 queries each in registers: MFMA loop, epilogue, candidate
     // buffers), waves 4-7 are PRODUCERS (bring the next tile: global loads, bf16 split, row norms, LDS
@@ -359,7 +372,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
     const uint32_t pw = wave & 3u;                 // consumer: query group; producer: row group of the tile
     const uint32_t k = a.k, n_rows = a.n_rows;
     const uint32_t n_tiles = (n_rows + BT_ROWS - 1) / BT_ROWS;
-    if (tid < BT_Q) { c_cnt[tid] = 0; c_tau[tid] = 0ull; c_tsq[tid] = -1.0f; }
+    if (tid < BT_Q) { c_cnt[tid] = 0; c_tau[tid] = 0ull; c_tsq[tid] = -1.0f; c_pub[tid] = 0; c_shr[tid] = 0; c_qq[tid] = 0.0f; }
 
     unsigned long long t_stage = 0, t_mfma = 0, t_epi = 0, t_bar = 0, t_prev = 0, t_wait = 0, t_write = 0;
     auto stamp = [&](unsigned long long &acc) {
@@ -384,7 +397,11 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
 #pragma unroll
             for (int e = 0; e < C::LOADS; e++) ld[e] = __builtin_nontemporal_load(base + e * 64 + lane);
         };
-        auto write_tile = [&](uint32_t buf) {
+        // split + write the tile held in ld[], and put each register back in flight for tile `reload` as soon as
+        // it has been consumed: the loads get a whole tile interval of flight time with one register set
+        auto write_tile = [&](uint32_t buf, uint32_t reload) {
+            const uint32_t rl = reload < n_tiles ? reload : n_tiles - 1u;   // past the end: a valid tile, never used
+            const f32x4 *rbase = reinterpret_cast<const f32x4 *>(a.rows + ((size_t)rl * BT_ROWS + pw * 4u) * D);
             char *hi_img = tiles + buf * C::TILE_BYTES, *lo_img = hi_img + C::IMG_BYTES;
             float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -396,6 +413,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
                 if (base_c + 256u <= (uint32_t)D) { r = base_r; col = base_c + lane * 4u; }
                 else { const uint32_t c2 = base_c + lane * 4u; r = base_r + (c2 >= (uint32_t)D ? 1u : 0u); col = c2 >= (uint32_t)D ? c2 - D : c2; }
                 const f32x4 v = ld[e];
+                ld[e] = __builtin_nontemporal_load(rbase + e * 64 + lane);
                 bf16x4_t h, l;
                 split4(v, h, l);
                 const float s2 = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
@@ -413,20 +431,123 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
             for (uint32_t rr_ = 0; rr_ < 4; rr_++) sums[rr_] = wave_sum_dpp(part[rr_]);
             if (lane == 0) *reinterpret_cast<f32x4 *>(c_rr + buf * BT_ROWS + pw * 4u) = f32x4{sums[0], sums[1], sums[2], sums[3]};
         };
+        // Candidate-list compaction runs HERE, on the producer waves (they have the registers; the consumers hold
+        // 16 queries in 192 VGPRs).  Producer wave pw owns the lists of consumer wave pw.  A list is compacted when
+        // its published length n0 reaches capq - 32: the best k of entries [0, n0) move to [0, k) in any order and
+        // tau is refreshed; the consumer keeps appending at [cnt, ...) meanwhile and, behind the next barrier,
+        // slides what it appended since down to k (c_shr = n0 tells it).  The k-th best score comes from a radix
+        // select over the 32-bit score order: one ballot + popcount per bit, all scalar.  Invariant: cnt <= capq - 16
+        // at every barrier, so 16 appends always fit.
+        //
+        // Global slots: a block only ever sees n_rows / grid rows, so its own k-th best is a loose bound for most
+        // of its life.  Blocks therefore share one: every survivor of a compaction is pushed into slot
+        // hash(row) % k of its query with an agent-scope atomic max on the bits of its cosine (> 0).  The k slots
+        // hold cosines of k DIFFERENT rows, so their minimum is a valid lower bound of the query's global k-th best
+        // cosine whichever blocks contributed — rows below it can be skipped by everyone.  Results do not depend
+        // on timing: the bound only removes rows that cannot be in the top k.
+        unsigned long long n_pcompact = 0;
+        uint64_t gv[4] = {0ull, 0ull, 0ull, 0ull};
+        const uint32_t g_q = pw * 16u + (lane >> 2), g_g = lane & 3u;
+        const uint32_t n_gld = (k + 7u) / 8u;   // lane (query, g) reads slot pairs 8 i + 2 g, 8 i + 2 g + 1
+        auto refresh_issue = [&]() {
+            const uint64_t *G = reinterpret_cast<const uint64_t *>(a.gslots + g_q * 32u) + g_g;
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++)
+                if (i < n_gld) gv[i] = __hip_atomic_load(G + 4u * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        auto refresh_apply = [&]() {
+            uint32_t mn = 0xFFFFFFFFu;
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++) {
+                const uint32_t s0 = 8u * i + 2u * g_g, lo = (uint32_t)gv[i], hi = (uint32_t)(gv[i] >> 32);
+                if (s0 < k) mn = lo < mn ? lo : mn;
+                if (s0 + 1u < k) mn = hi < mn ? hi : mn;
+            }
+            uint32_t o = (uint32_t)__shfl_xor((int)mn, 1, 64);
+            mn = o < mn ? o : mn;
+            o = (uint32_t)__shfl_xor((int)mn, 2, 64);
+            mn = o < mn ? o : mn;
+            if (g_g == 0u && mn != 0u && mn != 0xFFFFFFFFu) {   // every slot filled
+                const float sm = __uint_as_float(mn);
+                const float t = sm * sm * (1.0f - 1.0e-4f);
+                if (t > c_tsq[g_q]) c_tsq[g_q] = t;
+            }
+        };
+        auto producer_compact = [&]() {
+            uint32_t pubv = 0, shrv = 1;
+            if (lane < 16u) { pubv = c_pub[pw * 16u + lane]; shrv = c_shr[pw * 16u + lane]; }
+            uint64_t need = __ballot(lane < 16u && shrv == 0u && pubv + 32u >= capq && pubv > k);
+            while (need) {
+                const int l = __ffsll((unsigned long long)need) - 1;
+                need &= need - 1;
+                if constexpr (DIAG) n_pcompact++;
+                const uint32_t qs = pw * 16u + (uint32_t)l;
+                uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)pubv, l);
+                n = n < 64u ? n : 64u;
+                const float qq_of = c_qq[qs];
+                uint32_t *rws = c_rows + qs * capq;
+                float *dts = c_dots + qs * capq, *rrs = c_rrs + qs * capq;
+                const bool valid = lane < n;
+                uint32_t r0 = 0, ord = 0; float d0 = 0.0f, n0 = 1.0f, sim = 0.0f;
+                if (valid) { r0 = rws[lane]; d0 = dts[lane]; n0 = rrs[lane]; sim = cosine_from_sums(d0, qq_of, n0); ord = score_ord(score_of(distance_of(sim))); }
+                uint32_t T = 0;
+#pragma unroll 1
+                for (int b = 31; b >= 0; b--) {
+                    const uint32_t candT = T | (1u << b);
+                    if ((uint32_t)__popcll(__ballot(valid && ord >= candT)) >= k) T = candT;
+                }
+                const uint64_t gt = __ballot(valid && ord > T), eq = __ballot(valid && ord == T);
+                const uint32_t want_eq = k - (uint32_t)__popcll(gt);   // >= 1 of the lanes tied on the k-th score
+                uint64_t keep_eq = eq;
+                if ((uint32_t)__popcll(eq) != want_eq) {   // equal scores straddle the cut: lower rows win
+                    uint32_t rk = 0;
+                    for (uint64_t m = eq; m; m &= m - 1) {
+                        const uint32_t ro = (uint32_t)__builtin_amdgcn_readlane((int)r0, __ffsll((unsigned long long)m) - 1);
+                        rk += ro < r0 ? 1u : 0u;
+                    }
+                    keep_eq = __ballot(valid && ord == T && rk < want_eq);
+                }
+                uint32_t trow = 0; float tsim = 0.0f;   // the k-th best: score order T, largest kept row
+                for (uint64_t m = keep_eq; m; m &= m - 1) {
+                    const int le = __ffsll((unsigned long long)m) - 1;
+                    const uint32_t ro = (uint32_t)__builtin_amdgcn_readlane((int)r0, le);
+                    if (ro >= trow) { trow = ro; tsim = readlane_f32(sim, le); }
+                }
+                const uint64_t keep = gt | keep_eq;
+                if ((keep >> lane) & 1ull) {
+                    const uint32_t slot = (uint32_t)__popcll(keep & ((1ull << lane) - 1ull));   // <= lane: every lane read first
+                    rws[slot] = r0; dts[slot] = d0; rrs[slot] = n0;
+                }
+                if (((keep >> lane) & 1ull) && sim > 0.0f)
+                    __hip_atomic_fetch_max(a.gslots + qs * 32u + ((r0 * 2654435761u) >> 16) % k, __float_as_uint(sim),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) {
+                    c_tau[qs] = cand_key(trow, tsim);
+                    const float t = tsim > 0.0f ? tsim * tsim * (1.0f - 1.0e-4f) : -1.0f;
+                    if (t > c_tsq[qs]) c_tsq[qs] = t;
+                    c_shr[qs] = n;
+                }
+            }
+        };
         uint32_t tile = blockIdx.x;
-        if (tile < n_tiles) { issue_loads(tile); write_tile(0); }
-        if (tile + gridDim.x < n_tiles) issue_loads(tile + gridDim.x);
+        if (tile < n_tiles) { issue_loads(tile); write_tile(0, tile + gridDim.x); }
         __syncthreads();
         stamp0();
-        uint32_t buf = 0;
+        uint32_t buf = 0, it = 0;
         for (; tile < n_tiles; tile += gridDim.x) {
             const uint32_t next = tile + gridDim.x;
+            // the slots are re-read every 4th tile (agent-scope loads go past the L2) and applied one tile later,
+            // behind the wait the row loads need anyway
+            if ((it & 3u) == 1u) refresh_apply();
             if (next < n_tiles) {
                 if constexpr (DIAG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(t_wait); }
-                write_tile(buf ^ 1u);     // buffer last read one tile ago, behind that tile's barrier
+                write_tile(buf ^ 1u, next + gridDim.x);     // buffer last read one tile ago, behind that tile's barrier
                 stamp(t_write);
-                if (next + gridDim.x < n_tiles) issue_loads(next + gridDim.x);
             }
+            if ((it & 3u) == 0u) refresh_issue();
+            it++;
+            producer_compact();
+            stamp(t_stage);
             __syncthreads();
             stamp(t_bar);
             buf ^= 1u;
@@ -434,7 +555,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
         if constexpr (DIAG) {
             if (lane == 0) {
                 unsigned long long *o = a.diag + ((size_t)blockIdx.x * 8 + wave) * 8;
-                o[3] = t_bar; o[5] = t_wait; o[6] = t_write;
+                o[0] = t_stage; o[3] = t_bar; o[5] = t_wait; o[6] = t_write; o[7] = n_pcompact;
             }
         }
         return;
@@ -506,18 +627,27 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
         if (lane == 0) c_cnt[qs] = n < k ? n : k;
     };
 
+    // behind a barrier: slide what this wave appended since a producer's compaction snapshot down to k
+    auto apply_shrink = [&]() {
+        const uint32_t shr = c_shr[qslot];
+        if (__ballot(shr != 0u)) {
+            if (shr != 0u) {
+                const uint32_t cnt = c_cnt[qslot], m = cnt - shr;   // m <= 16 and k + 16 <= shr: no overlap
+                for (uint32_t e = kq; e < m; e += 4u) {
+                    const uint32_t src = qslot * capq + shr + e, dst = qslot * capq + k + e;
+                    c_rows[dst] = c_rows[src]; c_dots[dst] = c_dots[src]; c_rrs[dst] = c_rrs[src];
+                }
+                if (kq == 0u) { c_cnt[qslot] = k + m; c_pub[qslot] = k + m; c_shr[qslot] = 0u; }
+            }
+        }
+    };
+    if (kq == 0u) c_qq[qslot] = qq;
+
     __syncthreads();   // tile 0 is in buffer 0
     stamp0();
     uint32_t buf = 0;
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        {   // make room in the candidate buffers
-            uint64_t need = __ballot(kq == 0u && c_cnt[qslot] + 16u > capq);
-            while (need) {
-                const int l = __ffsll((unsigned long long)need) - 1;
-                need &= need - 1;
-                compact(pw * 16u + (uint32_t)l, readlane_f32(qq, l));
-            }
-        }
+        apply_shrink();
         stamp(t_stage);
         const char *Thi = tiles + buf * C::TILE_BYTES, *Tlo = Thi + C::IMG_BYTES;
         // epilogue operands are read now, under the MFMA loop, not after it
@@ -542,8 +672,9 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
 #pragma unroll
             for (int u = 0; u < CH; u++) {
                 const int ks = c * CH + u;
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cl[u], ql[ks], acc, 0, 0, 0);   // small terms first
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cl[u], qh[ks], acc, 0, 0, 0);
+                // x.y = xh.yh + xh.yl + xl.yh (+ xl.yl, left out: <= 2^-18 of a term, below the 2^-17 the two-piece
+                // split itself leaves behind; measured |cos error| 9e-7 against 6e-7 with it — tuning.md)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cl[u], qh[ks], acc, 0, 0, 0);   // small terms first
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ch[u], ql[ks], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ch[u], qh[ks], acc, 0, 0, 0);
             }
@@ -573,12 +704,16 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
                     if (slot < capq) { c_rows[qslot * capq + slot] = row; c_dots[qslot * capq + slot] = acc[r]; c_rrs[qslot * capq + slot] = rr4[r]; }
                 }
             }
+            // entries are written before the length the producers read (LDS operations of one wave stay in order)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (kq == 0u) c_pub[qslot] = c_cnt[qslot];
         }
         stamp(t_epi);
         __syncthreads();
         stamp(t_bar);
         buf ^= 1u;
     }
+    apply_shrink();
     if constexpr (DIAG) {
         if (lane == 0) {
             unsigned long long *o = a.diag + ((size_t)blockIdx.x * 8 + wave) * 8;
@@ -617,7 +752,7 @@ bool batch_supported(uint32_t dim, uint32_t k) { return (dim == 384 || dim == 76
 template <int D>
 static int launch_batch_d(BatchArgs a, uint32_t grid, hipStream_t stream) {
     static const int use_f32 = getenv("CX_BATCH_F32MFMA") ? atoi(getenv("CX_BATCH_F32MFMA")) : 0;
-    const size_t tail = (size_t)BT_Q * a.capq * 12 + BT_Q * 8 + BT_Q * 4 + BT_Q * 4;
+    const size_t tail = (size_t)BT_Q * a.capq * 12 + BT_Q * 8 + BT_Q * 4 + BT_Q * 4 + 3 * BT_Q * 4;
     const size_t lds = use_f32 ? 2 * (size_t)BatchCfg<D>::TILE_BYTES + tail
                                : 2 * (size_t)Batch2Cfg<D>::TILE_BYTES + 2 * BT_ROWS * 4 + tail;
     static bool attr_set = false;
@@ -643,12 +778,12 @@ static int launch_batch_d(BatchArgs a, uint32_t grid, hipStream_t stream) {
         for (size_t w = 0; w < (size_t)grid * 8; w++) {
             const bool cons = use_f32 || (w % 8) < 4;
             if (cons) { for (int p = 0; p < 4; p++) s[p] += (double)h[w * 8 + p]; tiles += (double)h[w * 8 + 4]; ncomp += (double)h[w * 8 + 5]; nappend += (double)h[w * 8 + 6]; }
-            else { pbar += (double)h[w * 8 + 3]; s[5] += (double)h[w * 8 + 5]; s[6] += (double)h[w * 8 + 6]; }
+            else { pbar += (double)h[w * 8 + 3]; s[5] += (double)h[w * 8 + 5]; s[6] += (double)h[w * 8 + 6]; ncomp += (double)h[w * 8 + 7]; s[4] += (double)h[w * 8 + 0]; }
         }
         fprintf(stderr, "[batch diag] producer barrier wait per tile %.0f; per consumer wave-tile: compactions %.3f, tiles with appends %.3f\n", pbar / (tiles > 0 ? tiles : 1), ncomp / (tiles > 0 ? tiles : 1), nappend / (tiles > 0 ? tiles : 1));
         fprintf(stderr, "[batch diag] cycles per tile per wave: stage+check %.0f  mfma-loop %.0f  epilogue %.0f  barrier %.0f"
-                        "  (load wait %.0f, split+write %.0f)\n",
-                s[0] / tiles, s[1] / tiles, s[2] / tiles, s[3] / tiles, s[5] / tiles, s[6] / tiles);
+                        "  (producer: load wait %.0f, split+write %.0f, compaction %.0f)\n",
+                s[0] / tiles, s[1] / tiles, s[2] / tiles, s[3] / tiles, s[5] / tiles, s[6] / tiles, s[4] / tiles);
         return CX_OK;
     }
     if (use_f32) hipLaunchKernelGGL((batch_scan_kernel<D, false>), dim3(grid), dim3(256), lds, stream, a);
@@ -660,7 +795,9 @@ static int launch_batch_d(BatchArgs a, uint32_t grid, hipStream_t stream) {
 int launch_batch_scan(BatchArgs a, uint32_t grid, hipStream_t stream) {
     if (!batch_supported(a.dim, a.k)) return set_err(CX_ERR_VALIDATION, "batch scan: unsupported dim %u / k %u", a.dim, a.k);
     if (a.nq == 0 || a.nq > BT_Q) return set_err(CX_ERR_VALIDATION, "batch scan: 1..64 queries per pass");
-    a.capq = a.k <= 16 ? 64u : 80u;  // >= k + 16 appends per tile, <= 128 (two entries per lane in compact); 12 B per entry
+    // batch2: lists are compacted at capq - 32 entries (<= 64: one per lane) and never exceed capq; k + 16 <= capq - 32
+    static const int use_f32 = getenv("CX_BATCH_F32MFMA") ? atoi(getenv("CX_BATCH_F32MFMA")) : 0;
+    a.capq = use_f32 ? (a.k <= 16 ? 64u : 80u) : 80u;
     if (a.dim == 384) return launch_batch_d<384>(a, grid, stream);
     return launch_batch_d<768>(a, grid, stream);
 }

@@ -63,6 +63,7 @@ struct Ctx {
     float *d_query = nullptr; size_t q_cap = 0;
     uint64_t *d_part_keys = nullptr; size_t pk_cap = 0;
     float *d_part_sims = nullptr; size_t ps_cap = 0;
+    uint32_t *d_gslots = nullptr; size_t gs_cap = 0;   // batched search: cross-block bound slots [64][32]
     uint32_t *d_out_rows = nullptr; size_t or_cap = 0;
     float *d_out_scores = nullptr; size_t os_cap = 0;
     float *d_out_dists = nullptr; size_t od_cap = 0;
@@ -84,7 +85,7 @@ struct Ctx {
 
     ~Ctx() {
         if (pass_scratch && pass_scratch_free) pass_scratch_free(pass_scratch);
-        (void)hipFree(d_query); (void)hipFree(d_part_keys); (void)hipFree(d_part_sims); (void)hipFree(d_out_rows);
+        (void)hipFree(d_query); (void)hipFree(d_gslots); (void)hipFree(d_part_keys); (void)hipFree(d_part_sims); (void)hipFree(d_out_rows);
         (void)hipFree(d_out_scores); (void)hipFree(d_out_dists); (void)hipFree(d_out_counts); (void)hipFree(d_excl);
         (void)hipFree(d_kinds); (void)hipFree(d_keys); (void)hipFree(d_keys2); (void)hipFree(d_sims); (void)hipFree(d_sims2);
         (void)hipFree(d_temp);

@@ -72,6 +72,7 @@ struct BatchArgs {
     uint64_t *part_keys;    // [nq][grid][k]
     float *part_sims;
     unsigned long long *diag;  // diagnostic build only (CX_BATCH_DIAG=1): [grid*4 waves][5] cycle sums
+    uint32_t *gslots;       // [64][32] zeroed before the launch: cross-block score bound (batch.hip, "global slots")
 };
 bool batch_supported(uint32_t dim, uint32_t k);
 uint32_t batch_grid_blocks(uint32_t n_rows);
