@@ -332,6 +332,18 @@ __device__ inline uint32_t img_off(uint32_t i, uint32_t p, uint32_t half) {
     return i * Batch2Cfg<D>::ROW_BYTES + (((p & ~15u) | ((p ^ i) & 15u)) << 4) + half * 8u;
 }
 
+// minimum over the 64 lanes, result in every lane (same exchange pattern as wave_sum_dpp)
+__device__ inline uint32_t wave_min_u32(uint32_t v) {
+    uint32_t o;
+    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);  v = o < v ? o : v;
+    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);  v = o < v ? o : v;
+    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true); v = o < v ? o : v;
+    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true); v = o < v ? o : v;
+    o = (uint32_t)__shfl_xor((int)v, 16, 64); v = o < v ? o : v;
+    o = (uint32_t)__shfl_xor((int)v, 32, 64); v = o < v ? o : v;
+    return v;
+}
+
 // sum over the 64 lanes, result in every lane: four DPP steps inside each 16-lane row (VALU rate), then
 // two cross-row exchanges
 __device__ inline float wave_sum_dpp(float v) {
@@ -490,25 +502,36 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
                 const bool valid = lane < n;
                 uint32_t r0 = 0, ord = 0; float d0 = 0.0f, n0 = 1.0f, sim = 0.0f;
                 if (valid) { r0 = rws[lane]; d0 = dts[lane]; n0 = rrs[lane]; sim = cosine_from_sums(d0, qq_of, n0); ord = score_ord(score_of(distance_of(sim))); }
+                // radix select of the k-th largest score order, most significant bit first.  Scores are <= 1.0, so
+                // bits 31..30 are clear unless something odd is in the list; the walk stops as soon as exactly k
+                // entries lie at or above the prefix (then they ARE the top k and no tie can straddle the cut)
                 uint32_t T = 0;
+                bool exact_k = false;
+                int b = __ballot(valid && ord >= 0x40000000u) ? 31 : 29;
 #pragma unroll 1
-                for (int b = 31; b >= 0; b--) {
+                for (; b >= 0; b--) {
                     const uint32_t candT = T | (1u << b);
-                    if ((uint32_t)__popcll(__ballot(valid && ord >= candT)) >= k) T = candT;
+                    const uint32_t c = (uint32_t)__popcll(__ballot(valid && ord >= candT));
+                    if (c >= k) { T = candT; if (c == k) { exact_k = true; break; } }
                 }
                 const uint64_t gt = __ballot(valid && ord > T), eq = __ballot(valid && ord == T);
-                const uint32_t want_eq = k - (uint32_t)__popcll(gt);   // >= 1 of the lanes tied on the k-th score
                 uint64_t keep_eq = eq;
-                if ((uint32_t)__popcll(eq) != want_eq) {   // equal scores straddle the cut: lower rows win
-                    uint32_t rk = 0;
-                    for (uint64_t m = eq; m; m &= m - 1) {
-                        const uint32_t ro = (uint32_t)__builtin_amdgcn_readlane((int)r0, __ffsll((unsigned long long)m) - 1);
-                        rk += ro < r0 ? 1u : 0u;
+                if (!exact_k) {   // T is the k-th largest value itself
+                    const uint32_t want_eq = k - (uint32_t)__popcll(gt);   // >= 1 of the lanes tied on it
+                    if ((uint32_t)__popcll(eq) != want_eq) {   // equal scores straddle the cut: lower rows win
+                        uint32_t rk = 0;
+                        for (uint64_t m = eq; m; m &= m - 1) {
+                            const uint32_t ro = (uint32_t)__builtin_amdgcn_readlane((int)r0, __ffsll((unsigned long long)m) - 1);
+                            rk += ro < r0 ? 1u : 0u;
+                        }
+                        keep_eq = __ballot(valid && ord == T && rk < want_eq);
                     }
-                    keep_eq = __ballot(valid && ord == T && rk < want_eq);
                 }
-                uint32_t trow = 0; float tsim = 0.0f;   // the k-th best: score order T, largest kept row
-                for (uint64_t m = keep_eq; m; m &= m - 1) {
+                // the k-th best = the smallest kept score order, and among equal ones the largest row
+                const bool kept = ((gt | keep_eq) >> lane) & 1ull;
+                const uint32_t mn = wave_min_u32(kept ? ord : 0xFFFFFFFFu);
+                uint32_t trow = 0; float tsim = 0.0f;
+                for (uint64_t m = __ballot(kept && ord == mn); m; m &= m - 1) {
                     const int le = __ffsll((unsigned long long)m) - 1;
                     const uint32_t ro = (uint32_t)__builtin_amdgcn_readlane((int)r0, le);
                     if (ro >= trow) { trow = ro; tsim = readlane_f32(sim, le); }

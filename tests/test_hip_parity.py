@@ -299,3 +299,42 @@ def test_search_batch_with_filter_and_tombstones(hip, oracle):
         e = o.search(qs[i], 10, of)
         m = int(bc[i])
         assert_topk_parity(rows_of(ids, bi[i, :m]), bs[i, :m], e["row"], e["score"], what=f"batch filter q{i}")
+
+
+@pytest.mark.parametrize("n,d,k,nq", [
+    (60000, 384, 10, 64),    # ~15 tiles per block: lists fill, producers compact, blocks share their bound
+    (50000, 768, 32, 20),    # k = 32: compaction threshold == k + 16, every compaction keeps 2/3 of the list
+    (33000, 768, 1, 33),     # k = 1, ragged query group
+])
+def test_search_batch_long_lists(hip, oracle, n, d, k, nq):
+    """Enough rows per block that the in-kernel candidate lists overflow and are compacted many times
+    (batch.hip: producer_compact / apply_shrink / global slots)."""
+    rows = oracle.synth_rows(n, d)
+    qs = oracle.synth_queries(n, d, nq)
+    h, o, ids = build_both(hip, oracle, rows)
+    for r in (5, 17, 40000 % n):
+        h.remove(ids[r].tobytes()); o.remove(ids[r].tobytes())
+    bi, bs, bd, bc = h.search_batch_arrays(qs, k)
+    for i in range(nq):
+        e = o.search(qs[i], k)
+        m = int(bc[i])
+        assert m == len(e["row"])
+        assert_topk_parity(rows_of(ids, bi[i, :m]), bs[i, :m], e["row"], e["score"], what=f"batch long n={n} k={k} q{i}")
+
+
+def test_search_batch_massive_ties(hip, oracle):
+    """50 distinct vectors repeated 800 times: almost every cut falls inside a run of equal scores, so the
+    compaction's tie rule (lower insertion row wins) decides the result.  ids must match exactly."""
+    n, d, k = 40000, 384, 32
+    base = oracle.synth_rows(50, d)
+    rows = np.ascontiguousarray(base[np.arange(n) % 50])
+    qs = np.ascontiguousarray(base[:16] + 0.05 * oracle.synth_queries(50, d, 16))
+    h, o, ids = build_both(hip, oracle, rows)
+    bi, bs, bd, bc = h.search_batch_arrays(qs, k)
+    for i in range(len(qs)):
+        e = o.search(qs[i], k)
+        m = int(bc[i])
+        assert m == k
+        got = rows_of(ids, bi[i, :m])
+        # equal vectors give bit-equal scores on both sides, so the order is fully determined
+        assert list(map(int, got)) == list(map(int, e["row"])), f"q{i}: {got[:8]} vs {e['row'][:8]}"
