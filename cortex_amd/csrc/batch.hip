@@ -316,10 +316,11 @@ __device__ inline void split4(const f32x4 v, bf16x4_t &hi, bf16x4_t &lo) {
     // unpacked with one shift / one mask per pair instead of being converted a second time element by element.
     const uint32_t p01 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v.x, v.y}, bf16x2_t));
     const uint32_t p23 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v.z, v.w}, bf16x2_t));
-    const float b0 = __uint_as_float(p01 << 16), b1 = __uint_as_float(p01 & 0xFFFF0000u);
-    const float b2 = __uint_as_float(p23 << 16), b3 = __uint_as_float(p23 & 0xFFFF0000u);
-    const uint32_t q01 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v.x - b0, v.y - b1}, bf16x2_t));
-    const uint32_t q23 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v.z - b2, v.w - b3}, bf16x2_t));
+    const f32x2 b01 = {__uint_as_float(p01 << 16), __uint_as_float(p01 & 0xFFFF0000u)};
+    const f32x2 b23 = {__uint_as_float(p23 << 16), __uint_as_float(p23 & 0xFFFF0000u)};
+    const f32x2 d01 = (f32x2){v.x, v.y} - b01, d23 = (f32x2){v.z, v.w} - b23;   // v_pk_add_f32
+    const uint32_t q01 = __builtin_bit_cast(uint32_t, __builtin_convertvector(d01, bf16x2_t));
+    const uint32_t q23 = __builtin_bit_cast(uint32_t, __builtin_convertvector(d23, bf16x2_t));
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     hi = __builtin_bit_cast(bf16x4_t, (u32x2){p01, p23});
     lo = __builtin_bit_cast(bf16x4_t, (u32x2){q01, q23});
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
             const uint32_t rl = reload < n_tiles ? reload : n_tiles - 1u;   // past the end: a valid tile, never used
             const f32x4 *rbase = reinterpret_cast<const f32x4 *>(a.rows + ((size_t)rl * BT_ROWS + pw * 4u) * D);
             char *hi_img = tiles + buf * C::TILE_BYTES, *lo_img = hi_img + C::IMG_BYTES;
-            float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            f32x2 part[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};   // two partial sums each: v_pk_fma_f32
 #pragma unroll
             for (int e = 0; e < C::LOADS; e++) {
                 // float index of the load inside the wave's 4 rows = e*256 + 4*lane: for dim % 256 == 0 the row
@@ -428,11 +429,12 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
                 ld[e] = __builtin_nontemporal_load(rbase + e * 64 + lane);
                 bf16x4_t h, l;
                 split4(v, h, l);
-                const float s2 = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-                if (base_c + 256u <= (uint32_t)D) part[base_r] += s2;
+                const f32x2 v01 = {v.x, v.y}, v23 = {v.z, v.w};
+                if (base_c + 256u <= (uint32_t)D) part[base_r] = v23 * v23 + (v01 * v01 + part[base_r]);
                 else {
+                    const f32x2 s2 = v23 * v23 + v01 * v01;
 #pragma unroll
-                    for (uint32_t rr_ = 0; rr_ < 4; rr_++) part[rr_] += (r == rr_) ? s2 : 0.0f;
+                    for (uint32_t rr_ = 0; rr_ < 4; rr_++) part[rr_] += (r == rr_) ? s2 : (f32x2){0.0f, 0.0f};
                 }
                 const uint32_t o = img_off<D>(pw * 4u + r, col >> 3, (col >> 2) & 1u);
                 *reinterpret_cast<bf16x4_t *>(hi_img + o) = h;
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
             }
             float sums[4];
 #pragma unroll
-            for (uint32_t rr_ = 0; rr_ < 4; rr_++) sums[rr_] = wave_sum_dpp(part[rr_]);
+            for (uint32_t rr_ = 0; rr_ < 4; rr_++) sums[rr_] = wave_sum_dpp(part[rr_].x + part[rr_].y);
             if (lane == 0) *reinterpret_cast<f32x4 *>(c_rr + buf * BT_ROWS + pw * 4u) = f32x4{sums[0], sums[1], sums[2], sums[3]};
         };
         // Candidate-list compaction runs HERE, on the producer waves (they have the registers; the consumers hold
@@ -619,7 +621,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
 #pragma unroll
     for (uint32_t ksl = 0; ksl < 4; ksl++) a_off[ksl] = j * C::ROW_BYTES + ((((4u * ksl + kq) ^ j) & 15u) << 4);
 
-    unsigned long long n_compact = 0, n_append_steps = 0;
+    unsigned long long n_compact = 0, n_append_steps = 0, t_x1 = 0, t_x2 = 0;
     auto compact = [&](uint32_t qs, float qq_of) {
         if constexpr (DIAG) n_compact++;
         const uint32_t n = c_cnt[qs] < capq ? c_cnt[qs] : capq;
@@ -704,6 +706,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
         stamp(t_mfma);
+        if constexpr (DIAG) { asm volatile("v_mov_b32 %0, %0" : "+v"(acc[3])); asm volatile("s_nop 0" ::: "memory"); stamp(t_x1); }
 
         // epilogue: lane (j, kq) holds rows 4 kq + r of query j.  All four tests first, one wave-level branch:
         // after warm-up no lane has a survivor and the wave falls through
@@ -714,9 +717,14 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
 #pragma unroll
         for (uint32_t r = 0; r < 4; r++) {
             const float rr = rr4[r], dot = acc[r];
-            const bool maybe = tsq < 0.0f || (dot > 0.0f && dot * dot >= tq * rr) || !(dot == dot) || !(rr == rr);
-            mask |= (maybe && live && row0 + 4u * kq + r < n_rows) ? (1u << r) : 0u;
+            // bitwise, not short-circuit: hipcc turns || and && on float compares into a chain of divergent
+            // branches (1.2k cycles per tile, measured); these are four v_cmp and a few s_and/s_or
+            const bool beats = (dot > 0.0f) & (dot * dot >= tq * rr);
+            const bool odd = (dot != dot) | (rr != rr);
+            const bool maybe = (tsq < 0.0f) | beats | odd;
+            mask |= (maybe & live & (row0 + 4u * kq + r < n_rows)) ? (1u << r) : 0u;
         }
+        stamp(t_x2);
         if (__ballot(mask != 0u)) {
             if constexpr (DIAG) n_append_steps++;
 #pragma unroll
@@ -742,6 +750,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
             unsigned long long *o = a.diag + ((size_t)blockIdx.x * 8 + wave) * 8;
             o[0] = t_stage; o[1] = t_mfma; o[2] = t_epi; o[3] = t_bar; o[4] = (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
             o[5] = n_compact; o[6] = n_append_steps;
+            if (blockIdx.x == 9 && wave == 1) printf("[epi] per tile: drain %llu tests %llu append %llu\n", t_x1 / o[4], t_x2 / o[4], t_epi / o[4]);
         }
     }
     for (uint32_t l = 0; l < 16u; l++) compact(pw * 16u + l, readlane_f32(qq, (int)l));
