@@ -404,15 +404,18 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
 
     if (!consumer) {
         // ------------------------------------------------------------------ producer
-        f32x4 ld[C::LOADS];
-        auto issue_loads = [&](uint32_t tile) {
+        // two register sets, tiles alternate between them: every load has two tile intervals of flight time
+        // (one set left the producers waiting ~800 cycles per tile for HBM — tuning.md)
+        f32x4 ldA[C::LOADS], ldB[C::LOADS];
+        auto issue_loads = [&](f32x4 (&ld)[C::LOADS], uint32_t t) {
+            const uint32_t tile = t < n_tiles ? t : n_tiles - 1u;
             const f32x4 *base = reinterpret_cast<const f32x4 *>(a.rows + ((size_t)tile * BT_ROWS + pw * 4u) * D);
 #pragma unroll
             for (int e = 0; e < C::LOADS; e++) ld[e] = __builtin_nontemporal_load(base + e * 64 + lane);
         };
         // split + write the tile held in ld[], and put each register back in flight for tile `reload` as soon as
-        // it has been consumed: the loads get a whole tile interval of flight time with one register set
-        auto write_tile = [&](uint32_t buf, uint32_t reload) {
+        // it has been consumed
+        auto write_tile = [&](f32x4 (&ld)[C::LOADS], uint32_t buf, uint32_t reload) {
             const uint32_t rl = reload < n_tiles ? reload : n_tiles - 1u;   // past the end: a valid tile, never used
             const f32x4 *rbase = reinterpret_cast<const f32x4 *>(a.rows + ((size_t)rl * BT_ROWS + pw * 4u) * D);
             char *hi_img = tiles + buf * C::TILE_BYTES, *lo_img = hi_img + C::IMG_BYTES;
@@ -555,18 +558,22 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
             }
         };
         uint32_t tile = blockIdx.x;
-        if (tile < n_tiles) { issue_loads(tile); write_tile(0, tile + gridDim.x); }
+        if (tile < n_tiles) {
+            issue_loads(ldA, tile);
+            issue_loads(ldB, tile + gridDim.x);
+            write_tile(ldA, 0, tile + 2u * gridDim.x);
+        }
         __syncthreads();
         stamp0();
         uint32_t buf = 0, it = 0;
-        for (; tile < n_tiles; tile += gridDim.x) {
+        // one tile interval: the consumers work on `tile`; this wave writes tile + grid (held in `ld`) into the
+        // other buffer and sends `ld` for tile + 3 grid
+        auto step = [&](f32x4 (&ld)[C::LOADS]) {
             const uint32_t next = tile + gridDim.x;
-            // the slots are re-read every 4th tile (agent-scope loads go past the L2) and applied one tile later,
-            // behind the wait the row loads need anyway
+            // the slots are re-read every 4th tile (agent-scope loads go past the L2) and applied one tile later
             if ((it & 3u) == 1u) refresh_apply();
             if (next < n_tiles) {
-                if constexpr (DIAG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(t_wait); }
-                write_tile(buf ^ 1u, next + gridDim.x);     // buffer last read one tile ago, behind that tile's barrier
+                write_tile(ld, buf ^ 1u, next + 2u * gridDim.x);     // buffer last read one tile ago, behind that tile's barrier
                 stamp(t_write);
             }
             if ((it & 3u) == 0u) refresh_issue();
@@ -576,6 +583,12 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
             __syncthreads();
             stamp(t_bar);
             buf ^= 1u;
+            tile += gridDim.x;
+        };
+        while (tile < n_tiles) {
+            step(ldB);
+            if (tile >= n_tiles) break;
+            step(ldA);
         }
         if constexpr (DIAG) {
             if (lane == 0) {
@@ -621,7 +634,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
 #pragma unroll
     for (uint32_t ksl = 0; ksl < 4; ksl++) a_off[ksl] = j * C::ROW_BYTES + ((((4u * ksl + kq) ^ j) & 15u) << 4);
 
-    unsigned long long n_compact = 0, n_append_steps = 0, t_x1 = 0, t_x2 = 0;
+    unsigned long long n_compact = 0, n_append_steps = 0;
     auto compact = [&](uint32_t qs, float qq_of) {
         if constexpr (DIAG) n_compact++;
         const uint32_t n = c_cnt[qs] < capq ? c_cnt[qs] : capq;
@@ -706,7 +719,6 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
         stamp(t_mfma);
-        if constexpr (DIAG) { asm volatile("v_mov_b32 %0, %0" : "+v"(acc[3])); asm volatile("s_nop 0" ::: "memory"); stamp(t_x1); }
 
         // epilogue: lane (j, kq) holds rows 4 kq + r of query j.  All four tests first, one wave-level branch:
         // after warm-up no lane has a survivor and the wave falls through
@@ -724,7 +736,6 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
             const bool maybe = (tsq < 0.0f) | beats | odd;
             mask |= (maybe & live & (row0 + 4u * kq + r < n_rows)) ? (1u << r) : 0u;
         }
-        stamp(t_x2);
         if (__ballot(mask != 0u)) {
             if constexpr (DIAG) n_append_steps++;
 #pragma unroll
@@ -750,7 +761,6 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
             unsigned long long *o = a.diag + ((size_t)blockIdx.x * 8 + wave) * 8;
             o[0] = t_stage; o[1] = t_mfma; o[2] = t_epi; o[3] = t_bar; o[4] = (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
             o[5] = n_compact; o[6] = n_append_steps;
-            if (blockIdx.x == 9 && wave == 1) printf("[epi] per tile: drain %llu tests %llu append %llu\n", t_x1 / o[4], t_x2 / o[4], t_epi / o[4]);
         }
     }
     for (uint32_t l = 0; l < 16u; l++) compact(pw * 16u + l, readlane_f32(qq, (int)l));
