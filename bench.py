@@ -304,7 +304,7 @@ def autolink_leg(L, device: int, d: int, skip_cpu: bool, n: int = 100_000, thr: 
         "pairs_per_s": n * float(n) / wall, "wall_ms": wall * 1e3, "edges": ne,
         "phase_ms": {"shadow_refresh": ph[0], "mfma_filter_gemm": ph[1], "exact_rescore": ph[2], "link_rules": ph[3]},
         "roofline": {"bound": "mfma", "achieved": flops / (ph[1] * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
-                     "frac": flops / (ph[1] * 1e-3) / 2.5e15, "kernel": "cx::pair_filter_kernel",
+                     "frac": flops / (ph[1] * 1e-3) / 2.5e15, "kernel": "cx::pair_filter256_kernel",
                      "algorithmic_flops_per_launch": flops, "dtype": "bf16 in, f32 accumulate",
                      "executed_flops_per_launch": executed, "executed_tflops": executed / (ph[1] * 1e-3) / 1e12,
                      "executed_frac": executed / (ph[1] * 1e-3) / 2.5e15,

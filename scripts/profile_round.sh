@@ -1,0 +1,31 @@
+#!/bin/bash
+# Collects the round's judged artifacts on the GPU box (run through gpurun from the repo root):
+#   bench.py JSON line, rocprofv3 kernel-trace summaries for the three workloads, and the HBM PMC passes of the
+#   dominant kernel (FETCH_SIZE and WRITE_SIZE in separate runs, as MI355X_MICROARCH.md prescribes).
+# Output: gpurun_out/prof_round/ ; copy the *_kernel_stats.csv / *.json you want judged into profiles/rNN/.
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/prof_round
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+step() { echo "== $1"; }
+step bench; timeout -k 10 500 python3 $R/bench.py > $O/bench.json 2> $O/bench.err || { tail -5 $O/bench.err; exit 1; }
+step knn-trace; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/knn_trace -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-autolink > $O/knn_trace.json 2> $O/knn_trace.err || { tail -5 $O/knn_trace.err; exit 1; }
+step knn-fetch; timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/knn_fetch -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-autolink > $O/knn_fetch.json 2> $O/knn_fetch.err || { tail -5 $O/knn_fetch.err; exit 1; }
+step knn-write; timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/knn_write -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-autolink > $O/knn_write.json 2> $O/knn_write.err || { tail -5 $O/knn_write.err; exit 1; }
+step autolink-trace; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/al_trace -- python3 $R/scripts/bench_autolink.py > $O/autolink.json 2> $O/al_trace.err || { tail -5 $O/al_trace.err; exit 1; }
+step batch-trace; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/batch_trace -- python3 $R/scripts/bench_batch.py > $O/batch.json 2> $O/batch_trace.err || { tail -5 $O/batch_trace.err; exit 1; }
+step batch-fetch; timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/batch_fetch -- python3 $R/scripts/bench_batch.py --steps 5 > $O/batch_fetch.json 2> $O/batch_fetch.err || { tail -5 $O/batch_fetch.err; exit 1; }
+# keep only the summaries (traces are large)
+for d in knn_trace al_trace batch_trace; do f=$(ls -t $O/$d/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/${d}_kernel_stats.csv; done
+for d in knn_fetch knn_write batch_fetch; do f=$(ls -t $O/$d/*/*counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && python3 - "$f" > $O/${d}_summary.json <<'PY'
+import csv, sys, json, collections
+agg = collections.defaultdict(lambda: [0.0, 0])
+for r in csv.DictReader(open(sys.argv[1])):
+    k = (r["Kernel_Name"].split("(")[0][:80], r["Counter_Name"])
+    agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
+print(json.dumps([{"kernel": k[0], "counter": k[1], "sum": v[0], "dispatches": v[1], "per_dispatch": v[0] / v[1]} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]], indent=1))
+PY
+done
+rm -rf $O/knn_trace $O/al_trace $O/batch_trace $O/knn_fetch $O/knn_write $O/batch_fetch
+ls -la $O; cat $O/bench.json
