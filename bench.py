@@ -178,6 +178,8 @@ def main() -> None:
         out.setdefault("extra", {})["config1_10k_x_384_k5"] = config1_leg(L, local_rank)
     if rank == 0 and world == 1 and not args.no_autolink:
         out.setdefault("extra", {})["autolink_allpairs"] = autolink_leg(L, local_rank, d, args.no_cpu_baseline)
+        # the same pass over the bench corpus itself: BASELINE.json's metric names "auto-link pairs/sec at 1Mx768"
+        out["extra"]["autolink_allpairs_bench_corpus"] = autolink_on_index(ix, n, d)
     if rank == 0:
         print(json.dumps(out), flush=True)
     ix.close()
@@ -276,6 +278,30 @@ def config1_leg(L, device: int, n: int = 10_000, d: int = 384, k: int = 5, nq: i
                                      "note": "restatement of instant-distance 0.6.1 from the HNSW paper; parity unpinned"}}
 
 
+def autolink_on_index(ix, n: int, d: int, thr: float = 0.85, reps: int = 2):
+    """All-pairs auto-link pass (threshold 0.85, top-100, cap 50) over an index that is already resident;
+    first call builds the bf16 shadow and the tile list, the best of the following `reps` is reported."""
+    thr32 = float(np.float32(thr))
+    best = None
+    for rep in range(reps + 1):
+        t0 = time.perf_counter()
+        ne, ph = ix.autolink_pass_timed(100, thr32, 50)
+        wall = time.perf_counter() - t0
+        if rep and (best is None or wall < best[0]):
+            best = (wall, ph, ne)
+    wall, ph, ne = best
+    flops = 2.0 * n * n * d
+    tiles = -(-n // 256)
+    executed = 2.0 * 256 * 256 * d * (tiles * (tiles + 1) // 2)
+    return {"workload": f"auto-link all-pairs {n} x {d}, threshold {thr}, top-100, 50 edges/node, similarity rule only",
+            "pairs_per_s": n * float(n) / wall, "wall_ms": wall * 1e3, "edges": ne,
+            "phase_ms": {"shadow_refresh": ph[0], "mfma_filter_gemm": ph[1], "exact_rescore": ph[2], "link_rules": ph[3]},
+            "roofline": {"bound": "mfma", "achieved": flops / (ph[1] * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": flops / (ph[1] * 1e-3) / 2.5e15, "kernel": "cx::pair_filter256_kernel",
+                         "algorithmic_flops_per_launch": flops, "executed_flops_per_launch": executed,
+                         "executed_frac": executed / (ph[1] * 1e-3) / 2.5e15}}
+
+
 def autolink_leg(L, device: int, d: int, skip_cpu: bool, n: int = 100_000, thr: float = 0.85):
     """BASELINE config 3: auto-link all-pairs over n x d rows, threshold 0.85, top-100, cap 50 edges per
     node (cx_autolink_pass_timed: edges stay in HBM).  MFMA roofline for the filter GEMM; the CPU figure is
@@ -297,8 +323,8 @@ def autolink_leg(L, device: int, d: int, skip_cpu: bool, n: int = 100_000, thr: 
             best = (wall, ph, ne)
     wall, ph, ne = best
     flops = 2.0 * n * n * d           # the full ordered matrix, no symmetry credit
-    tiles = -(-n // 128)
-    executed = 2.0 * 128 * 128 * d * (tiles * (tiles + 1) // 2)   # what the MFMAs actually ran: tiles tj >= ti only
+    tiles = -(-n // 256)
+    executed = 2.0 * 256 * 256 * d * (tiles * (tiles + 1) // 2)   # what the MFMAs actually ran: 256x256 tiles, tj >= ti only
     res = {
         "workload": f"auto-link all-pairs {n} x {d}, threshold {thr}, top-100, 50 edges/node, similarity rule only",
         "pairs_per_s": n * float(n) / wall, "wall_ms": wall * 1e3, "edges": ne,
