@@ -17,6 +17,9 @@
 //  - 16-byte pieces of a 64-byte row are stored at piece ^ ((row >> 3 & 1) << 1): with rows at a 64-byte
 //    stride this makes every ds_read_b128 lane group hit 16 different bank groups.
 #include "kernels.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 
 namespace cx {
 
@@ -31,6 +34,7 @@ constexpr int LDS_BYTES = NS * SLOT_BYTES;     // 128 KiB
 __device__ inline uint32_t off(uint32_t row, uint32_t piece) { return row * 64u + ((piece ^ (((row >> 3) & 1u) << 1)) << 4); }
 }  // namespace p256
 
+template <bool DIAG>
 __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArgs a) {
     using namespace p256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -143,6 +147,8 @@ __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArg
         __builtin_amdgcn_s_barrier();
     };
 
+    unsigned long long t0 = 0, t1 = 0, t2 = 0;
+    if constexpr (DIAG) t0 = __builtin_readcyclecounter();
     // prologue: steps 0..2 in flight; 0 and 1 must land (0 is read now, 1 during step 0)
     stage(0, 0);
     if (KT > 1) stage(1, 1);
@@ -150,6 +156,7 @@ __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArg
     if (KT > 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if constexpr (DIAG) t1 = __builtin_readcyclecounter();
     read_frags(0, fa0, fb0);
     uint32_t kt = 0;
     for (; kt + 5 <= KT; kt += 2) {          // both steps of the pair have their kt+3 inside the K range
@@ -161,6 +168,7 @@ __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArg
         if (kt + 1 < KT) step_tail(kt + 1, fa1, fb1, fa0, fb0);
     }
 
+    if constexpr (DIAG) { asm volatile("s_nop 0" :: "v"(acc[7][3][3])); t2 = __builtin_readcyclecounter(); }
     // epilogue: C[row][col], col = lane & 15 (j), row = 4*(lane >> 4) + e (i)
     const bool mirror = a.symmetric && ti != tj;
     auto emit = [&](uint32_t i, uint32_t j) {
@@ -169,20 +177,36 @@ __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArg
             if (slot < a.cap) a.cand[(size_t)i * a.cap + slot] = j;
         }
     };
+    // Hits are rare (a handful per 128x64 wave tile), so the 128 accumulator values are screened 16 at a time
+    // with a running maximum and ONE wave-uniform branch per 16x64 strip; only strips with a hit somewhere in
+    // the wave walk their elements (one test per element took 9.6k cycles per tile, 19 % of the kernel).
 #pragma unroll
-    for (uint32_t m = 0; m < 8; m++)
+    for (uint32_t m = 0; m < 8; m++) {
+        float mx = acc[m][0][0];
+#pragma unroll
+        for (uint32_t n = 0; n < 4; n++)
+#pragma unroll
+            for (uint32_t e = 0; e < 4; e++) mx = fmaxf(mx, acc[m][n][e]);
+        if (__ballot(mx >= a.thr_lo) == 0ull) continue;
 #pragma unroll
         for (uint32_t n = 0; n < 4; n++) {
             const uint32_t j = j0 + wn * 64u + n * 16u + fr;
 #pragma unroll
             for (uint32_t e = 0; e < 4; e++) {
-                if (acc[m][n][e] >= a.thr_lo) {
+                const bool hit = acc[m][n][e] >= a.thr_lo;
+                if (__ballot(hit) == 0ull) continue;
+                if (hit) {
                     const uint32_t i = i0 + wm * 128u + m * 16u + 4u * fq + e;
                     emit(i, j);
                     if (mirror) emit(j, i);
                 }
             }
         }
+    }
+    if constexpr (DIAG) {
+        const unsigned long long t3 = __builtin_readcyclecounter();
+        if (lane == 0) { unsigned long long *o = a.diag + ((size_t)blockIdx.x * 8 + wave) * 4; o[0] = t1 - t0; o[1] = t2 - t1; o[2] = t3 - t2; o[3] = t3 - t0; }
+    }
 }
 
 void pair_filter256_tile_list(uint32_t n_rows, std::vector<uint32_t> &out) {
@@ -206,11 +230,29 @@ int launch_pair_filter256(const PairFilterArgs &a, hipStream_t stream) {
     if (tiles > 0x7FFFFFFFull) return set_err(CX_ERR_VALIDATION, "pair filter 256: too many tiles");
     static bool attr_set = false;
     if (!attr_set) {
-        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_filter256_kernel),
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_filter256_kernel<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_filter256_kernel<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL(pair_filter256_kernel, dim3((uint32_t)tiles), dim3(512), LDS_BYTES, stream, a);
+    if (getenv("CX_PAIR_DIAG")) {   // diagnostic build: per-phase cycles per tile on stderr, results still valid
+        PairFilterArgs d = a;
+        const size_t n = (size_t)tiles * 8 * 4;
+        CX_HIP(hipMalloc((void **)&d.diag, n * 8));
+        hipLaunchKernelGGL(pair_filter256_kernel<true>, dim3((uint32_t)tiles), dim3(512), LDS_BYTES, stream, d);
+        CX_HIP(hipStreamSynchronize(stream));
+        std::vector<unsigned long long> h(n);
+        CX_HIP(hipMemcpy(h.data(), d.diag, n * 8, hipMemcpyDeviceToHost));
+        CX_HIP(hipFree(d.diag));
+        double s[4] = {0, 0, 0, 0};
+        for (size_t w = 0; w < (size_t)tiles * 8; w++) for (int p = 0; p < 4; p++) s[p] += (double)h[w * 4 + p];
+        const double nw = (double)tiles * 8;
+        fprintf(stderr, "[pair256 diag] %llu tiles; cycles per tile per wave: prologue %.0f  main loop %.0f  epilogue %.0f  total %.0f\n",
+                (unsigned long long)tiles, s[0] / nw, s[1] / nw, s[2] / nw, s[3] / nw);
+        return CX_OK;
+    }
+    hipLaunchKernelGGL(pair_filter256_kernel<false>, dim3((uint32_t)tiles), dim3(512), LDS_BYTES, stream, a);
     CX_HIP(hipGetLastError());
     return CX_OK;
 }

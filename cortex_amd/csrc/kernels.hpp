@@ -97,6 +97,7 @@ struct PairFilterArgs {
     uint32_t symmetric;         // scan set == all rows in order: compute tiles tj >= ti only, emit (i,j) and (j,i)
     const uint32_t *tile_list;  // symmetric only: (ti << 16) | tj of every live tile, in launch order
     uint32_t n_tiles;           // entries in tile_list
+    unsigned long long *diag;   // CX_PAIR_DIAG=1 only: [tiles][4] cycle stamps (prologue, main loop, epilogue)
 };
 // live tiles of the symmetric pass in L2-friendly order (host side); tile = 128 rows
 void pair_filter_tile_list(uint32_t n_rows, std::vector<uint32_t> &out);
