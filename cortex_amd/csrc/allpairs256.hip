@@ -3,10 +3,10 @@
 //
 // Same contract as pair_filter_kernel (allpairs.hip): bf16 shadow rows in, candidate columns out, no score
 // matrix.  What changes is the pipeline (cdna_hip_programming.md §5 "Pipelining across barriers", T3+T4):
-//  - 256x256 block tile, BK = 32 (one mfma_f32_16x16x32_bf16 k-step), 8 waves as 2(M) x 4(N), each wave a
-//    128x64 sub-tile = 8x4 MFMA tiles (128 accumulator registers), two waves per SIMD;
-//  - per K-step a wave issues 4 LDS-DMA instructions (2 A + 2 B, 1 KiB each), 12 ds_read_b128 and 32 MFMAs:
-//    twice the MFMAs per DMA and 1.3x per LDS read of the 128^2 kernel;
+//  - 256x256 block tile, BK = 32, 8 waves as 2(M) x 4(N), each wave a 128x64 sub-tile = 4x2 tiles of
+//    mfma_f32_32x32x16_bf16 (128 accumulator registers), two waves per SIMD;
+//  - per K-step a wave issues 4 LDS-DMA instructions (2 A + 2 B, 1 KiB each), 12 ds_read_b128 and 16 MFMAs,
+//    interleaved one-for-one (step_full): twice the MFMA work per DMA and 1.3x per LDS read of the 128^2 kernel;
 //  - LDS = ring of 4 slots x (A 16 KiB + B 16 KiB) = 128 KiB.  In step t a wave issues the DMA of step t+3 and
 //    the fragment reads of step t+1 (double-buffered registers), then the MFMAs of step t; the wait at the end
 //    of a step is `s_waitcnt vmcnt(4)` — this wave's part of step t+2 has landed, step t+3 stays in flight —
@@ -14,8 +14,9 @@
 //    are no ordinary global loads in the loop, so hipcc adds no vmcnt(0) of its own (checked in the ISA).
 //  - RAW: slot t+2 is read (in step t+1) one barrier after the wait that retired it.  WAR: slot (t+3)%4 was
 //    last read in step t-2; those ds_reads retired before the MFMAs of step t-1 that consumed them.
-//  - 16-byte pieces of a 64-byte row are stored at piece ^ ((row >> 3 & 1) << 1): with rows at a 64-byte
-//    stride this makes every ds_read_b128 lane group hit 16 different bank groups.
+//  - 16-byte pieces of a 64-byte row are stored at piece ^ (row >> 3 & 3): with rows at a 64-byte stride this
+//    makes every ds_read_b128 lane group (MI355X_MICROARCH.md §LDS) of the 32-row x 2-piece operand pattern hit
+//    16 different 16-byte bank groups (SQ_LDS_BANK_CONFLICT stays 0).
 #include "kernels.hpp"
 #include <cstdio>
 #include <cstdlib>
@@ -24,6 +25,7 @@
 namespace cx {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace p256 {
@@ -31,10 +33,12 @@ constexpr int BM = 256, BN = 256, BK = 32, NS = 4;
 constexpr int OP_BYTES = BM * BK * 2;          // 16 KiB per operand per slot
 constexpr int SLOT_BYTES = 2 * OP_BYTES;       // 32 KiB
 constexpr int LDS_BYTES = NS * SLOT_BYTES;     // 128 KiB
-__device__ inline uint32_t off(uint32_t row, uint32_t piece) { return row * 64u + ((piece ^ (((row >> 3) & 1u) << 1)) << 4); }
+// 16-byte piece p of a 64-byte row sits at slot p ^ (row >> 3 & 3): a ds_read_b128 lane group (16 lanes, 256 B of
+// banks) of the 32-row x 2-piece MFMA operand pattern then covers all sixteen 16-byte bank groups
+__device__ inline uint32_t off(uint32_t row, uint32_t piece) { return row * 64u + ((piece ^ ((row >> 3) & 3u)) << 4); }
 }  // namespace p256
 
-template <bool DIAG>
+template <bool DIAG, bool IL>
 __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArgs a) {
     using namespace p256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -61,6 +65,7 @@ __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArg
         tj = (b % per_group) / gsz;
     }
     const uint32_t i0 = ti * BM, j0 = tj * BN;
+    unsigned long long c_vm = 0, c_bar = 0;
 
     // loader: one LDS-DMA = 16 rows x 64 B; 16 per operand per slot, 2 per wave
     const uint32_t lrow = lane >> 2, lpos = lane & 3u;
@@ -68,7 +73,7 @@ __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArg
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         const uint32_t r = (wave * 2u + (uint32_t)q) * 16u + lrow;
-        const uint32_t piece = lpos ^ (((r >> 3) & 1u) << 1);
+        const uint32_t piece = lpos ^ ((r >> 3) & 3u);
         uint32_t gi = i0 + r;
         gi = gi < a.n_scan ? gi : a.n_scan - 1u;
         const uint32_t ga = a.scan_rows ? a.scan_rows[gi] : gi;
@@ -89,20 +94,30 @@ __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArg
         }
     };
 
-    f32x4 acc[8][4];
+    // 128x64 per wave = 4 x 2 tiles of v_mfma_f32_32x32x16_bf16 (16 accumulator registers each): half the MFMA
+    // instructions of the 16x16x32 form for the same LDS reads, and each leaves 24 of its 32 cycles (not 8 of
+    // 16) for the step's LDS-DMA / ds_read issue
+    f32x16 acc[4][2];
 #pragma unroll
-    for (int m = 0; m < 8; m++)
+    for (int m = 0; m < 4; m++)
 #pragma unroll
-        for (int n = 0; n < 4; n++) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[m][n][e] = 0.0f;
 
     const uint32_t KT = a.dim / BK;
-    const uint32_t fr = lane & 15u, fq = lane >> 4;
-    // fragment read offsets inside an operand image (loop invariant)
-    uint32_t offA[8], offB[4];
+    const uint32_t fr = lane & 31u, fq = lane >> 5;
+    // fragment read offsets inside an operand image (loop invariant): [32-row block][k half h]: lane (fr, fq)
+    // reads piece 2 h + fq of row fr
+    uint32_t offA[4][2], offB[2][2];
 #pragma unroll
-    for (uint32_t m = 0; m < 8; m++) offA[m] = off(wm * 128u + m * 16u + fr, fq);
+    for (uint32_t m = 0; m < 4; m++)
 #pragma unroll
-    for (uint32_t n = 0; n < 4; n++) offB[n] = OP_BYTES + off(wn * 64u + n * 16u + fr, fq);
+        for (uint32_t h = 0; h < 2; h++) offA[m][h] = off(wm * 128u + m * 32u + fr, 2u * h + fq);
+#pragma unroll
+    for (uint32_t n = 0; n < 2; n++)
+#pragma unroll
+        for (uint32_t h = 0; h < 2; h++) offB[n][h] = OP_BYTES + off(wn * 64u + n * 32u + fr, 2u * h + fq);
 
     // Software pipeline.  Fragment registers are double buffered (statically indexed: the K loop is unrolled
     // by two): in step kt a wave first issues the DMA of step kt+3 and the ds_reads of step kt+1, then the 32
@@ -113,9 +128,13 @@ __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArg
     auto read_frags = [&](uint32_t kt, bf16x8 *fa, bf16x8 *fb) {
         const char *S = smem + (kt & 3u) * SLOT_BYTES;
 #pragma unroll
-        for (int n = 0; n < 4; n++) fb[n] = *reinterpret_cast<const bf16x8 *>(S + offB[n]);
+        for (int n = 0; n < 2; n++)
 #pragma unroll
-        for (int m = 0; m < 8; m++) fa[m] = *reinterpret_cast<const bf16x8 *>(S + offA[m]);
+            for (int h = 0; h < 2; h++) fb[n * 2 + h] = *reinterpret_cast<const bf16x8 *>(S + offB[n][h]);
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) fa[m * 2 + h] = *reinterpret_cast<const bf16x8 *>(S + offA[m][h]);
     };
     // FULL = steady state (steps kt+1 and kt+3 exist): no branches in the body, so hipcc keeps counted
     // lgkmcnt waits; with the conditions inside it joins control flow and falls back to lgkmcnt(0) right
@@ -124,19 +143,57 @@ __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArg
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int m = 0; m < 8; m++)
+        for (int h = 0; h < 2; h++)
 #pragma unroll
-            for (int n = 0; n < 4; n++)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m], fb[n], acc[m][n], 0, 0, 0);
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int n = 0; n < 2; n++)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m * 2 + h], fb[n * 2 + h], acc[m][n], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
     };
+    // Steady-state step, interleaved: after each of the 16 MFMAs ONE other vector-memory / LDS instruction of
+    // the step is issued — the 4 LDS-DMAs of step kt+3 and the 12 fragment reads of step kt+1 — so that their
+    // issue time (an LDS-DMA holds the wave's issue for 60-185 cycles) runs under this wave's own MFMAs instead
+    // of in front of them.  As [stage][reads][MFMAs] a wave's non-MFMA issue took ~790 cycles per step against
+    // the 512 its SIMD partner computes for, and the pipe idled the difference (tuning.md).
     auto step_full = [&](uint32_t kt, const bf16x8 *fa, const bf16x8 *fb, bf16x8 *na, bf16x8 *nb) {
-        stage((kt + 3) & 3u, kt + 3);   // slot (kt-1)&3: its last ds_read was issued in step kt-2
-        read_frags(kt + 1, na, nb);      // landed: waited for before the barrier of step kt-1
-        mfmas(fa, fb);
+        char *SA = smem + ((kt + 3) & 3u) * SLOT_BYTES, *SB = SA + OP_BYTES;   // slot (kt-1)&3: last read in step kt-2
+        const char *S = smem + ((kt + 1) & 3u) * SLOT_BYTES;                    // landed before the barrier of step kt-1
+        const uint32_t ko = (kt + 3) * BK;
+        if constexpr (!IL) {   // A/B arm (CX_PAIR_INTERLEAVE=0): the same work as [stage][reads][MFMAs]
+            stage((kt + 3) & 3u, kt + 3);
+            read_frags(kt + 1, na, nb);
+            mfmas(fa, fb);
+        } else {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int idx = 0; idx < 16; idx++) {
+            const int h = idx >> 3, m = (idx >> 1) & 3, n = idx & 1;
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m * 2 + h], fb[n * 2 + h], acc[m][n], 0, 0, 0);
+            if ((idx & 3) == 0) {
+                const int d = idx >> 2, q = d >> 1;
+                const uint32_t o = (wave * 2u + (uint32_t)q) * 1024u;
+                if ((d & 1) == 0)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcA[q] + ko),
+                                                     (__attribute__((address_space(3))) void *)(SA + o), 16, 0, 0);
+                else
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcB[q] + ko),
+                                                     (__attribute__((address_space(3))) void *)(SB + o), 16, 0, 0);
+            } else {
+                const int r = idx - (idx >> 2) - 1;   // 0..11: B fragments first, then A
+                if (r < 4) nb[r] = *reinterpret_cast<const bf16x8 *>(S + offB[r >> 1][r & 1]);
+                else na[r - 4] = *reinterpret_cast<const bf16x8 *>(S + offA[(r - 4) >> 1][(r - 4) & 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        }
+        unsigned long long w0 = 0, w1 = 0;
+        if constexpr (DIAG) { asm volatile("s_nop 0" :: "v"(acc[3][1][15])); w0 = __builtin_readcyclecounter(); }
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // step kt+2 landed (read next step); kt+3 stays in flight
+        if constexpr (DIAG) w1 = __builtin_readcyclecounter();
         __builtin_amdgcn_s_barrier();
+        if constexpr (DIAG) { const unsigned long long w2 = __builtin_readcyclecounter(); c_vm += w1 - w0; c_bar += w2 - w1; }
     };
     auto step_tail = [&](uint32_t kt, const bf16x8 *fa, const bf16x8 *fb, bf16x8 *na, bf16x8 *nb) {
         if (kt + 3 < KT) stage((kt + 3) & 3u, kt + 3);
@@ -168,7 +225,7 @@ __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArg
         if (kt + 1 < KT) step_tail(kt + 1, fa1, fb1, fa0, fb0);
     }
 
-    if constexpr (DIAG) { asm volatile("s_nop 0" :: "v"(acc[7][3][3])); t2 = __builtin_readcyclecounter(); }
+    if constexpr (DIAG) { asm volatile("s_nop 0" :: "v"(acc[3][1][15])); t2 = __builtin_readcyclecounter(); }
     // epilogue: C[row][col], col = lane & 15 (j), row = 4*(lane >> 4) + e (i)
     const bool mirror = a.symmetric && ti != tj;
     auto emit = [&](uint32_t i, uint32_t j) {
@@ -180,32 +237,31 @@ __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArg
     // Hits are rare (a handful per 128x64 wave tile), so the 128 accumulator values are screened 16 at a time
     // with a running maximum and ONE wave-uniform branch per 16x64 strip; only strips with a hit somewhere in
     // the wave walk their elements (one test per element took 9.6k cycles per tile, 19 % of the kernel).
+    // C layout of the 32x32 tile: register e of lane l holds row 8 (e / 4) + 4 (l >> 5) + e % 4, column l & 31
 #pragma unroll
-    for (uint32_t m = 0; m < 8; m++) {
-        float mx = acc[m][0][0];
+    for (uint32_t m = 0; m < 4; m++)
 #pragma unroll
-        for (uint32_t n = 0; n < 4; n++)
+        for (uint32_t n = 0; n < 2; n++) {
+            float mx = acc[m][n][0];
 #pragma unroll
-            for (uint32_t e = 0; e < 4; e++) mx = fmaxf(mx, acc[m][n][e]);
-        if (__ballot(mx >= a.thr_lo) == 0ull) continue;
+            for (uint32_t e = 1; e < 16; e++) mx = fmaxf(mx, acc[m][n][e]);
+            if (__ballot(mx >= a.thr_lo) == 0ull) continue;
+            const uint32_t j = j0 + wn * 64u + n * 32u + fr;
 #pragma unroll
-        for (uint32_t n = 0; n < 4; n++) {
-            const uint32_t j = j0 + wn * 64u + n * 16u + fr;
-#pragma unroll
-            for (uint32_t e = 0; e < 4; e++) {
+            for (uint32_t e = 0; e < 16; e++) {
                 const bool hit = acc[m][n][e] >= a.thr_lo;
                 if (__ballot(hit) == 0ull) continue;
                 if (hit) {
-                    const uint32_t i = i0 + wm * 128u + m * 16u + 4u * fq + e;
+                    const uint32_t i = i0 + wm * 128u + m * 32u + 8u * (e >> 2) + 4u * fq + (e & 3u);
                     emit(i, j);
                     if (mirror) emit(j, i);
                 }
             }
         }
-    }
     if constexpr (DIAG) {
         const unsigned long long t3 = __builtin_readcyclecounter();
-        if (lane == 0) { unsigned long long *o = a.diag + ((size_t)blockIdx.x * 8 + wave) * 4; o[0] = t1 - t0; o[1] = t2 - t1; o[2] = t3 - t2; o[3] = t3 - t0; }
+        if (lane == 0) { unsigned long long *o = a.diag + ((size_t)blockIdx.x * 8 + wave) * 4; o[0] = t1 - t0; o[1] = t2 - t1; o[2] = t3 - t2; o[3] = t3 - t0;
+            if (blockIdx.x == 5017 && wave == 5) printf("[pair256] main-loop waits of one tile: vmcnt %llu  barrier %llu\n", c_vm, c_bar); }
     }
 }
 
@@ -230,17 +286,20 @@ int launch_pair_filter256(const PairFilterArgs &a, hipStream_t stream) {
     if (tiles > 0x7FFFFFFFull) return set_err(CX_ERR_VALIDATION, "pair filter 256: too many tiles");
     static bool attr_set = false;
     if (!attr_set) {
-        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_filter256_kernel<false>),
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_filter256_kernel<false, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_filter256_kernel<true>),
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_filter256_kernel<true, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_filter256_kernel<false, false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set = true;
     }
+    static const int il = getenv("CX_PAIR_INTERLEAVE") ? atoi(getenv("CX_PAIR_INTERLEAVE")) : 1;
     if (getenv("CX_PAIR_DIAG")) {   // diagnostic build: per-phase cycles per tile on stderr, results still valid
         PairFilterArgs d = a;
         const size_t n = (size_t)tiles * 8 * 4;
         CX_HIP(hipMalloc((void **)&d.diag, n * 8));
-        hipLaunchKernelGGL(pair_filter256_kernel<true>, dim3((uint32_t)tiles), dim3(512), LDS_BYTES, stream, d);
+        hipLaunchKernelGGL((pair_filter256_kernel<true, true>), dim3((uint32_t)tiles), dim3(512), LDS_BYTES, stream, d);
         CX_HIP(hipStreamSynchronize(stream));
         std::vector<unsigned long long> h(n);
         CX_HIP(hipMemcpy(h.data(), d.diag, n * 8, hipMemcpyDeviceToHost));
@@ -252,7 +311,8 @@ int launch_pair_filter256(const PairFilterArgs &a, hipStream_t stream) {
                 (unsigned long long)tiles, s[0] / nw, s[1] / nw, s[2] / nw, s[3] / nw);
         return CX_OK;
     }
-    hipLaunchKernelGGL(pair_filter256_kernel<false>, dim3((uint32_t)tiles), dim3(512), LDS_BYTES, stream, a);
+    if (il) hipLaunchKernelGGL((pair_filter256_kernel<false, true>), dim3((uint32_t)tiles), dim3(512), LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL((pair_filter256_kernel<false, false>), dim3((uint32_t)tiles), dim3(512), LDS_BYTES, stream, a);
     CX_HIP(hipGetLastError());
     return CX_OK;
 }
