@@ -41,6 +41,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BT_ROWS = 16;   // rows per tile
 constexpr int BT_Q = 64;      // queries per pass (4 waves x 16)
+constexpr uint32_t BATCH_K_WIDE = 104;   // largest k of the wide mode (lists of k + 48 for 32 queries next to two 48 KiB tiles)
 
 template <int D>
 struct BatchCfg {
@@ -357,7 +358,9 @@ __device__ inline float wave_sum_dpp(float v) {
     return v;
 }
 
-template <int D, bool DIAG>
+// E = candidate-list entries a lane holds in a compaction: 1 for k <= 32 (64 queries per pass, lists of 80),
+// 3 for k <= 104 ("wide": 32 queries per pass — the auto-linker's top-100 lists — lists of k + 48)
+template <int D, bool DIAG, int E>
 __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
     using C = Batch2Cfg<D>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -365,10 +368,11 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
     char *tiles = smem;
     float *c_rr = reinterpret_cast<float *>(smem + 2 * C::TILE_BYTES);
     const uint32_t capq = a.capq;
+    constexpr uint32_t QC = E == 1 ? BT_Q : BT_Q / 2;   // queries that own a candidate list
     uint32_t *c_rows = reinterpret_cast<uint32_t *>(c_rr + 2 * BT_ROWS);
-    float *c_dots = reinterpret_cast<float *>(c_rows + BT_Q * capq);
-    float *c_rrs = c_dots + BT_Q * capq;
-    uint64_t *c_tau = reinterpret_cast<uint64_t *>(c_rrs + BT_Q * capq);
+    float *c_dots = reinterpret_cast<float *>(c_rows + QC * capq);
+    float *c_rrs = c_dots + QC * capq;
+    uint64_t *c_tau = reinterpret_cast<uint64_t *>(c_rrs + QC * capq);
     uint32_t *c_cnt = reinterpret_cast<uint32_t *>(c_tau + BT_Q);
     float *c_tsq = reinterpret_cast<float *>(c_cnt + BT_Q);
     uint32_t *c_pub = reinterpret_cast<uint32_t *>(c_tsq + BT_Q);   // entries of a list that are completely written
@@ -463,28 +467,36 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
         // cosine whichever blocks contributed — rows below it can be skipped by everyone.  Results do not depend
         // on timing: the bound only removes rows that cannot be in the top k.
         unsigned long long n_pcompact = 0;
-        uint64_t gv[4] = {0ull, 0ull, 0ull, 0ull};
-        const uint32_t g_q = pw * 16u + (lane >> 2), g_g = lane & 3u;
-        const uint32_t n_gld = (k + 7u) / 8u;   // lane (query, g) reads slot pairs 8 i + 2 g, 8 i + 2 g + 1
-        auto refresh_issue = [&]() {
-            const uint64_t *G = reinterpret_cast<const uint64_t *>(a.gslots + g_q * 32u) + g_g;
+        // E = 1: 4 lanes per query, all 16 queries of the group per refresh, slots at stride 32;
+        // wide (E = 3): 8 lanes per query, 8 queries per refresh (the two halves of the group alternate), stride 128
+        constexpr uint32_t LPQ = E == 1 ? 4u : 8u, NG = E == 1 ? 4u : 7u, GSTRIDE = E == 1 ? 32u : 128u;
+        uint64_t gv[NG];
 #pragma unroll
-            for (uint32_t i = 0; i < 4; i++)
-                if (i < n_gld) gv[i] = __hip_atomic_load(G + 4u * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t i = 0; i < NG; i++) gv[i] = 0ull;
+        const uint32_t g_g = lane & (LPQ - 1u);
+        uint32_t g_q = pw * 16u + lane / LPQ;       // query whose slots this lane reads (wide: + 8 on odd refreshes)
+        const uint32_t n_gld = (k + 2u * LPQ - 1u) / (2u * LPQ);   // lane (query, g) reads slot pairs 2 (g + LPQ i), + 1
+        auto refresh_issue = [&](uint32_t half) {
+            g_q = pw * 16u + (E == 1 ? 0u : 8u * (half & 1u)) + lane / LPQ;
+            const uint64_t *G = reinterpret_cast<const uint64_t *>(a.gslots + g_q * GSTRIDE) + g_g;
+#pragma unroll
+            for (uint32_t i = 0; i < NG; i++)
+                if (i < n_gld) gv[i] = __hip_atomic_load(G + LPQ * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
         auto refresh_apply = [&]() {
             uint32_t mn = 0xFFFFFFFFu;
 #pragma unroll
-            for (uint32_t i = 0; i < 4; i++) {
-                const uint32_t s0 = 8u * i + 2u * g_g, lo = (uint32_t)gv[i], hi = (uint32_t)(gv[i] >> 32);
-                if (s0 < k) mn = lo < mn ? lo : mn;
-                if (s0 + 1u < k) mn = hi < mn ? hi : mn;
+            for (uint32_t i = 0; i < NG; i++) {
+                const uint32_t s0 = 2u * (g_g + LPQ * i), lo = (uint32_t)gv[i], hi = (uint32_t)(gv[i] >> 32);
+                if (i < n_gld && s0 < k) mn = lo < mn ? lo : mn;
+                if (i < n_gld && s0 + 1u < k) mn = hi < mn ? hi : mn;
             }
-            uint32_t o = (uint32_t)__shfl_xor((int)mn, 1, 64);
-            mn = o < mn ? o : mn;
-            o = (uint32_t)__shfl_xor((int)mn, 2, 64);
-            mn = o < mn ? o : mn;
-            if (g_g == 0u && mn != 0u && mn != 0xFFFFFFFFu) {   // every slot filled
+#pragma unroll
+            for (uint32_t x = 1; x < LPQ; x <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_xor((int)mn, (int)x, 64);
+                mn = o < mn ? o : mn;
+            }
+            if (g_g == 0u && g_q < QC && mn != 0u && mn != 0xFFFFFFFFu) {   // every slot filled
                 const float sm = __uint_as_float(mn);
                 const float t = sm * sm * (1.0f - 1.0e-4f);
                 if (t > c_tsq[g_q]) c_tsq[g_q] = t;
@@ -492,7 +504,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
         };
         auto producer_compact = [&]() {
             uint32_t pubv = 0, shrv = 1;
-            if (lane < 16u) { pubv = c_pub[pw * 16u + lane]; shrv = c_shr[pw * 16u + lane]; }
+            if (lane < 16u && pw * 16u < QC) { pubv = c_pub[pw * 16u + lane]; shrv = c_shr[pw * 16u + lane]; }
             uint64_t need = __ballot(lane < 16u && shrv == 0u && pubv + 32u >= capq && pubv > k);
             while (need) {
                 const int l = __ffsll((unsigned long long)need) - 1;
@@ -500,55 +512,95 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
                 if constexpr (DIAG) n_pcompact++;
                 const uint32_t qs = pw * 16u + (uint32_t)l;
                 uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)pubv, l);
-                n = n < 64u ? n : 64u;
+                n = n < 64u * E ? n : 64u * E;
                 const float qq_of = c_qq[qs];
                 uint32_t *rws = c_rows + qs * capq;
                 float *dts = c_dots + qs * capq, *rrs = c_rrs + qs * capq;
-                const bool valid = lane < n;
-                uint32_t r0 = 0, ord = 0; float d0 = 0.0f, n0 = 1.0f, sim = 0.0f;
-                if (valid) { r0 = rws[lane]; d0 = dts[lane]; n0 = rrs[lane]; sim = cosine_from_sums(d0, qq_of, n0); ord = score_ord(score_of(distance_of(sim))); }
+                // entry 64 e + lane of the list sits in slot e of this lane
+                bool valid[E];
+                uint32_t r0[E], ord[E]; float d0[E], n0[E], sim[E];
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    const uint32_t idx = lane + 64u * e;
+                    valid[e] = idx < n;
+                    r0[e] = 0; ord[e] = 0; d0[e] = 0.0f; n0[e] = 1.0f; sim[e] = 0.0f;
+                    if (valid[e]) {
+                        r0[e] = rws[idx]; d0[e] = dts[idx]; n0[e] = rrs[idx];
+                        sim[e] = cosine_from_sums(d0[e], qq_of, n0[e]);
+                        ord[e] = score_ord(score_of(distance_of(sim[e])));
+                    }
+                }
+                auto count_ge = [&](uint32_t t) {
+                    uint32_t c = 0;
+#pragma unroll
+                    for (int e = 0; e < E; e++) c += (uint32_t)__popcll(__ballot(valid[e] && ord[e] >= t));
+                    return c;
+                };
                 // radix select of the k-th largest score order, most significant bit first.  Scores are <= 1.0, so
                 // bits 31..30 are clear unless something odd is in the list; the walk stops as soon as exactly k
                 // entries lie at or above the prefix (then they ARE the top k and no tie can straddle the cut)
                 uint32_t T = 0;
                 bool exact_k = false;
-                int b = __ballot(valid && ord >= 0x40000000u) ? 31 : 29;
+                int b = count_ge(0x40000000u) ? 31 : 29;
 #pragma unroll 1
                 for (; b >= 0; b--) {
                     const uint32_t candT = T | (1u << b);
-                    const uint32_t c = (uint32_t)__popcll(__ballot(valid && ord >= candT));
+                    const uint32_t c = count_ge(candT);
                     if (c >= k) { T = candT; if (c == k) { exact_k = true; break; } }
                 }
-                const uint64_t gt = __ballot(valid && ord > T), eq = __ballot(valid && ord == T);
-                uint64_t keep_eq = eq;
-                if (!exact_k) {   // T is the k-th largest value itself
-                    const uint32_t want_eq = k - (uint32_t)__popcll(gt);   // >= 1 of the lanes tied on it
-                    if ((uint32_t)__popcll(eq) != want_eq) {   // equal scores straddle the cut: lower rows win
-                        uint32_t rk = 0;
-                        for (uint64_t m = eq; m; m &= m - 1) {
-                            const uint32_t ro = (uint32_t)__builtin_amdgcn_readlane((int)r0, __ffsll((unsigned long long)m) - 1);
-                            rk += ro < r0 ? 1u : 0u;
+                uint64_t gt[E], eq[E], keep[E];
+                uint32_t n_gt = 0, n_eq = 0;
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    gt[e] = __ballot(valid[e] && ord[e] > T);
+                    eq[e] = __ballot(valid[e] && ord[e] == T);
+                    n_gt += (uint32_t)__popcll(gt[e]);
+                    n_eq += (uint32_t)__popcll(eq[e]);
+                    keep[e] = gt[e] | eq[e];
+                }
+                if (!exact_k && n_eq != k - n_gt) {   // equal scores straddle the cut: lower rows win
+                    const uint32_t want_eq = k - n_gt;
+                    uint32_t rk[E];
+#pragma unroll
+                    for (int e = 0; e < E; e++) rk[e] = 0;
+#pragma unroll
+                    for (int f = 0; f < E; f++)
+                        for (uint64_t m = eq[f]; m; m &= m - 1) {
+                            const uint32_t ro = (uint32_t)__builtin_amdgcn_readlane((int)r0[f], __ffsll((unsigned long long)m) - 1);
+#pragma unroll
+                            for (int e = 0; e < E; e++) rk[e] += ro < r0[e] ? 1u : 0u;
                         }
-                        keep_eq = __ballot(valid && ord == T && rk < want_eq);
-                    }
+#pragma unroll
+                    for (int e = 0; e < E; e++) keep[e] = gt[e] | __ballot(valid[e] && ord[e] == T && rk[e] < want_eq);
                 }
                 // the k-th best = the smallest kept score order, and among equal ones the largest row
-                const bool kept = ((gt | keep_eq) >> lane) & 1ull;
-                const uint32_t mn = wave_min_u32(kept ? ord : 0xFFFFFFFFu);
+                uint32_t mine = 0xFFFFFFFFu;
+#pragma unroll
+                for (int e = 0; e < E; e++) mine = (((keep[e] >> lane) & 1ull) && ord[e] < mine) ? ord[e] : mine;
+                const uint32_t mn = wave_min_u32(mine);
                 uint32_t trow = 0; float tsim = 0.0f;
-                for (uint64_t m = __ballot(kept && ord == mn); m; m &= m - 1) {
-                    const int le = __ffsll((unsigned long long)m) - 1;
-                    const uint32_t ro = (uint32_t)__builtin_amdgcn_readlane((int)r0, le);
-                    if (ro >= trow) { trow = ro; tsim = readlane_f32(sim, le); }
+#pragma unroll
+                for (int e = 0; e < E; e++)
+                    for (uint64_t m = __ballot(((keep[e] >> lane) & 1ull) && ord[e] == mn); m; m &= m - 1) {
+                        const int le = __ffsll((unsigned long long)m) - 1;
+                        const uint32_t ro = (uint32_t)__builtin_amdgcn_readlane((int)r0[e], le);
+                        if (ro >= trow) { trow = ro; tsim = readlane_f32(sim[e], le); }
+                    }
+                // survivors to [0, k): rank in (slot, lane) order <= the entry's old index, and every lane read first
+                uint32_t base = 0;
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    if ((keep[e] >> lane) & 1ull) {
+                        const uint32_t slot = base + (uint32_t)__popcll(keep[e] & ((1ull << lane) - 1ull));
+                        rws[slot] = r0[e]; dts[slot] = d0[e]; rrs[slot] = n0[e];
+                    }
+                    base += (uint32_t)__popcll(keep[e]);
                 }
-                const uint64_t keep = gt | keep_eq;
-                if ((keep >> lane) & 1ull) {
-                    const uint32_t slot = (uint32_t)__popcll(keep & ((1ull << lane) - 1ull));   // <= lane: every lane read first
-                    rws[slot] = r0; dts[slot] = d0; rrs[slot] = n0;
-                }
-                if (((keep >> lane) & 1ull) && sim > 0.0f)
-                    __hip_atomic_fetch_max(a.gslots + qs * 32u + ((r0 * 2654435761u) >> 16) % k, __float_as_uint(sim),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int e = 0; e < E; e++)
+                    if (((keep[e] >> lane) & 1ull) && sim[e] > 0.0f)
+                        __hip_atomic_fetch_max(a.gslots + qs * GSTRIDE + ((r0[e] * 2654435761u) >> 16) % k, __float_as_uint(sim[e]),
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (lane == 0) {
                     c_tau[qs] = cand_key(trow, tsim);
                     const float t = tsim > 0.0f ? tsim * tsim * (1.0f - 1.0e-4f) : -1.0f;
@@ -576,7 +628,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
                 write_tile(ld, buf ^ 1u, next + 2u * gridDim.x);     // buffer last read one tile ago, behind that tile's barrier
                 stamp(t_write);
             }
-            if ((it & 3u) == 0u) refresh_issue();
+            if ((it & 3u) == 0u) refresh_issue(it >> 2);
             it++;
             producer_compact();
             stamp(t_stage);
@@ -635,33 +687,39 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
     for (uint32_t ksl = 0; ksl < 4; ksl++) a_off[ksl] = j * C::ROW_BYTES + ((((4u * ksl + kq) ^ j) & 15u) << 4);
 
     unsigned long long n_compact = 0, n_append_steps = 0;
+    // final, ORDERED compaction of one list (rank counting: entry 64 e + lane sits in slot e of this lane)
+    constexpr int NE = E == 1 ? 2 : 3;
     auto compact = [&](uint32_t qs, float qq_of) {
         if constexpr (DIAG) n_compact++;
         const uint32_t n = c_cnt[qs] < capq ? c_cnt[qs] : capq;
         uint32_t *rws = c_rows + qs * capq;
         float *dts = c_dots + qs * capq, *rrs = c_rrs + qs * capq;
-        uint32_t r0 = 0, r1 = 0; float d0 = 0.0f, d1 = 0.0f, n0 = 1.0f, n1 = 1.0f; uint64_t k0 = 0ull, k1 = 0ull;
-        if (lane < n) { r0 = rws[lane]; d0 = dts[lane]; n0 = rrs[lane]; k0 = cand_key(r0, cosine_from_sums(d0, qq_of, n0)); }
-        if (lane + 64u < n) { r1 = rws[lane + 64u]; d1 = dts[lane + 64u]; n1 = rrs[lane + 64u]; k1 = cand_key(r1, cosine_from_sums(d1, qq_of, n1)); }
-        uint32_t rank0 = 0, rank1 = 0;
-        const uint32_t n_lo = n < 64u ? n : 64u;
-        for (uint32_t f = 0; f < n_lo; f++) {
-            const uint64_t kf = readlane_u64(k0, (int)f);
-            rank0 += kf > k0 ? 1u : 0u;
-            rank1 += kf > k1 ? 1u : 0u;
+        uint32_t r[NE], rank[NE]; float d[NE], nr[NE]; uint64_t key[NE];
+#pragma unroll
+        for (int e = 0; e < NE; e++) {
+            const uint32_t idx = lane + 64u * e;
+            r[e] = 0; d[e] = 0.0f; nr[e] = 1.0f; key[e] = 0ull; rank[e] = 0;
+            if (idx < n) { r[e] = rws[idx]; d[e] = dts[idx]; nr[e] = rrs[idx]; key[e] = cand_key(r[e], cosine_from_sums(d[e], qq_of, nr[e])); }
         }
-        for (uint32_t f = 64u; f < n; f++) {
-            const uint64_t kf = readlane_u64(k1, (int)(f - 64u));
-            rank0 += kf > k0 ? 1u : 0u;
-            rank1 += kf > k1 ? 1u : 0u;
+#pragma unroll
+        for (int g = 0; g < NE; g++) {
+            const uint32_t hi = n < 64u * (g + 1) ? n : 64u * (g + 1);
+            for (uint32_t f = 64u * g; f < hi; f++) {
+                const uint64_t kf = readlane_u64(key[g], (int)(f - 64u * g));
+#pragma unroll
+                for (int e = 0; e < NE; e++) rank[e] += kf > key[e] ? 1u : 0u;
+            }
         }
-        auto set_tau = [&](uint64_t kk, float dt, float nr) {
-            const float sm = cosine_from_sums(dt, qq_of, nr);
-            c_tau[qs] = kk;
-            c_tsq[qs] = sm > 0.0f ? sm * sm * (1.0f - 1.0e-4f) : -1.0f;
-        };
-        if (lane < n && rank0 < k) { rws[rank0] = r0; dts[rank0] = d0; rrs[rank0] = n0; if (rank0 == k - 1u) set_tau(k0, d0, n0); }
-        if (lane + 64u < n && rank1 < k) { rws[rank1] = r1; dts[rank1] = d1; rrs[rank1] = n1; if (rank1 == k - 1u) set_tau(k1, d1, n1); }
+#pragma unroll
+        for (int e = 0; e < NE; e++)
+            if (lane + 64u * e < n && rank[e] < k) {
+                rws[rank[e]] = r[e]; dts[rank[e]] = d[e]; rrs[rank[e]] = nr[e];
+                if (rank[e] == k - 1u) {
+                    const float sm = cosine_from_sums(d[e], qq_of, nr[e]);
+                    c_tau[qs] = key[e];
+                    c_tsq[qs] = sm > 0.0f ? sm * sm * (1.0f - 1.0e-4f) : -1.0f;
+                }
+            }
         if (lane == 0) c_cnt[qs] = n < k ? n : k;
     };
 
@@ -684,7 +742,9 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
     __syncthreads();   // tile 0 is in buffer 0
     stamp0();
     uint32_t buf = 0;
+    const bool wave_dead = pw * 16u >= QC;   // wide mode: consumer waves 2, 3 own no queries; they only keep the barriers
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        if (wave_dead) { __syncthreads(); buf ^= 1u; continue; }
         apply_shrink();
         stamp(t_stage);
         const char *Thi = tiles + buf * C::TILE_BYTES, *Tlo = Thi + C::IMG_BYTES;
@@ -789,20 +849,27 @@ uint32_t batch_grid_blocks(uint32_t n_rows) {
     return tiles < (uint32_t)cus ? (tiles ? tiles : 1u) : (uint32_t)cus;
 }
 
-bool batch_supported(uint32_t dim, uint32_t k) { return (dim == 384 || dim == 768) && k >= 1 && k <= 32; }
+bool batch_supported(uint32_t dim, uint32_t k) { return (dim == 384 || dim == 768) && k >= 1 && k <= BATCH_K_WIDE; }
+uint32_t batch_queries_per_pass(uint32_t k) { return k <= 32 ? 64u : 32u; }
 
 template <int D>
 static int launch_batch_d(BatchArgs a, uint32_t grid, hipStream_t stream) {
-    static const int use_f32 = getenv("CX_BATCH_F32MFMA") ? atoi(getenv("CX_BATCH_F32MFMA")) : 0;
-    const size_t tail = (size_t)BT_Q * a.capq * 12 + BT_Q * 8 + BT_Q * 4 + BT_Q * 4 + 3 * BT_Q * 4;
+    static const int use_f32_env = getenv("CX_BATCH_F32MFMA") ? atoi(getenv("CX_BATCH_F32MFMA")) : 0;
+    const int use_f32 = use_f32_env && a.k <= 32;   // the f32-MFMA kernel has no wide mode
+    const bool wide = a.k > 32;   // 32 queries per pass, lists of k + 48, three entries per lane in a compaction
+    const size_t qc = wide ? BT_Q / 2 : BT_Q;
+    const size_t tail = qc * a.capq * 12 + BT_Q * 8 + BT_Q * 4 + BT_Q * 4 + 3 * BT_Q * 4;
     const size_t lds = use_f32 ? 2 * (size_t)BatchCfg<D>::TILE_BYTES + tail
                                : 2 * (size_t)Batch2Cfg<D>::TILE_BYTES + 2 * BT_ROWS * 4 + tail;
+    if (lds > 160 * 1024) return set_err(CX_ERR_VALIDATION, "batch scan: %zu bytes of LDS for k = %u", lds, a.k);
     static bool attr_set = false;
     if (!attr_set) {
         CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch_scan_kernel<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch_scan_kernel<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch2_kernel<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch2_kernel<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch2_kernel<D, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch2_kernel<D, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch2_kernel<D, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch2_kernel<D, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     if (getenv("CX_BATCH_DIAG")) {  // diagnostic build: per-phase cycle shares on stderr, results still valid
@@ -810,7 +877,8 @@ static int launch_batch_d(BatchArgs a, uint32_t grid, hipStream_t stream) {
         CX_HIP(hipMalloc((void **)&a.diag, n * 8));
         CX_HIP(hipMemset(a.diag, 0, n * 8));
         if (use_f32) hipLaunchKernelGGL((batch_scan_kernel<D, true>), dim3(grid), dim3(256), lds, stream, a);
-        else hipLaunchKernelGGL((batch2_kernel<D, true>), dim3(grid), dim3(512), lds, stream, a);
+        else if (wide) hipLaunchKernelGGL((batch2_kernel<D, true, 3>), dim3(grid), dim3(512), lds, stream, a);
+        else hipLaunchKernelGGL((batch2_kernel<D, true, 1>), dim3(grid), dim3(512), lds, stream, a);
         CX_HIP(hipStreamSynchronize(stream));
         std::vector<unsigned long long> h(n);
         CX_HIP(hipMemcpy(h.data(), a.diag, n * 8, hipMemcpyDeviceToHost));
@@ -829,17 +897,25 @@ static int launch_batch_d(BatchArgs a, uint32_t grid, hipStream_t stream) {
         return CX_OK;
     }
     if (use_f32) hipLaunchKernelGGL((batch_scan_kernel<D, false>), dim3(grid), dim3(256), lds, stream, a);
-    else hipLaunchKernelGGL((batch2_kernel<D, false>), dim3(grid), dim3(512), lds, stream, a);
+    else if (wide) hipLaunchKernelGGL((batch2_kernel<D, false, 3>), dim3(grid), dim3(512), lds, stream, a);
+    else hipLaunchKernelGGL((batch2_kernel<D, false, 1>), dim3(grid), dim3(512), lds, stream, a);
     CX_HIP(hipGetLastError());
     return CX_OK;
 }
 
 int launch_batch_scan(BatchArgs a, uint32_t grid, hipStream_t stream) {
     if (!batch_supported(a.dim, a.k)) return set_err(CX_ERR_VALIDATION, "batch scan: unsupported dim %u / k %u", a.dim, a.k);
-    if (a.nq == 0 || a.nq > BT_Q) return set_err(CX_ERR_VALIDATION, "batch scan: 1..64 queries per pass");
+    if (a.nq == 0 || a.nq > batch_queries_per_pass(a.k)) return set_err(CX_ERR_VALIDATION, "batch scan: 1..%u queries per pass at k = %u", batch_queries_per_pass(a.k), a.k);
     // batch2: lists are compacted at capq - 32 entries (<= 64: one per lane) and never exceed capq; k + 16 <= capq - 32
-    static const int use_f32 = getenv("CX_BATCH_F32MFMA") ? atoi(getenv("CX_BATCH_F32MFMA")) : 0;
+    static const int use_f32_env = getenv("CX_BATCH_F32MFMA") ? atoi(getenv("CX_BATCH_F32MFMA")) : 0;
+    const int use_f32 = use_f32_env && a.k <= 32;
     a.capq = use_f32 ? (a.k <= 16 ? 64u : 80u) : 80u;
+    if (a.k > 32) {   // wide: as long as LDS allows (a compaction absorbs capq - 32 - k new entries), at most 3 x 64 + 16
+        const size_t tiles = 2 * (a.dim == 384 ? (size_t)Batch2Cfg<384>::TILE_BYTES : (size_t)Batch2Cfg<768>::TILE_BYTES);
+        const size_t room = 160 * 1024 - tiles - 2 * BT_ROWS * 4 - (BT_Q * 8 + BT_Q * 4 + BT_Q * 4 + 3 * BT_Q * 4);
+        uint32_t c = (uint32_t)(room / ((BT_Q / 2) * 12)) & ~7u;
+        a.capq = c > 208u ? 208u : c;
+    }
     if (a.dim == 384) return launch_batch_d<384>(a, grid, stream);
     return launch_batch_d<768>(a, grid, stream);
 }

@@ -245,9 +245,10 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
         const uint32_t bgrid = batch_grid_blocks(n);
         if (int rc = ensure_dev(c->d_part_keys, c->pk_cap, (size_t)64 * bgrid * k_eff)) return rc;
         if (int rc = ensure_dev(c->d_part_sims, c->ps_cap, (size_t)64 * bgrid * k_eff)) return rc;
-        if (int rc = ensure_dev(c->d_gslots, c->gs_cap, (size_t)64 * 32)) return rc;
-        for (uint64_t q0 = 0; q0 < nq; q0 += 64) {
-            const uint32_t m = (uint32_t)std::min<uint64_t>(64, nq - q0);
+        if (int rc = ensure_dev(c->d_gslots, c->gs_cap, (size_t)64 * 128)) return rc;
+        const uint32_t qpp = batch_queries_per_pass(k_eff);
+        for (uint64_t q0 = 0; q0 < nq; q0 += qpp) {
+            const uint32_t m = (uint32_t)std::min<uint64_t>(qpp, nq - q0);
             BatchArgs b;
             memset(&b, 0, sizeof b);
             b.rows = ix->d_rows;
@@ -260,7 +261,7 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
             b.part_keys = c->d_part_keys;
             b.part_sims = c->d_part_sims;
             b.gslots = c->d_gslots;
-            CX_HIP(hipMemsetAsync(c->d_gslots, 0, 64 * 32 * sizeof(uint32_t), s));
+            CX_HIP(hipMemsetAsync(c->d_gslots, 0, 64 * 128 * sizeof(uint32_t), s));
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (ix->profiling) {
                 CX_HIP(hipEventCreate(&e0));

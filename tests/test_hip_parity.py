@@ -305,6 +305,9 @@ def test_search_batch_with_filter_and_tombstones(hip, oracle):
     (60000, 384, 10, 64),    # ~15 tiles per block: lists fill, producers compact, blocks share their bound
     (50000, 768, 32, 20),    # k = 32: compaction threshold == k + 16, every compaction keeps 2/3 of the list
     (33000, 768, 1, 33),     # k = 1, ragged query group
+    (50000, 768, 100, 40),   # wide mode: the auto-linker's top-100 lists, 32 queries per pass, 3 entries per lane
+    (20000, 384, 104, 33),   # largest fused k; second pass holds one query
+    (9000, 768, 33, 5),      # smallest wide k
 ])
 def test_search_batch_long_lists(hip, oracle, n, d, k, nq):
     """Enough rows per block that the in-kernel candidate lists overflow and are compacted many times
@@ -322,10 +325,11 @@ def test_search_batch_long_lists(hip, oracle, n, d, k, nq):
         assert_topk_parity(rows_of(ids, bi[i, :m]), bs[i, :m], e["row"], e["score"], what=f"batch long n={n} k={k} q{i}")
 
 
-def test_search_batch_massive_ties(hip, oracle):
+@pytest.mark.parametrize("k", [32, 100])
+def test_search_batch_massive_ties(hip, oracle, k):
     """50 distinct vectors repeated 800 times: almost every cut falls inside a run of equal scores, so the
     compaction's tie rule (lower insertion row wins) decides the result.  ids must match exactly."""
-    n, d, k = 40000, 384, 32
+    n, d = 40000, 384
     base = oracle.synth_rows(50, d)
     rows = np.ascontiguousarray(base[np.arange(n) % 50])
     qs = np.ascontiguousarray(base[:16] + 0.05 * oracle.synth_queries(50, d, 16))
