@@ -361,8 +361,22 @@ __device__ inline float wave_sum_dpp(float v) {
 // E = candidate-list entries a lane holds in a compaction: 1 for k <= 32 (64 queries per pass, lists of 80),
 // 3 for k <= 104 ("wide": 32 queries per pass — the auto-linker's top-100 lists — lists of k + 48)
 template <int D, bool DIAG, int E>
-__global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
+__global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
     using C = Batch2Cfg<D>;
+    // grid = (row chunks, query groups): block (x, y) scans the tiles t = x (mod gridDim.x) for query group y
+    // (64 queries, 32 in the wide mode).  Small corpora get few chunks — so that a block still sees enough rows
+    // for its own bound to mean something — and many groups per launch; large ones one group on every CU.
+    BatchArgs a = a_in;
+    {
+        constexpr uint32_t QPP = E == 1 ? BT_Q : BT_Q / 2;
+        const uint32_t grp = blockIdx.y;
+        a.queries += (size_t)grp * QPP * D;
+        a.nq = a_in.nq - grp * QPP < QPP ? a_in.nq - grp * QPP : QPP;
+        a.part_keys += (size_t)grp * QPP * gridDim.x * a_in.k;
+        a.part_sims += (size_t)grp * QPP * gridDim.x * a_in.k;
+        a.gslots += (size_t)grp * BT_Q * 128u;
+        if constexpr (DIAG) a.diag += (size_t)grp * gridDim.x * 64u;
+    }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // LDS: [2 tiles: hi image | lo image][rr: 2 x 16 f32][cand rows | dots | rrs: 64 x capq][tau][cnt][tsq][pub][shr][qq]
     char *tiles = smem;
@@ -830,32 +844,56 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a) {
         const uint32_t n = c_cnt[qs];
         const size_t base = ((size_t)qs * gridDim.x + blockIdx.x) * k;
         const float qq_l = readlane_f32(qq, (int)l);
-        if (lane < k) {
-            const bool valid = lane < n;
-            const uint32_t row = valid ? c_rows[qs * capq + lane] : 0u;
-            const float sim = valid ? cosine_from_sums(c_dots[qs * capq + lane], qq_l, c_rrs[qs * capq + lane]) : 0.0f;
-            a.part_keys[base + lane] = valid ? cand_key(row, sim) : 0ull;
-            a.part_sims[base + lane] = sim;
+        for (uint32_t idx = lane; idx < k; idx += 64u) {   // k <= 104: up to two entries per lane
+            const bool valid = idx < n;
+            const uint32_t row = valid ? c_rows[qs * capq + idx] : 0u;
+            const float sim = valid ? cosine_from_sums(c_dots[qs * capq + idx], qq_l, c_rrs[qs * capq + idx]) : 0.0f;
+            a.part_keys[base + idx] = valid ? cand_key(row, sim) : 0ull;
+            a.part_sims[base + idx] = sim;
         }
     }
 }
 
-uint32_t batch_grid_blocks(uint32_t n_rows) {
+static uint32_t batch_cus() {
     int dev = 0, cus = 256;
     hipDeviceProp_t p;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
         cus = p.multiProcessorCount;
-    const uint32_t tiles = (n_rows + BT_ROWS - 1) / BT_ROWS;
-    return tiles < (uint32_t)cus ? (tiles ? tiles : 1u) : (uint32_t)cus;
+    return (uint32_t)cus;
+}
+uint32_t batch_grid_blocks(uint32_t n_rows) {
+    const uint32_t cus = batch_cus();
+    const uint32_t tiles = n_rows / BT_ROWS + (n_rows % BT_ROWS ? 1u : 0u);
+    return tiles < cus ? (tiles ? tiles : 1u) : cus;
 }
 
 bool batch_supported(uint32_t dim, uint32_t k) { return (dim == 384 || dim == 768) && k >= 1 && k <= BATCH_K_WIDE; }
 uint32_t batch_queries_per_pass(uint32_t k) { return k <= 32 ? 64u : 32u; }
 
+// launch shape for nq queries over n_rows rows: chunks x groups blocks.  A block should see >= 256 tiles (4096
+// rows) when the corpus allows; the CUs that leaves free take further query groups in the same launch.
+void batch_launch_shape(uint32_t n_rows, uint64_t nq, uint32_t k, uint32_t *chunks, uint32_t *groups) {
+    const uint32_t cus = batch_cus(), qpp = batch_queries_per_pass(k);
+    const uint32_t tiles = (n_rows + BT_ROWS - 1) / BT_ROWS;
+    uint32_t c = tiles / 256u;
+    if (c < 1u) c = 1u;
+    if (c * 2u > cus) c = cus;                 // large corpus: one group on every CU
+    const uint64_t g_all = (nq + qpp - 1) / qpp;
+    uint64_t g = cus / c;
+    if (g < 1) g = 1;
+    if (g > g_all) g = g_all;
+    if ((uint64_t)c * g < cus) c = (uint32_t)(cus / g);   // too few groups to fill the chip: more, smaller chunks
+    if (c > tiles) c = tiles ? tiles : 1u;
+    static const int one = getenv("CX_BATCH_ONE_GROUP") ? atoi(getenv("CX_BATCH_ONE_GROUP")) : 0;
+    if (one) { c = batch_grid_blocks(n_rows); g = 1; }
+    *chunks = c;
+    *groups = (uint32_t)g;
+}
+
 template <int D>
 static int launch_batch_d(BatchArgs a, uint32_t grid, hipStream_t stream) {
     static const int use_f32_env = getenv("CX_BATCH_F32MFMA") ? atoi(getenv("CX_BATCH_F32MFMA")) : 0;
-    const int use_f32 = use_f32_env && a.k <= 32;   // the f32-MFMA kernel has no wide mode
+    const int use_f32 = use_f32_env && a.k <= 32 && a.n_groups == 1;   // the f32-MFMA kernel has no wide mode and no query groups
     const bool wide = a.k > 32;   // 32 queries per pass, lists of k + 48, three entries per lane in a compaction
     const size_t qc = wide ? BT_Q / 2 : BT_Q;
     const size_t tail = qc * a.capq * 12 + BT_Q * 8 + BT_Q * 4 + BT_Q * 4 + 3 * BT_Q * 4;
@@ -873,19 +911,19 @@ static int launch_batch_d(BatchArgs a, uint32_t grid, hipStream_t stream) {
         attr_set = true;
     }
     if (getenv("CX_BATCH_DIAG")) {  // diagnostic build: per-phase cycle shares on stderr, results still valid
-        const size_t n = (size_t)grid * 8 * 8;   // up to 8 waves x 8 slots per block
+        const size_t n = (size_t)grid * a.n_groups * 8 * 8;   // up to 8 waves x 8 slots per block
         CX_HIP(hipMalloc((void **)&a.diag, n * 8));
         CX_HIP(hipMemset(a.diag, 0, n * 8));
         if (use_f32) hipLaunchKernelGGL((batch_scan_kernel<D, true>), dim3(grid), dim3(256), lds, stream, a);
-        else if (wide) hipLaunchKernelGGL((batch2_kernel<D, true, 3>), dim3(grid), dim3(512), lds, stream, a);
-        else hipLaunchKernelGGL((batch2_kernel<D, true, 1>), dim3(grid), dim3(512), lds, stream, a);
+        else if (wide) hipLaunchKernelGGL((batch2_kernel<D, true, 3>), dim3(grid, a.n_groups), dim3(512), lds, stream, a);
+        else hipLaunchKernelGGL((batch2_kernel<D, true, 1>), dim3(grid, a.n_groups), dim3(512), lds, stream, a);
         CX_HIP(hipStreamSynchronize(stream));
         std::vector<unsigned long long> h(n);
         CX_HIP(hipMemcpy(h.data(), a.diag, n * 8, hipMemcpyDeviceToHost));
         CX_HIP(hipFree(a.diag));
         double s[7] = {0, 0, 0, 0, 0, 0, 0}, tiles = 0;
         double pbar = 0, ncomp = 0, nappend = 0;
-        for (size_t w = 0; w < (size_t)grid * 8; w++) {
+        for (size_t w = 0; w < (size_t)grid * a.n_groups * 8; w++) {
             const bool cons = use_f32 || (w % 8) < 4;
             if (cons) { for (int p = 0; p < 4; p++) s[p] += (double)h[w * 8 + p]; tiles += (double)h[w * 8 + 4]; ncomp += (double)h[w * 8 + 5]; nappend += (double)h[w * 8 + 6]; }
             else { pbar += (double)h[w * 8 + 3]; s[5] += (double)h[w * 8 + 5]; s[6] += (double)h[w * 8 + 6]; ncomp += (double)h[w * 8 + 7]; s[4] += (double)h[w * 8 + 0]; }
@@ -897,18 +935,20 @@ static int launch_batch_d(BatchArgs a, uint32_t grid, hipStream_t stream) {
         return CX_OK;
     }
     if (use_f32) hipLaunchKernelGGL((batch_scan_kernel<D, false>), dim3(grid), dim3(256), lds, stream, a);
-    else if (wide) hipLaunchKernelGGL((batch2_kernel<D, false, 3>), dim3(grid), dim3(512), lds, stream, a);
-    else hipLaunchKernelGGL((batch2_kernel<D, false, 1>), dim3(grid), dim3(512), lds, stream, a);
+    else if (wide) hipLaunchKernelGGL((batch2_kernel<D, false, 3>), dim3(grid, a.n_groups), dim3(512), lds, stream, a);
+    else hipLaunchKernelGGL((batch2_kernel<D, false, 1>), dim3(grid, a.n_groups), dim3(512), lds, stream, a);
     CX_HIP(hipGetLastError());
     return CX_OK;
 }
 
 int launch_batch_scan(BatchArgs a, uint32_t grid, hipStream_t stream) {
     if (!batch_supported(a.dim, a.k)) return set_err(CX_ERR_VALIDATION, "batch scan: unsupported dim %u / k %u", a.dim, a.k);
-    if (a.nq == 0 || a.nq > batch_queries_per_pass(a.k)) return set_err(CX_ERR_VALIDATION, "batch scan: 1..%u queries per pass at k = %u", batch_queries_per_pass(a.k), a.k);
+    if (a.n_groups == 0) a.n_groups = 1;
+    if (a.nq == 0 || a.nq > batch_queries_per_pass(a.k) * a.n_groups || a.nq <= batch_queries_per_pass(a.k) * (a.n_groups - 1))
+        return set_err(CX_ERR_VALIDATION, "batch scan: %u queries do not fill %u groups of %u (k = %u)", a.nq, a.n_groups, batch_queries_per_pass(a.k), a.k);
     // batch2: lists are compacted at capq - 32 entries (<= 64: one per lane) and never exceed capq; k + 16 <= capq - 32
     static const int use_f32_env = getenv("CX_BATCH_F32MFMA") ? atoi(getenv("CX_BATCH_F32MFMA")) : 0;
-    const int use_f32 = use_f32_env && a.k <= 32;
+    const int use_f32 = use_f32_env && a.k <= 32 && a.n_groups == 1;
     a.capq = use_f32 ? (a.k <= 16 ? 64u : 80u) : 80u;
     if (a.k > 32) {   // wide: as long as LDS allows (a compaction absorbs capq - 32 - k new entries), at most 3 x 64 + 16
         const size_t tiles = 2 * (a.dim == 384 ? (size_t)Batch2Cfg<384>::TILE_BYTES : (size_t)Batch2Cfg<768>::TILE_BYTES);

@@ -242,26 +242,29 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
     for (uint64_t i = 0; tails && i < nq; i++) no_tails = no_tails && tails[i] == 0.0f;
     static const int batch_min = getenv("CX_BATCH_MIN") ? atoi(getenv("CX_BATCH_MIN")) : 3;
     if (topk_path && no_tails && nq >= (uint64_t)batch_min && k_eff >= 1 && batch_supported(ix->dim, k_eff)) {
-        const uint32_t bgrid = batch_grid_blocks(n);
-        if (int rc = ensure_dev(c->d_part_keys, c->pk_cap, (size_t)64 * bgrid * k_eff)) return rc;
-        if (int rc = ensure_dev(c->d_part_sims, c->ps_cap, (size_t)64 * bgrid * k_eff)) return rc;
-        if (int rc = ensure_dev(c->d_gslots, c->gs_cap, (size_t)64 * 128)) return rc;
         const uint32_t qpp = batch_queries_per_pass(k_eff);
-        for (uint64_t q0 = 0; q0 < nq; q0 += qpp) {
-            const uint32_t m = (uint32_t)std::min<uint64_t>(qpp, nq - q0);
+        uint32_t bgrid = 1, groups = 1;
+        batch_launch_shape(n, nq, k_eff, &bgrid, &groups);
+        const uint64_t per_launch = (uint64_t)qpp * groups;
+        if (int rc = ensure_dev(c->d_part_keys, c->pk_cap, (size_t)per_launch * bgrid * k_eff)) return rc;
+        if (int rc = ensure_dev(c->d_part_sims, c->ps_cap, (size_t)per_launch * bgrid * k_eff)) return rc;
+        if (int rc = ensure_dev(c->d_gslots, c->gs_cap, (size_t)groups * 64 * 128)) return rc;
+        for (uint64_t q0 = 0; q0 < nq; q0 += per_launch) {
+            const uint32_t m = (uint32_t)std::min<uint64_t>(per_launch, nq - q0);
             BatchArgs b;
             memset(&b, 0, sizeof b);
             b.rows = ix->d_rows;
             b.queries = d_queries + q0 * ix->dim;
             b.n_rows = n;
             b.nq = m;
+            b.n_groups = (m + qpp - 1) / qpp;
             b.dim = ix->dim;
             b.k = k_eff;
             b.flt = flt;
             b.part_keys = c->d_part_keys;
             b.part_sims = c->d_part_sims;
             b.gslots = c->d_gslots;
-            CX_HIP(hipMemsetAsync(c->d_gslots, 0, 64 * 128 * sizeof(uint32_t), s));
+            CX_HIP(hipMemsetAsync(c->d_gslots, 0, (size_t)b.n_groups * 64 * 128 * sizeof(uint32_t), s));
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (ix->profiling) {
                 CX_HIP(hipEventCreate(&e0));

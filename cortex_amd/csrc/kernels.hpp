@@ -68,15 +68,17 @@ struct BatchArgs {
     const float *rows;      // [n_rows][dim]
     const float *queries;   // [nq][dim] in HBM
     uint32_t n_rows, nq, dim, k, capq;
+    uint32_t n_groups;      // query groups in this launch (gridDim.y); nq covers all of them
     DevFilter flt;
     uint64_t *part_keys;    // [nq][grid][k]
     float *part_sims;
     unsigned long long *diag;  // diagnostic build only (CX_BATCH_DIAG=1): [grid*4 waves][5] cycle sums
-    uint32_t *gslots;       // [64][128] zeroed before the launch: cross-block score bound (batch.hip, "global slots")
+    uint32_t *gslots;       // [n_groups][64][128] zeroed before the launch: cross-block score bound (batch.hip, "global slots")
 };
 bool batch_supported(uint32_t dim, uint32_t k);
 uint32_t batch_grid_blocks(uint32_t n_rows);
 uint32_t batch_queries_per_pass(uint32_t k);   // 64 for k <= 32, 32 for the wide lists (k <= 104)
+void batch_launch_shape(uint32_t n_rows, uint64_t nq, uint32_t k, uint32_t *chunks, uint32_t *groups);
 // one pass of <= 64 queries; per-block lists, to be folded by launch_merge_batch
 int launch_batch_scan(BatchArgs a, uint32_t grid, hipStream_t stream);
 // second stage for nq queries at once: query q's lists are part[q*n_lists*k ...], outputs at [q*k]

@@ -308,6 +308,8 @@ def test_search_batch_with_filter_and_tombstones(hip, oracle):
     (50000, 768, 100, 40),   # wide mode: the auto-linker's top-100 lists, 32 queries per pass, 3 entries per lane
     (20000, 384, 104, 33),   # largest fused k; second pass holds one query
     (9000, 768, 33, 5),      # smallest wide k
+    (30000, 384, 10, 200),   # several query groups in one launch (grid = chunks x groups), ragged last group
+    (30000, 768, 100, 70),   # the same in the wide mode: 3 groups of 32, the last holds 6
 ])
 def test_search_batch_long_lists(hip, oracle, n, d, k, nq):
     """Enough rows per block that the in-kernel candidate lists overflow and are compacted many times
