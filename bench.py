@@ -256,6 +256,14 @@ def config1_leg(L, device: int, n: int = 10_000, d: int = 384, k: int = 5, nq: i
     t0 = time.perf_counter()
     got = [ix.search_arrays(q, k) for q in qs]
     t_gpu = time.perf_counter() - t0
+    # the same engine through search_batch (index.rs:390-410): 1024 queries in one call, host buffers both ways
+    qb = O.synth_queries(n, d, 1024)
+    ix.search_batch_arrays(qb, k)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        bi, bs, bd, bc = ix.search_batch_arrays(qb, k)
+    t_batch = (time.perf_counter() - t0) / 5
+    same = sum(int(np.array_equal(bi[i, :k], ix.search_arrays(qb[i], k)[0])) for i in range(32))
     o = O.OracleIndex(d)
     o.insert_batch(ids, rows)
     t0 = time.perf_counter()
@@ -272,6 +280,7 @@ def config1_leg(L, device: int, n: int = 10_000, d: int = 384, k: int = 5, nq: i
     rec_g = sum(len(set(g_rows[i].tolist()) & set(exact[i]["row"].tolist())) for i in range(50)) / (50.0 * k)
     ix.close()
     return {"gpu_host_api_qps": nq / t_gpu, "gpu_recall_at_5_vs_exact": rec_g,
+            "gpu_search_batch_host_api_qps": 1024 / t_batch, "gpu_search_batch_agrees_with_single": f"{same}/32 id lists",
             "cpu_brute_force_qps_1thread": 50 / t_bf,
             "cpu_hnsw_restatement": {"qps_1thread": nq / t_ann, "recall_at_5_vs_exact": rec_h, "build_s": t_build,
                                      "params": "M=32 M0=64 ef_construction=100 ef_search=100",
