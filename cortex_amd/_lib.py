@@ -45,6 +45,7 @@ SIGNATURES = {
     "cx_search_batch": (C.c_int, [_P, _U64, _P, _U64, _U64, _P, _P, _P, _P, _P]),
     "cx_autolink_pass_rows": (C.c_int, [_P, _U64, _P, _U64, C.c_float, _U64, _P, _U64, _P, _P, _P, _P, _P]),
     "cx_dedup_scan_rows": (C.c_int, [_P, C.c_float, _P, _U64, _P, _P, _P, _P, _P]),
+    "cx_topk_lists_rows": (C.c_int, [_P, _U64, _P, _U64, _P, _P, _P]),
     "cx_autolink_pass_timed": (C.c_int, [_P, _U64, _P, _U64, C.c_float, _U64, _P, _P]),
     "cx_autolink_lists_dev": (C.c_int, [_P, _U64, _P, _U64, C.c_float, _P, _P, _P, _P, _P]),
     "cx_copy_rows_dev": (C.c_int, [_P, _U64, _U64, _P, _P]),

@@ -442,6 +442,64 @@ int cx_autolink_lists_dev(const cx_index *ix, uint64_t nq64, const float *d_quer
     return CX_OK;
 }
 
+/* Ordered top-k lists of the scanned rows (see cortex_hip.h): gather the scanned vectors on the device, run the
+ * batched search over them block by block, copy the lists out. */
+int cx_topk_lists_rows(const cx_index *ix, uint64_t n_scan64, const uint32_t *scan_rows, uint64_t topk64,
+                       uint32_t *out_rows, float *out_scores, uint32_t *out_counts) {
+    if (!ix || !out_rows || !out_scores || !out_counts) return set_err(CX_ERR_VALIDATION, "null argument");
+    if (topk64 == 0 || topk64 > TOPK_MAX) return set_err(CX_ERR_VALIDATION, "topk lists: topk must be in 1..%u", TOPK_MAX);
+    if (int rc = use_device(ix)) return rc;
+    const uint32_t n_rows = (uint32_t)ix->n_rows, topk = (uint32_t)topk64;
+    const uint64_t n_scan = scan_rows ? n_scan64 : n_rows;
+    if (n_scan > 0xFFFFFFF0ull) return set_err(CX_ERR_VALIDATION, "too many scanned rows");
+    for (uint64_t i = 0; scan_rows && i < n_scan; i++)
+        if (scan_rows[i] >= n_rows) return set_err(CX_ERR_VALIDATION, "scan row %u out of range", scan_rows[i]);
+    if (!n_scan) return CX_OK;
+    CtxLease lease(ix);
+    if (!lease.c) return CX_ERR_DEVICE;
+    Ctx *c = lease.c;
+    hipStream_t s = c->stream;
+    PassScratch &ps = scratch_of(c);
+    const uint32_t k_eff = std::min<uint32_t>(topk, n_rows);
+    const uint32_t BLOCK = 16384;
+    const uint32_t blk = (uint32_t)std::min<uint64_t>(BLOCK, n_scan);
+    // scratch: gathered vectors (d_w), their row indices (d_scan), lists (d_list_*)
+    if (int rc = ensure_dev(ps.d_w, ps.c_w, (size_t)blk * ix->dim)) return rc;
+    if (int rc = ensure_dev(ps.d_scan, ps.c_scan, (size_t)blk)) return rc;
+    if (int rc = ensure_dev(ps.d_list_rows, ps.c_list_rows, (size_t)blk * topk)) return rc;
+    if (int rc = ensure_dev(ps.d_list_scores, ps.c_list_scores, (size_t)blk * topk)) return rc;
+    if (int rc = ensure_dev(ps.d_list_dists, ps.c_list_dists, (size_t)blk * topk)) return rc;
+    if (int rc = ensure_dev(ps.d_list_cnt, ps.c_list_cnt, (size_t)blk)) return rc;
+    DevFilter flt;
+    memset(&flt, 0, sizeof flt);
+    flt.meta = ix->d_meta;
+    flt.agent = ix->d_agent;
+    std::vector<uint32_t> ident;
+    for (uint64_t lo = 0; lo < n_scan; lo += blk) {
+        const uint32_t m = (uint32_t)std::min<uint64_t>(blk, n_scan - lo);
+        const float *d_q;
+        if (scan_rows) {
+            CX_HIP(hipMemcpyAsync(ps.d_scan, scan_rows + lo, (size_t)m * 4, hipMemcpyHostToDevice, s));
+            if (int rc = launch_gather_rows(ix->d_rows, ps.d_w, ps.d_scan, m, ix->dim, s)) return rc;
+            d_q = ps.d_w;
+        } else {
+            d_q = ix->d_rows + (size_t)lo * ix->dim;   // every row in order: the store itself is the query block
+        }
+        if (k_eff == 0) CX_HIP(hipMemsetAsync(ps.d_list_cnt, 0, (size_t)m * 4, s));
+        else if (int rc = search_core(ix, c, d_q, nullptr, m, k_eff, flt, 0.0f, false, ps.d_list_rows, ps.d_list_scores,
+                                      ps.d_list_dists, ps.d_list_cnt, s))
+            return rc;
+        // lists are k_eff wide on the device, topk wide for the caller
+        CX_HIP(hipMemcpy2DAsync(out_rows + (size_t)lo * topk, (size_t)topk * 4, ps.d_list_rows, (size_t)std::max(k_eff, 1u) * 4,
+                                (size_t)k_eff * 4, m, hipMemcpyDeviceToHost, s));
+        CX_HIP(hipMemcpy2DAsync(out_scores + (size_t)lo * topk, (size_t)topk * 4, ps.d_list_scores, (size_t)std::max(k_eff, 1u) * 4,
+                                (size_t)k_eff * 4, m, hipMemcpyDeviceToHost, s));
+        CX_HIP(hipMemcpyAsync(out_counts + lo, ps.d_list_cnt, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+        CX_HIP(hipStreamSynchronize(s));
+    }
+    return CX_OK;
+}
+
 /* rows [row_lo, row_lo + n) of the shard copied to a caller buffer in HBM (e.g. to broadcast them to the other
  * ranks as the scanned block of a sharded pass) */
 int cx_copy_rows_dev(const cx_index *ix, uint64_t row_lo, uint64_t n, float *d_dst, void *stream) {

@@ -325,6 +325,18 @@ class HipIndex:
             self._check(rc)
             return a[:n.value], b[:n.value], s[:n.value]
 
+    def topk_lists_rows(self, topk: int, scan_rows=None):
+        """cx_topk_lists_rows: (rows [n_scan, topk] u32, scores [n_scan, topk] f32, counts [n_scan]) — the ordered
+        top-k neighbour list of every scanned row, self included (auto_linker.rs:221 for a whole batch of nodes)."""
+        sr = None if scan_rows is None else np.ascontiguousarray(scan_rows, dtype=np.uint32)
+        n_scan = self.row_count() if sr is None else sr.size
+        rows = np.zeros((n_scan, int(topk)), np.uint32)
+        scores = np.zeros((n_scan, int(topk)), np.float32)
+        counts = np.zeros(n_scan, np.uint32)
+        self._check(self._L.cx_topk_lists_rows(self._h, n_scan, sr.ctypes.data if sr is not None else None, int(topk),
+                                               rows.ctypes.data, scores.ctypes.data, counts.ctypes.data))
+        return rows, scores, counts
+
     def autolink_pass_timed(self, topk: int, threshold: float, max_edges_per_node: int, scan_rows=None):
         """(n_edges, [shadow_ms, filter_ms, rescore_ms, rules_ms]) with the edges left in HBM."""
         sr = None if scan_rows is None else np.ascontiguousarray(scan_rows, dtype=np.uint32)

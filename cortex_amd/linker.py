@@ -77,3 +77,56 @@ def dedup_scan(index: HipIndex, config: SimilarityConfig,
                deleted_ids: Optional[Sequence[NodeId]] = None) -> List[DuplicatePair]:
     a, b, s = index.dedup_scan_rows(config.dedup_threshold, _deleted_flags(index, deleted_ids))
     return [DuplicatePair(index.row_id(int(x)), index.row_id(int(y)), float(z)) for x, y, z in zip(a, b, s)]
+
+
+def neighbour_lists(index: HipIndex, scan_ids: Optional[Sequence[NodeId]] = None, topk: int = AUTO_LINK_TOPK):
+    """`vector_index.search(&embedding, 100, None)` (auto_linker.rs:221) for every scanned node in one call:
+    (scan_rows, rows [n, topk], scores [n, topk], counts [n]); lists are ordered best first and contain the node
+    itself (the walk below skips it, like the reference)."""
+    scan_rows = None if scan_ids is None else _rows_of(index, scan_ids)
+    rows, scores, counts = index.topk_lists_rows(topk, scan_rows)
+    if scan_rows is None:
+        scan_rows = np.arange(index.row_count(), dtype=np.uint32)
+    return scan_rows, rows, scores, counts
+
+
+def autolink_walk(index: HipIndex, scan_ids: Optional[Sequence[NodeId]], rules, max_edges_per_node: int = 50,
+                  deleted_ids: Optional[Sequence[NodeId]] = None, existing=None, topk: int = AUTO_LINK_TOPK):
+    """The reference's per-node loop (auto_linker.rs:215-264) over the GPU's ordered neighbour lists, for ANY set
+    of link rules (SURVEY §8 a14': with the legacy structural rules on, every rule's edges count towards the
+    per-node cap, so the walk needs the ordered top-100 lists, not a thresholded pass).
+
+    rules: callables (node_row, neighbour_row, score) -> iterable of (relation, weight); applied in order for
+    each neighbour (apply_link_rules).  existing: optional callable node_row -> set of (to_row, relation)
+    (the pre-loaded `existing_set`, :226-230).  Returns [(from_row, to_row, relation, weight)] in the order
+    run_cycle proposes them.  The cap is tested after each NEIGHBOUR (:259-262), so a node can exceed it by the
+    edges its last neighbour added — exactly as the reference does."""
+    scan_rows, rows, scores, counts = neighbour_lists(index, scan_ids, topk)
+    deleted = _deleted_flags(index, deleted_ids)
+    out = []
+    for p, node in enumerate(scan_rows):
+        have = existing(int(node)) if existing is not None else ()
+        n_edges = 0
+        for c in range(int(counts[p])):
+            nb, score = int(rows[p, c]), float(scores[p, c])
+            if nb == int(node):
+                continue                                   # skip self (:233-236)
+            if deleted is not None and deleted[nb]:
+                continue                                   # storage-deleted neighbour (:238-242)
+            for rule in rules:
+                for relation, weight in rule(int(node), nb, score):
+                    if (nb, relation) not in have:         # existing-edge filter (:252-256)
+                        n_edges += 1
+                        out.append((int(node), nb, relation, float(weight)))
+            if n_edges >= max_edges_per_node:              # per-node limit (:259-262)
+                break
+    return out
+
+
+def similarity_rule(config: SimilarityConfig):
+    """SimilarityLinkRule::evaluate (linker/rules.rs:42-62) as an autolink_walk rule."""
+    thr = np.float32(config.auto_link_threshold)
+
+    def rule(node: int, neighbour: int, score: float):
+        return [("related_to", score)] if np.float32(score) >= thr else []
+    return rule

@@ -158,6 +158,16 @@ int cx_autolink_pass_rows(const cx_index *ix, uint64_t n_scan, const uint32_t *s
                           uint64_t cap, uint32_t *out_from, uint32_t *out_to, float *out_weight,
                           uint64_t *n_out, uint64_t *n_needed);
 
+/* The auto-linker's neighbour query for a set of nodes at once (auto_linker.rs:221: `search(&emb, 100, None)`
+ * per scanned node; SURVEY §8 a14': "ordered top-100 (j, score) per i" is the engine's contract, every rule —
+ * structural and config rules included — walks these lists on the host in reference order).  For each scanned
+ * row, in scan order: its `topk` nearest rows, best first, self included (the reference's walk skips it),
+ * removed rows excluded, no filter.  scan_rows = NULL: every row.  out_rows / out_scores: [n_scan][topk],
+ * out_counts: [n_scan] (= min(topk, live rows)).  One batched search per <= 16384 scanned rows (cx_search_batch's
+ * engine: rows are read once per 32 or 64 queries). */
+int cx_topk_lists_rows(const cx_index *ix, uint64_t n_scan, const uint32_t *scan_rows, uint64_t topk,
+                       uint32_t *out_rows, float *out_scores, uint32_t *out_counts);
+
 /* DedupScanner::scan's pair emission (linker/dedup.rs:65-127): every indexed,
  * non-deleted node in row order, its neighbours with score >= dedup_threshold
  * in score order, self skipped, each unordered pair reported once by the node

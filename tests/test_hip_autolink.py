@@ -9,7 +9,7 @@ near-threshold-tolerant prefixes."""
 import numpy as np
 import pytest
 
-from conftest import SCORE_TOL, ids_for
+from conftest import SCORE_TOL, assert_topk_parity, ids_for
 
 pytestmark = pytest.mark.gpu
 
@@ -210,3 +210,49 @@ def test_full_size_pass_is_consistent_with_search(hip, oracle):
         for (j1, s1), (j2, s2) in zip(g, walk):
             if j1 == j2:
                 assert abs(s1 - s2) <= SCORE_TOL
+
+
+def test_topk_lists_and_generic_walk(hip, oracle):
+    """cx_topk_lists_rows = the reference's search(emb, 100, None) per scanned node; autolink_walk over those
+    lists with the similarity rule alone reproduces the fused pass edge for edge, and with an always-firing
+    structural rule added (SURVEY a14': legacy rules on) it matches the same walk over the ORACLE's lists."""
+    from cortex_amd import linker
+    n, d = 3000, 768
+    rows = oracle.synth_rows(n, d)
+    ids = ids_for(n)
+    h = hip.HipIndex(d); h.insert_batch(ids, rows)
+    o = oracle.OracleIndex(d); o.insert_batch(ids, rows)
+    for r in (7, 1500):
+        h.remove(ids[r].tobytes()); o.remove(ids[r].tobytes())
+    scan = np.array([0, 5, 8, 999, 1501, 2999, 42, 43, 44, 45], dtype=np.uint32)
+    scan_ids = [ids[i].tobytes() for i in scan]
+    lr, ls, lc = h.topk_lists_rows(100, scan)
+    for p, i in enumerate(scan):
+        e = o.search(rows[i], 100)
+        m = int(lc[p])
+        assert m == len(e["row"])
+        assert_topk_parity(lr[p, :m].astype(np.int64), ls[p, :m], e["row"], e["score"], what=f"lists row {i}")
+    cfg = hip.SimilarityConfig(auto_link_threshold=0.6, dedup_threshold=0.95, contradiction_threshold=0.8)
+    # similarity rule only: the generic walk == the fused GPU pass
+    walk = linker.autolink_walk(h, scan_ids, [linker.similarity_rule(cfg)], max_edges_per_node=7)
+    fr, to, w = h.autolink_pass_rows(scan, 100, cfg.auto_link_threshold, 7)
+    assert [(a, b) for a, b, _, _ in walk] == list(zip(fr.tolist(), to.tolist()))
+    assert np.allclose([x[3] for x in walk], w, atol=SCORE_TOL)
+    # plus a structural rule that fires for every neighbour: the cap is hit early and may be overshot by one
+    def same_agent(node, nb, score):
+        return [("same_agent", 0.5)]
+    walk2 = linker.autolink_walk(h, scan_ids, [linker.similarity_rule(cfg), same_agent], max_edges_per_node=7)
+    thr = np.float32(cfg.auto_link_threshold)
+    exp = []
+    for i in scan:
+        e = o.search(rows[i], 100)
+        cnt = 0
+        for j, s in zip(e["row"], e["score"]):
+            if int(j) == int(i):
+                continue
+            if np.float32(s) >= thr:
+                exp.append((int(i), int(j), "related_to")); cnt += 1
+            exp.append((int(i), int(j), "same_agent")); cnt += 1
+            if cnt >= 7:
+                break
+    assert [(a, b, r) for a, b, r, _ in walk2] == exp
