@@ -43,6 +43,15 @@ extern "C" {
                            n_out: *mut u64, n_needed: *mut u64) -> c_int;
     fn cx_search_batch(ix: *const c_void, nq: u64, qs: *const f32, len: u64, k: u64, f: *const CxFilter,
                        ids: *mut u8, scores: *mut f32, dists: *mut f32, counts: *mut u64) -> c_int;
+    // auto-linker / dedup passes
+    fn cx_autolink_pass_rows(ix: *const c_void, n_scan: u64, scan_rows: *const u32, topk: u64, threshold: f32,
+                             max_edges_per_node: u64, deleted: *const u8, cap: u64, out_from: *mut u32,
+                             out_to: *mut u32, out_weight: *mut f32, n_out: *mut u64, n_needed: *mut u64) -> c_int;
+    fn cx_topk_lists_rows(ix: *const c_void, n_scan: u64, scan_rows: *const u32, topk: u64, out_rows: *mut u32,
+                          out_scores: *mut f32, out_counts: *mut u32) -> c_int;
+    fn cx_dedup_scan_rows(ix: *const c_void, dedup_threshold: f32, deleted: *const u8, cap: u64, out_a: *mut u32,
+                          out_b: *mut u32, out_similarity: *mut f32, n_out: *mut u64, n_needed: *mut u64) -> c_int;
+    fn cx_row_id(ix: *const c_void, row: u64, out_id16: *mut u8) -> c_int;
     fn cx_save(ix: *const c_void, path: *const c_char) -> c_int;
     fn cx_load(path: *const c_char, device: c_int) -> *mut c_void;
 }
