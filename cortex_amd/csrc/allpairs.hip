@@ -276,13 +276,12 @@ int launch_pair_filter(const PairFilterArgs &a, hipStream_t stream) {
     if (!a.n_scan || !a.n_rows) return CX_OK;
     const uint64_t tiles = a.symmetric ? a.n_tiles : (uint64_t)((a.n_scan + BM - 1) / BM) * ((a.n_rows + BN - 1) / BN);
     if (tiles > 0x7FFFFFFFull) return set_err(CX_ERR_VALIDATION, "pair filter: too many tiles");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_devices{0};
+    if (first_use_on_device(attr_devices)) {
         CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_filter_kernel<32>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_filter_kernel<16>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set = true;
     }
     static const int shape = getenv("CX_PAIR_MFMA") ? atoi(getenv("CX_PAIR_MFMA")) : 16;  // +5 % over 32x32x16 (profiles/r01)
     if (shape == 16) hipLaunchKernelGGL(pair_filter_kernel<16>, dim3((uint32_t)tiles), dim3(256), LDS_BYTES, stream, a);

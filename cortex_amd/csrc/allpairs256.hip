@@ -284,15 +284,14 @@ int launch_pair_filter256(const PairFilterArgs &a, hipStream_t stream) {
         return set_err(CX_ERR_VALIDATION, "pair filter 256: symmetric pass needs a tile list");
     const uint64_t tiles = a.symmetric ? a.n_tiles : (uint64_t)((a.n_scan + BM - 1) / BM) * ((a.n_rows + BN - 1) / BN);
     if (tiles > 0x7FFFFFFFull) return set_err(CX_ERR_VALIDATION, "pair filter 256: too many tiles");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_devices{0};
+    if (first_use_on_device(attr_devices)) {
         CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_filter256_kernel<false, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_filter256_kernel<true, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_filter256_kernel<false, false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set = true;
     }
     static const int il = getenv("CX_PAIR_INTERLEAVE") ? atoi(getenv("CX_PAIR_INTERLEAVE")) : 1;
     if (getenv("CX_PAIR_DIAG")) {   // diagnostic build: per-phase cycles per tile on stderr, results still valid

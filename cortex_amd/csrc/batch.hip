@@ -854,13 +854,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
     }
 }
 
-static uint32_t batch_cus() {
-    int dev = 0, cus = 256;
-    hipDeviceProp_t p;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
-        cus = p.multiProcessorCount;
-    return (uint32_t)cus;
-}
+static uint32_t batch_cus() { return device_cus(); }
 uint32_t batch_grid_blocks(uint32_t n_rows) {
     const uint32_t cus = batch_cus();
     const uint32_t tiles = n_rows / BT_ROWS + (n_rows % BT_ROWS ? 1u : 0u);
@@ -900,15 +894,14 @@ static int launch_batch_d(BatchArgs a, uint32_t grid, hipStream_t stream) {
     const size_t lds = use_f32 ? 2 * (size_t)BatchCfg<D>::TILE_BYTES + tail
                                : 2 * (size_t)Batch2Cfg<D>::TILE_BYTES + 2 * BT_ROWS * 4 + tail;
     if (lds > 160 * 1024) return set_err(CX_ERR_VALIDATION, "batch scan: %zu bytes of LDS for k = %u", lds, a.k);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_devices{0};
+    if (first_use_on_device(attr_devices)) {
         CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch_scan_kernel<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch_scan_kernel<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch2_kernel<D, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch2_kernel<D, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch2_kernel<D, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch2_kernel<D, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
     }
     if (getenv("CX_BATCH_DIAG")) {  // diagnostic build: per-phase cycle shares on stderr, results still valid
         const size_t n = (size_t)grid * a.n_groups * 8 * 8;   // up to 8 waves x 8 slots per block

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <atomic>
 
 #include <cstdarg>
 #include <cstdint>
@@ -24,6 +25,30 @@ int set_err(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3))
             return ::cx::set_err(CX_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr,            \
                                  hipGetErrorString(e__), __FILE__, __LINE__);              \
     } while (0)
+
+// true exactly once per (call site, device): kernels that need more than 64 KiB of LDS set their
+// hipFuncAttributeMaxDynamicSharedMemorySize on every device they are launched on (the attribute is per device;
+// a process may hold indexes on several).  `mask` is the call site's static state.
+inline bool first_use_on_device(std::atomic<uint64_t> &mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+    const uint64_t bit = 1ull << dev;
+    return (mask.fetch_or(bit) & bit) == 0;
+}
+
+// compute units of the current device (cached per device: hipGetDeviceProperties is slow)
+inline uint32_t device_cus() {
+    static std::atomic<uint32_t> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return 256;
+    uint32_t v = cache[dev].load(std::memory_order_relaxed);
+    if (!v) {
+        hipDeviceProp_t p;
+        v = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? (uint32_t)p.multiProcessorCount : 256u;
+        cache[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
 
 // A candidate's order key: (ord(score) << 32) | ~row.  Larger = better, so
 // "score descending, then row ascending"; 0 = empty slot.  ord() maps a

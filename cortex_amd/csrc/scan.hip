@@ -334,17 +334,7 @@ __global__ __launch_bounds__(1024) void merge_small_kernel(const MergeArgs m) { 
 
 // ------------------------------------------------------------------ host
 
-static int g_num_cus = 0;
-static int num_cus() {
-    if (!g_num_cus) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
-            g_num_cus = p.multiProcessorCount;
-        if (g_num_cus <= 0) g_num_cus = 256;
-    }
-    return g_num_cus;
-}
+static int num_cus() { return (int)device_cus(); }
 
 static uint32_t blocks_per_cu() {
     static int v = 0;
