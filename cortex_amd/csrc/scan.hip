@@ -405,6 +405,13 @@ static void dispatch_scan(const ScanArgs &a, uint32_t grid, int ks, bool nt, hip
     launch_generic<MODE>(a, grid, ks, s);
 }
 
+__global__ void merge_radix_kernel(const MergeArgs m0);   // defined below
+
+static bool use_old_merge() {   // CX_MERGE_WAVETOPK=1: the previous second stage, for A/B runs
+    static const int v = getenv("CX_MERGE_WAVETOPK") ? atoi(getenv("CX_MERGE_WAVETOPK")) : 0;
+    return v != 0;
+}
+
 int launch_scan_topk(const ScanArgs &a, const MergeArgs &m, bool nontemporal, hipStream_t stream, hipEvent_t ev0,
                      hipEvent_t ev1) {
     if (a.k > TOPK_MAX) return set_err(CX_ERR_VALIDATION, "launch_scan_topk: k=%u exceeds %u", a.k, TOPK_MAX);
@@ -415,9 +422,11 @@ int launch_scan_topk(const ScanArgs &a, const MergeArgs &m, bool nontemporal, hi
     dispatch_scan<0>(a, grid, ks, nontemporal, stream);
     if (ev1) CX_HIP(hipEventRecord(ev1, stream));
     if (a.k <= 32 && grid <= MERGE_SMALL_MAX_LISTS) hipLaunchKernelGGL(merge_small_kernel, dim3(1), dim3(1024), 0, stream, m);
-    else if (ks == 1) hipLaunchKernelGGL((merge_kernel<1>), dim3(1), dim3(1024), 0, stream, m);
-    else if (ks == 2) hipLaunchKernelGGL((merge_kernel<2>), dim3(1), dim3(1024), 0, stream, m);
-    else hipLaunchKernelGGL((merge_kernel<4>), dim3(1), dim3(1024), 0, stream, m);
+    else if (use_old_merge()) {
+        if (ks == 1) hipLaunchKernelGGL((merge_kernel<1>), dim3(1), dim3(1024), 0, stream, m);
+        else if (ks == 2) hipLaunchKernelGGL((merge_kernel<2>), dim3(1), dim3(1024), 0, stream, m);
+        else hipLaunchKernelGGL((merge_kernel<4>), dim3(1), dim3(1024), 0, stream, m);
+    } else hipLaunchKernelGGL(merge_radix_kernel, dim3(1), dim3(1024), 0, stream, m);
     CX_HIP(hipGetLastError());
     return CX_OK;
 }
@@ -425,9 +434,11 @@ int launch_scan_topk(const ScanArgs &a, const MergeArgs &m, bool nontemporal, hi
 int launch_merge_batch(const MergeArgs &m, uint32_t nq, hipStream_t stream) {
     if (!nq || !m.k) return CX_OK;
     if (m.k <= 32 && m.n_lists <= MERGE_SMALL_MAX_LISTS) hipLaunchKernelGGL(merge_small_kernel, dim3(nq), dim3(1024), 0, stream, m);
-    else if (m.k <= 64) hipLaunchKernelGGL((merge_kernel<1>), dim3(nq), dim3(1024), 0, stream, m);
-    else if (m.k <= 128) hipLaunchKernelGGL((merge_kernel<2>), dim3(nq), dim3(1024), 0, stream, m);
-    else hipLaunchKernelGGL((merge_kernel<4>), dim3(nq), dim3(1024), 0, stream, m);
+    else if (use_old_merge()) {
+        if (m.k <= 64) hipLaunchKernelGGL((merge_kernel<1>), dim3(nq), dim3(1024), 0, stream, m);
+        else if (m.k <= 128) hipLaunchKernelGGL((merge_kernel<2>), dim3(nq), dim3(1024), 0, stream, m);
+        else hipLaunchKernelGGL((merge_kernel<4>), dim3(nq), dim3(1024), 0, stream, m);
+    } else hipLaunchKernelGGL(merge_radix_kernel, dim3(nq), dim3(1024), 0, stream, m);
     CX_HIP(hipGetLastError());
     return CX_OK;
 }
@@ -444,6 +455,107 @@ int launch_scan_dense(const ScanArgs &a, bool nontemporal, hipStream_t stream) {
 // One block per query: fold n_parts lists of k (already sorted per shard, but
 // order is not relied on) into the global top-k.  Keys are rebuilt with the
 // global row so ties resolve by global insertion order.
+// Second stage for k > 32 (or very many lists): block-wide RADIX SELECT of the k-th largest key over all
+// n_lists * k candidates, most significant byte first (256-bin histogram in LDS per pass; candidates stay in
+// L2).  As soon as "keys above the selected bin + keys in it" fit the survivor buffer the walk stops, those
+// keys are collected and ranked against each other (keys are unique: the row is part of the key).  Typically 3-4
+// passes of ~2 us; the WaveTopK merge it replaces inserted candidates one at a time (0.23 ms at k = 100 and
+// 0.9 ms at k = 256 for 512 lists — as long as the scan itself).
+constexpr uint32_t MERGE_RADIX_CAP = 2048;
+__global__ __launch_bounds__(1024) void merge_radix_kernel(const MergeArgs m0) {
+    MergeArgs m = m0;  // one block per query
+    m.part_keys += (size_t)blockIdx.x * m0.n_lists * m0.k;
+    m.part_sims += (size_t)blockIdx.x * m0.n_lists * m0.k;
+    m.out_rows += (size_t)blockIdx.x * m0.k;
+    m.out_scores += (size_t)blockIdx.x * m0.k;
+    m.out_dists += (size_t)blockIdx.x * m0.k;
+    m.out_count += blockIdx.x;
+    __shared__ uint32_t hist[256];
+    __shared__ uint64_t surv_k[MERGE_RADIX_CAP];
+    __shared__ float surv_s[MERGE_RADIX_CAP];
+    __shared__ uint64_t s_prefix, s_mask;
+    __shared__ uint32_t s_need, s_bin_cnt, s_n, s_found;
+    const uint32_t tid = threadIdx.x, NT = 1024;
+    const uint32_t k = m.k, total = m.n_lists * k;
+    if (tid == 0) { s_prefix = 0ull; s_mask = 0ull; s_need = k; s_bin_cnt = 0; s_n = 0; s_found = 0; }
+    uint64_t low = 1ull;   // collect every key >= low (1 = every non-empty key)
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const uint64_t prefix = s_prefix, mask = s_mask;
+        // eight keys in flight per thread: one block has to pull the whole candidate set through one CU, and
+        // with a single load outstanding per thread a pass is latency-bound (15 us for 51k keys)
+        for (uint32_t e0 = tid; e0 < total; e0 += 8u * NT) {
+            uint64_t key[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) { const uint32_t e = e0 + u * NT; key[u] = e < total ? m.part_keys[e] : 0ull; }
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) {
+                const bool act = key[u] != 0ull && (key[u] & mask) == prefix;
+                const uint32_t bin = (uint32_t)(key[u] >> shift) & 255u;
+                const uint64_t am = __ballot(act);
+                if (am == 0ull) continue;
+                // the leading bytes of score keys are nearly constant: when the whole wave lands in one bin, one
+                // lane adds the count (64 same-address LDS atomics serialise: 25 us for such a pass).  Peeling
+                // off several popular bins per wave measured no better than this.
+                const int first = __ffsll((unsigned long long)am) - 1;
+                const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, first);
+                if (__ballot(act && bin == b0) == am) {
+                    if ((int)(tid & 63u) == first) atomicAdd(&hist[b0], (uint32_t)__popcll(am));
+                } else if (act) {
+                    atomicAdd(&hist[bin], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 256) {   // the bin that holds the need-th largest of the keys still in play
+            const uint32_t need = s_need;
+            uint32_t above = 0;
+            for (uint32_t b = tid + 1; b < 256; b++) above += hist[b];
+            const uint32_t mine = hist[tid];
+            if (above < need && need <= above + mine) {
+                s_prefix = prefix | ((uint64_t)tid << shift);
+                s_mask = mask | (0xFFull << shift);
+                s_need = need - above;
+                s_bin_cnt = mine;
+                s_found = 1;
+            }
+        }
+        __syncthreads();
+        if (!s_found) break;           // fewer than k non-empty keys in all: everything is a result (low stays 1)
+        low = s_prefix;                // keys >= low: the (k - need) above the bin + the bin itself
+        if ((k - s_need) + s_bin_cnt <= MERGE_RADIX_CAP) break;
+        __syncthreads();
+        if (tid == 0) s_found = 0;
+    }
+    __syncthreads();
+    for (uint32_t e0 = tid; e0 < total; e0 += 8u * NT) {
+        uint64_t key[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) { const uint32_t e = e0 + u * NT; key[u] = e < total ? m.part_keys[e] : 0ull; }
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++)
+            if (key[u] != 0ull && key[u] >= low) {
+                const uint32_t pos = atomicAdd(&s_n, 1u);
+                if (pos < MERGE_RADIX_CAP) { surv_k[pos] = key[u]; surv_s[pos] = m.part_sims[e0 + u * NT]; }
+            }
+    }
+    __syncthreads();
+    const uint32_t S = s_n < MERGE_RADIX_CAP ? s_n : MERGE_RADIX_CAP;
+    for (uint32_t i = tid; i < S; i += NT) {
+        const uint64_t ki = surv_k[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < S; j++) rank += surv_k[j] > ki ? 1u : 0u;
+        if (rank < k) {
+            const float dist = distance_of(surv_s[i]);
+            m.out_rows[rank] = key_row(ki);
+            m.out_dists[rank] = dist;
+            m.out_scores[rank] = score_of(dist);
+        }
+    }
+    if (tid == 0) *m.out_count = S < k ? S : k;
+}
+
 template <int KS>
 __global__ __launch_bounds__(256) void merge_parts_kernel(uint32_t n_parts, uint32_t nq, uint32_t k, uint64_t lstride, uint64_t cstride,
                                                           const PartBase part_base, const uint32_t *rows,
