@@ -336,21 +336,29 @@ __global__ __launch_bounds__(1024) void merge_small_kernel(const MergeArgs m) { 
 
 static int num_cus() { return (int)device_cus(); }
 
-static uint32_t blocks_per_cu() {
-    static int v = 0;
-    if (!v) {
+// Blocks per CU of the scan grid: enough row bytes in flight per CU to cover HBM latency.  Measured optimum per
+// dim at 1-4M rows (profiles/r01/tuning.md): short rows need more blocks, 1024 wants one more than 768.
+static uint32_t blocks_per_cu(uint32_t dim) {
+    static int env = -1;
+    if (env < 0) {
         const char *e = getenv("CX_SCAN_BLOCKS_PER_CU");
-        v = e ? atoi(e) : 2;  // 8 waves x 12 KiB of loads in flight per CU measured best (profiles/r01)
-        if (v < 1) v = 1;
-        if (v > 8) v = 8;
+        env = e ? atoi(e) : 0;
+        if (env < 0) env = 0;
+        if (env > 8) env = 8;
     }
-    return (uint32_t)v;
+    if (env) return (uint32_t)env;
+    if (dim <= 128) return 5;
+    if (dim <= 256) return 4;
+    if (dim <= 384) return 2;
+    if (dim <= 512) return 3;
+    if (dim <= 768) return 2;
+    if (dim <= 1024) return 3;
+    return 2;
 }
 
 uint32_t scan_grid_blocks(uint32_t n_rows, uint32_t dim) {
-    (void)dim;
     uint32_t want = (n_rows + 3u) / 4u;  // at least one row per wave
-    uint32_t cap = (uint32_t)num_cus() * blocks_per_cu();
+    uint32_t cap = (uint32_t)num_cus() * blocks_per_cu(dim);
     if (want < 1u) want = 1u;
     return want < cap ? want : cap;
 }
