@@ -176,6 +176,8 @@ def main() -> None:
     del gen
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out.setdefault("extra", {})["config1_10k_x_384_k5"] = config1_leg(L, local_rank)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and (n, d) != (1_000_000, 384):
+        out.setdefault("extra", {})["config2_1M_x_384_k10"] = config2_leg(L, local_rank, dev)
     if rank == 0 and world == 1 and not args.no_autolink:
         out.setdefault("extra", {})["autolink_allpairs"] = autolink_leg(L, local_rank, d, args.no_cpu_baseline)
         # the same pass over the bench corpus itself: BASELINE.json's metric names "auto-link pairs/sec at 1Mx768"
@@ -285,6 +287,49 @@ def config1_leg(L, device: int, n: int = 10_000, d: int = 384, k: int = 5, nq: i
             "cpu_hnsw_restatement": {"qps_1thread": nq / t_ann, "recall_at_5_vs_exact": rec_h, "build_s": t_build,
                                      "params": "M=32 M0=64 ef_construction=100 ef_search=100",
                                      "note": "restatement of instant-distance 0.6.1 from the HNSW paper; parity unpinned"}}
+
+
+def config2_leg(L, device: int, dev, n: int = 1_000_000, d: int = 384, k: int = 10, steps: int = 300):
+    """BASELINE configs[1] (1M x 384 f32, cosine kNN k=10, single query per step, HBM-resident): the headline
+    workload at the other embedding width, same measurement (cx_search_dev, HIP events around every scan)."""
+    import cortex_amd
+    gen = torch.empty((n, d), dtype=torch.float32, device=dev)
+    assert L.cx_synth_fill_dev(device, gen.data_ptr(), SEED_CORPUS, SEED_CORPUS, SEED_DUP, n // 50, 0, n, d, 1) == 0
+    ix = cortex_amd.HipIndex(d, device=device)
+    ix.reserve(n)
+    ix.insert_batch_dev(synth_ids(0, n), gen.data_ptr(), n, d)
+    del gen
+    qs = torch.empty((64, d), dtype=torch.float32, device=dev)
+    assert L.cx_synth_fill_dev(device, qs.data_ptr(), SEED_CORPUS, SEED_QUERIES, SEED_DUP, n // 50, 0, 64, d, 0) == 0
+    o_rows = torch.empty(k, dtype=torch.int32, device=dev)
+    o_sc = torch.empty(k, dtype=torch.float32, device=dev)
+    o_di = torch.empty(k, dtype=torch.float32, device=dev)
+    o_cnt = torch.empty(1, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def one(i):
+        ix.search_batch_dev(qs.data_ptr() + (i % 64) * d * 4, 1, k, o_rows.data_ptr(), o_sc.data_ptr(), o_di.data_ptr(),
+                            o_cnt.data_ptr(), stream)
+    for i in range(30):
+        one(i)
+    torch.cuda.synchronize()
+    ix.profile_read(reset=True)
+    ix.profile_enable(True)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one(i)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ix.profile_enable(False)
+    kern_ms, kern_n = ix.profile_read(reset=True)
+    ix.close()
+    avg = kern_ms / max(1, kern_n)
+    algo = float(n) * d * 4.0
+    return {"workload": f"cosine kNN k={k}, single query per step, {n} x {d} f32 rows (exact brute force, HBM-resident)",
+            "queries_per_s": steps / el, "ms_per_step": el / steps * 1e3,
+            "roofline": {"bound": "hbm", "achieved": algo / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": algo / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": "cx::scan_kernel", "avg_kernel_ms": avg,
+                         "launches": kern_n, "algorithmic_bytes_per_launch": algo}}
 
 
 def autolink_on_index(ix, n: int, d: int, thr: float = 0.85, reps: int = 2):
