@@ -146,6 +146,11 @@ size_t scan_temp_bytes(uint32_t n);
 int launch_exclusive_scan(const uint32_t *in, uint64_t *out, uint32_t n, void *temp, size_t temp_bytes,
                           hipStream_t stream);
 
+// lists of the redo rows (contiguous, k_src wide) -> their places in the pass's list arrays (k_dst wide)
+int launch_scatter_lists(const uint32_t *src_rows, const float *src_scores, const float *src_dists, const uint32_t *src_cnt,
+                         const uint32_t *d_pos, uint32_t n, uint32_t k_src, uint32_t k_dst, uint32_t *dst_rows,
+                         float *dst_scores, float *dst_dists, uint32_t *dst_cnt, hipStream_t stream);
+
 // row maintenance
 int launch_gather_rows(const float *src, float *dst, const uint32_t *d_src_rows, uint32_t n_dst, uint32_t dim,
                        hipStream_t stream);

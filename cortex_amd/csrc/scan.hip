@@ -662,6 +662,29 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float *src, floa
     }
 }
 
+__global__ __launch_bounds__(256) void scatter_lists_kernel(const uint32_t *src_rows, const float *src_scores, const float *src_dists,
+                                                            const uint32_t *src_cnt, const uint32_t *pos, uint32_t k_src,
+                                                            uint32_t k_dst, uint32_t *dst_rows, float *dst_scores,
+                                                            float *dst_dists, uint32_t *dst_cnt) {
+    const uint32_t i = blockIdx.x, p = pos[i], c = src_cnt[i] < k_src ? src_cnt[i] : k_src;
+    for (uint32_t e = threadIdx.x; e < c && e < k_dst; e += 256u) {
+        dst_rows[(size_t)p * k_dst + e] = src_rows[(size_t)i * k_src + e];
+        dst_scores[(size_t)p * k_dst + e] = src_scores[(size_t)i * k_src + e];
+        if (dst_dists) dst_dists[(size_t)p * k_dst + e] = src_dists[(size_t)i * k_src + e];
+    }
+    if (threadIdx.x == 0) dst_cnt[p] = c < k_dst ? c : k_dst;
+}
+
+int launch_scatter_lists(const uint32_t *src_rows, const float *src_scores, const float *src_dists, const uint32_t *src_cnt,
+                         const uint32_t *d_pos, uint32_t n, uint32_t k_src, uint32_t k_dst, uint32_t *dst_rows,
+                         float *dst_scores, float *dst_dists, uint32_t *dst_cnt, hipStream_t stream) {
+    if (!n) return CX_OK;
+    hipLaunchKernelGGL(scatter_lists_kernel, dim3(n), dim3(256), 0, stream, src_rows, src_scores, src_dists, src_cnt, d_pos, k_src,
+                       k_dst, dst_rows, dst_scores, dst_dists, dst_cnt);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+
 int launch_gather_rows(const float *src, float *dst, const uint32_t *d_src_rows, uint32_t n_dst, uint32_t dim,
                        hipStream_t stream) {
     if (!n_dst) return CX_OK;
