@@ -24,6 +24,12 @@ int cx_synth_fill_dev(int device, float *d_out, uint64_t seed_centres, uint64_t 
                       uint64_t seed_dup, uint64_t n_centres, uint64_t row_lo, uint64_t n_rows,
                       uint32_t dim, uint32_t flags);
 
+/* Measured peaks of the device for the rooflines: sustained HBM read bandwidth of a plain
+ * streaming-read kernel (GB/s, best of `reps` passes over `bytes`), and the sustained dense bf16 MFMA rate of a
+ * register-only v_mfma_f32_32x32x16_bf16 loop running for about `ms_target` ms (TFLOP/s, clock settled). */
+int cx_probe_read_bw(int device, uint64_t bytes, uint32_t reps, double *out_gbs);
+int cx_probe_mfma_tflops(int device, double ms_target, double *out_tflops);
+
 #ifdef __cplusplus
 }
 #endif
