@@ -482,16 +482,20 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
         // on timing: the bound only removes rows that cannot be in the top k.
         unsigned long long n_pcompact = 0;
         // E = 1: 4 lanes per query, all 16 queries of the group per refresh, slots at stride 32;
-        // wide (E = 3): 8 lanes per query, 8 queries per refresh (the two halves of the group alternate), stride 128
+        // wide (E = 3): 8 lanes per query, the 8 queries this producer owns per refresh, stride 128
         constexpr uint32_t LPQ = E == 1 ? 4u : 8u, NG = E == 1 ? 4u : 7u, GSTRIDE = E == 1 ? 32u : 128u;
         uint64_t gv[NG];
 #pragma unroll
         for (uint32_t i = 0; i < NG; i++) gv[i] = 0ull;
         const uint32_t g_g = lane & (LPQ - 1u);
-        uint32_t g_q = pw * 16u + lane / LPQ;       // query whose slots this lane reads (wide: + 8 on odd refreshes)
+        // Ownership of the lists: E = 1: producer pw owns the 16 lists of consumer wave pw.  Wide mode has only two
+        // live consumer waves, so all four producers share their lists: producer pw owns the queries of group pw & 1
+        // whose index has parity pw >> 1 (twice the compaction throughput; the same producer refreshes their bounds).
+        const uint32_t own_grp = E == 1 ? pw : (pw & 1u), own_par = pw >> 1;
+        uint32_t g_q = E == 1 ? pw * 16u + lane / LPQ : own_grp * 16u + 2u * (lane / LPQ) + own_par;
         const uint32_t n_gld = (k + 2u * LPQ - 1u) / (2u * LPQ);   // lane (query, g) reads slot pairs 2 (g + LPQ i), + 1
         auto refresh_issue = [&](uint32_t half) {
-            g_q = pw * 16u + (E == 1 ? 0u : 8u * (half & 1u)) + lane / LPQ;
+            (void)half;
             const uint64_t *G = reinterpret_cast<const uint64_t *>(a.gslots + g_q * GSTRIDE) + g_g;
 #pragma unroll
             for (uint32_t i = 0; i < NG; i++)
@@ -518,13 +522,14 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
         };
         auto producer_compact = [&]() {
             uint32_t pubv = 0, shrv = 1;
-            if (lane < 16u && pw * 16u < QC) { pubv = c_pub[pw * 16u + lane]; shrv = c_shr[pw * 16u + lane]; }
-            uint64_t need = __ballot(lane < 16u && shrv == 0u && pubv + 32u >= capq && pubv > k);
+            const bool mine_q = lane < 16u && own_grp * 16u < QC && (E == 1 || (lane & 1u) == own_par);
+            if (mine_q) { pubv = c_pub[own_grp * 16u + lane]; shrv = c_shr[own_grp * 16u + lane]; }
+            uint64_t need = __ballot(mine_q && shrv == 0u && pubv + 32u >= capq && pubv > k);
             while (need) {
                 const int l = __ffsll((unsigned long long)need) - 1;
                 need &= need - 1;
                 if constexpr (DIAG) n_pcompact++;
-                const uint32_t qs = pw * 16u + (uint32_t)l;
+                const uint32_t qs = own_grp * 16u + (uint32_t)l;
                 uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)pubv, l);
                 n = n < 64u * E ? n : 64u * E;
                 const float qq_of = c_qq[qs];
