@@ -359,7 +359,9 @@ __device__ inline float wave_sum_dpp(float v) {
 }
 
 // E = candidate-list entries a lane holds in a compaction: 1 for k <= 32 (64 queries per pass, lists of 80),
-// 3 for k <= 104 ("wide": 32 queries per pass — the auto-linker's top-100 lists — lists of k + 48)
+// 4 for k <= 104 ("wide": 32 queries per pass — the auto-linker's top-100 lists — lists of up to 272).
+// A list entry is (row, dot): 8 bytes; |row|^2 comes from the index's norm cache (a.norms) wherever an exact
+// cosine is formed, and the producers copy it per tile into LDS for the consumers' per-tile test.
 template <int D, bool DIAG, int E>
 __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
     using C = Batch2Cfg<D>;
@@ -378,15 +380,14 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
         if constexpr (DIAG) a.diag += (size_t)grp * gridDim.x * 64u;
     }
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // LDS: [2 tiles: hi image | lo image][rr: 2 x 16 f32][cand rows | dots | rrs: 64 x capq][tau][cnt][tsq][pub][shr][qq]
+    // LDS: [2 tiles: hi image | lo image][rr: 2 x 16 f32][cand rows | dots: QC x capq][tau][cnt][tsq][pub][shr][qq]
     char *tiles = smem;
     float *c_rr = reinterpret_cast<float *>(smem + 2 * C::TILE_BYTES);
     const uint32_t capq = a.capq;
     constexpr uint32_t QC = E == 1 ? BT_Q : BT_Q / 2;   // queries that own a candidate list
     uint32_t *c_rows = reinterpret_cast<uint32_t *>(c_rr + 2 * BT_ROWS);
     float *c_dots = reinterpret_cast<float *>(c_rows + QC * capq);
-    float *c_rrs = c_dots + QC * capq;
-    uint64_t *c_tau = reinterpret_cast<uint64_t *>(c_rrs + QC * capq);
+    uint64_t *c_tau = reinterpret_cast<uint64_t *>(c_dots + QC * capq);
     uint32_t *c_cnt = reinterpret_cast<uint32_t *>(c_tau + BT_Q);
     float *c_tsq = reinterpret_cast<float *>(c_cnt + BT_Q);
     uint32_t *c_pub = reinterpret_cast<uint32_t *>(c_tsq + BT_Q);   // entries of a list that are completely written
@@ -424,20 +425,22 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
         // ------------------------------------------------------------------ producer
         // two register sets, tiles alternate between them: every load has two tile intervals of flight time
         // (one set left the producers waiting ~800 cycles per tile for HBM — tuning.md)
-        f32x4 ldA[C::LOADS], ldB[C::LOADS];
-        auto issue_loads = [&](f32x4 (&ld)[C::LOADS], uint32_t t) {
+        f32x4 ldA[C::LOADS], ldB[C::LOADS], nrA, nrB;   // rows and their four cached norms
+        auto issue_loads = [&](f32x4 (&ld)[C::LOADS], f32x4 &nr, uint32_t t) {
             const uint32_t tile = t < n_tiles ? t : n_tiles - 1u;
             const f32x4 *base = reinterpret_cast<const f32x4 *>(a.rows + ((size_t)tile * BT_ROWS + pw * 4u) * D);
 #pragma unroll
             for (int e = 0; e < C::LOADS; e++) ld[e] = __builtin_nontemporal_load(base + e * 64 + lane);
+            nr = *reinterpret_cast<const f32x4 *>(a.norms + (size_t)tile * BT_ROWS + pw * 4u);
         };
         // split + write the tile held in ld[], and put each register back in flight for tile `reload` as soon as
         // it has been consumed
-        auto write_tile = [&](f32x4 (&ld)[C::LOADS], uint32_t buf, uint32_t reload) {
+        auto write_tile = [&](f32x4 (&ld)[C::LOADS], f32x4 &nr, uint32_t buf, uint32_t reload) {
             const uint32_t rl = reload < n_tiles ? reload : n_tiles - 1u;   // past the end: a valid tile, never used
             const f32x4 *rbase = reinterpret_cast<const f32x4 *>(a.rows + ((size_t)rl * BT_ROWS + pw * 4u) * D);
             char *hi_img = tiles + buf * C::TILE_BYTES, *lo_img = hi_img + C::IMG_BYTES;
-            f32x2 part[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};   // two partial sums each: v_pk_fma_f32
+            const f32x4 rr_now = nr;
+            nr = *reinterpret_cast<const f32x4 *>(a.norms + (size_t)rl * BT_ROWS + pw * 4u);
 #pragma unroll
             for (int e = 0; e < C::LOADS; e++) {
                 // float index of the load inside the wave's 4 rows = e*256 + 4*lane: for dim % 256 == 0 the row
@@ -450,21 +453,11 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
                 ld[e] = __builtin_nontemporal_load(rbase + e * 64 + lane);
                 bf16x4_t h, l;
                 split4(v, h, l);
-                const f32x2 v01 = {v.x, v.y}, v23 = {v.z, v.w};
-                if (base_c + 256u <= (uint32_t)D) part[base_r] = v23 * v23 + (v01 * v01 + part[base_r]);
-                else {
-                    const f32x2 s2 = v23 * v23 + v01 * v01;
-#pragma unroll
-                    for (uint32_t rr_ = 0; rr_ < 4; rr_++) part[rr_] += (r == rr_) ? s2 : (f32x2){0.0f, 0.0f};
-                }
                 const uint32_t o = img_off<D>(pw * 4u + r, col >> 3, (col >> 2) & 1u);
                 *reinterpret_cast<bf16x4_t *>(hi_img + o) = h;
                 *reinterpret_cast<bf16x4_t *>(lo_img + o) = l;
             }
-            float sums[4];
-#pragma unroll
-            for (uint32_t rr_ = 0; rr_ < 4; rr_++) sums[rr_] = wave_sum_dpp(part[rr_].x + part[rr_].y);
-            if (lane == 0) *reinterpret_cast<f32x4 *>(c_rr + buf * BT_ROWS + pw * 4u) = f32x4{sums[0], sums[1], sums[2], sums[3]};
+            if (lane == 0) *reinterpret_cast<f32x4 *>(c_rr + buf * BT_ROWS + pw * 4u) = rr_now;
         };
         // Candidate-list compaction runs HERE, on the producer waves (they have the registers; the consumers hold
         // 16 queries in 192 VGPRs).  Producer wave pw owns the lists of consumer wave pw.  A list is compacted when
@@ -482,7 +475,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
         // on timing: the bound only removes rows that cannot be in the top k.
         unsigned long long n_pcompact = 0;
         // E = 1: 4 lanes per query, all 16 queries of the group per refresh, slots at stride 32;
-        // wide (E = 3): 8 lanes per query, the 8 queries this producer owns per refresh, stride 128
+        // wide (E = 4): 8 lanes per query, the 8 queries this producer owns per refresh, stride 128
         constexpr uint32_t LPQ = E == 1 ? 4u : 8u, NG = E == 1 ? 4u : 7u, GSTRIDE = E == 1 ? 32u : 128u;
         uint64_t gv[NG];
 #pragma unroll
@@ -534,7 +527,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
                 n = n < 64u * E ? n : 64u * E;
                 const float qq_of = c_qq[qs];
                 uint32_t *rws = c_rows + qs * capq;
-                float *dts = c_dots + qs * capq, *rrs = c_rrs + qs * capq;
+                float *dts = c_dots + qs * capq;
                 // entry 64 e + lane of the list sits in slot e of this lane
                 bool valid[E];
                 uint32_t r0[E], ord[E]; float d0[E], n0[E], sim[E];
@@ -544,7 +537,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
                     valid[e] = idx < n;
                     r0[e] = 0; ord[e] = 0; d0[e] = 0.0f; n0[e] = 1.0f; sim[e] = 0.0f;
                     if (valid[e]) {
-                        r0[e] = rws[idx]; d0[e] = dts[idx]; n0[e] = rrs[idx];
+                        r0[e] = rws[idx]; d0[e] = dts[idx]; n0[e] = a.norms[r0[e]];
                         sim[e] = cosine_from_sums(d0[e], qq_of, n0[e]);
                         ord[e] = score_ord(score_of(distance_of(sim[e])));
                     }
@@ -611,7 +604,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
                 for (int e = 0; e < E; e++) {
                     if ((keep[e] >> lane) & 1ull) {
                         const uint32_t slot = base + (uint32_t)__popcll(keep[e] & ((1ull << lane) - 1ull));
-                        rws[slot] = r0[e]; dts[slot] = d0[e]; rrs[slot] = n0[e];
+                        rws[slot] = r0[e]; dts[slot] = d0[e];
                     }
                     base += (uint32_t)__popcll(keep[e]);
                 }
@@ -630,21 +623,21 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
         };
         uint32_t tile = blockIdx.x;
         if (tile < n_tiles) {
-            issue_loads(ldA, tile);
-            issue_loads(ldB, tile + gridDim.x);
-            write_tile(ldA, 0, tile + 2u * gridDim.x);
+            issue_loads(ldA, nrA, tile);
+            issue_loads(ldB, nrB, tile + gridDim.x);
+            write_tile(ldA, nrA, 0, tile + 2u * gridDim.x);
         }
         __syncthreads();
         stamp0();
         uint32_t buf = 0, it = 0;
         // one tile interval: the consumers work on `tile`; this wave writes tile + grid (held in `ld`) into the
         // other buffer and sends `ld` for tile + 3 grid
-        auto step = [&](f32x4 (&ld)[C::LOADS]) {
+        auto step = [&](f32x4 (&ld)[C::LOADS], f32x4 &nr) {
             const uint32_t next = tile + gridDim.x;
             // the slots are re-read every 4th tile (agent-scope loads go past the L2) and applied one tile later
             if ((it & 3u) == 1u) refresh_apply();
             if (next < n_tiles) {
-                write_tile(ld, buf ^ 1u, next + 2u * gridDim.x);     // buffer last read one tile ago, behind that tile's barrier
+                write_tile(ld, nr, buf ^ 1u, next + 2u * gridDim.x);     // buffer last read one tile ago, behind that tile's barrier
                 stamp(t_write);
             }
             if ((it & 3u) == 0u) refresh_issue(it >> 2);
@@ -657,9 +650,9 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
             tile += gridDim.x;
         };
         while (tile < n_tiles) {
-            step(ldB);
+            step(ldB, nrB);
             if (tile >= n_tiles) break;
-            step(ldA);
+            step(ldA, nrA);
         }
         if constexpr (DIAG) {
             if (lane == 0) {
@@ -707,18 +700,18 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
 
     unsigned long long n_compact = 0, n_append_steps = 0;
     // final, ORDERED compaction of one list (rank counting: entry 64 e + lane sits in slot e of this lane)
-    constexpr int NE = E == 1 ? 2 : 3;
+    constexpr int NE = E == 1 ? 2 : 5;   // a final list holds up to capq entries: 80, or 272 in the wide mode
     auto compact = [&](uint32_t qs, float qq_of) {
         if constexpr (DIAG) n_compact++;
         const uint32_t n = c_cnt[qs] < capq ? c_cnt[qs] : capq;
         uint32_t *rws = c_rows + qs * capq;
-        float *dts = c_dots + qs * capq, *rrs = c_rrs + qs * capq;
+        float *dts = c_dots + qs * capq;
         uint32_t r[NE], rank[NE]; float d[NE], nr[NE]; uint64_t key[NE];
 #pragma unroll
         for (int e = 0; e < NE; e++) {
             const uint32_t idx = lane + 64u * e;
             r[e] = 0; d[e] = 0.0f; nr[e] = 1.0f; key[e] = 0ull; rank[e] = 0;
-            if (idx < n) { r[e] = rws[idx]; d[e] = dts[idx]; nr[e] = rrs[idx]; key[e] = cand_key(r[e], cosine_from_sums(d[e], qq_of, nr[e])); }
+            if (idx < n) { r[e] = rws[idx]; d[e] = dts[idx]; nr[e] = a.norms[r[e]]; key[e] = cand_key(r[e], cosine_from_sums(d[e], qq_of, nr[e])); }
         }
 #pragma unroll
         for (int g = 0; g < NE; g++) {
@@ -732,7 +725,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
 #pragma unroll
         for (int e = 0; e < NE; e++)
             if (lane + 64u * e < n && rank[e] < k) {
-                rws[rank[e]] = r[e]; dts[rank[e]] = d[e]; rrs[rank[e]] = nr[e];
+                rws[rank[e]] = r[e]; dts[rank[e]] = d[e];
                 if (rank[e] == k - 1u) {
                     const float sm = cosine_from_sums(d[e], qq_of, nr[e]);
                     c_tau[qs] = key[e];
@@ -750,7 +743,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
                 const uint32_t cnt = c_cnt[qslot], m = cnt - shr;   // m <= 16 and k + 16 <= shr: no overlap
                 for (uint32_t e = kq; e < m; e += 4u) {
                     const uint32_t src = qslot * capq + shr + e, dst = qslot * capq + k + e;
-                    c_rows[dst] = c_rows[src]; c_dots[dst] = c_dots[src]; c_rrs[dst] = c_rrs[src];
+                    c_rows[dst] = c_rows[src]; c_dots[dst] = c_dots[src];
                 }
                 if (kq == 0u) { c_cnt[qslot] = k + m; c_pub[qslot] = k + m; c_shr[qslot] = 0u; }
             }
@@ -822,7 +815,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
                 const uint32_t row = row0 + 4u * kq + r;
                 if (((mask >> r) & 1u) && row_passes(a.flt, row)) {
                     const uint32_t slot = atomicAdd(&c_cnt[qslot], 1u);
-                    if (slot < capq) { c_rows[qslot * capq + slot] = row; c_dots[qslot * capq + slot] = acc[r]; c_rrs[qslot * capq + slot] = rr4[r]; }
+                    if (slot < capq) { c_rows[qslot * capq + slot] = row; c_dots[qslot * capq + slot] = acc[r]; }
                 }
             }
             // entries are written before the length the producers read (LDS operations of one wave stay in order)
@@ -852,7 +845,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
         for (uint32_t idx = lane; idx < k; idx += 64u) {   // k <= 104: up to two entries per lane
             const bool valid = idx < n;
             const uint32_t row = valid ? c_rows[qs * capq + idx] : 0u;
-            const float sim = valid ? cosine_from_sums(c_dots[qs * capq + idx], qq_l, c_rrs[qs * capq + idx]) : 0.0f;
+            const float sim = valid ? cosine_from_sums(c_dots[qs * capq + idx], qq_l, a.norms[row]) : 0.0f;
             a.part_keys[base + idx] = valid ? cand_key(row, sim) : 0ull;
             a.part_sims[base + idx] = sim;
         }
@@ -893,9 +886,9 @@ template <int D>
 static int launch_batch_d(BatchArgs a, uint32_t grid, hipStream_t stream) {
     static const int use_f32_env = getenv("CX_BATCH_F32MFMA") ? atoi(getenv("CX_BATCH_F32MFMA")) : 0;
     const int use_f32 = use_f32_env && a.k <= 32 && a.n_groups == 1;   // the f32-MFMA kernel has no wide mode and no query groups
-    const bool wide = a.k > 32;   // 32 queries per pass, lists of k + 48, three entries per lane in a compaction
+    const bool wide = a.k > 32;   // 32 queries per pass, lists of up to 272, four entries per lane in a compaction
     const size_t qc = wide ? BT_Q / 2 : BT_Q;
-    const size_t tail = qc * a.capq * 12 + BT_Q * 8 + BT_Q * 4 + BT_Q * 4 + 3 * BT_Q * 4;
+    const size_t tail = qc * a.capq * (use_f32 ? 12 : 8) + BT_Q * 8 + BT_Q * 4 + BT_Q * 4 + 3 * BT_Q * 4;
     const size_t lds = use_f32 ? 2 * (size_t)BatchCfg<D>::TILE_BYTES + tail
                                : 2 * (size_t)Batch2Cfg<D>::TILE_BYTES + 2 * BT_ROWS * 4 + tail;
     if (lds > 160 * 1024) return set_err(CX_ERR_VALIDATION, "batch scan: %zu bytes of LDS for k = %u", lds, a.k);
@@ -905,15 +898,15 @@ static int launch_batch_d(BatchArgs a, uint32_t grid, hipStream_t stream) {
         CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch_scan_kernel<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch2_kernel<D, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch2_kernel<D, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch2_kernel<D, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch2_kernel<D, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch2_kernel<D, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch2_kernel<D, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     if (getenv("CX_BATCH_DIAG")) {  // diagnostic build: per-phase cycle shares on stderr, results still valid
         const size_t n = (size_t)grid * a.n_groups * 8 * 8;   // up to 8 waves x 8 slots per block
         CX_HIP(hipMalloc((void **)&a.diag, n * 8));
         CX_HIP(hipMemset(a.diag, 0, n * 8));
         if (use_f32) hipLaunchKernelGGL((batch_scan_kernel<D, true>), dim3(grid), dim3(256), lds, stream, a);
-        else if (wide) hipLaunchKernelGGL((batch2_kernel<D, true, 3>), dim3(grid, a.n_groups), dim3(512), lds, stream, a);
+        else if (wide) hipLaunchKernelGGL((batch2_kernel<D, true, 4>), dim3(grid, a.n_groups), dim3(512), lds, stream, a);
         else hipLaunchKernelGGL((batch2_kernel<D, true, 1>), dim3(grid, a.n_groups), dim3(512), lds, stream, a);
         CX_HIP(hipStreamSynchronize(stream));
         std::vector<unsigned long long> h(n);
@@ -933,7 +926,7 @@ static int launch_batch_d(BatchArgs a, uint32_t grid, hipStream_t stream) {
         return CX_OK;
     }
     if (use_f32) hipLaunchKernelGGL((batch_scan_kernel<D, false>), dim3(grid), dim3(256), lds, stream, a);
-    else if (wide) hipLaunchKernelGGL((batch2_kernel<D, false, 3>), dim3(grid, a.n_groups), dim3(512), lds, stream, a);
+    else if (wide) hipLaunchKernelGGL((batch2_kernel<D, false, 4>), dim3(grid, a.n_groups), dim3(512), lds, stream, a);
     else hipLaunchKernelGGL((batch2_kernel<D, false, 1>), dim3(grid, a.n_groups), dim3(512), lds, stream, a);
     CX_HIP(hipGetLastError());
     return CX_OK;
@@ -948,11 +941,11 @@ int launch_batch_scan(BatchArgs a, uint32_t grid, hipStream_t stream) {
     static const int use_f32_env = getenv("CX_BATCH_F32MFMA") ? atoi(getenv("CX_BATCH_F32MFMA")) : 0;
     const int use_f32 = use_f32_env && a.k <= 32 && a.n_groups == 1;
     a.capq = use_f32 ? (a.k <= 16 ? 64u : 80u) : 80u;
-    if (a.k > 32) {   // wide: as long as LDS allows (a compaction absorbs capq - 32 - k new entries), at most 3 x 64 + 16
+    if (a.k > 32) {   // wide: as long as LDS allows (a compaction absorbs capq - 32 - k new entries), at most 4 x 64 + 16
         const size_t tiles = 2 * (a.dim == 384 ? (size_t)Batch2Cfg<384>::TILE_BYTES : (size_t)Batch2Cfg<768>::TILE_BYTES);
         const size_t room = 160 * 1024 - tiles - 2 * BT_ROWS * 4 - (BT_Q * 8 + BT_Q * 4 + BT_Q * 4 + 3 * BT_Q * 4);
-        uint32_t c = (uint32_t)(room / ((BT_Q / 2) * 12)) & ~7u;
-        a.capq = c > 208u ? 208u : c;
+        uint32_t c = (uint32_t)(room / ((BT_Q / 2) * 8)) & ~7u;
+        a.capq = c > 272u ? 272u : c;
     }
     if (a.dim == 384) return launch_batch_d<384>(a, grid, stream);
     return launch_batch_d<768>(a, grid, stream);

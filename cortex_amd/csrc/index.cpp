@@ -124,6 +124,7 @@ int upsert_impl(cx_index *ix, uint64_t n, const uint8_t *ids, const float *embs,
         auto it = ix->map.find(key);
         if (it != ix->map.end()) {  // replace in place, row position kept
             if (it->second < ix->shadow_rows) ix->shadow_stale.push_back(it->second);
+            if (it->second < ix->norms_rows) ix->norms_stale.push_back(it->second);
             if (row_bytes)
                 CX_HIP(hipMemcpyAsync(ix->d_rows + (size_t)it->second * ix->dim, embs + i * len, row_bytes, kind, ix->up_stream));
             i++;
@@ -219,6 +220,39 @@ namespace {
 namespace cx {
 // nq single-query scans enqueued on s; query i's results at [i*k_out, ...).
 // threshold searches (has_thr) and k > TOPK_MAX take the dense+sort path.
+// |row|^2 of every row, kept lazily (see internal.hpp).  Work is enqueued on s and waited for under the mutex:
+// another reader on another stream must not see norms_rows advance before the values exist.
+int ensure_norms(const cx_index *ix, hipStream_t s) {
+    std::lock_guard<std::mutex> g(ix->norms_mu);
+    const uint64_t n = ix->n_rows;
+    bool work = false;
+    if (ix->norms_cap < n) {
+        if (ix->d_norms) CX_HIP(hipFree(ix->d_norms));
+        ix->d_norms = nullptr;
+        ix->norms_cap = 0;
+        const uint64_t cap = std::max<uint64_t>(n, ix->cap);
+        CX_HIP(hipMalloc((void **)&ix->d_norms, (cap + 64) * sizeof(float)));   // + a tile of readable padding
+        CX_HIP(hipMemsetAsync(ix->d_norms, 0, (cap + 64) * sizeof(float), s));
+        ix->norms_cap = cap;
+        ix->norms_rows = 0;
+        ix->norms_stale.clear();
+        work = true;
+    }
+    for (uint32_t r : ix->norms_stale)
+        if (r < ix->norms_rows) {
+            if (int rc = launch_row_norms(ix->d_rows, ix->d_norms, r, r + 1, ix->dim, s)) return rc;
+            work = true;
+        }
+    ix->norms_stale.clear();
+    if (ix->norms_rows < n) {
+        if (int rc = launch_row_norms(ix->d_rows, ix->d_norms, (uint32_t)ix->norms_rows, (uint32_t)n, ix->dim, s)) return rc;
+        ix->norms_rows = n;
+        work = true;
+    }
+    if (work) CX_HIP(hipStreamSynchronize(s));
+    return CX_OK;
+}
+
 int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float *tails, uint64_t nq, uint32_t k_eff,
                 const DevFilter &flt, float thr, bool has_thr, uint32_t *d_rows, float *d_scores, float *d_dists,
                 uint32_t *d_counts, hipStream_t s) {
@@ -242,6 +276,7 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
     for (uint64_t i = 0; tails && i < nq; i++) no_tails = no_tails && tails[i] == 0.0f;
     static const int batch_min = getenv("CX_BATCH_MIN") ? atoi(getenv("CX_BATCH_MIN")) : 3;
     if (topk_path && no_tails && nq >= (uint64_t)batch_min && k_eff >= 1 && batch_supported(ix->dim, k_eff)) {
+        if (int rc = ensure_norms(ix, s)) return rc;
         const uint32_t qpp = batch_queries_per_pass(k_eff);
         uint32_t bgrid = 1, groups = 1;
         batch_launch_shape(n, nq, k_eff, &bgrid, &groups);
@@ -255,6 +290,7 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
             memset(&b, 0, sizeof b);
             b.rows = ix->d_rows;
             b.queries = d_queries + q0 * ix->dim;
+            b.norms = ix->d_norms;
             b.n_rows = n;
             b.nq = m;
             b.n_groups = (m + qpp - 1) / qpp;
@@ -446,6 +482,7 @@ void cx_destroy(cx_index *ix) {
     (void)hipFree(ix->d_meta);
     (void)hipFree(ix->d_agent);
     (void)hipFree(ix->d_shadow);
+    (void)hipFree(ix->d_norms);
     (void)hipFree(ix->d_tile_list);
     if (ix->up_stream) (void)hipStreamDestroy(ix->up_stream);
     delete ix;
@@ -557,6 +594,8 @@ int cx_rebuild(cx_index *ix) {
     ix->n_removed = 0;
     ix->shadow_rows = 0;  // rows moved: the bf16 shadow is rebuilt on next use
     ix->shadow_stale.clear();
+    ix->norms_rows = 0;   // and so are the row norms
+    ix->norms_stale.clear();
     return CX_OK;
 }
 

@@ -124,6 +124,13 @@ struct cx_index {
     mutable uint64_t shadow_cap = 0;
     mutable uint64_t shadow_rows = 0;
     mutable std::vector<uint32_t> shadow_stale;
+    // |row|^2 per row for the batched search (batch.hip reads it instead of re-summing every row per batch);
+    // same lazy scheme as the shadow: rows [0, norms_rows) valid, in-place upserts listed in norms_stale
+    mutable std::mutex norms_mu;
+    mutable float *d_norms = nullptr;
+    mutable uint64_t norms_cap = 0;
+    mutable uint64_t norms_rows = 0;
+    mutable std::vector<uint32_t> norms_stale;
     mutable uint32_t *d_tile_list = nullptr;   // live tiles of the symmetric all-pairs pass, cached per row count
     mutable uint32_t tile_list_rows = 0, tile_list_n = 0, tile_list_big = 0;
     // measurement (cx_profile_*): event pairs around the scan kernel
@@ -148,6 +155,7 @@ struct CtxLease {
 };
 bool use_nontemporal(const cx_index *ix);
 // nq single-query scans (query i = d_queries + i*dim) enqueued on s; results at [i*k_eff, ...)
+int ensure_norms(const cx_index *ix, hipStream_t s);   // index.cpp
 int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float *tails, uint64_t nq, uint32_t k_eff,
                 const DevFilter &flt, float thr, bool has_thr, uint32_t *d_rows, float *d_scores, float *d_dists,
                 uint32_t *d_counts, hipStream_t s);

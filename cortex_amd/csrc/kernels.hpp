@@ -67,6 +67,7 @@ int launch_merge_parts(uint32_t n_parts, uint32_t nq, uint32_t k, uint64_t part_
 struct BatchArgs {
     const float *rows;      // [n_rows][dim]
     const float *queries;   // [nq][dim] in HBM
+    const float *norms;     // [n_rows (+16 readable)] |row|^2 (cx_index::d_norms)
     uint32_t n_rows, nq, dim, k, capq;
     uint32_t n_groups;      // query groups in this launch (gridDim.y); nq covers all of them
     DevFilter flt;
@@ -150,6 +151,9 @@ int launch_exclusive_scan(const uint32_t *in, uint64_t *out, uint32_t n, void *t
 int launch_scatter_lists(const uint32_t *src_rows, const float *src_scores, const float *src_dists, const uint32_t *src_cnt,
                          const uint32_t *d_pos, uint32_t n, uint32_t k_src, uint32_t k_dst, uint32_t *dst_rows,
                          float *dst_scores, float *dst_dists, uint32_t *dst_cnt, hipStream_t stream);
+
+// |row|^2 of rows [row_lo, row_hi) -> norms[row] (one wave per row)
+int launch_row_norms(const float *rows, float *norms, uint32_t row_lo, uint32_t row_hi, uint32_t dim, hipStream_t stream);
 
 // row maintenance
 int launch_gather_rows(const float *src, float *dst, const uint32_t *d_src_rows, uint32_t n_dst, uint32_t dim,

@@ -662,6 +662,28 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float *src, floa
     }
 }
 
+__global__ __launch_bounds__(256) void row_norms_kernel(const float *rows, float *norms, uint32_t row_lo, uint32_t row_hi, uint32_t dim) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t r = row_lo + wave; r < row_hi; r += n_waves) {
+        const float *p = rows + (size_t)r * dim;
+        float s = 0.0f;
+        for (uint32_t c = lane; c < dim; c += 64u) s = fmaf(p[c], p[c], s);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) norms[r] = s;
+    }
+}
+
+int launch_row_norms(const float *rows, float *norms, uint32_t row_lo, uint32_t row_hi, uint32_t dim, hipStream_t stream) {
+    if (row_hi <= row_lo) return CX_OK;
+    const uint32_t n = row_hi - row_lo;
+    const uint32_t blocks = n / 4u + 1u < 4096u ? n / 4u + 1u : 4096u;
+    hipLaunchKernelGGL(row_norms_kernel, dim3(blocks), dim3(256), 0, stream, rows, norms, row_lo, row_hi, dim);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+
 __global__ __launch_bounds__(256) void scatter_lists_kernel(const uint32_t *src_rows, const float *src_scores, const float *src_dists,
                                                             const uint32_t *src_cnt, const uint32_t *pos, uint32_t k_src,
                                                             uint32_t k_dst, uint32_t *dst_rows, float *dst_scores,

@@ -344,3 +344,45 @@ def test_search_batch_massive_ties(hip, oracle, k):
         got = rows_of(ids, bi[i, :m])
         # equal vectors give bit-equal scores on both sides, so the order is fully determined
         assert list(map(int, got)) == list(map(int, e["row"])), f"q{i}: {got[:8]} vs {e['row'][:8]}"
+
+
+def test_search_batch_after_upserts_removes_and_rebuild(hip, oracle):
+    """The batched search reads |row|^2 from a cache kept next to the rows: in-place upserts, appends, removes
+    and rebuild (compaction) must all leave it in step with the store."""
+    n, d, k = 6000, 768, 10
+    rows = oracle.synth_rows(n + 500, d)
+    qs = oracle.synth_queries(n, d, 70)
+    ids = ids_for(n + 500)
+    h = hip.HipIndex(d); o = oracle.OracleIndex(d)
+    h.insert_batch(ids[:n], rows[:n]); o.insert_batch(ids[:n], rows[:n])
+
+    def check(tag):
+        bi, bs, bd, bc = h.search_batch_arrays(qs, k)
+        for i in range(len(qs)):
+            e = o.search(qs[i], k)
+            m = int(bc[i])
+            got_ids = [bytes(x) for x in bi[i, :m]]
+            want_ids = [bytes(x) for x in e["node_id"]]
+            assert m == len(want_ids), tag
+            # ids exact except near-ties
+            for j, (g, w) in enumerate(zip(got_ids, want_ids)):
+                if g != w:
+                    assert abs(float(bs[i, j]) - float(e["score"][j])) <= SCORE_TOL, f"{tag} q{i} pos {j}"
+            assert np.allclose(bs[i, :m], e["score"], atol=SCORE_TOL), tag
+
+    check("fresh")
+    # in-place upserts: scaled copies of other rows (norms change by 4x and 0.25x)
+    for r, src, sc in ((5, 100, 2.0), (4000, 7, 0.5), (5999, 3000, 3.0)):
+        v = (rows[src] * sc).astype(np.float32)
+        h.insert(ids[r].tobytes(), v); o.insert(ids[r].tobytes(), v)
+    check("after in-place upserts")
+    h.insert_batch(ids[n:], rows[n:]); o.insert_batch(ids[n:], rows[n:])
+    check("after appends")
+    for r in range(0, 3000, 7):
+        h.remove(ids[r].tobytes()); o.remove(ids[r].tobytes())
+    check("after removes")
+    h.rebuild(); o.rebuild()
+    check("after rebuild")
+    v = (rows[11] * 1.5).astype(np.float32)
+    h.insert(ids[6100].tobytes(), v); o.insert(ids[6100].tobytes(), v)
+    check("upsert after rebuild")
