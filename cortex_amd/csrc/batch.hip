@@ -423,39 +423,32 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
 
     if (!consumer) {
         // ------------------------------------------------------------------ producer
-        // two register sets, tiles alternate between them: every load has two tile intervals of flight time
-        // (one set left the producers waiting ~800 cycles per tile for HBM — tuning.md)
-        f32x4 ldA[C::LOADS], ldB[C::LOADS], nrA, nrB;   // rows and their four cached norms
+        // The rows arrive already split: the index keeps a bf16 hi/lo copy of the store laid out tile by tile exactly
+        // like the LDS images (cx_index::d_split, build_split_kernel), 4 bytes per element like the f32 rows, so a
+        // producer only moves its 12 KiB share of a tile — 16-byte loads into registers, ds_write_b128 to the same
+        // offsets — and the per-batch split (2.5k cycles of VALU per tile, the kernel's critical path) is gone.
+        // Two register sets, tiles alternate between them: every load has two tile intervals of flight time.
+        f32x4 ldA[C::LOADS], ldB[C::LOADS], nrA, nrB;   // tile bytes and the wave's four cached row norms
+        const uint32_t my_off = pw * (uint32_t)C::LOADS * 1024u + lane * 16u;
         auto issue_loads = [&](f32x4 (&ld)[C::LOADS], f32x4 &nr, uint32_t t) {
             const uint32_t tile = t < n_tiles ? t : n_tiles - 1u;
-            const f32x4 *base = reinterpret_cast<const f32x4 *>(a.rows + ((size_t)tile * BT_ROWS + pw * 4u) * D);
+            const char *base = a.split + (size_t)tile * C::TILE_BYTES + my_off;
 #pragma unroll
-            for (int e = 0; e < C::LOADS; e++) ld[e] = __builtin_nontemporal_load(base + e * 64 + lane);
+            for (int e = 0; e < C::LOADS; e++) ld[e] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(base + e * 1024));
             nr = *reinterpret_cast<const f32x4 *>(a.norms + (size_t)tile * BT_ROWS + pw * 4u);
         };
-        // split + write the tile held in ld[], and put each register back in flight for tile `reload` as soon as
-        // it has been consumed
+        // write the tile held in ld[] and put each register back in flight for tile `reload` as soon as it is out
         auto write_tile = [&](f32x4 (&ld)[C::LOADS], f32x4 &nr, uint32_t buf, uint32_t reload) {
             const uint32_t rl = reload < n_tiles ? reload : n_tiles - 1u;   // past the end: a valid tile, never used
-            const f32x4 *rbase = reinterpret_cast<const f32x4 *>(a.rows + ((size_t)rl * BT_ROWS + pw * 4u) * D);
-            char *hi_img = tiles + buf * C::TILE_BYTES, *lo_img = hi_img + C::IMG_BYTES;
+            const char *rbase = a.split + (size_t)rl * C::TILE_BYTES + my_off;
+            char *dst = tiles + buf * C::TILE_BYTES + my_off;
             const f32x4 rr_now = nr;
             nr = *reinterpret_cast<const f32x4 *>(a.norms + (size_t)rl * BT_ROWS + pw * 4u);
 #pragma unroll
             for (int e = 0; e < C::LOADS; e++) {
-                // float index of the load inside the wave's 4 rows = e*256 + 4*lane: for dim % 256 == 0 the row
-                // is a compile-time constant and the column needs no division
-                const uint32_t base_r = (uint32_t)(e * 256) / D, base_c = (uint32_t)(e * 256) % D;
-                uint32_t r, col;
-                if (base_c + 256u <= (uint32_t)D) { r = base_r; col = base_c + lane * 4u; }
-                else { const uint32_t c2 = base_c + lane * 4u; r = base_r + (c2 >= (uint32_t)D ? 1u : 0u); col = c2 >= (uint32_t)D ? c2 - D : c2; }
                 const f32x4 v = ld[e];
-                ld[e] = __builtin_nontemporal_load(rbase + e * 64 + lane);
-                bf16x4_t h, l;
-                split4(v, h, l);
-                const uint32_t o = img_off<D>(pw * 4u + r, col >> 3, (col >> 2) & 1u);
-                *reinterpret_cast<bf16x4_t *>(hi_img + o) = h;
-                *reinterpret_cast<bf16x4_t *>(lo_img + o) = l;
+                ld[e] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(rbase + e * 1024));
+                *reinterpret_cast<f32x4 *>(dst + e * 1024) = v;
             }
             if (lane == 0) *reinterpret_cast<f32x4 *>(c_rr + buf * BT_ROWS + pw * 4u) = rr_now;
         };
@@ -850,6 +843,40 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
             a.part_sims[base + idx] = sim;
         }
     }
+}
+
+// rows [row_lo, row_hi) of the f32 store -> the split store: tile t = rows 16 t .. 16 t + 15 as [hi image | lo image],
+// each image 16 rows x D bf16 with the 16-byte pieces of a row XOR-swizzled inside 256-byte segments (img_off) — byte
+// for byte what the consumers read from LDS.  One wave per row.
+template <int D>
+__global__ __launch_bounds__(256) void build_split_kernel(const float *rows, char *split, uint32_t row_lo, uint32_t row_hi) {
+    using C = Batch2Cfg<D>;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t r = row_lo + wave; r < row_hi; r += n_waves) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(rows + (size_t)r * D);
+        char *hi_img = split + (size_t)(r / BT_ROWS) * C::TILE_BYTES, *lo_img = hi_img + C::IMG_BYTES;
+        const uint32_t i = r % BT_ROWS;
+        for (uint32_t c4 = lane; c4 < (uint32_t)D / 4u; c4 += 64u) {
+            bf16x4_t h, l;
+            split4(src[c4], h, l);
+            const uint32_t col = c4 * 4u;
+            const uint32_t o = img_off<D>(i, col >> 3, (col >> 2) & 1u);
+            *reinterpret_cast<bf16x4_t *>(hi_img + o) = h;
+            *reinterpret_cast<bf16x4_t *>(lo_img + o) = l;
+        }
+    }
+}
+
+int launch_build_split(const float *rows, char *split, uint32_t row_lo, uint32_t row_hi, uint32_t dim, hipStream_t stream) {
+    if (row_hi <= row_lo) return CX_OK;
+    const uint32_t n = row_hi - row_lo;
+    const uint32_t blocks = n / 4u + 1u < 8192u ? n / 4u + 1u : 8192u;
+    if (dim == 384) hipLaunchKernelGGL((build_split_kernel<384>), dim3(blocks), dim3(256), 0, stream, rows, split, row_lo, row_hi);
+    else if (dim == 768) hipLaunchKernelGGL((build_split_kernel<768>), dim3(blocks), dim3(256), 0, stream, rows, split, row_lo, row_hi);
+    else return set_err(CX_ERR_VALIDATION, "split store: dim %u not supported", dim);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
 }
 
 static uint32_t batch_cus() { return device_cus(); }

@@ -220,32 +220,47 @@ namespace {
 namespace cx {
 // nq single-query scans enqueued on s; query i's results at [i*k_out, ...).
 // threshold searches (has_thr) and k > TOPK_MAX take the dense+sort path.
-// |row|^2 of every row, kept lazily (see internal.hpp).  Work is enqueued on s and waited for under the mutex:
-// another reader on another stream must not see norms_rows advance before the values exist.
+// What the batched search reads besides the rows — |row|^2 and, for the dims its kernel serves, the bf16 hi/lo split
+// copy of the store — kept lazily (see internal.hpp).  Work is enqueued on s and waited for under the mutex: another
+// reader on another stream must not see norms_rows advance before the values exist.
 int ensure_norms(const cx_index *ix, hipStream_t s) {
     std::lock_guard<std::mutex> g(ix->norms_mu);
     const uint64_t n = ix->n_rows;
+    const bool want_split = batch_supported(ix->dim, 1);
     bool work = false;
     if (ix->norms_cap < n) {
         if (ix->d_norms) CX_HIP(hipFree(ix->d_norms));
+        if (ix->d_split) CX_HIP(hipFree(ix->d_split));
         ix->d_norms = nullptr;
+        ix->d_split = nullptr;
         ix->norms_cap = 0;
         const uint64_t cap = std::max<uint64_t>(n, ix->cap);
         CX_HIP(hipMalloc((void **)&ix->d_norms, (cap + 64) * sizeof(float)));   // + a tile of readable padding
         CX_HIP(hipMemsetAsync(ix->d_norms, 0, (cap + 64) * sizeof(float), s));
+        if (want_split) {
+            const size_t bytes = (size_t)((cap + 31) / 16) * 16 * ix->dim * sizeof(float);   // whole tiles
+            CX_HIP(hipMalloc((void **)&ix->d_split, bytes));
+            CX_HIP(hipMemsetAsync(ix->d_split, 0, bytes, s));
+        }
         ix->norms_cap = cap;
         ix->norms_rows = 0;
         ix->norms_stale.clear();
         work = true;
     }
+    auto refresh = [&](uint32_t lo, uint32_t hi) -> int {
+        if (int rc = launch_row_norms(ix->d_rows, ix->d_norms, lo, hi, ix->dim, s)) return rc;
+        if (want_split)
+            if (int rc = launch_build_split(ix->d_rows, ix->d_split, lo, hi, ix->dim, s)) return rc;
+        return CX_OK;
+    };
     for (uint32_t r : ix->norms_stale)
         if (r < ix->norms_rows) {
-            if (int rc = launch_row_norms(ix->d_rows, ix->d_norms, r, r + 1, ix->dim, s)) return rc;
+            if (int rc = refresh(r, r + 1)) return rc;
             work = true;
         }
     ix->norms_stale.clear();
     if (ix->norms_rows < n) {
-        if (int rc = launch_row_norms(ix->d_rows, ix->d_norms, (uint32_t)ix->norms_rows, (uint32_t)n, ix->dim, s)) return rc;
+        if (int rc = refresh((uint32_t)ix->norms_rows, (uint32_t)n)) return rc;
         ix->norms_rows = n;
         work = true;
     }
@@ -291,6 +306,7 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
             b.rows = ix->d_rows;
             b.queries = d_queries + q0 * ix->dim;
             b.norms = ix->d_norms;
+            b.split = ix->d_split;
             b.n_rows = n;
             b.nq = m;
             b.n_groups = (m + qpp - 1) / qpp;
@@ -483,6 +499,7 @@ void cx_destroy(cx_index *ix) {
     (void)hipFree(ix->d_agent);
     (void)hipFree(ix->d_shadow);
     (void)hipFree(ix->d_norms);
+    (void)hipFree(ix->d_split);
     (void)hipFree(ix->d_tile_list);
     if (ix->up_stream) (void)hipStreamDestroy(ix->up_stream);
     delete ix;

@@ -131,6 +131,9 @@ struct cx_index {
     mutable uint64_t norms_cap = 0;
     mutable uint64_t norms_rows = 0;
     mutable std::vector<uint32_t> norms_stale;
+    // bf16 hi/lo split copy of the rows for the batched search (same bytes as the f32 rows, tile-image layout);
+    // maintained together with the norms (same validity prefix and stale list)
+    mutable char *d_split = nullptr;
     mutable uint32_t *d_tile_list = nullptr;   // live tiles of the symmetric all-pairs pass, cached per row count
     mutable uint32_t tile_list_rows = 0, tile_list_n = 0, tile_list_big = 0;
     // measurement (cx_profile_*): event pairs around the scan kernel

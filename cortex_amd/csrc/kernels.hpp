@@ -68,6 +68,7 @@ struct BatchArgs {
     const float *rows;      // [n_rows][dim]
     const float *queries;   // [nq][dim] in HBM
     const float *norms;     // [n_rows (+16 readable)] |row|^2 (cx_index::d_norms)
+    const char *split;      // bf16 hi/lo copy of the rows, tile by tile in the LDS image layout (cx_index::d_split)
     uint32_t n_rows, nq, dim, k, capq;
     uint32_t n_groups;      // query groups in this launch (gridDim.y); nq covers all of them
     DevFilter flt;
@@ -78,6 +79,8 @@ struct BatchArgs {
 };
 bool batch_supported(uint32_t dim, uint32_t k);
 uint32_t batch_grid_blocks(uint32_t n_rows);
+// rows [row_lo, row_hi) -> the split store the batched search reads (dim 384 / 768)
+int launch_build_split(const float *rows, char *split, uint32_t row_lo, uint32_t row_hi, uint32_t dim, hipStream_t stream);
 uint32_t batch_queries_per_pass(uint32_t k);   // 64 for k <= 32, 32 for the wide lists (k <= 104)
 void batch_launch_shape(uint32_t n_rows, uint64_t nq, uint32_t k, uint32_t *chunks, uint32_t *groups);
 // one pass of <= 64 queries; per-block lists, to be folded by launch_merge_batch
