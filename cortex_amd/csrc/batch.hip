@@ -427,9 +427,8 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
         // like the LDS images (cx_index::d_split, build_split_kernel), 4 bytes per element like the f32 rows, so a
         // producer only moves its 12 KiB share of a tile — 16-byte loads into registers, ds_write_b128 to the same
         // offsets — and the per-batch split (2.5k cycles of VALU per tile, the kernel's critical path) is gone.
-        // Three register sets, tiles rotate through them: every load has three tile intervals of flight time
-        // (144 KiB in flight per CU at dim 768).
-        f32x4 ldA[C::LOADS], ldB[C::LOADS], ldC[C::LOADS], nrA, nrB, nrC;   // tile bytes and the wave's four cached row norms
+        // Two register sets, tiles alternate between them: every load has two tile intervals of flight time.
+        f32x4 ldA[C::LOADS], ldB[C::LOADS], nrA, nrB;   // tile bytes and the wave's four cached row norms
         const uint32_t my_off = pw * (uint32_t)C::LOADS * 1024u + lane * 16u;
         auto issue_loads = [&](f32x4 (&ld)[C::LOADS], f32x4 &nr, uint32_t t) {
             const uint32_t tile = t < n_tiles ? t : n_tiles - 1u;
@@ -619,20 +618,19 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
         if (tile < n_tiles) {
             issue_loads(ldA, nrA, tile);
             issue_loads(ldB, nrB, tile + gridDim.x);
-            issue_loads(ldC, nrC, tile + 2u * gridDim.x);
-            write_tile(ldA, nrA, 0, tile + 3u * gridDim.x);
+            write_tile(ldA, nrA, 0, tile + 2u * gridDim.x);
         }
         __syncthreads();
         stamp0();
         uint32_t buf = 0, it = 0;
         // one tile interval: the consumers work on `tile`; this wave writes tile + grid (held in `ld`) into the
-        // other buffer and sends `ld` for tile + 4 grid
+        // other buffer and sends `ld` for tile + 3 grid
         auto step = [&](f32x4 (&ld)[C::LOADS], f32x4 &nr) {
             const uint32_t next = tile + gridDim.x;
             // the slots are re-read every 4th tile (agent-scope loads go past the L2) and applied one tile later
             if ((it & 3u) == 1u) refresh_apply();
             if (next < n_tiles) {
-                write_tile(ld, nr, buf ^ 1u, next + 3u * gridDim.x);     // buffer last read one tile ago, behind that tile's barrier
+                write_tile(ld, nr, buf ^ 1u, next + 2u * gridDim.x);     // buffer last read one tile ago, behind that tile's barrier
                 stamp(t_write);
             }
             if ((it & 3u) == 0u) refresh_issue(it >> 2);
@@ -646,8 +644,6 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
         };
         while (tile < n_tiles) {
             step(ldB, nrB);
-            if (tile >= n_tiles) break;
-            step(ldC, nrC);
             if (tile >= n_tiles) break;
             step(ldA, nrA);
         }
