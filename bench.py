@@ -165,7 +165,7 @@ def main() -> None:
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": float(traffic) if traffic else None, "traffic_source": traffic_src,
-            "kernel": "cx::scan_kernel" if B < 3 else "cx::batch_scan_kernel", "avg_kernel_ms": avg_ms, "launches": kern_n,
+            "kernel": "cx::scan_kernel" if B < 3 else "cx::batch2_kernel", "avg_kernel_ms": avg_ms, "launches": kern_n,
             "algorithmic_bytes_per_launch": algo_bytes,
         },
     }
