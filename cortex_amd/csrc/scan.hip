@@ -397,7 +397,12 @@ static void dispatch_scan(const ScanArgs &a, uint32_t grid, int ks, bool nt, hip
         switch (a.dim) {
             case 128: return launch_fixed<128, 32, 4, MODE>(a, grid, ks, nt, s);
             case 256: return launch_fixed<256, 64, 8, MODE>(a, grid, ks, nt, s);
-            case 384: return launch_fixed<384, 32, 4, MODE>(a, grid, ks, nt, s);
+            case 384: {
+                static const int r384 = getenv("CX_SCAN_R384") ? atoi(getenv("CX_SCAN_R384")) : 4;  // tuning knob
+                if (r384 == 2) return launch_fixed<384, 32, 2, MODE>(a, grid, ks, nt, s);
+                if (r384 == 8) return launch_fixed<384, 32, 8, MODE>(a, grid, ks, nt, s);
+                return launch_fixed<384, 32, 4, MODE>(a, grid, ks, nt, s);
+            }
             case 512: return launch_fixed<512, 64, 4, MODE>(a, grid, ks, nt, s);
             case 768: {
                 static const int r768 = getenv("CX_SCAN_R") ? atoi(getenv("CX_SCAN_R")) : 4;  // tuning knob
