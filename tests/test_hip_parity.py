@@ -386,3 +386,18 @@ def test_search_batch_after_upserts_removes_and_rebuild(hip, oracle):
     v = (rows[11] * 1.5).astype(np.float32)
     h.insert(ids[6100].tobytes(), v); o.insert(ids[6100].tobytes(), v)
     check("upsert after rebuild")
+
+
+@pytest.mark.parametrize("k,nq", [(10, 64), (100, 40)])
+def test_search_batch_is_deterministic(hip, oracle, k, nq):
+    """The batched kernel filters with bounds that depend on timing (list compactions, the cross-block slots); the
+    bounds only ever drop rows that cannot be in the top k, so the RESULT must not move: twenty runs, bit for bit."""
+    n, d = 200_000, 384
+    rows = oracle.synth_rows(n, d)
+    qs = oracle.synth_queries(n, d, nq)
+    h = hip.HipIndex(d); h.insert_batch(ids_for(n), rows)
+    ref = h.search_batch_arrays(qs, k)
+    for _ in range(20):
+        got = h.search_batch_arrays(qs, k)
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b)
