@@ -158,6 +158,62 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
         if constexpr (DIAG) { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); t_prev = t; }
     };
 
+    // final, ORDERED compaction of one list (rank counting: entry 64 e + lane sits in slot e of this lane)
+    constexpr int NE = E == 1 ? 2 : 5;   // a final list holds up to capq entries: 80, or 272 in the wide mode
+    auto compact = [&](uint32_t qs, float qq_of) {
+        const uint32_t n = c_cnt[qs] < capq ? c_cnt[qs] : capq;
+        uint32_t *rws = c_rows + qs * capq;
+        float *dts = c_dots + qs * capq;
+        uint32_t r[NE], rank[NE]; float d[NE], nr[NE]; uint64_t key[NE];
+#pragma unroll
+        for (int e = 0; e < NE; e++) {
+            const uint32_t idx = lane + 64u * e;
+            r[e] = 0; d[e] = 0.0f; nr[e] = 1.0f; key[e] = 0ull; rank[e] = 0;
+            if (idx < n) { r[e] = rws[idx]; d[e] = dts[idx]; nr[e] = a.norms[r[e]]; key[e] = cand_key(r[e], cosine_from_sums(d[e], qq_of, nr[e])); }
+        }
+#pragma unroll
+        for (int g = 0; g < NE; g++) {
+            const uint32_t hi = n < 64u * (g + 1) ? n : 64u * (g + 1);
+            for (uint32_t f = 64u * g; f < hi; f++) {
+                const uint64_t kf = readlane_u64(key[g], (int)(f - 64u * g));
+#pragma unroll
+                for (int e = 0; e < NE; e++) rank[e] += kf > key[e] ? 1u : 0u;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < NE; e++)
+            if (lane + 64u * e < n && rank[e] < k) {
+                rws[rank[e]] = r[e]; dts[rank[e]] = d[e];
+                if (rank[e] == k - 1u) {
+                    const float sm = cosine_from_sums(d[e], qq_of, nr[e]);
+                    c_tau[qs] = key[e];
+                    c_tsq[qs] = sm > 0.0f ? sm * sm * (1.0f - 1.0e-4f) : -1.0f;
+                }
+            }
+        if (lane == 0) c_cnt[qs] = n < k ? n : k;
+    };
+
+    // Final phase, shared by all eight waves once the last tile's barrier is behind them: wave w orders and writes the
+    // lists [w QC/8, (w+1) QC/8) — per-block lists go to part[(q * grid + block) * k + r].
+    auto finalize_lists = [&]() {
+        constexpr uint32_t PER = QC / 8u;
+        for (uint32_t l = 0; l < PER; l++) {
+            const uint32_t qs = wave * PER + l;
+            if (qs >= a.nq) break;
+            const float qq_l = c_qq[qs];
+            compact(qs, qq_l);
+            const uint32_t n = c_cnt[qs];
+            const size_t base = ((size_t)qs * gridDim.x + blockIdx.x) * k;
+            for (uint32_t idx = lane; idx < k; idx += 64u) {   // k <= 104: up to two entries per lane
+                const bool valid = idx < n;
+                const uint32_t row = valid ? c_rows[qs * capq + idx] : 0u;
+                const float sim = valid ? cosine_from_sums(c_dots[qs * capq + idx], qq_l, a.norms[row]) : 0.0f;
+                a.part_keys[base + idx] = valid ? cand_key(row, sim) : 0ull;
+                a.part_sims[base + idx] = sim;
+            }
+        }
+    };
+
     if (!consumer) {
         // ------------------------------------------------------------------ producer
         // The rows arrive already split: the index keeps a bf16 hi/lo copy of the store laid out tile by tile exactly
@@ -390,6 +446,8 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
                 o[0] = t_stage; o[3] = t_bar; o[5] = t_wait; o[6] = t_write; o[7] = n_pcompact;
             }
         }
+        __syncthreads();   // the consumers have slid their last appends into place
+        finalize_lists();
         return;
     }
 
@@ -428,43 +486,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
 #pragma unroll
     for (uint32_t ksl = 0; ksl < 4; ksl++) a_off[ksl] = j * C::ROW_BYTES + ((((4u * ksl + kq) ^ j) & 15u) << 4);
 
-    unsigned long long n_compact = 0, n_append_steps = 0;
-    // final, ORDERED compaction of one list (rank counting: entry 64 e + lane sits in slot e of this lane)
-    constexpr int NE = E == 1 ? 2 : 5;   // a final list holds up to capq entries: 80, or 272 in the wide mode
-    auto compact = [&](uint32_t qs, float qq_of) {
-        if constexpr (DIAG) n_compact++;
-        const uint32_t n = c_cnt[qs] < capq ? c_cnt[qs] : capq;
-        uint32_t *rws = c_rows + qs * capq;
-        float *dts = c_dots + qs * capq;
-        uint32_t r[NE], rank[NE]; float d[NE], nr[NE]; uint64_t key[NE];
-#pragma unroll
-        for (int e = 0; e < NE; e++) {
-            const uint32_t idx = lane + 64u * e;
-            r[e] = 0; d[e] = 0.0f; nr[e] = 1.0f; key[e] = 0ull; rank[e] = 0;
-            if (idx < n) { r[e] = rws[idx]; d[e] = dts[idx]; nr[e] = a.norms[r[e]]; key[e] = cand_key(r[e], cosine_from_sums(d[e], qq_of, nr[e])); }
-        }
-#pragma unroll
-        for (int g = 0; g < NE; g++) {
-            const uint32_t hi = n < 64u * (g + 1) ? n : 64u * (g + 1);
-            for (uint32_t f = 64u * g; f < hi; f++) {
-                const uint64_t kf = readlane_u64(key[g], (int)(f - 64u * g));
-#pragma unroll
-                for (int e = 0; e < NE; e++) rank[e] += kf > key[e] ? 1u : 0u;
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < NE; e++)
-            if (lane + 64u * e < n && rank[e] < k) {
-                rws[rank[e]] = r[e]; dts[rank[e]] = d[e];
-                if (rank[e] == k - 1u) {
-                    const float sm = cosine_from_sums(d[e], qq_of, nr[e]);
-                    c_tau[qs] = key[e];
-                    c_tsq[qs] = sm > 0.0f ? sm * sm * (1.0f - 1.0e-4f) : -1.0f;
-                }
-            }
-        if (lane == 0) c_cnt[qs] = n < k ? n : k;
-    };
-
+    unsigned long long n_compact = 0, n_append_steps = 0;   // n_compact: kept for the diag record layout
     // behind a barrier: slide what this wave appended since a producer's compaction snapshot down to k
     auto apply_shrink = [&]() {
         const uint32_t shr = c_shr[qslot];
@@ -565,21 +587,8 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
             o[5] = n_compact; o[6] = n_append_steps;
         }
     }
-    for (uint32_t l = 0; l < 16u; l++) compact(pw * 16u + l, readlane_f32(qq, (int)l));
-    for (uint32_t l = 0; l < 16u; l++) {
-        const uint32_t qs = pw * 16u + l;
-        if (qs >= a.nq) break;
-        const uint32_t n = c_cnt[qs];
-        const size_t base = ((size_t)qs * gridDim.x + blockIdx.x) * k;
-        const float qq_l = readlane_f32(qq, (int)l);
-        for (uint32_t idx = lane; idx < k; idx += 64u) {   // k <= 104: up to two entries per lane
-            const bool valid = idx < n;
-            const uint32_t row = valid ? c_rows[qs * capq + idx] : 0u;
-            const float sim = valid ? cosine_from_sums(c_dots[qs * capq + idx], qq_l, a.norms[row]) : 0.0f;
-            a.part_keys[base + idx] = valid ? cand_key(row, sim) : 0ull;
-            a.part_sims[base + idx] = sim;
-        }
-    }
+    __syncthreads();   // every wave's lists are final
+    finalize_lists();
 }
 
 // rows [row_lo, row_hi) of the f32 store -> the split store: tile t = rows 16 t .. 16 t + 15 as [hi image | lo image],
