@@ -660,6 +660,15 @@ int cx_row_id(const cx_index *ix, uint64_t row, uint8_t out_id[16]) {
     return CX_OK;
 }
 
+int cx_rows_of(const cx_index *ix, uint64_t n, const uint8_t *ids, uint32_t *out_rows) {
+    if (!ix || (n && (!ids || !out_rows))) return set_err(CX_ERR_VALIDATION, "null argument");
+    for (uint64_t i = 0; i < n; i++) {
+        auto it = ix->map.find(id_key(ids + 16 * i));
+        out_rows[i] = it == ix->map.end() ? 0xFFFFFFFFu : it->second;
+    }
+    return CX_OK;
+}
+
 int cx_search_batch(const cx_index *ix, uint64_t nq, const float *queries, uint64_t len, uint64_t k,
                     const cx_filter *filter, uint8_t *out_ids, float *out_scores, float *out_distances,
                     uint64_t *out_counts) {

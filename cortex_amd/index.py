@@ -325,6 +325,14 @@ class HipIndex:
             self._check(rc)
             return a[:n.value], b[:n.value], s[:n.value]
 
+    def rows_of(self, ids) -> np.ndarray:
+        """cx_rows_of: insertion rows of ids (u8 [n,16] or a sequence of 16-byte ids); UINT32_MAX = not indexed."""
+        arr = ids if isinstance(ids, np.ndarray) else np.frombuffer(b"".join(_id16(i) for i in ids), dtype=np.uint8)
+        arr = np.ascontiguousarray(arr, dtype=np.uint8).reshape(-1, 16)
+        out = np.zeros(len(arr), np.uint32)
+        self._check(self._L.cx_rows_of(self._h, len(arr), arr.ctypes.data, out.ctypes.data))
+        return out
+
     def topk_lists_rows(self, topk: int, scan_rows=None):
         """cx_topk_lists_rows: (rows [n_scan, topk] u32, scores [n_scan, topk] f32, counts [n_scan]) — the ordered
         top-k neighbour list of every scanned row, self included (auto_linker.rs:221 for a whole batch of nodes)."""

@@ -41,7 +41,12 @@ class DuplicatePair:
 
 
 def _rows_of(index: HipIndex, ids: Iterable[NodeId]) -> np.ndarray:
-    lut = {index.row_id(r).bytes: r for r in range(index.row_count())}
+    if hasattr(index, "rows_of"):
+        rows = index.rows_of(list(ids))
+        if np.any(rows == np.uint32(0xFFFFFFFF)):
+            raise KeyError("id not in the index")
+        return rows
+    lut = {index.row_id(r).bytes: r for r in range(index.row_count())}   # duck-typed indexes (tests)
     return np.array([lut[_id16(i)] for i in ids], dtype=np.uint32)
 
 

@@ -112,6 +112,9 @@ uint32_t cx_dimension(const cx_index *ix);
 uint64_t cx_row_count(const cx_index *ix);
 /* id of a row (for callers that work with row indices); 0 ok */
 int cx_row_id(const cx_index *ix, uint64_t row, uint8_t out_id[16]);
+/* rows of n ids (the linker passes take row indices): out_rows[i] = row of ids[16 i ..], or UINT32_MAX if the id
+ * is not in the index (a node without an embedding: auto_linker.rs:217-218 skips it).  0 ok. */
+int cx_rows_of(const cx_index *ix, uint64_t n, const uint8_t *ids, uint32_t *out_rows);
 
 /* VectorIndex::search — vector/index.rs:325-374 on its exact path
  * (:338-340 -> brute_force_search :259-294).  Writes n_out <= k results,

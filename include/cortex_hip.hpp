@@ -9,6 +9,7 @@
 #include <array>
 #include <cstdint>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <optional>
 #include <stdexcept>
@@ -174,6 +175,116 @@ struct SimilarityConfig {  // vector/config.rs:3-87
         if (contradiction_threshold >= dedup_threshold) throw CortexError(CX_ERR_VALIDATION, "contradiction_threshold must be less than dedup_threshold");
         if (auto_link_k == 0) throw CortexError(CX_ERR_VALIDATION, "auto_link_k must be greater than 0");
     }
+};
+
+
+// ---- auto-linker / dedup scanner over the index (linker/auto_linker.rs:215-264, rules.rs:42-62, dedup.rs:65-127) ----
+
+struct ProposedEdge {   // linker/rules.rs:7-14 as SimilarityLinkRule fills it: relation "related_to", weight = score
+    NodeId from, to;
+    float weight;
+};
+struct DuplicatePair {  // linker/dedup.rs: DuplicatePair { node_a, node_b, similarity }
+    NodeId node_a, node_b;
+    float similarity;
+};
+struct NeighbourLists {  // `search(&embedding, 100, None)` of every scanned node, in scan order
+    size_t topk = 0;
+    std::vector<NodeId> scanned;
+    std::vector<uint32_t> rows, counts;   // rows [n][topk] (insertion rows), counts [n]
+    std::vector<float> scores;            // [n][topk]
+};
+
+class Linker {
+    const HipIndex &ix_;
+    static void check(int rc) {
+        if (rc != CX_OK) throw CortexError(rc, cx_last_error());
+    }
+    std::vector<uint32_t> rows_of(const std::vector<NodeId> &ids) const {
+        std::vector<uint8_t> flat;
+        flat.reserve(ids.size() * 16);
+        for (auto &id : ids) flat.insert(flat.end(), id.begin(), id.end());
+        std::vector<uint32_t> rows(ids.size());
+        check(cx_rows_of(ix_.raw(), ids.size(), flat.data(), rows.data()));
+        for (uint32_t r : rows)
+            if (r == 0xFFFFFFFFu) throw CortexError(CX_ERR_VALIDATION, "node has no embedding in the index");
+        return rows;
+    }
+    std::vector<uint8_t> deleted_flags(const std::vector<NodeId> *deleted) const {
+        std::vector<uint8_t> f;
+        if (!deleted || deleted->empty()) return f;
+        f.assign((size_t)cx_row_count(ix_.raw()), 0);
+        for (uint32_t r : rows_of(*deleted)) f[r] = 1;
+        return f;
+    }
+    NodeId id_of(uint32_t row) const {
+        NodeId id;
+        check(cx_row_id(ix_.raw(), row, id.data()));
+        return id;
+    }
+
+public:
+    explicit Linker(const HipIndex &ix) : ix_(ix) {}
+
+    /// The edges `run_cycle` proposes from SimilarityLinkRule for the scanned nodes (scan order, then score order),
+    /// before its existing-edge and per-cycle filters.  scan = nullptr scans every node.
+    std::vector<ProposedEdge> similarity_edges(const std::vector<NodeId> *scan, const SimilarityConfig &cfg,
+                                               size_t max_edges_per_node = 50, const std::vector<NodeId> *deleted = nullptr,
+                                               size_t topk = 100) const {
+        cfg.validate();
+        std::vector<uint32_t> scan_rows;
+        if (scan) scan_rows = rows_of(*scan);
+        const std::vector<uint8_t> del = deleted_flags(deleted);
+        const uint64_t n_scan = scan ? scan_rows.size() : cx_row_count(ix_.raw());
+        uint64_t cap = std::max<uint64_t>(1024, n_scan * 4), n = 0, need = 0;
+        std::vector<uint32_t> from, to;
+        std::vector<float> w;
+        for (;;) {
+            from.resize(cap); to.resize(cap); w.resize(cap);
+            const int rc = cx_autolink_pass_rows(ix_.raw(), n_scan, scan ? scan_rows.data() : nullptr, topk, cfg.auto_link_threshold,
+                                                 max_edges_per_node, del.empty() ? nullptr : del.data(), cap, from.data(), to.data(),
+                                                 w.data(), &n, &need);
+            if (rc == CX_ERR_CAPACITY && need > cap) { cap = need; continue; }
+            check(rc);
+            break;
+        }
+        std::vector<ProposedEdge> out(n);
+        for (uint64_t i = 0; i < n; i++) out[i] = ProposedEdge{id_of(from[i]), id_of(to[i]), w[i]};
+        return out;
+    }
+
+    /// DedupScanner::scan's pairs: every indexed node in row order, neighbours with score >= dedup_threshold.
+    std::vector<DuplicatePair> dedup_scan(const SimilarityConfig &cfg, const std::vector<NodeId> *deleted = nullptr) const {
+        const std::vector<uint8_t> del = deleted_flags(deleted);
+        uint64_t cap = std::max<uint64_t>(1024, cx_row_count(ix_.raw())), n = 0, need = 0;
+        std::vector<uint32_t> a, b;
+        std::vector<float> s;
+        for (;;) {
+            a.resize(cap); b.resize(cap); s.resize(cap);
+            const int rc = cx_dedup_scan_rows(ix_.raw(), cfg.dedup_threshold, del.empty() ? nullptr : del.data(), cap, a.data(),
+                                              b.data(), s.data(), &n, &need);
+            if (rc == CX_ERR_CAPACITY && need > cap) { cap = need; continue; }
+            check(rc);
+            break;
+        }
+        std::vector<DuplicatePair> out(n);
+        for (uint64_t i = 0; i < n; i++) out[i] = DuplicatePair{id_of(a[i]), id_of(b[i]), s[i]};
+        return out;
+    }
+
+    /// `search(&embedding, 100, None)` (auto_linker.rs:221) for a whole batch of nodes: what every other rule walks.
+    NeighbourLists neighbour_lists(const std::vector<NodeId> &scan, size_t topk = 100) const {
+        NeighbourLists L;
+        L.topk = topk;
+        L.scanned = scan;
+        const std::vector<uint32_t> scan_rows = rows_of(scan);
+        L.rows.assign(scan.size() * topk, 0);
+        L.scores.assign(scan.size() * topk, 0.0f);
+        L.counts.assign(scan.size(), 0);
+        check(cx_topk_lists_rows(ix_.raw(), scan.size(), scan_rows.data(), topk, L.rows.data(), L.scores.data(), L.counts.data()));
+        return L;
+    }
+    NodeId node_of_row(uint32_t row) const { return id_of(row); }
 };
 
 }  // namespace cortex

@@ -1,6 +1,7 @@
 // The reference's own vector-layer tests (crates/cortex-core/src/vector/index.rs:484-728 and
 // vector/config.rs:93-135), written against the C++ host mirror (include/cortex_hip.hpp).
 // Needs a GPU; run by tests/test_hip_cpp_mirror.py.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -155,12 +156,64 @@ TEST(test_config) {  // vector/config.rs:93-135
     CHECK(cl.auto_link_threshold == 1.0f && cl.dedup_threshold == 0.0f);
 }
 
+// ---- linker passes over the index (no counterpart test in the reference: its auto-linker tests need storage and an
+// embedding model; these pin the rule semantics of auto_linker.rs:215-264 / rules.rs:42-62 / dedup.rs:65-127 on
+// hand-made vectors)
+static Embedding unit3(float a, float b, float c, size_t dim) {
+    Embedding v(dim, 0.0f);
+    v[0] = a; v[1] = b; v[2] = c;
+    return v;
+}
+TEST(test_linker_similarity_edges_and_dedup) {
+    const size_t dim = 64;   // a multiple of 64: the MFMA filter path; exact rescoring decides
+    HipIndex index(dim);
+    NodeId a = now_v7(), b = now_v7(), c = now_v7(), d = now_v7();
+    index.insert(a, unit3(1.0f, 0.0f, 0.0f, dim));
+    index.insert(b, unit3(0.99f, 0.1f, 0.0f, dim));    // cos(a,b) = 0.9949
+    index.insert(c, unit3(0.8f, 0.6f, 0.0f, dim));     // cos(a,c) = 0.8, cos(b,c) = 0.852/0.9950*... ~0.8563
+    index.insert(d, unit3(0.0f, 0.0f, 1.0f, dim));     // orthogonal to all
+    Linker linker(index);
+    SimilarityConfig cfg;
+    cfg.with_auto_link_threshold(0.75f).with_dedup_threshold(0.99f);
+    auto edges = linker.similarity_edges(nullptr, cfg);
+    // a: b (0.995), c (0.8);  b: a, c (0.856);  c: b, a;  d: none  -> 6 directed edges, scan order then score order
+    CHECK(edges.size() == 6);
+    if (edges.size() == 6) {
+        CHECK(edges[0].from == a && edges[0].to == b && edges[1].from == a && edges[1].to == c);
+        CHECK(edges[2].from == b && edges[2].to == a && edges[3].from == b && edges[3].to == c);
+        CHECK(edges[4].from == c && edges[4].to == b && edges[5].from == c && edges[5].to == a);
+        CHECK(std::fabs(edges[0].weight - edges[2].weight) < 1e-6f);   // the same pair scores the same both ways
+        CHECK(edges[1].weight > 0.79f && edges[1].weight < 0.81f);
+    }
+    // per-node cap of 1: only the best neighbour of each node
+    auto capped = linker.similarity_edges(nullptr, cfg, 1);
+    CHECK(capped.size() == 3);
+    // a deleted (storage-tombstoned) neighbour is skipped; its own scan still runs (the reference scans new nodes only,
+    // the caller decides what to scan)
+    std::vector<NodeId> del{b};
+    std::vector<NodeId> scan{a};
+    auto e2 = linker.similarity_edges(&scan, cfg, 50, &del);
+    CHECK(e2.size() == 1 && e2[0].to == c);
+    // dedup: only (a, b) is >= 0.99, reported once by the node scanned first
+    auto dups = linker.dedup_scan(cfg);
+    CHECK(dups.size() == 1);
+    if (dups.size() == 1) CHECK(dups[0].node_a == a && dups[0].node_b == b && dups[0].similarity > 0.99f);
+    // the ordered neighbour lists every other rule walks: self first (score 1), then by score
+    auto L = linker.neighbour_lists(scan, 3);
+    CHECK(L.counts.size() == 1 && L.counts[0] == 3);
+    if (L.counts.size() == 1 && L.counts[0] == 3) {
+        CHECK(linker.node_of_row(L.rows[0]) == a && linker.node_of_row(L.rows[1]) == b && linker.node_of_row(L.rows[2]) == c);
+        CHECK(L.scores[0] > 0.9999f && L.scores[1] > L.scores[2]);
+    }
+}
+
 int main() {
     if (cx_device_count() <= 0) { std::fprintf(stderr, "no HIP device: %s\n", "this test needs a GPU"); return 2; }
     run_test_index_insert_and_search(); run_test_threshold_search(); run_test_index_persistence();
     run_test_dimension_mismatch_rejected(); run_test_empty_index_search(); run_test_brute_force_fallback();
     run_test_filter_by_kind(); run_test_filter_exclude(); run_test_remove_doesnt_crash_search(); run_test_search_batch();
     run_test_similarity_score_range(); run_test_threshold_returns_only_above(); run_test_config();
+    run_test_linker_similarity_edges_and_dedup();
     std::printf("%d tests run, %d checks failed\n", g_run, g_failed);
     return g_failed ? 1 : 0;
 }
