@@ -158,6 +158,15 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
         if constexpr (DIAG) { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); t_prev = t; }
     };
 
+    // The per-tile barrier.  __syncthreads() would also drain every outstanding global load (its fence waits for
+    // vmcnt(0)), i.e. the producers' prefetched tiles — measured as ~2k idle cycles per tile on the producers.  What the
+    // hand-over needs is only that this wave's LDS writes have completed: lgkmcnt(0), then the raw barrier.
+    auto tile_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
     // final, ORDERED compaction of one list (rank counting: entry 64 e + lane sits in slot e of this lane)
     constexpr int NE = E == 1 ? 2 : 5;   // a final list holds up to capq entries: 80, or 272 in the wide mode
     auto compact = [&](uint32_t qs, float qq_of) {
@@ -239,9 +248,11 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
             nr = *reinterpret_cast<const f32x4 *>(a.norms + (size_t)rl * BT_ROWS + pw * 4u);
 #pragma unroll
             for (int e = 0; e < C::LOADS; e++) {
-                const f32x4 v = ld[e];
+                // store first, then reload INTO THE SAME REGISTER: with the load ahead of the store the compiler needs a
+                // second register for the new value and later copies it home — a v_mov of an in-flight load result,
+                // i.e. an s_waitcnt vmcnt(0) per tile that cut the prefetch distance to a fraction of a tile
+                *reinterpret_cast<f32x4 *>(dst + e * 1024) = ld[e];
                 ld[e] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(rbase + e * 1024));
-                *reinterpret_cast<f32x4 *>(dst + e * 1024) = v;
             }
             if (lane == 0) *reinterpret_cast<f32x4 *>(c_rr + buf * BT_ROWS + pw * 4u) = rr_now;
         };
@@ -422,22 +433,26 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
             const uint32_t next = tile + gridDim.x;
             // the slots are re-read every 4th tile (agent-scope loads go past the L2) and applied one tile later
             if ((it & 3u) == 1u) refresh_apply();
+            // the slot loads go out BEFORE this step's tile reloads: waiting for them next step then leaves the
+            // reloads in flight (vmcnt counts in issue order)
+            if ((it & 3u) == 0u) refresh_issue(it >> 2);
             if (next < n_tiles) {
                 write_tile(ld, nr, buf ^ 1u, next + 2u * gridDim.x);     // buffer last read one tile ago, behind that tile's barrier
                 stamp(t_write);
             }
-            if ((it & 3u) == 0u) refresh_issue(it >> 2);
             it++;
             producer_compact();
             stamp(t_stage);
-            __syncthreads();
+            tile_barrier();
             stamp(t_bar);
             buf ^= 1u;
             tile += gridDim.x;
         };
-        while (tile < n_tiles) {
+        // tiles are taken two per loop iteration, always both (a step past the last tile only keeps the barrier; the
+        // consumers do the same): one back edge, each register set written in one place
+        const uint32_t my_tiles = tile < n_tiles ? (n_tiles - 1u - tile) / gridDim.x + 1u : 0u;
+        for (uint32_t i = 0; i < my_tiles; i += 2u) {
             step(ldB, nrB);
-            if (tile >= n_tiles) break;
             step(ldA, nrA);
         }
         if constexpr (DIAG) {
@@ -507,8 +522,10 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
     stamp0();
     uint32_t buf = 0;
     const bool wave_dead = pw * 16u >= QC;   // wide mode: consumer waves 2, 3 own no queries; they only keep the barriers
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        if (wave_dead) { __syncthreads(); buf ^= 1u; continue; }
+    const uint32_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - 1u - blockIdx.x) / gridDim.x + 1u : 0u;
+    const uint32_t my_steps = (my_tiles + 1u) & ~1u;   // the producers step in pairs
+    for (uint32_t st = 0, tile = blockIdx.x; st < my_steps; st++, tile += gridDim.x) {
+        if (wave_dead || tile >= n_tiles) { tile_barrier(); buf ^= 1u; continue; }
         apply_shrink();
         stamp(t_stage);
         const char *Thi = tiles + buf * C::TILE_BYTES, *Tlo = Thi + C::IMG_BYTES;
@@ -575,7 +592,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
             if (kq == 0u) c_pub[qslot] = c_cnt[qslot];
         }
         stamp(t_epi);
-        __syncthreads();
+        tile_barrier();
         stamp(t_bar);
         buf ^= 1u;
     }
