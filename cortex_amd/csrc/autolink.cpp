@@ -214,7 +214,7 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
             f.cap = cap;
             // large scan sets: 256x256 tiles on the 4-slot ring (allpairs256.hip); small ones (streaming ingest) keep
             // the 128x128 kernel, where a mostly empty 256-row tile would waste MFMAs
-            static const int big_min = getenv("CX_PAIR_256_MIN") ? atoi(getenv("CX_PAIR_256_MIN")) : 1024;
+            static const int big_min = getenv("CX_PAIR_256_MIN") ? atoi(getenv("CX_PAIR_256_MIN")) : 129;
             const bool big = ix->dim % 32 == 0 && (int64_t)m >= big_min;
             static const int sym_ok = getenv("CX_PAIR_SYMMETRIC") ? atoi(getenv("CX_PAIR_SYMMETRIC")) : 1;
             f.symmetric = (sym_ok && !scan_rows && lo == 0 && m == n_rows && (n_rows + 127u) / 128u <= 0xFFFFu) ? 1u : 0u;
@@ -466,7 +466,7 @@ int cx_autolink_lists_dev(const cx_index *ix, uint64_t nq64, const float *d_quer
         f.cand_cnt = ps.d_cand_cnt;
         f.cand = ps.d_cand;
         f.cap = cap;
-        static const int big_min = getenv("CX_PAIR_256_MIN") ? atoi(getenv("CX_PAIR_256_MIN")) : 1024;
+        static const int big_min = getenv("CX_PAIR_256_MIN") ? atoi(getenv("CX_PAIR_256_MIN")) : 129;
         if (int rc = ((int64_t)nq >= big_min) ? launch_pair_filter256(f, s) : launch_pair_filter(f, s)) return rc;
         RescoreArgs r;
         memset(&r, 0, sizeof r);

@@ -13,6 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=6_250_000)   # 50M / 8 GPUs
 ap.add_argument("--dim", type=int, default=1024)
 ap.add_argument("--thr", type=float, default=0.85)
+ap.add_argument("--batches", type=str, default="64,500")
 a = ap.parse_args()
 L = _lib.load()
 n, d = a.rows, a.dim
@@ -26,7 +27,7 @@ for lo in range(0, n, chunk):                       # generate and hand over in 
     h.insert_batch_dev(ids, gen.data_ptr(), m, d); del gen
 out = {"rows": n, "dim": d, "thr": a.thr, "shadow_bytes": n * d * 2}
 h.autolink_pass_timed(100, float(np.float32(a.thr)), 50, np.arange(n - 64, n, dtype=np.uint32))  # builds the shadow
-for b in (64, 500):
+for b in [int(x) for x in a.batches.split(",")]:
     scan = np.arange(n - b, n, dtype=np.uint32)
     best = None
     for rep in range(4):
