@@ -247,7 +247,10 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
                 CX_HIP(hipStreamSynchronize(s));
                 f.scan_rows = ps.d_ident;
             }
-            if (int rc = big ? launch_pair_filter256(f, s) : launch_pair_filter(f, s)) return rc;
+            static const int stream_ok = getenv("CX_PAIR_STREAM") ? atoi(getenv("CX_PAIR_STREAM")) : 1;
+            if (!big && stream_ok && pair_filter_stream_supported(f)) {
+                if (int rc = launch_pair_filter_stream(f, s)) return rc;
+            } else if (int rc = big ? launch_pair_filter256(f, s) : launch_pair_filter(f, s)) return rc;
             if (phase_ms && lo == 0) CX_HIP(hipEventRecord(ev[2], s));
             RescoreArgs r;
             memset(&r, 0, sizeof r);
@@ -467,7 +470,10 @@ int cx_autolink_lists_dev(const cx_index *ix, uint64_t nq64, const float *d_quer
         f.cand = ps.d_cand;
         f.cap = cap;
         static const int big_min = getenv("CX_PAIR_256_MIN") ? atoi(getenv("CX_PAIR_256_MIN")) : 129;
-        if (int rc = ((int64_t)nq >= big_min) ? launch_pair_filter256(f, s) : launch_pair_filter(f, s)) return rc;
+        static const int stream_ok = getenv("CX_PAIR_STREAM") ? atoi(getenv("CX_PAIR_STREAM")) : 1;
+        if ((int64_t)nq < big_min && stream_ok && pair_filter_stream_supported(f)) {
+            if (int rc = launch_pair_filter_stream(f, s)) return rc;
+        } else if (int rc = ((int64_t)nq >= big_min) ? launch_pair_filter256(f, s) : launch_pair_filter(f, s)) return rc;
         RescoreArgs r;
         memset(&r, 0, sizeof r);
         r.rows = ix->d_rows;

@@ -112,6 +112,9 @@ void pair_filter_tile_list(uint32_t n_rows, std::vector<uint32_t> &out);
 void pair_filter256_tile_list(uint32_t n_rows, std::vector<uint32_t> &out);
 int launch_pair_filter256(const PairFilterArgs &a, hipStream_t stream);
 int launch_pair_filter(const PairFilterArgs &a, hipStream_t stream);
+// scan sets of <= 64 rows (streaming ingest): scanned rows in registers, the shard's shadow streamed tile by tile
+bool pair_filter_stream_supported(const PairFilterArgs &a);
+int launch_pair_filter_stream(const PairFilterArgs &a, hipStream_t stream);
 
 struct RescoreArgs {
     const float *rows;

@@ -256,3 +256,34 @@ def test_topk_lists_and_generic_walk(hip, oracle):
             if cnt >= 7:
                 break
     assert [(a, b, r) for a, b, r, _ in walk2] == exp
+
+
+@pytest.mark.parametrize("n,d,n_scan", [(5003, 1024, 64), (2000, 768, 17), (1031, 1024, 1), (4096, 768, 64)])
+def test_small_scan_sets_take_the_stream_filter(hip, oracle, n, d, n_scan):
+    """Scan sets of <= 64 rows at dim 768 / 1024 (streaming ingest, config 5) run pair_filter_stream_kernel: ragged
+    last tile (n not a multiple of 16), fewer scanned rows than a consumer wave holds, scanned rows anywhere."""
+    rows = oracle.synth_rows(n, d)
+    ids = ids_for(n)
+    h = hip.HipIndex(d); h.insert_batch(ids, rows)
+    o = oracle.OracleIndex(d); o.insert_batch(ids, rows)
+    rng = np.random.default_rng(n + n_scan)
+    scan = np.sort(rng.choice(n, size=n_scan, replace=False)).astype(np.uint32)
+    scan[-1] = n - 1                      # a scanned row inside the ragged tail
+    scan = np.unique(scan).astype(np.uint32)
+    thr = np.float32(0.8)
+    fr, to, w = h.autolink_pass_rows(scan, 100, float(thr), 50)
+    want = o.autolink_pass(scan, 100, thr, 50)
+    got = {}
+    for a, b, s in zip(fr, to, w):
+        got.setdefault(int(a), []).append((int(b), float(s)))
+    exp = {}
+    for e in want:
+        exp.setdefault(int(e["from_row"]), []).append((int(e["to_row"]), float(e["weight"])))
+    assert got.keys() == exp.keys()
+    for node in exp:
+        gs, es = dict(got[node]), dict(exp[node])
+        for nb in set(gs) ^ set(es):      # only pairs sitting on the threshold may differ
+            sc = gs.get(nb, es.get(nb))
+            assert abs(sc - float(thr)) <= SCORE_TOL, f"node {node} neighbour {nb} score {sc}"
+        for nb in set(gs) & set(es):
+            assert abs(gs[nb] - es[nb]) <= SCORE_TOL
