@@ -181,6 +181,12 @@ def main() -> None:
         w = C.c_double(0)
         if L.cx_probe_mfma_tflops(local_rank, 50.0, C.byref(w)) == 0 and w.value > 0:
             out.setdefault("extra", {})["measured_mfma_bf16_TFLOPs"] = w.value
+        # the same loop fed from LDS at the filter GEMM's ratio, and with that kernel's LDS-DMA traffic on top: the
+        # ceilings of its main loop on this board
+        for mode, key in ((0, "measured_mfma_bf16_lds_fed_TFLOPs"), (1, "measured_mfma_bf16_lds_fed_with_dma_TFLOPs")):
+            w = C.c_double(0)
+            if L.cx_probe_mfma_lds_tflops(local_rank, 50.0, mode, C.byref(w)) == 0 and w.value > 0:
+                out.setdefault("extra", {})[key] = w.value
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"], extra = cpu_baseline(ix, gen, queries, n, d, k, args.cpu_seconds)
         out.setdefault("extra", {}).update(extra)
@@ -196,6 +202,10 @@ def main() -> None:
         mp = out["extra"].get("measured_mfma_bf16_TFLOPs")
         for leg in ("autolink_allpairs", "autolink_allpairs_bench_corpus"):
             r = out["extra"][leg]["roofline"]
+            cl = out["extra"].get("measured_mfma_bf16_lds_fed_with_dma_TFLOPs")
+            if cl:
+                r["main_loop_ceiling_TFLOPs"] = cl
+                r["executed_frac_of_main_loop_ceiling"] = r["executed_flops_per_launch"] / (out["extra"][leg]["phase_ms"]["mfma_filter_gemm"] * 1e-3) / 1e12 / cl
             if mp:
                 r["measured_peak_TFLOPs"] = mp
                 r["executed_frac_of_measured"] = r["executed_flops_per_launch"] / (out["extra"][leg]["phase_ms"]["mfma_filter_gemm"] * 1e-3) / 1e12 / mp

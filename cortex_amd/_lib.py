@@ -60,6 +60,7 @@ SIGNATURES = {
     "cx_synth_fill_dev": (C.c_int, [C.c_int, _P, _U64, _U64, _U64, _U64, _U64, _U64, _U32, _U32]),
     "cx_probe_read_bw": (C.c_int, [C.c_int, _U64, C.c_uint32, _P]),
     "cx_probe_mfma_tflops": (C.c_int, [C.c_int, C.c_double, _P]),
+    "cx_probe_mfma_lds_tflops": (C.c_int, [C.c_int, C.c_double, C.c_int, _P]),
 }
 
 _lib = None

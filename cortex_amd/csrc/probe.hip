@@ -53,6 +53,100 @@ __global__ __launch_bounds__(256) void probe_mfma_kernel(uint32_t iters, float *
     if (v == 123456.789f) *sink = v;
 }
 
+// The filter GEMM's inner step without its global traffic: per step a wave reads 12 fragments from LDS (ds_read_b128,
+// conflict-free: the pair_filter256 operand pattern) and issues 16 v_mfma_f32_32x32x16_bf16 on them, 2 waves per SIMD.
+// What the matrix pipe sustains when it is fed from LDS at the GEMM's ratio — the ceiling of that kernel's main loop.
+template <int DMA>   // 0 none, 1 LDS-DMA, 2 register-staged (global_load_dwordx4 -> ds_write_b128, three steps in flight)
+__global__ __launch_bounds__(512) void probe_mfma_lds_kernel(uint32_t iters, float *sink, const char *src) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 32 KiB read slot (A 16 KiB + B 16 KiB) [+ 96 KiB of DMA targets]
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t i = tid; i < 32768u / 16u; i += 512u) *reinterpret_cast<f32x4 *>(smem + i * 16u) = f32x4{1.0f, 0.5f, 0.25f, 0.125f};
+    __syncthreads();
+    const uint32_t wm = wave >> 2, wn = wave & 3u, fr = lane & 31u, fq = lane >> 5;
+    uint32_t offA[4][2], offB[2][2];
+    for (uint32_t m = 0; m < 4; m++)
+        for (uint32_t h = 0; h < 2; h++) {
+            const uint32_t row = wm * 128u + m * 32u + fr, piece = 2u * h + fq;
+            offA[m][h] = row * 64u + ((piece ^ ((row >> 3) & 3u)) << 4);
+        }
+    for (uint32_t n = 0; n < 2; n++)
+        for (uint32_t h = 0; h < 2; h++) {
+            const uint32_t row = wn * 64u + n * 32u + fr, piece = 2u * h + fq;
+            offB[n][h] = 16384u + row * 64u + ((piece ^ ((row >> 3) & 3u)) << 4);
+        }
+    f32x16 acc[4][2];
+    for (int m = 0; m < 4; m++)
+        for (int n = 0; n < 2; n++)
+            for (int e = 0; e < 16; e++) acc[m][n][e] = 0.0f;
+    f32x4 g0[4], g1[4], g2[4];
+    if constexpr (DMA == 2) {
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) { g0[q] = f32x4{0, 0, 0, 0}; g1[q] = g0[q]; g2[q] = g0[q]; }
+    }
+    auto staged = [&](f32x4 (&g)[4], uint32_t it) {
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+            *reinterpret_cast<f32x4 *>(smem + 32768u + ((it % 3u) * 32u + wave * 4u + q) * 1024u + lane * 16u) = g[q];   // store, then reload
+            g[q] = *reinterpret_cast<const f32x4 *>(src + (((it * 8u + wave) * 4u + q) & 1023u) * 1024u + lane * 16u);
+        }
+    };
+    for (uint32_t it = 0; it < iters; it += (DMA == 2 ? 3u : 1u)) {
+        if constexpr (DMA == 2) {
+            // three steps per loop iteration, one register set each
+            for (uint32_t sub = 0; sub < 3u; sub++) {
+                if (sub == 0) staged(g0, it); else if (sub == 1) staged(g1, it + 1); else staged(g2, it + 2);
+                bf16x8 fa[8], fb[4];
+#pragma unroll
+                for (int n = 0; n < 2; n++)
+#pragma unroll
+                    for (int h = 0; h < 2; h++) fb[n * 2 + h] = *reinterpret_cast<const bf16x8 *>(smem + offB[n][h]);
+#pragma unroll
+                for (int m = 0; m < 4; m++)
+#pragma unroll
+                    for (int h = 0; h < 2; h++) fa[m * 2 + h] = *reinterpret_cast<const bf16x8 *>(smem + offA[m][h]);
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+#pragma unroll
+                    for (int m = 0; m < 4; m++)
+#pragma unroll
+                        for (int n = 0; n < 2; n++)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m * 2 + h], fb[n * 2 + h], acc[m][n], 0, 0, 0);
+                asm volatile("" ::: "memory");
+            }
+            continue;
+        }
+        if constexpr (DMA == 1) {   // the GEMM's global traffic too: 4 LDS-DMAs of 1 KiB per wave and step, from an L2-resident buffer
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (((it * 8u + wave) * 4u + q) & 1023u) * 1024u + lane * 16u),
+                                                 (__attribute__((address_space(3))) void *)(smem + 32768u + ((it % 3u) * 32u + wave * 4u + q) * 1024u), 16, 0, 0);
+            if ((it & 1u) == 1u) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        }
+        bf16x8 fa[8], fb[4];
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) fb[n * 2 + h] = *reinterpret_cast<const bf16x8 *>(smem + offB[n][h]);
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) fa[m * 2 + h] = *reinterpret_cast<const bf16x8 *>(smem + offA[m][h]);
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int n = 0; n < 2; n++)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m * 2 + h], fb[n * 2 + h], acc[m][n], 0, 0, 0);
+        asm volatile("" ::: "memory");   // the reads are re-issued every step
+    }
+    float v = 0.0f;
+    for (int m = 0; m < 4; m++)
+        for (int n = 0; n < 2; n++)
+            for (int e = 0; e < 16; e++) v += acc[m][n][e];
+    if (v == 123456.789f) *sink = v;
+}
+
 }  // namespace cx
 
 extern "C" {
@@ -119,6 +213,53 @@ int cx_probe_mfma_tflops(int device, double ms_target, double *out_tflops) {
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     (void)hipFree(sink);
+    *out_tflops = tf;
+    return CX_OK;
+}
+
+/* As cx_probe_mfma_tflops, but every step's operands are read from LDS at the filter GEMM's ratio (12 ds_read_b128 per
+ * 16 MFMAs per wave, 8 waves per CU); with_dma adds its global traffic (4 LDS-DMAs of 1 KiB per wave and step from an
+ * L2-resident buffer, counted waits, no barrier). */
+int cx_probe_mfma_lds_tflops(int device, double ms_target, int with_dma, double *out_tflops) {
+    using namespace cx;
+    if (!out_tflops) return set_err(CX_ERR_VALIDATION, "probe: null output");
+    CX_HIP(hipSetDevice(device));
+    float *sink = nullptr;
+    char *src = nullptr;
+    CX_HIP(hipMalloc((void **)&sink, 4));
+    CX_HIP(hipMalloc((void **)&src, 1 << 20));
+    CX_HIP(hipMemset(src, 0x3c, 1 << 20));
+    static bool attr = false;
+    if (!attr) {
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(probe_mfma_lds_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(probe_mfma_lds_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        attr = true;
+    }
+    hipEvent_t e0, e1;
+    CX_HIP(hipEventCreate(&e0));
+    CX_HIP(hipEventCreate(&e1));
+    const uint32_t grid = device_cus();
+    uint32_t iters = 5000;
+    double tf = 0.0;
+    for (int round = 0; round < 3; round++) {
+        CX_HIP(hipEventRecord(e0, nullptr));
+        if (with_dma == 2) hipLaunchKernelGGL(probe_mfma_lds_kernel<2>, dim3(grid), dim3(512), 131072, nullptr, iters / 3 * 3, sink, src);
+        else if (with_dma) hipLaunchKernelGGL(probe_mfma_lds_kernel<1>, dim3(grid), dim3(512), 131072, nullptr, iters, sink, src);
+        else hipLaunchKernelGGL(probe_mfma_lds_kernel<0>, dim3(grid), dim3(512), 32768, nullptr, iters, sink, src);
+        CX_HIP(hipEventRecord(e1, nullptr));
+        CX_HIP(hipEventSynchronize(e1));
+        float ms = 0.0f;
+        CX_HIP(hipEventElapsedTime(&ms, e0, e1));
+        const double flops = (double)grid * 8.0 * (with_dma == 2 ? iters / 3 * 3 : iters) * 16.0 * (2.0 * 32 * 32 * 16);
+        tf = flops / (ms * 1e-3) / 1e12;
+        if (round == 0 && ms > 0.0f) {
+            const double want = ms_target / ms * iters;
+            iters = (uint32_t)(want < 500.0 ? 500.0 : (want > 1.0e8 ? 1.0e8 : want));
+        }
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(sink);
+    (void)hipFree(src);
     *out_tflops = tf;
     return CX_OK;
 }

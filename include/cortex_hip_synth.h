@@ -29,6 +29,9 @@ int cx_synth_fill_dev(int device, float *d_out, uint64_t seed_centres, uint64_t 
  * register-only v_mfma_f32_32x32x16_bf16 loop running for about `ms_target` ms (TFLOP/s, clock settled). */
 int cx_probe_read_bw(int device, uint64_t bytes, uint32_t reps, double *out_gbs);
 int cx_probe_mfma_tflops(int device, double ms_target, double *out_tflops);
+/* the same with every step's operands read from LDS at the filter GEMM's ratio (12 ds_read_b128 per 16 MFMAs);
+ * with_dma != 0 adds that kernel's global traffic (4 LDS-DMAs of 1 KiB per wave and step, L2-resident source) */
+int cx_probe_mfma_lds_tflops(int device, double ms_target, int with_dma, double *out_tflops);
 
 #ifdef __cplusplus
 }

@@ -13,4 +13,8 @@ for ms in (5.0, 50.0, 500.0):
     v = C.c_double(0)
     assert L.cx_probe_mfma_tflops(0, ms, C.byref(v)) == 0, L.cx_last_error()
     out[f"mfma_bf16_TFLOPs_{int(ms)}ms"] = v.value
+for dma in (0, 1, 2):
+    w = C.c_double(0)
+    assert L.cx_probe_mfma_lds_tflops(0, 50.0, dma, C.byref(w)) == 0, L.cx_last_error()
+    out["mfma_bf16_lds_fed_TFLOPs" + ("", "_with_lds_dma", "_with_register_staged_loads")[dma]] = w.value
 print(json.dumps(out))
