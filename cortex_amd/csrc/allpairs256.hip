@@ -228,16 +228,24 @@ __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArg
     if constexpr (DIAG) { asm volatile("s_nop 0" :: "v"(acc[3][1][15])); t2 = __builtin_readcyclecounter(); }
     // epilogue: C[row][col], col = lane & 15 (j), row = 4*(lane >> 4) + e (i)
     const bool mirror = a.symmetric && ti != tj;
+    // One hit position: both directions' slot atomics are issued before either result is waited for (one round
+    // trip to L2 per position instead of two).
     auto emit = [&](uint32_t i, uint32_t j) {
-        if (i < a.n_scan && j < a.n_rows) {
-            const uint32_t slot = atomicAdd(a.cand_cnt + i, 1u);
-            if (slot < a.cap) a.cand[(size_t)i * a.cap + slot] = j;
-        }
+        const bool fwd = i < a.n_scan && j < a.n_rows;
+        const bool rev = mirror && fwd;   // symmetric pass: n_scan == n_rows
+        uint32_t s_f = a.cap, s_r = a.cap;
+        if (fwd) s_f = atomicAdd(a.cand_cnt + i, 1u);
+        if (rev) s_r = atomicAdd(a.cand_cnt + j, 1u);
+        if (s_f < a.cap) a.cand[(size_t)i * a.cap + s_f] = j;
+        if (s_r < a.cap) a.cand[(size_t)j * a.cap + s_r] = i;
     };
     // Hits are rare (a handful per 128x64 wave tile), so the 128 accumulator values are screened 16 at a time
     // with a running maximum and ONE wave-uniform branch per 16x64 strip; only strips with a hit somewhere in
     // the wave walk their elements (one test per element took 9.6k cycles per tile, 19 % of the kernel).
-    // C layout of the 32x32 tile: register e of lane l holds row 8 (e / 4) + 4 (l >> 5) + e % 4, column l & 31
+    // C layout of the 32x32 tile: register e of lane l holds row 8 (e / 4) + 4 (l >> 5) + e % 4, column l & 31.
+    // First all eight 32x32 tiles are screened in straight-line code (running maximum, one ballot each), then only
+    // the tiles with a hit somewhere in the wave are walked.
+    uint32_t strips = 0;
 #pragma unroll
     for (uint32_t m = 0; m < 4; m++)
 #pragma unroll
@@ -245,7 +253,15 @@ __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArg
             float mx = acc[m][n][0];
 #pragma unroll
             for (uint32_t e = 1; e < 16; e++) mx = fmaxf(mx, acc[m][n][e]);
-            if (__ballot(mx >= a.thr_lo) == 0ull) continue;
+            strips |= __ballot(mx >= a.thr_lo) != 0ull ? 1u << (m * 2u + n) : 0u;
+        }
+    unsigned long long t2b = 0;
+    if constexpr (DIAG) t2b = __builtin_readcyclecounter();
+#pragma unroll
+    for (uint32_t m = 0; m < 4; m++)
+#pragma unroll
+        for (uint32_t n = 0; n < 2; n++) {
+            if (!((strips >> (m * 2u + n)) & 1u)) continue;
             const uint32_t j = j0 + wn * 64u + n * 32u + fr;
 #pragma unroll
             for (uint32_t e = 0; e < 16; e++) {
@@ -254,14 +270,13 @@ __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArg
                 if (hit) {
                     const uint32_t i = i0 + wm * 128u + m * 32u + 8u * (e >> 2) + 4u * fq + (e & 3u);
                     emit(i, j);
-                    if (mirror) emit(j, i);
                 }
             }
         }
     if constexpr (DIAG) {
         const unsigned long long t3 = __builtin_readcyclecounter();
         if (lane == 0) { unsigned long long *o = a.diag + ((size_t)blockIdx.x * 8 + wave) * 4; o[0] = t1 - t0; o[1] = t2 - t1; o[2] = t3 - t2; o[3] = t3 - t0;
-            if (blockIdx.x == 5017 && wave == 5) printf("[pair256] main-loop waits of one tile: vmcnt %llu  barrier %llu\n", c_vm, c_bar); }
+            if (blockIdx.x % 9000 == 5017 % 9000 && wave == 5) printf("[pair256] tile %u: main-loop waits vmcnt %llu barrier %llu; epilogue: screen %llu walk %llu\n", blockIdx.x, c_vm, c_bar, t2b - t2, t3 - t2b); }
     }
 }
 
