@@ -16,6 +16,31 @@ class cx_filter(C.Structure):
     ]
 
 
+class cx_node_view(C.Structure):
+    _fields_ = [
+        ("id", C.c_uint8 * 16),
+        ("kind", C.c_void_p), ("kind_len", C.c_uint64),
+        ("title", C.c_void_p), ("title_len", C.c_uint64),
+        ("body", C.c_void_p), ("body_len", C.c_uint64),
+        ("n_tags", C.c_uint64),
+        ("agent", C.c_void_p), ("agent_len", C.c_uint64),
+        ("embedding", C.c_void_p), ("embedding_len", C.c_uint64),
+        ("has_embedding", C.c_int32), ("importance", C.c_float),
+        ("access_count", C.c_uint64),
+        ("last_accessed_at_s", C.c_int64), ("last_accessed_at_ns", C.c_uint32),
+        ("created_at_s", C.c_int64), ("created_at_ns", C.c_uint32),
+        ("updated_at_s", C.c_int64), ("updated_at_ns", C.c_uint32),
+        ("deleted", C.c_uint8),
+        ("bytes_used", C.c_uint64),
+    ]
+
+
+class cx_bulk_stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("records", "undecodable", "deleted", "no_embedding", "dim_mismatch", "indexed")]
+
+
+BULK_STRICT, BULK_INCLUDE_DELETED, BULK_SET_METADATA, BULK_KEEP_ORDER = 1, 2, 4, 8
+
 _P = C.c_void_p
 _U64 = C.c_uint64
 _U32 = C.c_uint32
@@ -32,7 +57,10 @@ SIGNATURES = {
     "cx_upsert_batch_dev": (C.c_int, [_P, _U64, _P, _P, _U64]),
     "cx_remove": (C.c_int, [_P, _P]),
     "cx_set_metadata": (C.c_int, [_P, _P, _U32, _U32]),
+    "cx_set_metadata_batch": (C.c_int, [_P, _U64, _P, _P, _P]),
     "cx_intern": (_U32, [_P, C.c_char_p, _U64]),
+    "cx_node_decode": (C.c_int, [_P, _U64, _P]),
+    "cx_bulk_load_nodes": (C.c_int, [_P, _U64, _P, _P, _U32, _P]),
     "cx_rebuild": (C.c_int, [_P]),
     "cx_save": (C.c_int, [_P, C.c_char_p]),
     "cx_load": (_P, [C.c_char_p, C.c_int]),

@@ -549,6 +549,31 @@ int cx_set_metadata(cx_index *ix, const uint8_t id[16], uint32_t kind_code, uint
     return push_meta(ix, row);
 }
 
+int cx_set_metadata_batch(cx_index *ix, uint64_t n, const uint8_t *ids, const uint32_t *kind_codes, const uint32_t *agent_codes) {
+    if (!ix) return set_err(CX_ERR_VALIDATION, "null index");
+    if (!n) return CX_OK;
+    if (!ids || !kind_codes || !agent_codes) return set_err(CX_ERR_VALIDATION, "null argument");
+    for (uint64_t i = 0; i < n; i++)
+        if (kind_codes[i] >= (1u << 24)) return set_err(CX_ERR_VALIDATION, "kind code out of range");
+    uint32_t lo = UINT32_MAX, hi = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        auto it = ix->map.find(id_key(ids + 16 * i));
+        if (it == ix->map.end()) continue;  // as cx_set_metadata: no vector, no effect
+        const uint32_t row = it->second;
+        ix->h_meta[row] = META_HAS | (kind_codes[i] << 8);
+        ix->h_agent[row] = agent_codes[i];
+        lo = std::min(lo, row);
+        hi = std::max(hi, row);
+    }
+    if (lo > hi) return CX_OK;
+    if (int rc = use_device(ix)) return rc;
+    // one copy of the touched row range (bulk loads touch consecutive rows)
+    CX_HIP(hipMemcpyAsync(ix->d_meta + lo, &ix->h_meta[lo], (size_t)(hi - lo + 1) * 4, hipMemcpyHostToDevice, ix->up_stream));
+    CX_HIP(hipMemcpyAsync(ix->d_agent + lo, &ix->h_agent[lo], (size_t)(hi - lo + 1) * 4, hipMemcpyHostToDevice, ix->up_stream));
+    CX_HIP(hipStreamSynchronize(ix->up_stream));
+    return CX_OK;
+}
+
 uint32_t cx_intern(cx_index *ix, const char *utf8, uint64_t len) {
     if (!ix || (!utf8 && len)) return 0;
     std::string s(utf8 ? utf8 : "", (size_t)len);

@@ -166,6 +166,34 @@ class HipIndex:
     def set_metadata(self, node_id: NodeId, kind: str, source_agent: str) -> None:
         self._check(self._L.cx_set_metadata(self._h, _id16(node_id), self.intern(kind), self.intern(source_agent)))
 
+    def set_metadata_batch(self, ids, kinds, source_agents) -> None:
+        """cx_set_metadata_batch: set_metadata for many ids with one device copy."""
+        arr = ids if isinstance(ids, np.ndarray) else np.frombuffer(b"".join(_id16(i) for i in ids), dtype=np.uint8)
+        arr = np.ascontiguousarray(arr, dtype=np.uint8).reshape(-1, 16)
+        kc = np.asarray([self.intern(k) for k in kinds], np.uint32)
+        ac = np.asarray([self.intern(a) for a in source_agents], np.uint32)
+        if not (len(arr) == len(kc) == len(ac)):
+            raise ValidationError("ids, kinds and source_agents must have the same length")
+        self._check(self._L.cx_set_metadata_batch(self._h, len(arr), arr.ctypes.data, kc.ctypes.data, ac.ctypes.data))
+
+    def bulk_load_nodes(self, records, strict: bool = False, include_deleted: bool = False,
+                        set_metadata: bool = False, keep_order: bool = False) -> dict:
+        """The start-up loop of serve.rs:105-123 / api.rs:56-70 over raw bincode `Node` records (the values
+        of the reference's nodes table): decode, drop deleted / embedding-less nodes, insert newest first.
+        Returns the counters of cx_bulk_stats.  strict=True is Cortex::open's behaviour (a wrong-length
+        embedding is an error), False is the server's (the node is skipped)."""
+        recs = [bytes(r) for r in records]
+        offs = np.zeros(len(recs) + 1, np.uint64)
+        if recs:
+            offs[1:] = np.cumsum([len(r) for r in recs], dtype=np.uint64)
+        blob = np.frombuffer(b"".join(recs) or b"\0", dtype=np.uint8)
+        flags = ((_lib.BULK_STRICT if strict else 0) | (_lib.BULK_INCLUDE_DELETED if include_deleted else 0)
+                 | (_lib.BULK_SET_METADATA if set_metadata else 0) | (_lib.BULK_KEEP_ORDER if keep_order else 0))
+        st = _lib.cx_bulk_stats()
+        rc = self._L.cx_bulk_load_nodes(self._h, len(recs), blob.ctypes.data, offs.ctypes.data, flags, C.byref(st))
+        self._check(rc)
+        return {n: int(getattr(st, n)) for n, _ in st._fields_}
+
     def rebuild(self) -> None:
         self._check(self._L.cx_rebuild(self._h))
 

@@ -88,6 +88,9 @@ int cx_upsert_batch_dev(cx_index *ix, uint64_t n, const uint8_t *ids, const floa
 int cx_remove(cx_index *ix, const uint8_t id[16]);
 /* HnswIndex::set_metadata — vector/index.rs:219-222 (kind, source_agent interned) */
 int cx_set_metadata(cx_index *ix, const uint8_t id[16], uint32_t kind_code, uint32_t agent_code);
+/* n set_metadata calls in one (ids n*16 bytes); ids without a vector are ignored like above */
+int cx_set_metadata_batch(cx_index *ix, uint64_t n, const uint8_t *ids, const uint32_t *kind_codes,
+                          const uint32_t *agent_codes);
 /* string -> stable code for cx_set_metadata / cx_filter (NodeKind / agent names) */
 uint32_t cx_intern(cx_index *ix, const char *utf8, uint64_t len);
 /* VectorIndex::rebuild — vector/index.rs:416-435.  The exact engine needs no
@@ -102,6 +105,62 @@ int cx_rebuild(cx_index *ix);
  * "Failed to deserialize index: ...").  cx_load returns NULL on failure. */
 int cx_save(const cx_index *ix, const char *path);
 cx_index *cx_load(const char *path, int device);
+
+/* ---- bulk load from stored nodes ----------------------- */
+
+/* One stored `Node` (types.rs:26-68) as the reference keeps it in its nodes table: bincode 1.3 with
+ * `bincode::deserialize` options (little endian, fixed-width integers, u64 lengths, trailing bytes
+ * allowed), layout pinned by the reference's golden bytes (storage/redb_storage.rs:1827-1857).
+ * Pointers point INTO the record; strings are validated UTF-8, not NUL-terminated. */
+typedef struct cx_node_view {
+    uint8_t id[16];
+    const char *kind;          uint64_t kind_len;   /* NodeKind */
+    const char *title;         uint64_t title_len;  /* data.title */
+    const char *body;          uint64_t body_len;   /* data.body */
+    uint64_t n_tags;                                 /* data.tags.len() */
+    const char *agent;         uint64_t agent_len;  /* source.agent */
+    const uint8_t *embedding;  /* embedding_len f32 LE values, not necessarily 4-byte aligned; NULL = None */
+    uint64_t embedding_len;
+    int32_t has_embedding;
+    float importance;
+    uint64_t access_count;
+    int64_t last_accessed_at_s; uint32_t last_accessed_at_ns; /* DateTime<Utc>: seconds since the epoch + ns */
+    int64_t created_at_s;       uint32_t created_at_ns;
+    int64_t updated_at_s;       uint32_t updated_at_ns;
+    uint8_t deleted;
+    uint64_t bytes_used;       /* bytes of the record the node occupies */
+} cx_node_view;
+
+/* RedbStorage::deserialize_node (storage/redb_storage.rs:230-232).  Host only — needs no device.
+ * Failure = CX_ERR_VALIDATION "Failed to deserialize node: ..." (the record list_nodes would skip,
+ * :709-712): truncated input, bad Option/bool byte, invalid UTF-8 or timestamp, and any record whose
+ * data.metadata map is non-empty (bincode cannot deserialize serde_json::Value, so the reference
+ * cannot read those either). */
+int cx_node_decode(const uint8_t *record, uint64_t len, cx_node_view *out);
+
+typedef struct cx_bulk_stats {
+    uint64_t records;      /* given */
+    uint64_t undecodable;  /* skipped like list_nodes skips corrupt records */
+    uint64_t deleted;      /* tombstoned nodes the default NodeFilter hides (redb_storage.rs:345-349) */
+    uint64_t no_embedding; /* embedding == None */
+    uint64_t dim_mismatch; /* insert would fail: wrong length */
+    uint64_t indexed;      /* successful inserts (the reference's `indexed`, serve.rs:108-114) */
+} cx_bulk_stats;
+
+#define CX_BULK_STRICT 1u          /* a dimension mismatch fails the load (Cortex::open, api.rs:59-63) instead
+                                      of skipping the node (serve.rs:111-115) */
+#define CX_BULK_INCLUDE_DELETED 2u /* NodeFilter::include_deleted() */
+#define CX_BULK_SET_METADATA 4u    /* also set_metadata(id, kind, source.agent) per node (the reference does not) */
+#define CX_BULK_KEEP_ORDER 8u      /* insert in the order given instead of list_nodes' newest-first order */
+
+/* The start-up loop `for node in list_nodes(NodeFilter::new()) { if let Some(e) = &node.embedding
+ * { index.insert(node.id, e) } }` (serve.rs:105-123, api.rs:56-70) over n raw table values:
+ * record i = blob[offsets[i] .. offsets[i+1]).  Nodes are inserted newest `created_at` first, stable
+ * (list_nodes' order, redb_storage.rs:727-728), so rows — and with them the tie order of searches —
+ * come out as in the reference.  stats may be NULL.  The `rebuild()` that follows in the reference
+ * is a no-op here. */
+int cx_bulk_load_nodes(cx_index *ix, uint64_t n, const uint8_t *blob, const uint64_t *offsets,
+                       uint32_t flags, cx_bulk_stats *stats);
 
 /* ---- queries: &self --------------------------------------------------- */
 

@@ -159,6 +159,17 @@ public:
         if (!h) throw CortexError(CX_ERR_VALIDATION, cx_last_error());
         return HipIndex(h);
     }
+    // The start-up loop over stored nodes (serve.rs:105-123 / api.rs:56-70) in one call: `records` are the raw
+    // bincode values of the reference's nodes table.  strict = Cortex::open (a wrong-length embedding throws).
+    cx_bulk_stats bulk_load_nodes(const std::vector<std::vector<uint8_t>> &records, bool strict = false, uint32_t extra_flags = 0) {
+        std::vector<uint64_t> offs(records.size() + 1, 0);
+        for (size_t i = 0; i < records.size(); i++) offs[i + 1] = offs[i] + records[i].size();
+        std::vector<uint8_t> blob((size_t)offs.back() + 1);
+        for (size_t i = 0; i < records.size(); i++) std::copy(records[i].begin(), records[i].end(), blob.begin() + (size_t)offs[i]);
+        cx_bulk_stats st{};
+        check(cx_bulk_load_nodes(h_, records.size(), blob.data(), offs.data(), (strict ? CX_BULK_STRICT : 0u) | extra_flags, &st));
+        return st;
+    }
     cx_index *raw() const { return h_; }
 };
 

@@ -54,7 +54,22 @@ extern "C" {
     fn cx_row_id(ix: *const c_void, row: u64, out_id16: *mut u8) -> c_int;
     fn cx_save(ix: *const c_void, path: *const c_char) -> c_int;
     fn cx_load(path: *const c_char, device: c_int) -> *mut c_void;
+    // start-up bulk load from the nodes table
+    fn cx_bulk_load_nodes(ix: *mut c_void, n: u64, blob: *const u8, offsets: *const u64, flags: u32,
+                          stats: *mut CxBulkStats) -> c_int;
 }
+
+#[repr(C)]
+#[derive(Default, Debug, Clone, Copy)]
+pub struct CxBulkStats {
+    pub records: u64,
+    pub undecodable: u64,
+    pub deleted: u64,
+    pub no_embedding: u64,
+    pub dim_mismatch: u64,
+    pub indexed: u64,
+}
+pub const CX_BULK_STRICT: u32 = 1;
 
 const CX_ERR_CAPACITY: c_int = 4;
 
@@ -84,6 +99,25 @@ impl HipIndex {
         if h.is_null() { Err(last_error()) } else { Ok(Self { h, dimension }) }
     }
     fn intern(&self, s: &str) -> u32 { unsafe { cx_intern(self.h, s.as_ptr() as *const c_char, s.len() as u64) } }
+    /// serve.rs:105-123 / api.rs:56-70 in one call: `values` are the raw bincode values of the nodes table
+    /// (a `RedbStorage::raw_node_values()` iterator a maintainer adds next to `list_nodes`), handed over
+    /// without deserialising a `Node` per row.  `strict` = Cortex::open's `?` on a wrong-length embedding.
+    pub fn bulk_load_nodes<'a>(&mut self, values: impl Iterator<Item = &'a [u8]>, strict: bool) -> Result<CxBulkStats> {
+        let mut blob: Vec<u8> = Vec::new();
+        let mut offsets: Vec<u64> = vec![0];
+        for v in values {
+            blob.extend_from_slice(v);
+            offsets.push(blob.len() as u64);
+        }
+        let mut st = CxBulkStats::default();
+        let rc = unsafe {
+            cx_bulk_load_nodes(self.h, (offsets.len() - 1) as u64, blob.as_ptr(), offsets.as_ptr(),
+                               if strict { CX_BULK_STRICT } else { 0 }, &mut st)
+        };
+        if rc != 0 { return Err(last_error()); }
+        Ok(st)
+    }
+
     pub fn set_metadata(&mut self, id: NodeId, kind: NodeKind, source_agent: String) {
         let (k, a) = (self.intern(kind.as_str()), self.intern(&source_agent));
         unsafe { cx_set_metadata(self.h, id.as_bytes().as_ptr(), k, a) };

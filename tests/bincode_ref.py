@@ -74,6 +74,34 @@ def decode_node(b: bytes) -> dict:
     n["importance"] = r.f32()
     n["access_count"] = r.u64()
     n["last_accessed_at"], n["created_at"], n["updated_at"] = r.string(), r.string(), r.string()
-    n["deleted"] = bool(r.u8())
+    d = r.u8()
+    assert d in (0, 1), "invalid bool encoding"
+    n["deleted"] = bool(d)
     assert r.o == len(b)
     return n
+
+
+def _s(x: str) -> bytes:
+    b = x.encode()
+    return struct.pack("<Q", len(b)) + b
+
+
+def _opt_s(x: Optional[str]) -> bytes:
+    return b"\x00" if x is None else b"\x01" + _s(x)
+
+
+def encode_node(id16: bytes, kind: str, title: str, body: str, tags: List[str], embedding, agent: str,
+                session: Optional[str], channel: Optional[str], importance: float, access_count: int,
+                last_accessed_at: str, created_at: str, updated_at: str, deleted: bool) -> bytes:
+    """bincode of `Node` (types.rs:26-68) with an empty data.metadata map; the inverse of decode_node, pinned by
+    re-encoding the reference's golden bytes (test_persist_format.py)."""
+    out = [struct.pack("<Q", 16), id16, _s(kind), _s(title), _s(body), struct.pack("<Q", 0),
+           struct.pack("<Q", len(tags))] + [_s(t) for t in tags]
+    if embedding is None:
+        out.append(b"\x00")
+    else:
+        e = np.asarray(embedding, dtype="<f4")
+        out += [b"\x01", struct.pack("<Q", e.size), e.tobytes()]
+    out += [_s(agent), _opt_s(session), _opt_s(channel), struct.pack("<f", importance), struct.pack("<Q", access_count),
+            _s(last_accessed_at), _s(created_at), _s(updated_at), b"\x01" if deleted else b"\x00"]
+    return b"".join(out)

@@ -207,13 +207,61 @@ TEST(test_linker_similarity_edges_and_dedup) {
     }
 }
 
+// Start-up bulk load (serve.rs:105-123) over stored-node records; the first record is the reference's golden
+// Node (redb_storage.rs:1827-1857: no embedding), the others are the same layout with an embedding appended.
+static void put_u64(std::vector<uint8_t> &o, uint64_t v) { for (int i = 0; i < 8; i++) o.push_back((uint8_t)(v >> (8 * i))); }
+static void put_str(std::vector<uint8_t> &o, const std::string &s) { put_u64(o, s.size()); o.insert(o.end(), s.begin(), s.end()); }
+static std::vector<uint8_t> node_record(const NodeId &id, const Embedding *e, const std::string &created, bool deleted) {
+    std::vector<uint8_t> o;
+    put_u64(o, 16); o.insert(o.end(), id.begin(), id.end());
+    put_str(o, "fact"); put_str(o, "title"); put_str(o, "body");
+    put_u64(o, 0); put_u64(o, 0);                      // metadata {}, tags []
+    if (e) { o.push_back(1); put_u64(o, e->size()); const uint8_t *p = (const uint8_t *)e->data(); o.insert(o.end(), p, p + 4 * e->size()); }
+    else o.push_back(0);
+    put_str(o, "kai"); o.push_back(0); o.push_back(0);  // source {agent, None, None}
+    const float imp = 0.5f; const uint8_t *ip = (const uint8_t *)&imp; o.insert(o.end(), ip, ip + 4);
+    put_u64(o, 0);
+    put_str(o, "1970-01-01T00:00:00Z"); put_str(o, created); put_str(o, created);
+    o.push_back(deleted ? 1 : 0);
+    return o;
+}
+TEST(test_bulk_load_nodes) {
+    HipIndex index(3);
+    NodeId a = now_v7(), b = now_v7(), c = now_v7(), d = now_v7(), e = now_v7();
+    Embedding ea{1.0f, 0.0f, 0.0f}, eb{0.9f, 0.1f, 0.0f}, ec{0.0f, 1.0f, 0.0f}, ed{1.0f, 0.0f}, ee{0.0f, 0.0f, 1.0f};
+    std::vector<std::vector<uint8_t>> recs{
+        node_record(a, &ea, "2024-01-01T00:00:00Z", false),
+        node_record(b, &eb, "2024-01-02T00:00:00Z", false),      // newest: row 0
+        node_record(c, &ec, "2024-01-01T00:00:00Z", true),       // deleted: not listed
+        node_record(d, &ed, "2024-01-01T12:00:00Z", false),      // wrong length: insert fails, skipped by the server
+        node_record(e, nullptr, "2024-01-03T00:00:00Z", false),  // no embedding
+        node_record(e, &ee, "2024-01-01T00:00:00Z", false),
+        std::vector<uint8_t>{1, 2, 3}};                          // corrupt
+    recs.back().resize(3);
+    auto st = index.bulk_load_nodes(recs);
+    CHECK(st.records == 7 && st.undecodable == 1 && st.deleted == 1 && st.no_embedding == 1 && st.dim_mismatch == 1 && st.indexed == 3);
+    CHECK(index.len() == 3);
+    uint8_t rid[16];
+    CHECK(cx_row_id(index.raw(), 0, rid) == 0 && std::equal(rid, rid + 16, b.begin()));   // newest first
+    CHECK(cx_row_id(index.raw(), 1, rid) == 0 && std::equal(rid, rid + 16, a.begin()));   // ties keep table order
+    CHECK(cx_row_id(index.raw(), 2, rid) == 0 && std::equal(rid, rid + 16, e.begin()));
+    auto res = index.search({1.0f, 0.0f, 0.0f}, 2);
+    CHECK(res.size() == 2 && res[0].node_id == a && res[1].node_id == b);
+    HipIndex strict(3);
+    bool threw = false;
+    try { strict.bulk_load_nodes(recs, true); } catch (const CortexError &err) {
+        threw = std::string(err.what()).find("Embedding dimension mismatch: expected 3, got 2") != std::string::npos;
+    }
+    CHECK(threw);
+}
+
 int main() {
     if (cx_device_count() <= 0) { std::fprintf(stderr, "no HIP device: %s\n", "this test needs a GPU"); return 2; }
     run_test_index_insert_and_search(); run_test_threshold_search(); run_test_index_persistence();
     run_test_dimension_mismatch_rejected(); run_test_empty_index_search(); run_test_brute_force_fallback();
     run_test_filter_by_kind(); run_test_filter_exclude(); run_test_remove_doesnt_crash_search(); run_test_search_batch();
     run_test_similarity_score_range(); run_test_threshold_returns_only_above(); run_test_config();
-    run_test_linker_similarity_edges_and_dedup();
+    run_test_linker_similarity_edges_and_dedup(); run_test_bulk_load_nodes();
     std::printf("%d tests run, %d checks failed\n", g_run, g_failed);
     return g_failed ? 1 : 0;
 }
