@@ -97,8 +97,9 @@ __device__ inline float wave_sum_dpp(float v) {
 
 // E = candidate-list entries a lane holds in a compaction: 1 for k <= 32 (64 queries per pass, lists of 80),
 // 4 for k <= 104 ("wide": 32 queries per pass — the auto-linker's top-100 lists — lists of up to 272).
-// A list entry is (row, dot): 8 bytes; |row|^2 comes from the index's norm cache (a.norms) wherever an exact
-// cosine is formed, and the producers copy it per tile into LDS for the consumers' per-tile test.
+// A list entry is (row, dot) plus, for E = 1, |row|^2 — 12 bytes, so that no compaction and no final ordering goes
+// back to HBM for the norm (the wide lists spend that LDS on length and gather it from the index's norm cache,
+// a.norms); the producers copy the norms per tile into LDS for the consumers' per-tile test.
 template <int D, bool DIAG, int E>
 __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
     using C = Batch2Cfg<D>;
@@ -117,14 +118,17 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
         if constexpr (DIAG) a.diag += (size_t)grp * gridDim.x * 64u;
     }
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // LDS: [2 tiles: hi image | lo image][rr: 2 x 16 f32][cand rows | dots: QC x capq][tau][cnt][tsq][pub][shr][qq]
+    // LDS: [2 tiles: hi image | lo image][rr: 2 x 16 f32][cand rows | dots | (E = 1) norms: QC x capq][tau][cnt][tsq][pub][shr][qq]
     char *tiles = smem;
     float *c_rr = reinterpret_cast<float *>(smem + 2 * C::TILE_BYTES);
     const uint32_t capq = a.capq;
     constexpr uint32_t QC = E == 1 ? BT_Q : BT_Q / 2;   // queries that own a candidate list
     uint32_t *c_rows = reinterpret_cast<uint32_t *>(c_rr + 2 * BT_ROWS);
     float *c_dots = reinterpret_cast<float *>(c_rows + QC * capq);
-    uint64_t *c_tau = reinterpret_cast<uint64_t *>(c_dots + QC * capq);
+    // E = 1 keeps |row|^2 beside each entry (the consumer has it in hand when it appends), so no compaction and no
+    // final ordering goes back to HBM for it; the wide lists spend that LDS on length instead and gather from a.norms
+    float *c_nrm = c_dots + QC * capq;
+    uint64_t *c_tau = reinterpret_cast<uint64_t *>(c_nrm + (E == 1 ? QC * capq : 0u));
     uint32_t *c_cnt = reinterpret_cast<uint32_t *>(c_tau + BT_Q);
     float *c_tsq = reinterpret_cast<float *>(c_cnt + BT_Q);
     uint32_t *c_pub = reinterpret_cast<uint32_t *>(c_tsq + BT_Q);   // entries of a list that are completely written
@@ -144,6 +148,8 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
     if (tid < BT_Q) { c_cnt[tid] = 0; c_tau[tid] = 0ull; c_tsq[tid] = -1.0f; c_pub[tid] = 0; c_shr[tid] = 0; c_qq[tid] = 0.0f; }
 
     unsigned long long t_stage = 0, t_mfma = 0, t_epi = 0, t_bar = 0, t_prev = 0, t_wait = 0, t_write = 0;
+    unsigned long long t_begin = 0;
+    if constexpr (DIAG) t_begin = __builtin_readcyclecounter();
     auto stamp = [&](unsigned long long &acc) {
         if constexpr (DIAG) {
             __builtin_amdgcn_sched_barrier(0);
@@ -167,59 +173,61 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
         asm volatile("" ::: "memory");
     };
 
-    // final, ORDERED compaction of one list (rank counting: entry 64 e + lane sits in slot e of this lane)
-    constexpr int NE = E == 1 ? 2 : 5;   // a final list holds up to capq entries: 80, or 272 in the wide mode
-    auto compact = [&](uint32_t qs, float qq_of) {
-        const uint32_t n = c_cnt[qs] < capq ? c_cnt[qs] : capq;
-        uint32_t *rws = c_rows + qs * capq;
-        float *dts = c_dots + qs * capq;
-        uint32_t r[NE], rank[NE]; float d[NE], nr[NE]; uint64_t key[NE];
-#pragma unroll
-        for (int e = 0; e < NE; e++) {
-            const uint32_t idx = lane + 64u * e;
-            r[e] = 0; d[e] = 0.0f; nr[e] = 1.0f; key[e] = 0ull; rank[e] = 0;
-            if (idx < n) { r[e] = rws[idx]; d[e] = dts[idx]; nr[e] = a.norms[r[e]]; key[e] = cand_key(r[e], cosine_from_sums(d[e], qq_of, nr[e])); }
-        }
-#pragma unroll
-        for (int g = 0; g < NE; g++) {
-            const uint32_t hi = n < 64u * (g + 1) ? n : 64u * (g + 1);
-            for (uint32_t f = 64u * g; f < hi; f++) {
-                const uint64_t kf = readlane_u64(key[g], (int)(f - 64u * g));
-#pragma unroll
-                for (int e = 0; e < NE; e++) rank[e] += kf > key[e] ? 1u : 0u;
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < NE; e++)
-            if (lane + 64u * e < n && rank[e] < k) {
-                rws[rank[e]] = r[e]; dts[rank[e]] = d[e];
-                if (rank[e] == k - 1u) {
-                    const float sm = cosine_from_sums(d[e], qq_of, nr[e]);
-                    c_tau[qs] = key[e];
-                    c_tsq[qs] = sm > 0.0f ? sm * sm * (1.0f - 1.0e-4f) : -1.0f;
-                }
-            }
-        if (lane == 0) c_cnt[qs] = n < k ? n : k;
-    };
-
     // Final phase, shared by all eight waves once the last tile's barrier is behind them: wave w orders and writes the
-    // lists [w QC/8, (w+1) QC/8) — per-block lists go to part[(q * grid + block) * k + r].
+    // lists [w QC/8, (w+1) QC/8) — per-block lists go to part[(q * grid + block) * k + r].  A list holds at most
+    // capq - 16 entries at a barrier (the producers' compaction invariant below): 64, or 256 in the wide mode — one,
+    // or four, per lane.  All of the wave's lists are read and turned into keys first (their LDS reads, norm
+    // gathers and divisions overlap), then each is ranked by counting (entry 64 e + lane sits in slot e of this
+    // lane) and the best k go straight from registers to their places in HBM.
+    constexpr int NE = E == 1 ? 1 : 4;
     auto finalize_lists = [&]() {
         constexpr uint32_t PER = QC / 8u;
+        uint64_t key[PER][NE];
+        float sim[PER][NE];
+        uint32_t nn[PER];
+#pragma unroll
+        for (uint32_t l = 0; l < PER; l++) {
+            const uint32_t qs = wave * PER + l;
+            const bool on = qs < a.nq;
+            const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)(on ? c_cnt[qs] : 0u));   // uniform: scalar loop bounds below
+            const uint32_t n = cnt < 64u * NE ? cnt : 64u * NE;
+            const float qq_l = c_qq[on ? qs : 0u];
+            nn[l] = n;
+#pragma unroll
+            for (int e = 0; e < NE; e++) {
+                const uint32_t idx = lane + 64u * e;
+                key[l][e] = 0ull; sim[l][e] = 0.0f;
+                if (idx < n) {
+                    const uint32_t r = c_rows[qs * capq + idx];
+                    const float nr = E == 1 ? c_nrm[qs * capq + idx] : a.norms[r];
+                    sim[l][e] = cosine_from_sums(c_dots[qs * capq + idx], qq_l, nr);
+                    key[l][e] = cand_key(r, sim[l][e]);
+                }
+            }
+        }
+#pragma unroll
         for (uint32_t l = 0; l < PER; l++) {
             const uint32_t qs = wave * PER + l;
             if (qs >= a.nq) break;
-            const float qq_l = c_qq[qs];
-            compact(qs, qq_l);
-            const uint32_t n = c_cnt[qs];
-            const size_t base = ((size_t)qs * gridDim.x + blockIdx.x) * k;
-            for (uint32_t idx = lane; idx < k; idx += 64u) {   // k <= 104: up to two entries per lane
-                const bool valid = idx < n;
-                const uint32_t row = valid ? c_rows[qs * capq + idx] : 0u;
-                const float sim = valid ? cosine_from_sums(c_dots[qs * capq + idx], qq_l, a.norms[row]) : 0.0f;
-                a.part_keys[base + idx] = valid ? cand_key(row, sim) : 0ull;
-                a.part_sims[base + idx] = sim;
+            const uint32_t n = nn[l];
+            uint32_t rank[NE];
+#pragma unroll
+            for (int e = 0; e < NE; e++) rank[e] = 0;
+#pragma unroll
+            for (int g = 0; g < NE; g++) {
+                const uint32_t hi = n < 64u * (g + 1) ? n : 64u * (g + 1);
+                for (uint32_t f = 64u * g; f < hi; f++) {
+                    const uint64_t kf = readlane_u64(key[l][g], (int)(f - 64u * g));
+#pragma unroll
+                    for (int e = 0; e < NE; e++) rank[e] += kf > key[l][e] ? 1u : 0u;
+                }
             }
+            const size_t base = ((size_t)qs * gridDim.x + blockIdx.x) * k;
+#pragma unroll
+            for (int e = 0; e < NE; e++)
+                if (lane + 64u * e < n && rank[e] < k) { a.part_keys[base + rank[e]] = key[l][e]; a.part_sims[base + rank[e]] = sim[l][e]; }
+            for (uint32_t idx = lane; idx < k; idx += 64u)   // a block that saw fewer than k rows pads its list
+                if (idx >= n) { a.part_keys[base + idx] = 0ull; a.part_sims[base + idx] = 0.0f; }
         }
     };
 
@@ -325,6 +333,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
                 const float qq_of = c_qq[qs];
                 uint32_t *rws = c_rows + qs * capq;
                 float *dts = c_dots + qs * capq;
+                float *nms = c_nrm + qs * capq;
                 // entry 64 e + lane of the list sits in slot e of this lane
                 bool valid[E];
                 uint32_t r0[E], ord[E]; float d0[E], n0[E], sim[E];
@@ -334,7 +343,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
                     valid[e] = idx < n;
                     r0[e] = 0; ord[e] = 0; d0[e] = 0.0f; n0[e] = 1.0f; sim[e] = 0.0f;
                     if (valid[e]) {
-                        r0[e] = rws[idx]; d0[e] = dts[idx]; n0[e] = a.norms[r0[e]];
+                        r0[e] = rws[idx]; d0[e] = dts[idx]; n0[e] = E == 1 ? nms[idx] : a.norms[r0[e]];
                         sim[e] = cosine_from_sums(d0[e], qq_of, n0[e]);
                         ord[e] = score_ord(score_of(distance_of(sim[e])));
                     }
@@ -402,6 +411,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
                     if ((keep[e] >> lane) & 1ull) {
                         const uint32_t slot = base + (uint32_t)__popcll(keep[e] & ((1ull << lane) - 1ull));
                         rws[slot] = r0[e]; dts[slot] = d0[e];
+                        if constexpr (E == 1) nms[slot] = n0[e];
                     }
                     base += (uint32_t)__popcll(keep[e]);
                 }
@@ -511,14 +521,19 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
                 for (uint32_t e = kq; e < m; e += 4u) {
                     const uint32_t src = qslot * capq + shr + e, dst = qslot * capq + k + e;
                     c_rows[dst] = c_rows[src]; c_dots[dst] = c_dots[src];
+                    if constexpr (E == 1) c_nrm[dst] = c_nrm[src];
                 }
                 if (kq == 0u) { c_cnt[qslot] = k + m; c_pub[qslot] = k + m; c_shr[qslot] = 0u; }
             }
         }
     };
     if (kq == 0u) c_qq[qslot] = qq;
+    unsigned long long t_q = 0;
+    if constexpr (DIAG) { asm volatile("s_nop 0" :: "v"(qh[KS - 1]), "v"(ql[KS - 1]), "v"(qq)); t_q = __builtin_readcyclecounter() - t_begin; }
 
     __syncthreads();   // tile 0 is in buffer 0
+    unsigned long long t_pro = 0;
+    if constexpr (DIAG) t_pro = __builtin_readcyclecounter() - t_begin;
     stamp0();
     uint32_t buf = 0;
     const bool wave_dead = pw * 16u >= QC;   // wide mode: consumer waves 2, 3 own no queries; they only keep the barriers
@@ -584,7 +599,10 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
                 const uint32_t row = row0 + 4u * kq + r;
                 if (((mask >> r) & 1u) && row_passes(a.flt, row)) {
                     const uint32_t slot = atomicAdd(&c_cnt[qslot], 1u);
-                    if (slot < capq) { c_rows[qslot * capq + slot] = row; c_dots[qslot * capq + slot] = acc[r]; }
+                    if (slot < capq) {
+                        c_rows[qslot * capq + slot] = row; c_dots[qslot * capq + slot] = acc[r];
+                        if constexpr (E == 1) c_nrm[qslot * capq + slot] = rr4[r];
+                    }
                 }
             }
             // entries are written before the length the producers read (LDS operations of one wave stay in order)
@@ -605,7 +623,16 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
         }
     }
     __syncthreads();   // every wave's lists are final
+    unsigned long long t_f0 = 0;
+    if constexpr (DIAG) t_f0 = __builtin_readcyclecounter();
     finalize_lists();
+    if constexpr (DIAG) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t_f1 = __builtin_readcyclecounter();
+        if (lane == 0 && blockIdx.x == 7 && wave == 1)
+            printf("[batch2 diag] block 7 wave 1: queries in registers %llu, prologue %llu cycles, tiles %llu, finalize %llu, whole kernel %llu\n", t_q, t_pro,
+                   t_f0 - t_begin - t_pro, t_f1 - t_f0, t_f1 - t_begin);
+    }
 }
 
 // rows [row_lo, row_hi) of the f32 store -> the split store: tile t = rows 16 t .. 16 t + 15 as [hi image | lo image],
@@ -676,7 +703,7 @@ template <int D>
 static int launch_batch_d(BatchArgs a, uint32_t grid, hipStream_t stream) {
     const bool wide = a.k > 32;   // 32 queries per pass, lists of up to 272, four entries per lane in a compaction
     const size_t qc = wide ? BT_Q / 2 : BT_Q;
-    const size_t tail = qc * a.capq * 8 + BT_Q * 8 + BT_Q * 4 + BT_Q * 4 + 3 * BT_Q * 4;
+    const size_t tail = qc * a.capq * (wide ? 8 : 12) + BT_Q * 8 + BT_Q * 4 + BT_Q * 4 + 3 * BT_Q * 4;
     const size_t lds = 2 * (size_t)Batch2Cfg<D>::TILE_BYTES + 2 * BT_ROWS * 4 + tail;
     if (lds > 160 * 1024) return set_err(CX_ERR_VALIDATION, "batch scan: %zu bytes of LDS for k = %u", lds, a.k);
     static std::atomic<uint64_t> attr_devices{0};
