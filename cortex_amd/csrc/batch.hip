@@ -357,15 +357,20 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
                 // radix select of the k-th largest score order, most significant bit first.  Scores are <= 1.0, so
                 // bits 31..30 are clear unless something odd is in the list; the walk stops as soon as exactly k
                 // entries lie at or above the prefix (then they ARE the top k and no tie can straddle the cut)
+                // (every value of the walk is wave-uniform; the readfirstlanes say so to the compiler, which otherwise
+                // keeps the bit index and the prefix in VGPRs: 24 instructions per bit instead of 8)
                 uint32_t T = 0;
-                bool exact_k = false;
-                int b = count_ge(0x40000000u) ? 31 : 29;
+                int b = __builtin_amdgcn_readfirstlane(count_ge(0x40000000u) ? 31 : 29);
+                uint32_t c_at_T = n;   // entries at or above the prefix T (T = 0: all of them)
 #pragma unroll 1
-                for (; b >= 0; b--) {
+                while (b >= 0 && c_at_T != k) {
                     const uint32_t candT = T | (1u << b);
-                    const uint32_t c = count_ge(candT);
-                    if (c >= k) { T = candT; if (c == k) { exact_k = true; break; } }
+                    const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)count_ge(candT));
+                    T = (uint32_t)__builtin_amdgcn_readfirstlane((int)(c >= k ? candT : T));
+                    c_at_T = (uint32_t)__builtin_amdgcn_readfirstlane((int)(c >= k ? c : c_at_T));
+                    b = __builtin_amdgcn_readfirstlane(b - 1);
                 }
+                const bool exact_k = c_at_T == k;
                 uint64_t gt[E], eq[E], keep[E];
                 uint32_t n_gt = 0, n_eq = 0;
 #pragma unroll
