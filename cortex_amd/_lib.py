@@ -35,11 +35,17 @@ class cx_node_view(C.Structure):
     ]
 
 
+class cx_decay_config(C.Structure):
+    _fields_ = [("enabled", C.c_int32), ("daily_rate", C.c_double), ("max_age_days", C.c_double), ("min_factor", C.c_double),
+                ("echo_weight", C.c_double), ("echo_cap", C.c_double), ("recency_weight", C.c_float),
+                ("n_by_kind", C.c_uint32), ("kind_codes", C.c_void_p), ("kind_rates", C.c_void_p)]
+
+
 class cx_bulk_stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("records", "undecodable", "deleted", "no_embedding", "dim_mismatch", "indexed")]
 
 
-BULK_STRICT, BULK_INCLUDE_DELETED, BULK_SET_METADATA, BULK_KEEP_ORDER = 1, 2, 4, 8
+BULK_STRICT, BULK_INCLUDE_DELETED, BULK_SET_METADATA, BULK_KEEP_ORDER, BULK_SET_STATS = 1, 2, 4, 8, 16
 
 _P = C.c_void_p
 _U64 = C.c_uint64
@@ -61,6 +67,9 @@ SIGNATURES = {
     "cx_intern": (_U32, [_P, C.c_char_p, _U64]),
     "cx_node_decode": (C.c_int, [_P, _U64, _P]),
     "cx_bulk_load_nodes": (C.c_int, [_P, _U64, _P, _P, _U32, _P]),
+    "cx_set_node_stats_batch": (C.c_int, [_P, _U64, _P, _P, _P, _P, _P]),
+    "cx_apply_score_decay": (C.c_float, [_P, C.c_float, C.c_float, C.c_int64, _U32, _U32, C.c_int64, _U32, _U64]),
+    "cx_search_decayed": (C.c_int, [_P, _P, _U64, _U64, _U64, _P, _P, C.c_float, C.c_int64, _U32, _P, _P, _P, _P]),
     "cx_rebuild": (C.c_int, [_P]),
     "cx_save": (C.c_int, [_P, C.c_char_p]),
     "cx_load": (_P, [C.c_char_p, C.c_int]),

@@ -603,12 +603,14 @@ int cx_rebuild(cx_index *ix) {
     CX_HIP(hipMemsetAsync(na, 0, ncap * sizeof(uint32_t), ix->up_stream));
     std::vector<uint8_t> nids(n_new * 16);
     std::vector<uint32_t> nmeta(n_new), nagent(n_new);
+    std::vector<NodeStats> nstats(ix->h_stats.empty() ? 0 : n_new);
     ix->map.clear();
     for (uint64_t i = 0; i < n_new; i++) {
         const uint32_t r = keep[i];
         memcpy(&nids[16 * i], &ix->ids[16 * (size_t)r], 16);
         nmeta[i] = ix->h_meta[r];
         nagent[i] = ix->h_agent[r];
+        if (!nstats.empty() && r < ix->h_stats.size()) nstats[i] = ix->h_stats[r];
         ix->map.emplace(id_key(&nids[16 * i]), (uint32_t)i);
     }
     if (n_new) {
@@ -631,6 +633,7 @@ int cx_rebuild(cx_index *ix) {
     ix->ids.swap(nids);
     ix->h_meta.swap(nmeta);
     ix->h_agent.swap(nagent);
+    ix->h_stats.swap(nstats);
     ix->n_rows = n_new;
     ix->n_alive = n_new;
     ix->n_removed = 0;

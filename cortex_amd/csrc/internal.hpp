@@ -99,6 +99,14 @@ struct Ctx {
 
 using namespace cx;
 
+// what apply_score_decay reads of a node (vector/scoring.rs:84-114), per row, host side (decay.cpp)
+struct NodeStats {
+    int64_t last_s = 0;     // last_accessed_at: seconds since the epoch (default = the epoch, types.rs:56)
+    uint32_t last_ns = 0;
+    uint32_t kind = 0;      // interned NodeKind (cx_intern)
+    uint64_t access = 0;    // access_count
+};
+
 struct cx_index {
     uint32_t dim = 0;
     int device = 0;
@@ -111,6 +119,7 @@ struct cx_index {
     uint64_t n_removed = 0;
     std::vector<uint8_t> ids;
     std::vector<uint32_t> h_meta, h_agent;
+    std::vector<NodeStats> h_stats;   // empty until cx_set_node_stats_batch; rows beyond its size read as defaults
     std::unordered_map<IdKey, uint32_t, IdHash> map;
     std::unordered_map<std::string, uint32_t> interned;
     hipStream_t up_stream = nullptr;

@@ -335,6 +335,17 @@ int cx_bulk_load_nodes(cx_index *ix, uint64_t n, const uint8_t *blob, const uint
         }
         if (int rc = cx_upsert_batch(ix, m, ids.data(), stage, dim)) { if (stats) *stats = st; return rc; }
         st.indexed += m;
+        if (flags & CX_BULK_SET_STATS) {
+            std::vector<uint32_t> kc((size_t)m), lns((size_t)m);
+            std::vector<int64_t> ls((size_t)m);
+            std::vector<uint64_t> ac((size_t)m);
+            for (uint64_t j = 0; j < m; j++) {
+                const cx_node_view &v = views[(size_t)take[(size_t)(lo + j)]];
+                kc[(size_t)j] = cx_intern(ix, v.kind, v.kind_len);
+                ls[(size_t)j] = v.last_accessed_at_s; lns[(size_t)j] = v.last_accessed_at_ns; ac[(size_t)j] = v.access_count;
+            }
+            if (int rc = cx_set_node_stats_batch(ix, m, ids.data(), kc.data(), ls.data(), lns.data(), ac.data())) { if (stats) *stats = st; return rc; }
+        }
         if (flags & CX_BULK_SET_METADATA) {
             kinds.resize((size_t)m);
             agents.resize((size_t)m);

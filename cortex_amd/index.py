@@ -177,7 +177,7 @@ class HipIndex:
         self._check(self._L.cx_set_metadata_batch(self._h, len(arr), arr.ctypes.data, kc.ctypes.data, ac.ctypes.data))
 
     def bulk_load_nodes(self, records, strict: bool = False, include_deleted: bool = False,
-                        set_metadata: bool = False, keep_order: bool = False) -> dict:
+                        set_metadata: bool = False, keep_order: bool = False, set_stats: bool = False) -> dict:
         """The start-up loop of serve.rs:105-123 / api.rs:56-70 over raw bincode `Node` records (the values
         of the reference's nodes table): decode, drop deleted / embedding-less nodes, insert newest first.
         Returns the counters of cx_bulk_stats.  strict=True is Cortex::open's behaviour (a wrong-length
@@ -188,11 +188,46 @@ class HipIndex:
             offs[1:] = np.cumsum([len(r) for r in recs], dtype=np.uint64)
         blob = np.frombuffer(b"".join(recs) or b"\0", dtype=np.uint8)
         flags = ((_lib.BULK_STRICT if strict else 0) | (_lib.BULK_INCLUDE_DELETED if include_deleted else 0)
-                 | (_lib.BULK_SET_METADATA if set_metadata else 0) | (_lib.BULK_KEEP_ORDER if keep_order else 0))
+                 | (_lib.BULK_SET_METADATA if set_metadata else 0) | (_lib.BULK_KEEP_ORDER if keep_order else 0)
+                 | (_lib.BULK_SET_STATS if set_stats else 0))
         st = _lib.cx_bulk_stats()
         rc = self._L.cx_bulk_load_nodes(self._h, len(recs), blob.ctypes.data, offs.ctypes.data, flags, C.byref(st))
         self._check(rc)
         return {n: int(getattr(st, n)) for n, _ in st._fields_}
+
+    def set_node_stats(self, ids, kinds, last_accessed_at, access_counts) -> None:
+        """cx_set_node_stats_batch: the node fields apply_score_decay reads (scoring.rs:84-114) for many ids;
+        last_accessed_at = sequence of (seconds, nanoseconds) since the epoch."""
+        arr = ids if isinstance(ids, np.ndarray) else np.frombuffer(b"".join(_id16(i) for i in ids), dtype=np.uint8)
+        arr = np.ascontiguousarray(arr, dtype=np.uint8).reshape(-1, 16)
+        kc = np.asarray([self.intern(k) for k in kinds], np.uint32)
+        ls = np.asarray([t[0] for t in last_accessed_at], np.int64)
+        lns = np.asarray([t[1] for t in last_accessed_at], np.uint32)
+        ac = np.asarray(access_counts, np.uint64)
+        if not (len(arr) == len(kc) == len(ls) == len(ac)):
+            raise ValidationError("ids, kinds, last_accessed_at and access_counts must have the same length")
+        self._check(self._L.cx_set_node_stats_batch(self._h, len(arr), arr.ctypes.data, kc.ctypes.data, ls.ctypes.data,
+                                                    lns.ctypes.data, ac.ctypes.data))
+
+    def search_decayed(self, query, limit: int, config, recency_bias: Optional[float] = None, now=None,
+                       filter: Optional["VectorFilter"] = None, candidate_limit: Optional[int] = None):
+        """The HTTP search handler's sequence (routes.rs:889-947) in one call: candidates, apply_score_decay,
+        stable re-rank, truncate.  -> [(node_id, score, raw_score)], len <= limit.  config: scoring.ScoreDecayConfig."""
+        from . import scoring
+        rb = config.recency_weight if recency_bias is None else recency_bias
+        cl = scoring.http_candidate_limit(limit, config, rb) if candidate_limit is None else candidate_limit
+        now = scoring.now_utc() if now is None else now
+        q = _f32(query).reshape(-1)
+        c, keep = config._c(self.intern)
+        cap = max(1, limit)
+        ids = np.zeros((cap, 16), np.uint8)
+        sc = np.zeros(cap, np.float32)
+        raw = np.zeros(cap, np.float32)
+        n = C.c_uint64(0)
+        f, fkeep = self._filter(filter)
+        self._check(self._L.cx_search_decayed(self._h, q.ctypes.data, len(q), limit, cl, C.byref(f) if f else None, C.byref(c), rb, now[0], now[1],
+                                              ids.ctypes.data, sc.ctypes.data, raw.ctypes.data, C.byref(n)))
+        return [(uuid.UUID(bytes=ids[j].tobytes()), float(sc[j]), float(raw[j])) for j in range(n.value)]
 
     def rebuild(self) -> None:
         self._check(self._L.cx_rebuild(self._h))

@@ -152,6 +152,8 @@ typedef struct cx_bulk_stats {
 #define CX_BULK_INCLUDE_DELETED 2u /* NodeFilter::include_deleted() */
 #define CX_BULK_SET_METADATA 4u    /* also set_metadata(id, kind, source.agent) per node (the reference does not) */
 #define CX_BULK_KEEP_ORDER 8u      /* insert in the order given instead of list_nodes' newest-first order */
+#define CX_BULK_SET_STATS 16u      /* also record kind / last_accessed_at / access_count per node for
+                                      cx_search_decayed (cx_set_node_stats_batch) */
 
 /* The start-up loop `for node in list_nodes(NodeFilter::new()) { if let Some(e) = &node.embedding
  * { index.insert(node.id, e) } }` (serve.rs:105-123, api.rs:56-70) over n raw table values:
@@ -161,6 +163,45 @@ typedef struct cx_bulk_stats {
  * is a no-op here. */
 int cx_bulk_load_nodes(cx_index *ix, uint64_t n, const uint8_t *blob, const uint64_t *offsets,
                        uint32_t flags, cx_bulk_stats *stats);
+
+/* ---- query-time score decay and re-rank ----------------- */
+
+/* ScoreDecayConfig (vector/scoring.rs:22-78); by_kind keys are interned NodeKind codes (cx_intern).
+ * Defaults of the reference: enabled, daily_rate 0.02, max_age_days 365, min_factor 0.1,
+ * echo_weight 0.05, echo_cap 2.0, recency_weight 0.15, by_kind {event .05, observation .04,
+ * decision .005, pattern .005, fact .01, preference .005}. */
+typedef struct cx_decay_config {
+    int32_t enabled;
+    double daily_rate, max_age_days, min_factor, echo_weight, echo_cap;
+    float recency_weight;
+    uint32_t n_by_kind;
+    const uint32_t *kind_codes; /* n_by_kind */
+    const double *kind_rates;   /* n_by_kind */
+} cx_decay_config;
+
+/* What apply_score_decay reads of a node — kind, last_accessed_at, access_count (types.rs:31,50,57) —
+ * for n ids (n*16 bytes); kept per row on the host.  Ids without a vector are ignored; rows never
+ * described read as last_accessed_at = the epoch, access_count 0, kind 0.  last_accessed_ns may be NULL. */
+int cx_set_node_stats_batch(cx_index *ix, uint64_t n, const uint8_t *ids, const uint32_t *kind_codes,
+                            const int64_t *last_accessed_s, const uint32_t *last_accessed_ns,
+                            const uint64_t *access_counts);
+
+/* apply_score_decay — vector/scoring.rs:84-114, with `now` passed in (the reference reads Utc::now()).
+ * Host only.  f64 for the two factors, then f32 left to right without FMA, like the reference. */
+float cx_apply_score_decay(const cx_decay_config *cfg, float raw_score, float recency_bias, int64_t now_s,
+                           uint32_t now_ns, uint32_t kind_code, int64_t last_accessed_s,
+                           uint32_t last_accessed_ns, uint64_t access_count);
+
+/* The HTTP search handler's sequence (cortex-server/src/http/routes.rs:889-947): search(query,
+ * candidate_limit, filter) -> final = apply_score_decay(node, raw, cfg, recency_bias) per candidate ->
+ * stable sort by final descending (NaN compares equal) -> truncate(limit).  The handler uses
+ * candidate_limit = max(3 limit, 30) when cfg.enabled && recency_bias > 0, else limit (:899-903);
+ * a smaller value than limit is raised to limit.  Writes n_out <= limit ids, decayed scores and
+ * the raw scores ("score" / "raw_score" of the response).  &self: re-entrant. */
+int cx_search_decayed(const cx_index *ix, const float *query, uint64_t len, uint64_t limit,
+                      uint64_t candidate_limit, const cx_filter *filter, const cx_decay_config *cfg,
+                      float recency_bias, int64_t now_s, uint32_t now_ns, uint8_t *out_ids,
+                      float *out_scores, float *out_raw_scores, uint64_t *n_out);
 
 /* ---- queries: &self --------------------------------------------------- */
 

@@ -59,6 +59,19 @@ struct VectorIndex {  // index.rs:50-99
     virtual void save(const std::string &path) const = 0;
 };
 
+// ScoreDecayConfig (vector/scoring.rs:22-78) with the reference's defaults
+struct ScoreDecayConfig {
+    bool enabled = true;
+    double daily_rate = 0.02, max_age_days = 365.0, min_factor = 0.1, echo_weight = 0.05, echo_cap = 2.0;
+    float recency_weight = 0.15f;
+    std::vector<std::pair<std::string, double>> by_kind{{"event", 0.05}, {"observation", 0.04}, {"decision", 0.005},
+                                                         {"pattern", 0.005}, {"fact", 0.01}, {"preference", 0.005}};
+};
+struct DecayedResult {  // "node", "score", "raw_score" of the HTTP search response (routes.rs:928-931)
+    NodeId node_id;
+    float score, raw_score;
+};
+
 class HipIndex final : public VectorIndex {
     cx_index *h_ = nullptr;
     explicit HipIndex(cx_index *h) : h_(h) {}
@@ -169,6 +182,34 @@ public:
         cx_bulk_stats st{};
         check(cx_bulk_load_nodes(h_, records.size(), blob.data(), offs.data(), (strict ? CX_BULK_STRICT : 0u) | extra_flags, &st));
         return st;
+    }
+    // kind / last_accessed_at / access_count of nodes: the inputs of apply_score_decay (scoring.rs:84-114)
+    void set_node_stats(const std::vector<NodeId> &ids, const std::vector<std::string> &kinds,
+                        const std::vector<int64_t> &last_accessed_s, const std::vector<uint64_t> &access_counts) {
+        std::vector<uint8_t> flat(16 * ids.size());
+        std::vector<uint32_t> kc(ids.size());
+        for (size_t i = 0; i < ids.size(); i++) { std::copy(ids[i].begin(), ids[i].end(), flat.begin() + 16 * i); kc[i] = intern(kinds[i]); }
+        check(cx_set_node_stats_batch(h_, ids.size(), flat.data(), kc.data(), last_accessed_s.data(), nullptr, access_counts.data()));
+    }
+    // the HTTP search handler's candidates -> decay -> stable re-rank -> truncate (routes.rs:889-947)
+    std::vector<DecayedResult> search_decayed(const Embedding &q, size_t limit, const ScoreDecayConfig &cfg, float recency_bias,
+                                              int64_t now_s, uint32_t now_ns = 0, const VectorFilter *filter = nullptr) {
+        std::vector<uint32_t> codes;
+        std::vector<double> rates;
+        for (auto &kv : cfg.by_kind) { codes.push_back(intern(kv.first)); rates.push_back(kv.second); }
+        cx_decay_config c{cfg.enabled ? 1 : 0, cfg.daily_rate, cfg.max_age_days, cfg.min_factor, cfg.echo_weight, cfg.echo_cap,
+                          cfg.recency_weight, (uint32_t)codes.size(), codes.data(), rates.data()};
+        const size_t cand = cfg.enabled && recency_bias > 0.0f ? std::max<size_t>(3 * limit, 30) : limit;   // :899-903
+        const size_t cap = std::max<size_t>(1, limit);
+        std::vector<uint8_t> ids(16 * cap);
+        std::vector<float> sc(cap), raw(cap);
+        uint64_t n = 0;
+        FilterBuf fb;
+        const cx_filter *cf = marshal(filter, fb) ? &fb.c : nullptr;
+        check(cx_search_decayed(h_, q.data(), q.size(), limit, cand, cf, &c, recency_bias, now_s, now_ns, ids.data(), sc.data(), raw.data(), &n));
+        std::vector<DecayedResult> out(n);
+        for (uint64_t i = 0; i < n; i++) { std::copy(ids.begin() + 16 * i, ids.begin() + 16 * i + 16, out[i].node_id.begin()); out[i].score = sc[i]; out[i].raw_score = raw[i]; }
+        return out;
     }
     cx_index *raw() const { return h_; }
 };

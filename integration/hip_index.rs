@@ -54,9 +54,29 @@ extern "C" {
     fn cx_row_id(ix: *const c_void, row: u64, out_id16: *mut u8) -> c_int;
     fn cx_save(ix: *const c_void, path: *const c_char) -> c_int;
     fn cx_load(path: *const c_char, device: c_int) -> *mut c_void;
+    // query-time score decay + re-rank
+    fn cx_set_node_stats_batch(ix: *mut c_void, n: u64, ids: *const u8, kind_codes: *const u32, last_accessed_s: *const i64,
+                               last_accessed_ns: *const u32, access_counts: *const u64) -> c_int;
+    fn cx_search_decayed(ix: *const c_void, q: *const f32, len: u64, limit: u64, candidate_limit: u64, f: *const CxFilter,
+                         cfg: *const CxDecayConfig, recency_bias: f32, now_s: i64, now_ns: u32, ids: *mut u8,
+                         scores: *mut f32, raw_scores: *mut f32, n_out: *mut u64) -> c_int;
     // start-up bulk load from the nodes table
     fn cx_bulk_load_nodes(ix: *mut c_void, n: u64, blob: *const u8, offsets: *const u64, flags: u32,
                           stats: *mut CxBulkStats) -> c_int;
+}
+
+#[repr(C)]
+pub struct CxDecayConfig {   // ScoreDecayConfig (vector/scoring.rs:22-78) with by_kind keys interned
+    pub enabled: i32,
+    pub daily_rate: f64,
+    pub max_age_days: f64,
+    pub min_factor: f64,
+    pub echo_weight: f64,
+    pub echo_cap: f64,
+    pub recency_weight: f32,
+    pub n_by_kind: u32,
+    pub kind_codes: *const u32,
+    pub kind_rates: *const f64,
 }
 
 #[repr(C)]
@@ -116,6 +136,23 @@ impl HipIndex {
         };
         if rc != 0 { return Err(last_error()); }
         Ok(st)
+    }
+
+    /// routes.rs:889-947 in one call: candidates, apply_score_decay, stable re-rank, truncate.
+    pub fn search_decayed(&self, q: &Vec<f32>, limit: usize, cfg: &ScoreDecayConfig, recency_bias: f32,
+                          now: DateTime<Utc>) -> Result<Vec<(NodeId, f32, f32)>> {
+        let (codes, rates): (Vec<u32>, Vec<f64>) = cfg.by_kind.iter()
+            .map(|(k, r)| (unsafe { cx_intern(self.h, k.as_ptr() as *const c_char, k.len() as u64) }, *r)).unzip();
+        let c = CxDecayConfig { enabled: cfg.enabled as i32, daily_rate: cfg.daily_rate, max_age_days: cfg.max_age_days,
+            min_factor: cfg.min_factor, echo_weight: cfg.echo_weight, echo_cap: cfg.echo_cap, recency_weight: cfg.recency_weight,
+            n_by_kind: codes.len() as u32, kind_codes: codes.as_ptr(), kind_rates: rates.as_ptr() };
+        let cand = if cfg.enabled && recency_bias > 0.0 { (limit * 3).max(30) } else { limit };
+        let cap = limit.max(1);
+        let (mut ids, mut sc, mut raw, mut n) = (vec![0u8; 16 * cap], vec![0f32; cap], vec![0f32; cap], 0u64);
+        let rc = unsafe { cx_search_decayed(self.h, q.as_ptr(), q.len() as u64, limit as u64, cand as u64, std::ptr::null(), &c,
+            recency_bias, now.timestamp(), now.timestamp_subsec_nanos(), ids.as_mut_ptr(), sc.as_mut_ptr(), raw.as_mut_ptr(), &mut n) };
+        if rc != 0 { return Err(last_error()); }
+        Ok((0..n as usize).map(|i| (Uuid::from_slice(&ids[16 * i..16 * i + 16]).unwrap(), sc[i], raw[i])).collect())
     }
 
     pub fn set_metadata(&mut self, id: NodeId, kind: NodeKind, source_agent: String) {

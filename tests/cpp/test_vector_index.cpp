@@ -255,13 +255,38 @@ TEST(test_bulk_load_nodes) {
     CHECK(threw);
 }
 
+// Query-time decay + re-rank (scoring.rs:84-114, routes.rs:889-947): a stale event falls behind a fresh fact that
+// the raw cosine ranks lower.
+TEST(test_search_decayed_reranks) {
+    HipIndex index(3);
+    NodeId stale = now_v7(), fresh = now_v7(), far = now_v7();
+    index.insert(stale, {1.0f, 0.0f, 0.0f});      // raw 1.0
+    index.insert(fresh, {0.98f, 0.199f, 0.0f});   // raw ~0.98
+    index.insert(far, {0.0f, 1.0f, 0.0f});
+    const int64_t now = 1760000000;
+    index.set_node_stats({stale, fresh, far}, {"event", "fact", "fact"}, {now - 400 * 86400, now, now}, {0, 10, 0});
+    ScoreDecayConfig cfg;
+    auto plain = index.search_decayed({1.0f, 0.0f, 0.0f}, 2, cfg, 0.0f, now);
+    CHECK(plain.size() == 2 && plain[0].node_id == stale && plain[0].score == plain[0].raw_score);
+    auto r = index.search_decayed({1.0f, 0.0f, 0.0f}, 2, cfg, 0.5f, now);
+    // stale: 1.0 * 0.5 + 1.0 * 0.1 * 1.0 * 0.5 = 0.55;  fresh: 0.98 * 0.5 + 0.98 * 1.0 * 1.5 * 0.5 = 1.225
+    CHECK(r.size() == 2 && r[0].node_id == fresh && r[1].node_id == stale);
+    if (r.size() == 2) {
+        CHECK(std::fabs(r[1].score - 0.55f) < 1e-3f && std::fabs(r[1].raw_score - 1.0f) < 1e-6f);
+        CHECK(std::fabs(r[0].score - 1.225f) < 5e-3f);
+    }
+    // scoring.rs:136-151: disabled config / zero bias return the raw score
+    cx_decay_config off{};
+    CHECK(cx_apply_score_decay(&off, 0.8f, 0.15f, now, 0, 0, now, 0, 0) == 0.8f);
+}
+
 int main() {
     if (cx_device_count() <= 0) { std::fprintf(stderr, "no HIP device: %s\n", "this test needs a GPU"); return 2; }
     run_test_index_insert_and_search(); run_test_threshold_search(); run_test_index_persistence();
     run_test_dimension_mismatch_rejected(); run_test_empty_index_search(); run_test_brute_force_fallback();
     run_test_filter_by_kind(); run_test_filter_exclude(); run_test_remove_doesnt_crash_search(); run_test_search_batch();
     run_test_similarity_score_range(); run_test_threshold_returns_only_above(); run_test_config();
-    run_test_linker_similarity_edges_and_dedup(); run_test_bulk_load_nodes();
+    run_test_linker_similarity_edges_and_dedup(); run_test_bulk_load_nodes(); run_test_search_decayed_reranks();
     std::printf("%d tests run, %d checks failed\n", g_run, g_failed);
     return g_failed ? 1 : 0;
 }
