@@ -376,7 +376,7 @@ extern "C" {
 int cx_autolink_pass_rows(const cx_index *ix, uint64_t n_scan, const uint32_t *scan_rows, uint64_t topk,
                           float threshold, uint64_t max_edges_per_node, const uint8_t *deleted, uint64_t cap,
                           uint32_t *out_from, uint32_t *out_to, float *out_weight, uint64_t *n_out,
-                          uint64_t *n_needed) {
+                          uint64_t *n_needed) try {
     if (!ix || !n_out) return set_err(CX_ERR_VALIDATION, "null argument");
     *n_out = 0;
     if (n_needed) *n_needed = 0;
@@ -391,11 +391,11 @@ int cx_autolink_pass_rows(const cx_index *ix, uint64_t n_scan, const uint32_t *s
                            (uint32_t)std::min<uint64_t>(max_edges_per_node, 0xFFFFFFFFull), deleted, false, &total, nullptr))
         return rc;
     return copy_edges_rows(lease.c, ps, total, cap, out_from, out_to, out_weight, n_out, n_needed);
-}
+} catch (...) { return cx::on_exception(); }
 
 int cx_dedup_scan_rows(const cx_index *ix, float dedup_threshold, const uint8_t *deleted, uint64_t cap,
                        uint32_t *out_a, uint32_t *out_b, float *out_similarity, uint64_t *n_out,
-                       uint64_t *n_needed) {
+                       uint64_t *n_needed) try {
     if (!ix || !n_out) return set_err(CX_ERR_VALIDATION, "null argument");
     *n_out = 0;
     if (n_needed) *n_needed = 0;
@@ -412,10 +412,10 @@ int cx_dedup_scan_rows(const cx_index *ix, float dedup_threshold, const uint8_t 
     if (int rc = pass_core(ix, lease.c, ps, scan.size(), scan.data(), TOPK_MAX, dedup_threshold, 0, deleted, true, &total, nullptr))
         return rc;
     return copy_edges_rows(lease.c, ps, total, cap, out_a, out_b, out_similarity, n_out, n_needed);
-}
+} catch (...) { return cx::on_exception(); }
 
 int cx_autolink_pass_timed(const cx_index *ix, uint64_t n_scan, const uint32_t *scan_rows, uint64_t topk,
-                           float threshold, uint64_t max_edges_per_node, uint64_t *n_edges, double *phase_ms) {
+                           float threshold, uint64_t max_edges_per_node, uint64_t *n_edges, double *phase_ms) try {
     if (!ix || !n_edges || !phase_ms) return set_err(CX_ERR_VALIDATION, "null argument");
     if (!scan_rows) n_scan = ix->n_rows;
     if (int rc = use_device(ix)) return rc;
@@ -424,7 +424,7 @@ int cx_autolink_pass_timed(const cx_index *ix, uint64_t n_scan, const uint32_t *
     PassScratch &ps = scratch_of(lease.c);
     return pass_core(ix, lease.c, ps, n_scan, scan_rows, (uint32_t)topk, threshold, (uint32_t)max_edges_per_node, nullptr,
                      false, n_edges, phase_ms);
-}
+} catch (...) { return cx::on_exception(); }
 
 /* Ordered neighbour lists of nq external vectors against this shard (the multi-GPU building block of the
  * all-pairs pass): bf16 shadow of the queries -> MFMA filter against the shard's shadow -> exact rescore.
@@ -432,7 +432,7 @@ int cx_autolink_pass_timed(const cx_index *ix, uint64_t n_scan, const uint32_t *
  * scan path; those lists are not thresholded (the rule walk applies the threshold anyway). */
 int cx_autolink_lists_dev(const cx_index *ix, uint64_t nq64, const float *d_queries, uint64_t topk64, float threshold,
                           uint32_t *d_out_rows, float *d_out_scores, float *d_out_dists, uint32_t *d_out_counts,
-                          void *stream) {
+                          void *stream) try {
     if (!ix || !d_queries || !d_out_rows || !d_out_scores || !d_out_dists || !d_out_counts)
         return set_err(CX_ERR_VALIDATION, "null argument");
     if (topk64 == 0 || topk64 > TOPK_MAX) return set_err(CX_ERR_VALIDATION, "autolink lists: topk must be in 1..%u", TOPK_MAX);
@@ -506,12 +506,12 @@ int cx_autolink_lists_dev(const cx_index *ix, uint64_t nq64, const float *d_quer
             return rc;
     CX_HIP(hipStreamSynchronize(s));   // the pooled scratch goes back with the lease
     return CX_OK;
-}
+} catch (...) { return cx::on_exception(); }
 
 /* Ordered top-k lists of the scanned rows (see cortex_hip.h): gather the scanned vectors on the device, run the
  * batched search over them block by block, copy the lists out. */
 int cx_topk_lists_rows(const cx_index *ix, uint64_t n_scan64, const uint32_t *scan_rows, uint64_t topk64,
-                       uint32_t *out_rows, float *out_scores, uint32_t *out_counts) {
+                       uint32_t *out_rows, float *out_scores, uint32_t *out_counts) try {
     if (!ix || !out_rows || !out_scores || !out_counts) return set_err(CX_ERR_VALIDATION, "null argument");
     if (topk64 == 0 || topk64 > TOPK_MAX) return set_err(CX_ERR_VALIDATION, "topk lists: topk must be in 1..%u", TOPK_MAX);
     if (int rc = use_device(ix)) return rc;
@@ -564,16 +564,16 @@ int cx_topk_lists_rows(const cx_index *ix, uint64_t n_scan64, const uint32_t *sc
         CX_HIP(hipStreamSynchronize(s));
     }
     return CX_OK;
-}
+} catch (...) { return cx::on_exception(); }
 
 /* rows [row_lo, row_lo + n) of the shard copied to a caller buffer in HBM (e.g. to broadcast them to the other
  * ranks as the scanned block of a sharded pass) */
-int cx_copy_rows_dev(const cx_index *ix, uint64_t row_lo, uint64_t n, float *d_dst, void *stream) {
+int cx_copy_rows_dev(const cx_index *ix, uint64_t row_lo, uint64_t n, float *d_dst, void *stream) try {
     if (!ix || !d_dst) return set_err(CX_ERR_VALIDATION, "null argument");
     if (row_lo + n > ix->n_rows) return set_err(CX_ERR_VALIDATION, "rows [%llu, %llu) out of range", (unsigned long long)row_lo, (unsigned long long)(row_lo + n));
     if (int rc = use_device(ix)) return rc;
     if (n) CX_HIP(hipMemcpyAsync(d_dst, ix->d_rows + (size_t)row_lo * ix->dim, (size_t)n * ix->dim * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return CX_OK;
-}
+} catch (...) { return cx::on_exception(); }
 
 }  // extern "C"

@@ -17,6 +17,9 @@ namespace cx {
 // CortexError::Validation(String) by the caller's shim.
 char *err_buf();
 int set_err(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+// inside a catch (...) of an extern "C" entry point: the exception becomes a status + message (nothing unwinds
+// across the C ABI)
+int on_exception() noexcept;
 
 #define CX_HIP(expr)                                                                       \
     do {                                                                                   \

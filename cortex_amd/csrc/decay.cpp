@@ -55,7 +55,7 @@ float decayed(const cx_decay_config &cfg, float raw, float rb, int64_t now_s, ui
 extern "C" {
 
 int cx_set_node_stats_batch(cx_index *ix, uint64_t n, const uint8_t *ids, const uint32_t *kind_codes,
-                            const int64_t *last_accessed_s, const uint32_t *last_accessed_ns, const uint64_t *access_counts) {
+                            const int64_t *last_accessed_s, const uint32_t *last_accessed_ns, const uint64_t *access_counts) try {
     if (!ix) return set_err(CX_ERR_VALIDATION, "null index");
     if (!n) return CX_OK;
     if (!ids || !kind_codes || !last_accessed_s || !access_counts) return set_err(CX_ERR_VALIDATION, "null argument");
@@ -70,7 +70,7 @@ int cx_set_node_stats_batch(cx_index *ix, uint64_t n, const uint8_t *ids, const 
         s.access = access_counts[i];
     }
     return CX_OK;
-}
+} catch (...) { return cx::on_exception(); }
 
 float cx_apply_score_decay(const cx_decay_config *cfg, float raw_score, float recency_bias, int64_t now_s, uint32_t now_ns,
                            uint32_t kind_code, int64_t last_accessed_s, uint32_t last_accessed_ns, uint64_t access_count) {
@@ -82,7 +82,7 @@ float cx_apply_score_decay(const cx_decay_config *cfg, float raw_score, float re
 
 int cx_search_decayed(const cx_index *ix, const float *query, uint64_t len, uint64_t limit, uint64_t candidate_limit,
                       const cx_filter *filter, const cx_decay_config *cfg, float recency_bias, int64_t now_s, uint32_t now_ns,
-                      uint8_t *out_ids, float *out_scores, float *out_raw_scores, uint64_t *n_out) {
+                      uint8_t *out_ids, float *out_scores, float *out_raw_scores, uint64_t *n_out) try {
     if (!ix || !query || !cfg || !n_out) return set_err(CX_ERR_VALIDATION, "null argument");
     *n_out = 0;
     if (cfg->n_by_kind && (!cfg->kind_codes || !cfg->kind_rates)) return set_err(CX_ERR_VALIDATION, "null by_kind table");
@@ -114,6 +114,6 @@ int cx_search_decayed(const cx_index *ix, const float *query, uint64_t len, uint
     }
     *n_out = take;
     return CX_OK;
-}
+} catch (...) { return cx::on_exception(); }
 
 }  // extern "C"

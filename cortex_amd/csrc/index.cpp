@@ -23,6 +23,18 @@ int set_err(int code, const char *fmt, ...) {
     return code;
 }
 
+int on_exception() noexcept {
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        return set_err(CX_ERR_DEVICE, "out of host memory");
+    } catch (const std::exception &e) {
+        return set_err(CX_ERR_DEVICE, "internal error: %s", e.what());
+    } catch (...) {
+        return set_err(CX_ERR_DEVICE, "internal error");
+    }
+}
+
 }  // namespace cx
 
 using namespace cx;
@@ -455,13 +467,13 @@ extern "C" {
 
 const char *cx_last_error(void) { return err_buf(); }
 
-int cx_device_count(void) {
+int cx_device_count(void) try {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
-}
+} catch (...) { return cx::on_exception(); }
 
-cx_index *cx_create(uint32_t dimension, int device) {
+cx_index *cx_create(uint32_t dimension, int device) try {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
@@ -486,7 +498,7 @@ cx_index *cx_create(uint32_t dimension, int device) {
         return nullptr;
     }
     return ix;
-}
+} catch (...) { cx::on_exception(); return nullptr; }
 
 void cx_destroy(cx_index *ix) {
     if (!ix) return;
@@ -505,23 +517,23 @@ void cx_destroy(cx_index *ix) {
     delete ix;
 }
 
-int cx_reserve(cx_index *ix, uint64_t rows) {
+int cx_reserve(cx_index *ix, uint64_t rows) try {
     if (!ix) return set_err(CX_ERR_VALIDATION, "null index");
     if (int rc = use_device(ix)) return rc;
     return grow_rows(ix, rows);
-}
+} catch (...) { return cx::on_exception(); }
 
-int cx_upsert(cx_index *ix, const uint8_t id[16], const float *embedding, uint64_t len) {
+int cx_upsert(cx_index *ix, const uint8_t id[16], const float *embedding, uint64_t len) try {
     return upsert_impl(ix, 1, id, embedding, len, false);
-}
-int cx_upsert_batch(cx_index *ix, uint64_t n, const uint8_t *ids, const float *embeddings, uint64_t len) {
+} catch (...) { return cx::on_exception(); }
+int cx_upsert_batch(cx_index *ix, uint64_t n, const uint8_t *ids, const float *embeddings, uint64_t len) try {
     return upsert_impl(ix, n, ids, embeddings, len, false);
-}
-int cx_upsert_batch_dev(cx_index *ix, uint64_t n, const uint8_t *ids, const float *d_embeddings, uint64_t len) {
+} catch (...) { return cx::on_exception(); }
+int cx_upsert_batch_dev(cx_index *ix, uint64_t n, const uint8_t *ids, const float *d_embeddings, uint64_t len) try {
     return upsert_impl(ix, n, ids, d_embeddings, len, true);
-}
+} catch (...) { return cx::on_exception(); }
 
-int cx_remove(cx_index *ix, const uint8_t id[16]) {
+int cx_remove(cx_index *ix, const uint8_t id[16]) try {
     if (!ix || !id) return set_err(CX_ERR_VALIDATION, "null argument");
     auto it = ix->map.find(id_key(id));
     if (it == ix->map.end()) return CX_OK;  // vector/index.rs:317 — HashMap::remove of a missing key
@@ -533,9 +545,9 @@ int cx_remove(cx_index *ix, const uint8_t id[16]) {
     ix->n_alive--;
     ix->n_removed++;
     return push_meta(ix, row);
-}
+} catch (...) { return cx::on_exception(); }
 
-int cx_set_metadata(cx_index *ix, const uint8_t id[16], uint32_t kind_code, uint32_t agent_code) {
+int cx_set_metadata(cx_index *ix, const uint8_t id[16], uint32_t kind_code, uint32_t agent_code) try {
     if (!ix || !id) return set_err(CX_ERR_VALIDATION, "null argument");
     if (kind_code >= (1u << 24)) return set_err(CX_ERR_VALIDATION, "kind code out of range");
     auto it = ix->map.find(id_key(id));
@@ -547,9 +559,9 @@ int cx_set_metadata(cx_index *ix, const uint8_t id[16], uint32_t kind_code, uint
     ix->h_meta[row] = META_HAS | (kind_code << 8);
     ix->h_agent[row] = agent_code;
     return push_meta(ix, row);
-}
+} catch (...) { return cx::on_exception(); }
 
-int cx_set_metadata_batch(cx_index *ix, uint64_t n, const uint8_t *ids, const uint32_t *kind_codes, const uint32_t *agent_codes) {
+int cx_set_metadata_batch(cx_index *ix, uint64_t n, const uint8_t *ids, const uint32_t *kind_codes, const uint32_t *agent_codes) try {
     if (!ix) return set_err(CX_ERR_VALIDATION, "null index");
     if (!n) return CX_OK;
     if (!ids || !kind_codes || !agent_codes) return set_err(CX_ERR_VALIDATION, "null argument");
@@ -572,7 +584,7 @@ int cx_set_metadata_batch(cx_index *ix, uint64_t n, const uint8_t *ids, const ui
     CX_HIP(hipMemcpyAsync(ix->d_agent + lo, &ix->h_agent[lo], (size_t)(hi - lo + 1) * 4, hipMemcpyHostToDevice, ix->up_stream));
     CX_HIP(hipStreamSynchronize(ix->up_stream));
     return CX_OK;
-}
+} catch (...) { return cx::on_exception(); }
 
 uint32_t cx_intern(cx_index *ix, const char *utf8, uint64_t len) {
     if (!ix || (!utf8 && len)) return 0;
@@ -584,7 +596,7 @@ uint32_t cx_intern(cx_index *ix, const char *utf8, uint64_t len) {
     return code;
 }
 
-int cx_rebuild(cx_index *ix) {
+int cx_rebuild(cx_index *ix) try {
     if (!ix) return set_err(CX_ERR_VALIDATION, "null index");
     if (!ix->n_removed) return CX_OK;
     if (int rc = use_device(ix)) return rc;
@@ -642,15 +654,15 @@ int cx_rebuild(cx_index *ix) {
     ix->norms_rows = 0;   // and so are the row norms
     ix->norms_stale.clear();
     return CX_OK;
-}
+} catch (...) { return cx::on_exception(); }
 
-int cx_profile_enable(cx_index *ix, int on) {
+int cx_profile_enable(cx_index *ix, int on) try {
     if (!ix) return set_err(CX_ERR_VALIDATION, "null index");
     ix->profiling = on != 0;
     return CX_OK;
-}
+} catch (...) { return cx::on_exception(); }
 
-int cx_profile_read(cx_index *ix, double *kernel_ms_sum, uint64_t *launches, int reset) {
+int cx_profile_read(cx_index *ix, double *kernel_ms_sum, uint64_t *launches, int reset) try {
     if (!ix || !kernel_ms_sum || !launches) return set_err(CX_ERR_VALIDATION, "null argument");
     if (int rc = use_device(ix)) return rc;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
@@ -674,32 +686,32 @@ int cx_profile_read(cx_index *ix, double *kernel_ms_sum, uint64_t *launches, int
         ix->prof_n = 0;
     }
     return CX_OK;
-}
+} catch (...) { return cx::on_exception(); }
 
 uint64_t cx_len(const cx_index *ix) { return ix ? ix->n_alive : 0; }
 uint32_t cx_dimension(const cx_index *ix) { return ix ? ix->dim : 0; }
 uint64_t cx_row_count(const cx_index *ix) { return ix ? ix->n_rows : 0; }
 const float *cx_device_rows(const cx_index *ix) { return ix ? ix->d_rows : nullptr; }
 
-int cx_row_id(const cx_index *ix, uint64_t row, uint8_t out_id[16]) {
+int cx_row_id(const cx_index *ix, uint64_t row, uint8_t out_id[16]) try {
     if (!ix || !out_id) return set_err(CX_ERR_VALIDATION, "null argument");
     if (row >= ix->n_rows) return set_err(CX_ERR_VALIDATION, "row %llu out of range", (unsigned long long)row);
     memcpy(out_id, &ix->ids[16 * (size_t)row], 16);
     return CX_OK;
-}
+} catch (...) { return cx::on_exception(); }
 
-int cx_rows_of(const cx_index *ix, uint64_t n, const uint8_t *ids, uint32_t *out_rows) {
+int cx_rows_of(const cx_index *ix, uint64_t n, const uint8_t *ids, uint32_t *out_rows) try {
     if (!ix || (n && (!ids || !out_rows))) return set_err(CX_ERR_VALIDATION, "null argument");
     for (uint64_t i = 0; i < n; i++) {
         auto it = ix->map.find(id_key(ids + 16 * i));
         out_rows[i] = it == ix->map.end() ? 0xFFFFFFFFu : it->second;
     }
     return CX_OK;
-}
+} catch (...) { return cx::on_exception(); }
 
 int cx_search_batch(const cx_index *ix, uint64_t nq, const float *queries, uint64_t len, uint64_t k,
                     const cx_filter *filter, uint8_t *out_ids, float *out_scores, float *out_distances,
-                    uint64_t *out_counts) {
+                    uint64_t *out_counts) try {
     if (!ix) return set_err(CX_ERR_VALIDATION, "null index");
     if (nq && (!queries || !out_counts)) return set_err(CX_ERR_VALIDATION, "null queries/out_counts");
     for (uint64_t i = 0; i < nq; i++) out_counts[i] = 0;
@@ -732,17 +744,17 @@ int cx_search_batch(const cx_index *ix, uint64_t nq, const float *queries, uint6
         }
     }
     return CX_OK;
-}
+} catch (...) { return cx::on_exception(); }
 
 int cx_search(const cx_index *ix, const float *query, uint64_t len, uint64_t k, const cx_filter *filter,
-              uint8_t *out_ids, float *out_scores, float *out_distances, uint64_t *n_out) {
+              uint8_t *out_ids, float *out_scores, float *out_distances, uint64_t *n_out) try {
     if (!n_out) return set_err(CX_ERR_VALIDATION, "null n_out");
     return cx_search_batch(ix, 1, query, len, k, filter, out_ids, out_scores, out_distances, n_out);
-}
+} catch (...) { return cx::on_exception(); }
 
 int cx_search_threshold(const cx_index *ix, const float *query, uint64_t len, float threshold,
                         const cx_filter *filter, uint64_t cap, uint8_t *out_ids, float *out_scores,
-                        float *out_distances, uint64_t *n_out, uint64_t *n_needed) {
+                        float *out_distances, uint64_t *n_out, uint64_t *n_needed) try {
     if (!ix || !query || !n_out) return set_err(CX_ERR_VALIDATION, "null argument");
     *n_out = 0;
     if (n_needed) *n_needed = 0;
@@ -783,11 +795,11 @@ int cx_search_threshold(const cx_index *ix, const float *query, uint64_t len, fl
         return set_err(CX_ERR_CAPACITY, "search_threshold: %llu results, buffer holds %llu",
                        (unsigned long long)total, (unsigned long long)cap);
     return CX_OK;
-}
+} catch (...) { return cx::on_exception(); }
 
 int cx_search_batch_dev(const cx_index *ix, uint64_t nq, const float *d_queries, uint64_t k,
                         const cx_filter *filter, uint32_t *d_rows, float *d_scores, float *d_distances,
-                        uint32_t *d_counts, void *stream) {
+                        uint32_t *d_counts, void *stream) try {
     if (!ix) return set_err(CX_ERR_VALIDATION, "null index");
     if (!nq) return CX_OK;
     if (!d_queries || !d_counts) return set_err(CX_ERR_VALIDATION, "null device pointer");
@@ -805,17 +817,17 @@ int cx_search_batch_dev(const cx_index *ix, uint64_t nq, const float *d_queries,
     if (int rc = build_filter(ix, c, filter, s, fu)) return rc;
     return search_core(ix, c, d_queries, nullptr, nq, (uint32_t)k, fu.f, 0.0f, false, d_rows, d_scores,
                        d_distances, d_counts, s);
-}
+} catch (...) { return cx::on_exception(); }
 
 int cx_search_dev(const cx_index *ix, const float *d_query, uint64_t k, const cx_filter *filter, uint32_t *d_rows,
-                  float *d_scores, float *d_distances, uint32_t *d_count, void *stream) {
+                  float *d_scores, float *d_distances, uint32_t *d_count, void *stream) try {
     return cx_search_batch_dev(ix, 1, d_query, k, filter, d_rows, d_scores, d_distances, d_count, stream);
-}
+} catch (...) { return cx::on_exception(); }
 
 int cx_merge_topk_dev(int device, uint64_t n_parts, uint64_t nq, uint64_t k, uint64_t part_stride, const uint64_t *part_base,
                       const uint32_t *d_rows, const float *d_scores, const float *d_distances,
                       const uint32_t *d_counts, uint64_t *d_out_rows, float *d_out_scores,
-                      float *d_out_distances, uint32_t *d_out_counts, void *stream) {
+                      float *d_out_distances, uint32_t *d_out_counts, void *stream) try {
     if (!part_base || !d_rows || !d_scores || !d_distances || !d_counts || !d_out_rows || !d_out_scores ||
         !d_out_distances || !d_out_counts)
         return set_err(CX_ERR_VALIDATION, "null argument");
@@ -827,6 +839,6 @@ int cx_merge_topk_dev(int device, uint64_t n_parts, uint64_t nq, uint64_t k, uin
     return launch_merge_parts((uint32_t)n_parts, (uint32_t)nq, (uint32_t)k, part_stride, pb, d_rows, d_scores, d_distances,
                               d_counts, d_out_rows, d_out_scores, d_out_distances, d_out_counts,
                               (hipStream_t)stream);
-}
+} catch (...) { return cx::on_exception(); }
 
 }  // extern "C"

@@ -221,15 +221,15 @@ bool decode(const uint8_t *rec, uint64_t len, cx_node_view *v, const char **why)
 
 extern "C" {
 
-int cx_node_decode(const uint8_t *record, uint64_t len, cx_node_view *out) {
+int cx_node_decode(const uint8_t *record, uint64_t len, cx_node_view *out) try {
     if (!record || !out) return set_err(CX_ERR_VALIDATION, "null argument");
     const char *why = "";
     if (!decode(record, len, out, &why)) return set_err(CX_ERR_VALIDATION, "Failed to deserialize node: %s", why);
     return CX_OK;
-}
+} catch (...) { return cx::on_exception(); }
 
 int cx_bulk_load_nodes(cx_index *ix, uint64_t n, const uint8_t *blob, const uint64_t *offsets, uint32_t flags,
-                       cx_bulk_stats *stats) {
+                       cx_bulk_stats *stats) try {
     cx_bulk_stats st{};
     if (stats) *stats = st;
     if (!ix) return set_err(CX_ERR_VALIDATION, "null index");
@@ -360,6 +360,6 @@ int cx_bulk_load_nodes(cx_index *ix, uint64_t n, const uint8_t *blob, const uint
     if (diag) fprintf(stderr, "[bulk] decode %.1f ms, order %.1f ms, stage+insert %.1f ms\n", ms(t_0, t_1), ms(t_1, t_2), ms(t_2, now()));
     if (stats) *stats = st;
     return CX_OK;
-}
+} catch (...) { return cx::on_exception(); }
 
 }  // extern "C"

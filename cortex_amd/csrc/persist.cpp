@@ -56,7 +56,7 @@ struct Reader {
 
 extern "C" {
 
-int cx_save(const cx_index *ix, const char *path) {
+int cx_save(const cx_index *ix, const char *path) try {
     if (!ix || !path) return set_err(CX_ERR_VALIDATION, "null argument");
     if (int rc = use_device(ix)) return rc;
     FILE *f = fopen(path, "wb");
@@ -104,9 +104,9 @@ int cx_save(const cx_index *ix, const char *path) {
     const bool ok = w.ok;
     if (fclose(f) != 0 || !ok) return set_err(CX_ERR_IO, "Failed to write index file: %s", strerror(errno));
     return CX_OK;
-}
+} catch (...) { return cx::on_exception(); }
 
-cx_index *cx_load(const char *path, int device) {
+cx_index *cx_load(const char *path, int device) try {
     if (!path) {
         set_err(CX_ERR_VALIDATION, "null path");
         return nullptr;
@@ -190,6 +190,6 @@ cx_index *cx_load(const char *path, int device) {
         if (cx_set_metadata(ix, m.id, kc, ac) != CX_OK) { cx_destroy(ix); return nullptr; }
     }
     return ix;
-}
+} catch (...) { cx::on_exception(); return nullptr; }
 
 }  // extern "C"
