@@ -28,6 +28,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
+
+
+def _baseline_metric() -> str:
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        return "kNN queries/sec + auto-link pairs/sec at 1M\u00d7768-d; recall@10 vs exact"
+
+
+BASELINE_METRIC = _baseline_metric()
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -144,7 +154,10 @@ def main() -> None:
         traffic = json.load(open(pmc)).get("scan_kernel_hbm_bytes_per_launch")
         traffic_src = "profiles/r01/knn_1Mx768_pmc_final.json"
     out = {
-        "metric": "knn_queries_per_sec_1Mx768",
+        # BASELINE.json's metric, verbatim; `value` is its first component (kNN queries/s), the auto-link pairs/s
+        # and recall@10 components are extra.autolink_allpairs* and extra.recall_at_k_vs_exact
+        "metric": BASELINE_METRIC,
+        "metric_component": "knn_queries_per_sec_1Mx768",
         "value": value,
         "unit": "queries/s (x 1M-row shards scanned per query)",
         "n_gpus": world,
