@@ -401,3 +401,64 @@ def test_search_batch_is_deterministic(hip, oracle, k, nq):
         got = h.search_batch_arrays(qs, k)
         for a, b in zip(ref, got):
             assert np.array_equal(a, b)
+
+
+def test_full_size_headline_corpus(hip, oracle):
+    """BASELINE's headline size, 1M x 768 f32 (generated in HBM): the oracle's exact answers for a handful of queries,
+    and size-independent properties for more — a row finds itself first with score 1, lists are ordered and hold
+    distinct ids, the batched path agrees with the single-query path, and searching the two halves of the corpus
+    separately and merging by (score, row) gives the whole-corpus answer."""
+    import torch
+    from cortex_amd import _lib
+    L = _lib.load()
+    n, d, k = 1_000_000, 768, 10
+    gen = torch.empty((n, d), dtype=torch.float32, device="cuda:0")
+    assert L.cx_synth_fill_dev(0, gen.data_ptr(), oracle.SEED_CORPUS, oracle.SEED_CORPUS, oracle.SEED_DUP, n // 50, 0, n, d, 1) == 0
+    ids = ids_for(n)
+    h = hip.HipIndex(d)
+    h.insert_batch_dev(ids, gen.data_ptr(), n, d)
+    lut = {ids[i].tobytes(): i for i in range(n)}
+    rng = np.random.default_rng(3)
+    probe = np.sort(rng.choice(n, 64, replace=False))
+    q_self = gen[torch.as_tensor(probe, device="cuda:0")].cpu().numpy()
+    q_new = oracle.synth_queries(n, d, 6)
+
+    # properties on 64 corpus rows used as queries
+    single = []
+    for p, q in zip(probe, q_self):
+        gi, gs, gd = h.search_arrays(q, k)
+        r = np.array([lut[x.tobytes()] for x in gi])
+        assert len(r) == k and len(set(r.tolist())) == k and np.all(np.diff(gs) <= 0)
+        assert gs[0] >= 1.0 - SCORE_TOL and (r[0] == p or gs[list(r).index(p)] >= 1.0 - SCORE_TOL)   # itself (or an exact duplicate with a lower row)
+        ties = gs[:-1] == gs[1:]
+        assert np.all(r[:-1][ties] < r[1:][ties])      # equal scores: insertion row ascending
+        single.append((r, gs))
+    bi, bs, bd, bc = h.search_batch_arrays(q_self, k)
+    for j in range(64):
+        assert int(bc[j]) == k
+        assert_topk_parity(np.array([lut[x.tobytes()] for x in bi[j]]), bs[j], single[j][0], single[j][1], what=f"batch vs single q{j}")
+
+    # two half-corpus indexes, merged by (score desc, row asc) == the whole corpus
+    half = n // 2
+    ha, hb = hip.HipIndex(d), hip.HipIndex(d)
+    ha.insert_batch_dev(ids[:half], gen.data_ptr(), half, d)
+    hb.insert_batch_dev(ids[half:], gen.data_ptr() + half * d * 4, n - half, d)
+    for j in range(8):
+        a = ha.search_arrays(q_self[j], k)
+        b = hb.search_arrays(q_self[j], k)
+        cand = [(-float(s), lut[i.tobytes()]) for i, s in zip(list(a[0]) + list(b[0]), list(a[1]) + list(b[1]))]
+        cand.sort()
+        assert_topk_parity(np.array([c[1] for c in cand[:k]]), np.array([-c[0] for c in cand[:k]]), single[j][0], single[j][1],
+                           what=f"halves q{j}")
+    del ha, hb
+
+    # the oracle's exact brute force over the same 1M rows (3 GB on the host), held-out queries
+    rows_h = gen.cpu().numpy()
+    del gen
+    o = oracle.OracleIndex(d)
+    o.insert_batch(ids, rows_h)
+    exp = o.search_batch(q_new, k, n_threads=6)
+    for j, q in enumerate(q_new):
+        gi, gs, gd = h.search_arrays(q, k)
+        assert_topk_parity(np.array([lut[x.tobytes()] for x in gi]), gs, exp[j]["row"], exp[j]["score"], what=f"1M oracle q{j}")
+        assert np.max(np.abs(gs - exp[j]["score"])) <= SCORE_TOL
