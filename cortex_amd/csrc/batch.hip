@@ -436,8 +436,8 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
         uint32_t tile = blockIdx.x;
         if (tile < n_tiles) {
             issue_loads(ldA, nrA, tile);
-            issue_loads(ldB, nrB, tile + gridDim.x);
             write_tile(ldA, nrA, 0, tile + 2u * gridDim.x);
+            issue_loads(ldB, nrB, tile + gridDim.x);   // after tile 0 is out: the first tile does not share the start-up burst with the second
         }
         __syncthreads();
         stamp0();
