@@ -100,15 +100,18 @@ __device__ inline float wave_sum_dpp(float v) {
 // A list entry is (row, dot) plus, for E = 1, |row|^2 — 12 bytes, so that no compaction and no final ordering goes
 // back to HBM for the norm (the wide lists spend that LDS on length and gather it from the index's norm cache,
 // a.norms); the producers copy the norms per tile into LDS for the consumers' per-tile test.
-template <int D, bool DIAG, int E>
+// MODE: 1 = lists of 80 (k <= 32), 64 queries; 4 = wide lists, 32 queries; 8 = wide lists, all 64 queries (384-d only)
+template <int D, bool DIAG, int MODE>
 __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
     using C = Batch2Cfg<D>;
+    constexpr int E = MODE == 1 ? 1 : 4;
+    static_assert(MODE == 1 || MODE == 4 || (MODE == 8 && D == 384), "wide lists for 64 queries fit LDS at 384-d only");
     // grid = (row chunks, query groups): block (x, y) scans the tiles t = x (mod gridDim.x) for query group y
     // (64 queries, 32 in the wide mode).  Small corpora get few chunks — so that a block still sees enough rows
     // for its own bound to mean something — and many groups per launch; large ones one group on every CU.
     BatchArgs a = a_in;
     {
-        constexpr uint32_t QPP = E == 1 ? BT_Q : BT_Q / 2;
+        constexpr uint32_t QPP = MODE != 4 ? BT_Q : BT_Q / 2;
         const uint32_t grp = blockIdx.y;
         a.queries += (size_t)grp * QPP * D;
         a.nq = a_in.nq - grp * QPP < QPP ? a_in.nq - grp * QPP : QPP;
@@ -122,7 +125,11 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
     char *tiles = smem;
     float *c_rr = reinterpret_cast<float *>(smem + 2 * C::TILE_BYTES);
     const uint32_t capq = a.capq;
-    constexpr uint32_t QC = E == 1 ? BT_Q : BT_Q / 2;   // queries that own a candidate list
+    // queries that own a candidate list: 64, or 32 for the wide lists (two 48 KiB tile buffers leave LDS for 32 lists
+    // of 248); at 384-d the tiles are half as big and MODE 8 keeps all 64 queries (lists of 216) — 1.4x the queries per
+    // second once a call has more than 32 of them, slower below (half the producers then own all the lists)
+    constexpr bool FULLQ = MODE != 4;
+    constexpr uint32_t QC = FULLQ ? BT_Q : BT_Q / 2;
     uint32_t *c_rows = reinterpret_cast<uint32_t *>(c_rr + 2 * BT_ROWS);
     float *c_dots = reinterpret_cast<float *>(c_rows + QC * capq);
     // E = 1 keeps |row|^2 beside each entry (the consumer has it in hand when it appends), so no compaction and no
@@ -289,11 +296,13 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
         // Ownership of the lists: E = 1: producer pw owns the 16 lists of consumer wave pw.  Wide mode has only two
         // live consumer waves, so all four producers share their lists: producer pw owns the queries of group pw & 1
         // whose index has parity pw >> 1 (twice the compaction throughput; the same producer refreshes their bounds).
-        const uint32_t own_grp = E == 1 ? pw : (pw & 1u), own_par = pw >> 1;
-        uint32_t g_q = E == 1 ? pw * 16u + lane / LPQ : own_grp * 16u + 2u * (lane / LPQ) + own_par;
+        constexpr bool SHARED = !FULLQ;   // two live consumer waves: the four producers share their lists by parity
+        const uint32_t own_grp = SHARED ? (pw & 1u) : pw, own_par = pw >> 1;
+        // wide with all 64 queries: a refresh covers 8 of the producer's 16 queries, alternating halves
+        uint32_t g_q = SHARED ? own_grp * 16u + 2u * (lane / LPQ) + own_par : pw * 16u + lane / LPQ;
         const uint32_t n_gld = (k + 2u * LPQ - 1u) / (2u * LPQ);   // lane (query, g) reads slot pairs 2 (g + LPQ i), + 1
         auto refresh_issue = [&](uint32_t half) {
-            (void)half;
+            if constexpr (E != 1 && FULLQ) g_q = pw * 16u + 8u * (half & 1u) + lane / LPQ;
             const uint64_t *G = reinterpret_cast<const uint64_t *>(a.gslots + g_q * GSTRIDE) + g_g;
 #pragma unroll
             for (uint32_t i = 0; i < NG; i++)
@@ -320,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
         };
         auto producer_compact = [&]() {
             uint32_t pubv = 0, shrv = 1;
-            const bool mine_q = lane < 16u && own_grp * 16u < QC && (E == 1 || (lane & 1u) == own_par);
+            const bool mine_q = lane < 16u && own_grp * 16u < QC && (!SHARED || (lane & 1u) == own_par);
             if (mine_q) { pubv = c_pub[own_grp * 16u + lane]; shrv = c_shr[own_grp * 16u + lane]; }
             uint64_t need = __ballot(mine_q && shrv == 0u && pubv + 32u >= capq && pubv > k);
             while (need) {
@@ -682,12 +691,15 @@ uint32_t batch_grid_blocks(uint32_t n_rows) {
 }
 
 bool batch_supported(uint32_t dim, uint32_t k) { return (dim == 384 || dim == 768) && k >= 1 && k <= BATCH_K_WIDE; }
-uint32_t batch_queries_per_pass(uint32_t k) { return k <= 32 ? 64u : 32u; }
+uint32_t batch_queries_per_pass(uint32_t dim, uint32_t k, uint64_t nq) {
+    static const int full = getenv("CX_BATCH_WIDE_FULL") ? atoi(getenv("CX_BATCH_WIDE_FULL")) : 1;   // 0: wide lists always 32 queries per pass
+    return (k <= 32 || (full && dim == 384 && nq > 32)) ? 64u : 32u;
+}
 
 // launch shape for nq queries over n_rows rows: chunks x groups blocks.  A block should see >= 256 tiles (4096
 // rows) when the corpus allows; the CUs that leaves free take further query groups in the same launch.
-void batch_launch_shape(uint32_t n_rows, uint64_t nq, uint32_t k, uint32_t *chunks, uint32_t *groups) {
-    const uint32_t cus = batch_cus(), qpp = batch_queries_per_pass(k);
+void batch_launch_shape(uint32_t n_rows, uint32_t dim, uint64_t nq, uint32_t k, uint32_t *chunks, uint32_t *groups) {
+    const uint32_t cus = batch_cus(), qpp = batch_queries_per_pass(dim, k, nq);
     const uint32_t tiles = (n_rows + BT_ROWS - 1) / BT_ROWS;
     uint32_t c = tiles / 256u;
     if (c < 1u) c = 1u;
@@ -707,7 +719,7 @@ void batch_launch_shape(uint32_t n_rows, uint64_t nq, uint32_t k, uint32_t *chun
 template <int D>
 static int launch_batch_d(BatchArgs a, uint32_t grid, hipStream_t stream) {
     const bool wide = a.k > 32;   // 32 queries per pass, lists of up to 272, four entries per lane in a compaction
-    const size_t qc = wide ? BT_Q / 2 : BT_Q;
+    const size_t qc = a.qpp;
     const size_t tail = qc * a.capq * (wide ? 8 : 12) + BT_Q * 8 + BT_Q * 4 + BT_Q * 4 + 3 * BT_Q * 4;
     const size_t lds = 2 * (size_t)Batch2Cfg<D>::TILE_BYTES + 2 * BT_ROWS * 4 + tail;
     if (lds > 160 * 1024) return set_err(CX_ERR_VALIDATION, "batch scan: %zu bytes of LDS for k = %u", lds, a.k);
@@ -717,12 +729,17 @@ static int launch_batch_d(BatchArgs a, uint32_t grid, hipStream_t stream) {
         CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch2_kernel<D, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch2_kernel<D, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch2_kernel<D, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if constexpr (D == 384) {
+            CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch2_kernel<D, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch2_kernel<D, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
     }
     if (getenv("CX_BATCH_DIAG")) {  // diagnostic build: per-phase cycle shares on stderr, results still valid
         const size_t n = (size_t)grid * a.n_groups * 8 * 8;   // up to 8 waves x 8 slots per block
         CX_HIP(hipMalloc((void **)&a.diag, n * 8));
         CX_HIP(hipMemset(a.diag, 0, n * 8));
-        if (wide) hipLaunchKernelGGL((batch2_kernel<D, true, 4>), dim3(grid, a.n_groups), dim3(512), lds, stream, a);
+        if (wide && a.qpp == 64u) { if constexpr (D == 384) hipLaunchKernelGGL((batch2_kernel<D, true, 8>), dim3(grid, a.n_groups), dim3(512), lds, stream, a); }
+        else if (wide) hipLaunchKernelGGL((batch2_kernel<D, true, 4>), dim3(grid, a.n_groups), dim3(512), lds, stream, a);
         else hipLaunchKernelGGL((batch2_kernel<D, true, 1>), dim3(grid, a.n_groups), dim3(512), lds, stream, a);
         CX_HIP(hipStreamSynchronize(stream));
         std::vector<unsigned long long> h(n);
@@ -741,7 +758,8 @@ static int launch_batch_d(BatchArgs a, uint32_t grid, hipStream_t stream) {
                 s[0] / tiles, s[1] / tiles, s[2] / tiles, s[3] / tiles, s[5] / tiles, s[6] / tiles, s[4] / tiles);
         return CX_OK;
     }
-    if (wide) hipLaunchKernelGGL((batch2_kernel<D, false, 4>), dim3(grid, a.n_groups), dim3(512), lds, stream, a);
+    if (wide && a.qpp == 64u) { if constexpr (D == 384) hipLaunchKernelGGL((batch2_kernel<D, false, 8>), dim3(grid, a.n_groups), dim3(512), lds, stream, a); }
+    else if (wide) hipLaunchKernelGGL((batch2_kernel<D, false, 4>), dim3(grid, a.n_groups), dim3(512), lds, stream, a);
     else hipLaunchKernelGGL((batch2_kernel<D, false, 1>), dim3(grid, a.n_groups), dim3(512), lds, stream, a);
     CX_HIP(hipGetLastError());
     return CX_OK;
@@ -750,14 +768,17 @@ static int launch_batch_d(BatchArgs a, uint32_t grid, hipStream_t stream) {
 int launch_batch_scan(BatchArgs a, uint32_t grid, hipStream_t stream) {
     if (!batch_supported(a.dim, a.k)) return set_err(CX_ERR_VALIDATION, "batch scan: unsupported dim %u / k %u", a.dim, a.k);
     if (a.n_groups == 0) a.n_groups = 1;
-    if (a.nq == 0 || a.nq > batch_queries_per_pass(a.k) * a.n_groups || a.nq <= batch_queries_per_pass(a.k) * (a.n_groups - 1))
-        return set_err(CX_ERR_VALIDATION, "batch scan: %u queries do not fill %u groups of %u (k = %u)", a.nq, a.n_groups, batch_queries_per_pass(a.k), a.k);
+    const uint32_t qpp = a.qpp;
+    if (qpp != 64u && !(qpp == 32u && a.k > 32)) return set_err(CX_ERR_VALIDATION, "batch scan: %u queries per pass for k = %u", qpp, a.k);
+    if (qpp == 64u && a.k > 32 && a.dim != 384) return set_err(CX_ERR_VALIDATION, "batch scan: wide lists for 64 queries need dim 384");
+    if (a.nq == 0 || a.nq > qpp * a.n_groups || a.nq <= qpp * (a.n_groups - 1))
+        return set_err(CX_ERR_VALIDATION, "batch scan: %u queries do not fill %u groups of %u (k = %u)", a.nq, a.n_groups, qpp, a.k);
     // batch2: lists are compacted at capq - 32 entries (<= 64: one per lane) and never exceed capq; k + 16 <= capq - 32
     a.capq = 80u;
     if (a.k > 32) {   // wide: as long as LDS allows (a compaction absorbs capq - 32 - k new entries), at most 4 x 64 + 16
         const size_t tiles = 2 * (a.dim == 384 ? (size_t)Batch2Cfg<384>::TILE_BYTES : (size_t)Batch2Cfg<768>::TILE_BYTES);
         const size_t room = 160 * 1024 - tiles - 2 * BT_ROWS * 4 - (BT_Q * 8 + BT_Q * 4 + BT_Q * 4 + 3 * BT_Q * 4);
-        uint32_t c = (uint32_t)(room / ((BT_Q / 2) * 8)) & ~7u;
+        uint32_t c = (uint32_t)(room / (qpp * 8)) & ~7u;
         a.capq = c > 272u ? 272u : c;
     }
     if (a.dim == 384) return launch_batch_d<384>(a, grid, stream);

@@ -304,9 +304,9 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
     static const int batch_min = getenv("CX_BATCH_MIN") ? atoi(getenv("CX_BATCH_MIN")) : 3;
     if (topk_path && no_tails && nq >= (uint64_t)batch_min && k_eff >= 1 && batch_supported(ix->dim, k_eff)) {
         if (int rc = ensure_norms(ix, s)) return rc;
-        const uint32_t qpp = batch_queries_per_pass(k_eff);
+        const uint32_t qpp = batch_queries_per_pass(ix->dim, k_eff, nq);
         uint32_t bgrid = 1, groups = 1;
-        batch_launch_shape(n, nq, k_eff, &bgrid, &groups);
+        batch_launch_shape(n, ix->dim, nq, k_eff, &bgrid, &groups);
         const uint64_t per_launch = (uint64_t)qpp * groups;
         if (int rc = ensure_dev(c->d_part_keys, c->pk_cap, (size_t)per_launch * bgrid * k_eff)) return rc;
         if (int rc = ensure_dev(c->d_part_sims, c->ps_cap, (size_t)per_launch * bgrid * k_eff)) return rc;
@@ -322,6 +322,7 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
             b.n_rows = n;
             b.nq = m;
             b.n_groups = (m + qpp - 1) / qpp;
+            b.qpp = qpp;
             b.dim = ix->dim;
             b.k = k_eff;
             b.flt = flt;

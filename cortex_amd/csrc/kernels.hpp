@@ -71,6 +71,7 @@ struct BatchArgs {
     const char *split;      // bf16 hi/lo copy of the rows, tile by tile in the LDS image layout (cx_index::d_split)
     uint32_t n_rows, nq, dim, k, capq;
     uint32_t n_groups;      // query groups in this launch (gridDim.y); nq covers all of them
+    uint32_t qpp;           // queries per group: batch_queries_per_pass(dim, k, queries of the whole call)
     DevFilter flt;
     uint64_t *part_keys;    // [nq][grid][k]
     float *part_sims;
@@ -81,8 +82,9 @@ bool batch_supported(uint32_t dim, uint32_t k);
 uint32_t batch_grid_blocks(uint32_t n_rows);
 // rows [row_lo, row_hi) -> the split store the batched search reads (dim 384 / 768)
 int launch_build_split(const float *rows, char *split, uint32_t row_lo, uint32_t row_hi, uint32_t dim, hipStream_t stream);
-uint32_t batch_queries_per_pass(uint32_t k);   // 64 for k <= 32, 32 for the wide lists (k <= 104)
-void batch_launch_shape(uint32_t n_rows, uint64_t nq, uint32_t k, uint32_t *chunks, uint32_t *groups);
+// 64; 32 for the wide lists (32 < k <= 104) unless the corpus is 384-d and the call has more than 32 queries
+uint32_t batch_queries_per_pass(uint32_t dim, uint32_t k, uint64_t nq);
+void batch_launch_shape(uint32_t n_rows, uint32_t dim, uint64_t nq, uint32_t k, uint32_t *chunks, uint32_t *groups);
 // one pass of <= 64 queries; per-block lists, to be folded by launch_merge_batch
 int launch_batch_scan(BatchArgs a, uint32_t grid, hipStream_t stream);
 // second stage for nq queries at once: query q's lists are part[q*n_lists*k ...], outputs at [q*k]

@@ -310,6 +310,8 @@ def test_search_batch_with_filter_and_tombstones(hip, oracle):
     (9000, 768, 33, 5),      # smallest wide k
     (30000, 384, 10, 200),   # several query groups in one launch (grid = chunks x groups), ragged last group
     (30000, 768, 100, 70),   # the same in the wide mode: 3 groups of 32, the last holds 6
+    (60000, 384, 100, 150),  # wide lists at 384-d keep all 64 queries per pass: 3 groups, the last holds 22
+    (25000, 384, 64, 64),    # one full 64-query wide group
 ])
 def test_search_batch_long_lists(hip, oracle, n, d, k, nq):
     """Enough rows per block that the in-kernel candidate lists overflow and are compacted many times
