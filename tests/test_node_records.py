@@ -128,3 +128,23 @@ def test_decoder_agrees_with_python_statement_on_random_nodes():
         assert (a["embedding"] is None) == (b["embedding"] is None)
         if b["embedding"] is not None:
             assert np.array_equal(a["embedding"], b["embedding"])
+
+
+def test_decoder_survives_mutations(tmp_path):
+    """The decoder reads database bytes, so it is fuzzed: tests/cpp/fuzz_node_decode.cpp builds nodes.cpp's decoder
+    alone with AddressSanitizer + UBSan (host only, no device) and feeds it 200k truncated / bit-flipped / length-
+    corrupted records held in exact-size heap blocks; any out-of-bounds read or undefined operation aborts."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None or not os.path.exists("/opt/rocm/include/hip/hip_runtime.h"):
+        pytest.skip("needs g++ and the HIP headers")
+    root = os.path.dirname(HERE)
+    exe = str(tmp_path / "fuzz_node_decode")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", f"-I{root}/include", f"-I{root}/cortex_amd/csrc",
+           f"{root}/tests/cpp/fuzz_node_decode.cpp", "-o", exe, "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-lpthread"]
+    b = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert b.returncode == 0, b.stderr[-2000:]
+    r = subprocess.run([exe, "200000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    assert "mutated records" in r.stdout
