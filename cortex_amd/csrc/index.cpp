@@ -730,10 +730,17 @@ int cx_search_batch(const cx_index *ix, uint64_t nq, const float *queries, uint6
     const size_t entries = (size_t)nq * k_eff;
     OutView dv, hv;
     if (int rc = ensure_out(c, entries, nq, dv, hv)) return rc;
-    if (int rc = search_core(ix, c, c->d_query, tails.data(), nq, k_eff, fu.f, 0.0f, false, dv.rows, dv.scores, dv.dists,
-                             dv.counts, c->stream))
+    // A small result block is written by the merge kernel straight into the pinned host buffer (device-visible
+    // memory): a search of a small corpus is launch-latency-bound and the separate device-to-host copy — a blit kernel
+    // of its own — was 5 of its 35 us.  Large blocks keep the HBM buffer and one bulk copy.
+    static const int direct_max = getenv("CX_DIRECT_RESULTS_MAX") ? atoi(getenv("CX_DIRECT_RESULTS_MAX")) : 4096;
+    const bool direct = k_eff <= TOPK_MAX && entries <= (size_t)direct_max;
+    const OutView &ov = direct ? hv : dv;
+    if (int rc = search_core(ix, c, c->d_query, tails.data(), nq, k_eff, fu.f, 0.0f, false, ov.rows, ov.scores, ov.dists,
+                             ov.counts, c->stream))
         return rc;
-    if (int rc = fetch_block(c, dv, hv)) return rc;
+    if (direct) CX_HIP(hipStreamSynchronize(c->stream));
+    else if (int rc = fetch_block(c, dv, hv)) return rc;
     for (uint64_t i = 0; i < nq; i++) {
         const uint32_t cnt = hv.counts[i];
         out_counts[i] = cnt;
