@@ -464,3 +464,43 @@ def test_full_size_headline_corpus(hip, oracle):
         gi, gs, gd = h.search_arrays(q, k)
         assert_topk_parity(np.array([lut[x.tobytes()] for x in gi]), gs, exp[j]["row"], exp[j]["score"], what=f"1M oracle q{j}")
         assert np.max(np.abs(gs - exp[j]["score"])) <= SCORE_TOL
+
+
+@pytest.mark.parametrize("d,k", [(384, 10), (768, 40), (384, 100)])
+def test_search_batch_zero_norm_rows_and_queries(hip, oracle, d, k):
+    """NaN scores (zero-norm rows, zero queries: vector/index.rs:173-176 divides by both norms) through the batched
+    MFMA path: NaN sorts after every number, in row order, exactly like the single-query path and the oracle."""
+    n = 3000
+    rows = oracle.synth_rows(n, d).copy()
+    zero_rows = [3, 500, 2999]
+    for r in zero_rows:
+        rows[r] = 0.0
+    h, o, ids = build_both(hip, oracle, rows)
+    qs = oracle.synth_queries(n, d, 6).copy()
+    qs[2] = 0.0                                     # a zero query: every score is NaN, results in row order
+    bi, bs, bd, bc = h.search_batch_arrays(qs, k)
+    for i in range(len(qs)):
+        m = int(bc[i])
+        e = o.search(qs[i], k)
+        assert m == len(e["row"]) == k
+        got = rows_of(ids, bi[i, :m])
+        if i == 2:
+            assert np.all(np.isnan(bs[i, :m])) and list(got) == list(range(k))
+        else:
+            assert not np.any(np.isnan(bs[i, :m]))  # 2997 real scores before any NaN
+            assert_topk_parity(got, bs[i, :m], e["row"], e["score"], what=f"zero rows d={d} k={k} q{i}")
+    # a corpus small enough that NaN rows reach the result: k = all rows
+    small = rows[:40].copy()
+    small[10] = 0.0
+    small[3] = 0.0
+    hs, os_, ids_s = build_both(hip, oracle, small)
+    bi, bs, bd, bc = hs.search_batch_arrays(qs[:4], 40)
+    for i in range(4):
+        e = os_.search(qs[i], 40)
+        got = rows_of(ids_s, bi[i, :int(bc[i])])
+        assert int(bc[i]) == 40
+        if i == 2:
+            assert list(got) == list(range(40))
+        else:
+            assert list(got[-2:]) == [3, 10] and np.all(np.isnan(bs[i, 38:40])) and not np.any(np.isnan(bs[i, :38]))
+            assert_topk_parity(got[:38], bs[i, :38], e["row"][:38], e["score"][:38], what=f"small d={d} q{i}")
