@@ -504,3 +504,30 @@ def test_search_batch_zero_norm_rows_and_queries(hip, oracle, d, k):
         else:
             assert list(got[-2:]) == [3, 10] and np.all(np.isnan(bs[i, 38:40])) and not np.any(np.isnan(bs[i, :38]))
             assert_topk_parity(got[:38], bs[i, :38], e["row"][:38], e["score"][:38], what=f"small d={d} q{i}")
+
+
+@pytest.mark.parametrize("d,k,nq", [(384, 100, 90), (384, 50, 64), (768, 100, 40), (384, 10, 130)])
+def test_search_batch_modes_with_filter_and_tombstones(hip, oracle, d, k, nq):
+    """The same filter / tombstone semantics through every batched kernel mode: lists of 80 (k <= 32), wide lists for
+    32 queries (768-d) and wide lists for all 64 queries (384-d, more than 32 queries in the call)."""
+    n = 24000
+    rows = oracle.synth_rows(n, d)
+    qs = oracle.synth_queries(n, d, nq)
+    h, o, ids = build_both(hip, oracle, rows)
+    for r in range(0, n, 3):
+        kind, agent = ("fact" if r % 2 else "event"), ("kai" if r % 5 else "rex")
+        h.set_metadata(ids[r].tobytes(), kind, agent)
+        o.set_metadata(ids[r].tobytes(), kind, agent)
+    for r in list(range(100, 160)) + [0, n - 1]:
+        h.remove(ids[r].tobytes()); o.remove(ids[r].tobytes())
+    excl = [ids[i].tobytes() for i in range(1, 40)]
+    hf, of = hip.VectorFilter(kinds=["fact"], exclude=excl, source_agent="kai"), oracle.Filter(kinds=["fact"], exclude=excl, source_agent="kai")
+    bi, bs, bd, bc = h.search_batch_arrays(qs, k, hf)
+    for i in range(nq):
+        e = o.search(qs[i], k, of)
+        m = int(bc[i])
+        assert m == len(e["row"])
+        assert_topk_parity(rows_of(ids, bi[i, :m]), bs[i, :m], e["row"], e["score"], what=f"modes d={d} k={k} q{i}")
+    # and twice the same call gives the same bytes
+    b2 = h.search_batch_arrays(qs, k, hf)
+    assert np.array_equal(bi, b2[0]) and np.array_equal(bs, b2[1]) and np.array_equal(bc, b2[3])
