@@ -100,12 +100,16 @@ __device__ inline float wave_sum_dpp(float v) {
 // A list entry is (row, dot) plus, for E = 1, |row|^2 — 12 bytes, so that no compaction and no final ordering goes
 // back to HBM for the norm (the wide lists spend that LDS on length and gather it from the index's norm cache,
 // a.norms); the producers copy the norms per tile into LDS for the consumers' per-tile test.
-// MODE: 1 = lists of 80 (k <= 32), 64 queries; 4 = wide lists, 32 queries; 8 = wide lists, all 64 queries (384-d only)
+// MODE: 1 = lists of 80 (k <= 32), 64 queries; 4 = wide lists, 32 queries; 8 = wide lists, all 64 queries (at 768-d with a
+// single tile buffer)
 template <int D, bool DIAG, int MODE>
 __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
     using C = Batch2Cfg<D>;
     constexpr int E = MODE == 1 ? 1 : 4;
-    static_assert(MODE == 1 || MODE == 4 || (MODE == 8 && D == 384), "wide lists for 64 queries fit LDS at 384-d only");
+    // tile buffers: two (the producers write tile t + 1 while the consumers read tile t), except for the wide lists of
+    // all 64 queries at 768-d, which leave LDS for one 48 KiB buffer: there the producers write between two barriers
+    // while the consumers wait, and compact while the consumers compute
+    constexpr uint32_t NBUF = (MODE == 8 && D == 768) ? 1u : 2u;
     // grid = (row chunks, query groups): block (x, y) scans the tiles t = x (mod gridDim.x) for query group y
     // (64 queries, 32 in the wide mode).  Small corpora get few chunks — so that a block still sees enough rows
     // for its own bound to mean something — and many groups per launch; large ones one group on every CU.
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // LDS: [2 tiles: hi image | lo image][rr: 2 x 16 f32][cand rows | dots | (E = 1) norms: QC x capq][tau][cnt][tsq][pub][shr][qq]
     char *tiles = smem;
-    float *c_rr = reinterpret_cast<float *>(smem + 2 * C::TILE_BYTES);
+    float *c_rr = reinterpret_cast<float *>(smem + NBUF * C::TILE_BYTES);
     const uint32_t capq = a.capq;
     // queries that own a candidate list: 64, or 32 for the wide lists (two 48 KiB tile buffers leave LDS for 32 lists
     // of 248); at 384-d the tiles are half as big and MODE 8 keeps all 64 queries (lists of 216) — 1.4x the queries per
@@ -460,16 +464,30 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
             // the slot loads go out BEFORE this step's tile reloads: waiting for them next step then leaves the
             // reloads in flight (vmcnt counts in issue order)
             if ((it & 3u) == 0u) refresh_issue(it >> 2);
-            if (next < n_tiles) {
-                write_tile(ld, nr, buf ^ 1u, next + 2u * gridDim.x);     // buffer last read one tile ago, behind that tile's barrier
-                stamp(t_write);
+            if constexpr (NBUF == 2) {
+                if (next < n_tiles) {
+                    write_tile(ld, nr, buf ^ 1u, next + 2u * gridDim.x);     // buffer last read one tile ago, behind that tile's barrier
+                    stamp(t_write);
+                }
+                it++;
+                producer_compact();
+                stamp(t_stage);
+                tile_barrier();
+                stamp(t_bar);
+                buf ^= 1u;
+            } else {
+                it++;
+                producer_compact();          // while the consumers work on `tile`
+                stamp(t_stage);
+                tile_barrier();              // the consumers are done with the buffer
+                stamp(t_bar);
+                if (next < n_tiles) {
+                    write_tile(ld, nr, 0u, next + 2u * gridDim.x);
+                    stamp(t_write);
+                }
+                tile_barrier();              // the next tile is in place
+                stamp(t_bar);
             }
-            it++;
-            producer_compact();
-            stamp(t_stage);
-            tile_barrier();
-            stamp(t_bar);
-            buf ^= 1u;
             tile += gridDim.x;
         };
         // tiles are taken two per loop iteration, always both (a step past the last tile only keeps the barrier; the
@@ -554,7 +572,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
     const uint32_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - 1u - blockIdx.x) / gridDim.x + 1u : 0u;
     const uint32_t my_steps = (my_tiles + 1u) & ~1u;   // the producers step in pairs
     for (uint32_t st = 0, tile = blockIdx.x; st < my_steps; st++, tile += gridDim.x) {
-        if (wave_dead || tile >= n_tiles) { tile_barrier(); buf ^= 1u; continue; }
+        if (wave_dead || tile >= n_tiles) { tile_barrier(); if constexpr (NBUF == 2) buf ^= 1u; else tile_barrier(); continue; }
         apply_shrink();
         stamp(t_stage);
         const char *Thi = tiles + buf * C::TILE_BYTES, *Tlo = Thi + C::IMG_BYTES;
@@ -625,8 +643,9 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
         }
         stamp(t_epi);
         tile_barrier();
+        if constexpr (NBUF == 2) buf ^= 1u;
+        else tile_barrier();   // single buffer: the producers write the next tile between the two barriers
         stamp(t_bar);
-        buf ^= 1u;
     }
     apply_shrink();
     if constexpr (DIAG) {
@@ -693,7 +712,7 @@ uint32_t batch_grid_blocks(uint32_t n_rows) {
 bool batch_supported(uint32_t dim, uint32_t k) { return (dim == 384 || dim == 768) && k >= 1 && k <= BATCH_K_WIDE; }
 uint32_t batch_queries_per_pass(uint32_t dim, uint32_t k, uint64_t nq) {
     static const int full = getenv("CX_BATCH_WIDE_FULL") ? atoi(getenv("CX_BATCH_WIDE_FULL")) : 1;   // 0: wide lists always 32 queries per pass
-    return (k <= 32 || (full && dim == 384 && nq > 32)) ? 64u : 32u;
+    return (k <= 32 || (full && nq > 32)) ? 64u : 32u;
 }
 
 // launch shape for nq queries over n_rows rows: chunks x groups blocks.  A block should see >= 256 tiles (4096
@@ -721,7 +740,8 @@ static int launch_batch_d(BatchArgs a, uint32_t grid, hipStream_t stream) {
     const bool wide = a.k > 32;   // 32 queries per pass, lists of up to 272, four entries per lane in a compaction
     const size_t qc = a.qpp;
     const size_t tail = qc * a.capq * (wide ? 8 : 12) + BT_Q * 8 + BT_Q * 4 + BT_Q * 4 + 3 * BT_Q * 4;
-    const size_t lds = 2 * (size_t)Batch2Cfg<D>::TILE_BYTES + 2 * BT_ROWS * 4 + tail;
+    const size_t nbuf = (wide && a.qpp == 64u && D == 768) ? 1 : 2;   // batch2_kernel: NBUF
+    const size_t lds = nbuf * (size_t)Batch2Cfg<D>::TILE_BYTES + 2 * BT_ROWS * 4 + tail;
     if (lds > 160 * 1024) return set_err(CX_ERR_VALIDATION, "batch scan: %zu bytes of LDS for k = %u", lds, a.k);
     static std::atomic<uint64_t> attr_devices{0};
     if (first_use_on_device(attr_devices)) {
@@ -729,16 +749,14 @@ static int launch_batch_d(BatchArgs a, uint32_t grid, hipStream_t stream) {
         CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch2_kernel<D, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch2_kernel<D, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch2_kernel<D, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        if constexpr (D == 384) {
-            CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch2_kernel<D, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch2_kernel<D, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        }
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch2_kernel<D, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batch2_kernel<D, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     if (getenv("CX_BATCH_DIAG")) {  // diagnostic build: per-phase cycle shares on stderr, results still valid
         const size_t n = (size_t)grid * a.n_groups * 8 * 8;   // up to 8 waves x 8 slots per block
         CX_HIP(hipMalloc((void **)&a.diag, n * 8));
         CX_HIP(hipMemset(a.diag, 0, n * 8));
-        if (wide && a.qpp == 64u) { if constexpr (D == 384) hipLaunchKernelGGL((batch2_kernel<D, true, 8>), dim3(grid, a.n_groups), dim3(512), lds, stream, a); }
+        if (wide && a.qpp == 64u) hipLaunchKernelGGL((batch2_kernel<D, true, 8>), dim3(grid, a.n_groups), dim3(512), lds, stream, a);
         else if (wide) hipLaunchKernelGGL((batch2_kernel<D, true, 4>), dim3(grid, a.n_groups), dim3(512), lds, stream, a);
         else hipLaunchKernelGGL((batch2_kernel<D, true, 1>), dim3(grid, a.n_groups), dim3(512), lds, stream, a);
         CX_HIP(hipStreamSynchronize(stream));
@@ -758,7 +776,7 @@ static int launch_batch_d(BatchArgs a, uint32_t grid, hipStream_t stream) {
                 s[0] / tiles, s[1] / tiles, s[2] / tiles, s[3] / tiles, s[5] / tiles, s[6] / tiles, s[4] / tiles);
         return CX_OK;
     }
-    if (wide && a.qpp == 64u) { if constexpr (D == 384) hipLaunchKernelGGL((batch2_kernel<D, false, 8>), dim3(grid, a.n_groups), dim3(512), lds, stream, a); }
+    if (wide && a.qpp == 64u) hipLaunchKernelGGL((batch2_kernel<D, false, 8>), dim3(grid, a.n_groups), dim3(512), lds, stream, a);
     else if (wide) hipLaunchKernelGGL((batch2_kernel<D, false, 4>), dim3(grid, a.n_groups), dim3(512), lds, stream, a);
     else hipLaunchKernelGGL((batch2_kernel<D, false, 1>), dim3(grid, a.n_groups), dim3(512), lds, stream, a);
     CX_HIP(hipGetLastError());
@@ -770,13 +788,12 @@ int launch_batch_scan(BatchArgs a, uint32_t grid, hipStream_t stream) {
     if (a.n_groups == 0) a.n_groups = 1;
     const uint32_t qpp = a.qpp;
     if (qpp != 64u && !(qpp == 32u && a.k > 32)) return set_err(CX_ERR_VALIDATION, "batch scan: %u queries per pass for k = %u", qpp, a.k);
-    if (qpp == 64u && a.k > 32 && a.dim != 384) return set_err(CX_ERR_VALIDATION, "batch scan: wide lists for 64 queries need dim 384");
     if (a.nq == 0 || a.nq > qpp * a.n_groups || a.nq <= qpp * (a.n_groups - 1))
         return set_err(CX_ERR_VALIDATION, "batch scan: %u queries do not fill %u groups of %u (k = %u)", a.nq, a.n_groups, qpp, a.k);
     // batch2: lists are compacted at capq - 32 entries (<= 64: one per lane) and never exceed capq; k + 16 <= capq - 32
     a.capq = 80u;
     if (a.k > 32) {   // wide: as long as LDS allows (a compaction absorbs capq - 32 - k new entries), at most 4 x 64 + 16
-        const size_t tiles = 2 * (a.dim == 384 ? (size_t)Batch2Cfg<384>::TILE_BYTES : (size_t)Batch2Cfg<768>::TILE_BYTES);
+        const size_t tiles = a.dim == 384 ? 2 * (size_t)Batch2Cfg<384>::TILE_BYTES : (qpp == 64u ? 1 : 2) * (size_t)Batch2Cfg<768>::TILE_BYTES;
         const size_t room = 160 * 1024 - tiles - 2 * BT_ROWS * 4 - (BT_Q * 8 + BT_Q * 4 + BT_Q * 4 + 3 * BT_Q * 4);
         uint32_t c = (uint32_t)(room / (qpp * 8)) & ~7u;
         a.capq = c > 272u ? 272u : c;

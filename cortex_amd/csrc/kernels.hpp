@@ -82,7 +82,7 @@ bool batch_supported(uint32_t dim, uint32_t k);
 uint32_t batch_grid_blocks(uint32_t n_rows);
 // rows [row_lo, row_hi) -> the split store the batched search reads (dim 384 / 768)
 int launch_build_split(const float *rows, char *split, uint32_t row_lo, uint32_t row_hi, uint32_t dim, hipStream_t stream);
-// 64; 32 for the wide lists (32 < k <= 104) unless the corpus is 384-d and the call has more than 32 queries
+// 64; 32 for the wide lists (32 < k <= 104) when the call has no more than 32 queries
 uint32_t batch_queries_per_pass(uint32_t dim, uint32_t k, uint64_t nq);
 void batch_launch_shape(uint32_t n_rows, uint32_t dim, uint64_t nq, uint32_t k, uint32_t *chunks, uint32_t *groups);
 // one pass of <= 64 queries; per-block lists, to be folded by launch_merge_batch
