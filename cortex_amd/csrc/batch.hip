@@ -100,16 +100,16 @@ __device__ inline float wave_sum_dpp(float v) {
 // A list entry is (row, dot) plus, for E = 1, |row|^2 — 12 bytes, so that no compaction and no final ordering goes
 // back to HBM for the norm (the wide lists spend that LDS on length and gather it from the index's norm cache,
 // a.norms); the producers copy the norms per tile into LDS for the consumers' per-tile test.
-// MODE: 1 = lists of 80 (k <= 32), 64 queries; 4 = wide lists, 32 queries; 8 = wide lists, all 64 queries (at 768-d with a
-// single tile buffer)
+// MODE: 1 = lists of 80 (k <= 32), 64 queries; 4 = wide lists, 32 queries; 8 = wide lists, all 64 queries, one tile buffer
 template <int D, bool DIAG, int MODE>
 __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
     using C = Batch2Cfg<D>;
     constexpr int E = MODE == 1 ? 1 : 4;
     // tile buffers: two (the producers write tile t + 1 while the consumers read tile t), except for the wide lists of
-    // all 64 queries at 768-d, which leave LDS for one 48 KiB buffer: there the producers write between two barriers
-    // while the consumers wait, and compact while the consumers compute
-    constexpr uint32_t NBUF = (MODE == 8 && D == 768) ? 1u : 2u;
+    // all 64 queries: at 768-d they leave LDS for one 48 KiB buffer only, so the producers write between two barriers
+    // while the consumers wait, and compact while the consumers compute; at 384-d two buffers would fit, but one
+    // buys lists of 264 instead of 216 (a third fewer compactions, and this mode is compaction-bound): 8 % faster
+    constexpr uint32_t NBUF = MODE == 8 ? 1u : 2u;
     // grid = (row chunks, query groups): block (x, y) scans the tiles t = x (mod gridDim.x) for query group y
     // (64 queries, 32 in the wide mode).  Small corpora get few chunks — so that a block still sees enough rows
     // for its own bound to mean something — and many groups per launch; large ones one group on every CU.
@@ -740,7 +740,7 @@ static int launch_batch_d(BatchArgs a, uint32_t grid, hipStream_t stream) {
     const bool wide = a.k > 32;   // 32 queries per pass, lists of up to 272, four entries per lane in a compaction
     const size_t qc = a.qpp;
     const size_t tail = qc * a.capq * (wide ? 8 : 12) + BT_Q * 8 + BT_Q * 4 + BT_Q * 4 + 3 * BT_Q * 4;
-    const size_t nbuf = (wide && a.qpp == 64u && D == 768) ? 1 : 2;   // batch2_kernel: NBUF
+    const size_t nbuf = (wide && a.qpp == 64u) ? 1 : 2;   // batch2_kernel: NBUF
     const size_t lds = nbuf * (size_t)Batch2Cfg<D>::TILE_BYTES + 2 * BT_ROWS * 4 + tail;
     if (lds > 160 * 1024) return set_err(CX_ERR_VALIDATION, "batch scan: %zu bytes of LDS for k = %u", lds, a.k);
     static std::atomic<uint64_t> attr_devices{0};
@@ -793,7 +793,7 @@ int launch_batch_scan(BatchArgs a, uint32_t grid, hipStream_t stream) {
     // batch2: lists are compacted at capq - 32 entries (<= 64: one per lane) and never exceed capq; k + 16 <= capq - 32
     a.capq = 80u;
     if (a.k > 32) {   // wide: as long as LDS allows (a compaction absorbs capq - 32 - k new entries), at most 4 x 64 + 16
-        const size_t tiles = a.dim == 384 ? 2 * (size_t)Batch2Cfg<384>::TILE_BYTES : (qpp == 64u ? 1 : 2) * (size_t)Batch2Cfg<768>::TILE_BYTES;
+        const size_t tiles = (qpp == 64u ? 1 : 2) * (a.dim == 384 ? (size_t)Batch2Cfg<384>::TILE_BYTES : (size_t)Batch2Cfg<768>::TILE_BYTES);
         const size_t room = 160 * 1024 - tiles - 2 * BT_ROWS * 4 - (BT_Q * 8 + BT_Q * 4 + BT_Q * 4 + 3 * BT_Q * 4);
         uint32_t c = (uint32_t)(room / (qpp * 8)) & ~7u;
         a.capq = c > 272u ? 272u : c;
