@@ -710,9 +710,14 @@ uint32_t batch_grid_blocks(uint32_t n_rows) {
 }
 
 bool batch_supported(uint32_t dim, uint32_t k) { return (dim == 384 || dim == 768) && k >= 1 && k <= BATCH_K_WIDE; }
+// k above which the wide lists are used
+static bool batch_wide_k(uint32_t k) {
+    static const int wide_min = getenv("CX_BATCH_WIDE_MIN_K") ? atoi(getenv("CX_BATCH_WIDE_MIN_K")) : 33;
+    return (int)k >= wide_min;
+}
 uint32_t batch_queries_per_pass(uint32_t dim, uint32_t k, uint64_t nq) {
     static const int full = getenv("CX_BATCH_WIDE_FULL") ? atoi(getenv("CX_BATCH_WIDE_FULL")) : 1;   // 0: wide lists always 32 queries per pass
-    return (k <= 32 || (full && nq > 32)) ? 64u : 32u;
+    return (!batch_wide_k(k) || (full && nq > 32)) ? 64u : 32u;
 }
 
 // launch shape for nq queries over n_rows rows: chunks x groups blocks.  A block should see >= 256 tiles (4096
@@ -737,7 +742,7 @@ void batch_launch_shape(uint32_t n_rows, uint32_t dim, uint64_t nq, uint32_t k, 
 
 template <int D>
 static int launch_batch_d(BatchArgs a, uint32_t grid, hipStream_t stream) {
-    const bool wide = a.k > 32;   // 32 queries per pass, lists of up to 272, four entries per lane in a compaction
+    const bool wide = batch_wide_k(a.k);   // 32 queries per pass, lists of up to 272, four entries per lane in a compaction
     const size_t qc = a.qpp;
     const size_t tail = qc * a.capq * (wide ? 8 : 12) + BT_Q * 8 + BT_Q * 4 + BT_Q * 4 + 3 * BT_Q * 4;
     const size_t nbuf = (wide && a.qpp == 64u) ? 1 : 2;   // batch2_kernel: NBUF
@@ -787,12 +792,12 @@ int launch_batch_scan(BatchArgs a, uint32_t grid, hipStream_t stream) {
     if (!batch_supported(a.dim, a.k)) return set_err(CX_ERR_VALIDATION, "batch scan: unsupported dim %u / k %u", a.dim, a.k);
     if (a.n_groups == 0) a.n_groups = 1;
     const uint32_t qpp = a.qpp;
-    if (qpp != 64u && !(qpp == 32u && a.k > 32)) return set_err(CX_ERR_VALIDATION, "batch scan: %u queries per pass for k = %u", qpp, a.k);
+    if (qpp != 64u && !(qpp == 32u && batch_wide_k(a.k))) return set_err(CX_ERR_VALIDATION, "batch scan: %u queries per pass for k = %u", qpp, a.k);
     if (a.nq == 0 || a.nq > qpp * a.n_groups || a.nq <= qpp * (a.n_groups - 1))
         return set_err(CX_ERR_VALIDATION, "batch scan: %u queries do not fill %u groups of %u (k = %u)", a.nq, a.n_groups, qpp, a.k);
     // batch2: lists are compacted at capq - 32 entries (<= 64: one per lane) and never exceed capq; k + 16 <= capq - 32
     a.capq = 80u;
-    if (a.k > 32) {   // wide: as long as LDS allows (a compaction absorbs capq - 32 - k new entries), at most 4 x 64 + 16
+    if (batch_wide_k(a.k)) {   // wide: as long as LDS allows (a compaction absorbs capq - 32 - k new entries), at most 4 x 64 + 16
         const size_t tiles = (qpp == 64u ? 1 : 2) * (a.dim == 384 ? (size_t)Batch2Cfg<384>::TILE_BYTES : (size_t)Batch2Cfg<768>::TILE_BYTES);
         const size_t room = 160 * 1024 - tiles - 2 * BT_ROWS * 4 - (BT_Q * 8 + BT_Q * 4 + BT_Q * 4 + 3 * BT_Q * 4);
         uint32_t c = (uint32_t)(room / (qpp * 8)) & ~7u;
