@@ -208,6 +208,8 @@ def main() -> None:
         out.setdefault("extra", {})["config1_10k_x_384_k5"] = config1_leg(L, local_rank)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and (n, d) != (1_000_000, 384):
         out.setdefault("extra", {})["config2_1M_x_384_k10"] = config2_leg(L, local_rank, dev)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_autolink and B == 1:
+        out.setdefault("extra", {})["config4_shard_1.25Mx768_batch64_k10"] = config4_leg(L, local_rank, dev)
     if rank == 0 and world == 1 and not args.no_autolink:
         out.setdefault("extra", {})["autolink_allpairs"] = autolink_leg(L, local_rank, d, args.no_cpu_baseline)
         # the same pass over the bench corpus itself: BASELINE.json's metric names "auto-link pairs/sec at 1Mx768"
@@ -222,6 +224,8 @@ def main() -> None:
             if mp:
                 r["measured_peak_TFLOPs"] = mp
                 r["executed_frac_of_measured"] = r["executed_flops_per_launch"] / (out["extra"][leg]["phase_ms"]["mfma_filter_gemm"] * 1e-3) / 1e12 / mp
+    if rank == 0 and world == 1 and not args.no_autolink and not args.no_cpu_baseline and B == 1:
+        out["extra"]["config5_shard_6.25Mx1024_streaming_ingest"] = config5_leg(L, local_rank, dev)
     if rank == 0:
         print(json.dumps(out), flush=True)
     ix.close()
@@ -339,6 +343,87 @@ def config1_leg(L, device: int, n: int = 10_000, d: int = 384, k: int = 5, nq: i
             "cpu_hnsw_restatement": {"qps_1thread": nq / t_ann, "recall_at_5_vs_exact": rec_h, "build_s": t_build,
                                      "params": "M=32 M0=64 ef_construction=100 ef_search=100",
                                      "note": "restatement of instant-distance 0.6.1 from the HNSW paper; parity unpinned"}}
+
+
+def config4_leg(L, device: int, dev, n: int = 1_250_000, d: int = 768, k: int = 10, B: int = 64, steps: int = 40):
+    """BASELINE configs[3], one GPU's share: 64 queries per step over a 1.25M x 768 f32 shard (10M rows / 8 GPUs),
+    k=10 — the batched MFMA kernel the sharded search runs before its all-gather; same measurement as the headline
+    (cx_search_batch_dev, HIP events around the kernel)."""
+    import cortex_amd
+    gen = torch.empty((n, d), dtype=torch.float32, device=dev)
+    assert L.cx_synth_fill_dev(device, gen.data_ptr(), SEED_CORPUS, SEED_CORPUS, SEED_DUP, n // 50, 0, n, d, 1) == 0
+    ix = cortex_amd.HipIndex(d, device=device)
+    ix.reserve(n)
+    ix.insert_batch_dev(synth_ids(0, n), gen.data_ptr(), n, d)
+    del gen
+    qs = torch.empty((256, d), dtype=torch.float32, device=dev)
+    assert L.cx_synth_fill_dev(device, qs.data_ptr(), SEED_CORPUS, SEED_QUERIES, SEED_DUP, n // 50, 0, 256, d, 0) == 0
+    o_rows = torch.empty((B, k), dtype=torch.int32, device=dev)
+    o_sc = torch.empty((B, k), dtype=torch.float32, device=dev)
+    o_di = torch.empty((B, k), dtype=torch.float32, device=dev)
+    o_cnt = torch.empty(B, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def one(i):
+        ix.search_batch_dev(qs.data_ptr() + ((i * B) % (256 - B + 1)) * d * 4, B, k, o_rows.data_ptr(), o_sc.data_ptr(),
+                            o_di.data_ptr(), o_cnt.data_ptr(), stream)
+    for i in range(5):
+        one(i)
+    torch.cuda.synchronize()
+    ix.profile_read(reset=True)
+    ix.profile_enable(True)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one(i)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ix.profile_enable(False)
+    kern_ms, kern_n = ix.profile_read(reset=True)
+    ix.close()
+    avg = kern_ms / max(1, kern_n)
+    algo = float(n) * d * 4.0
+    return {"workload": f"cosine kNN k={k}, batch of {B} queries per step, {n} x {d} f32 rows (one of 8 shards of 10M rows)",
+            "queries_per_s": steps * B / el, "ms_per_step": el / steps * 1e3,
+            "roofline": {"bound": "hbm", "achieved": algo / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": algo / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": "cx::batch2_kernel", "avg_kernel_ms": avg,
+                         "launches": kern_n, "algorithmic_bytes_per_launch": algo}}
+
+
+def config5_leg(L, device: int, dev, n: int = 6_250_000, d: int = 1024, thr: float = 0.85):
+    """BASELINE configs[4], one GPU's share: a 6.25M x 1024 shard (50M rows / 8 GPUs; 25.6 GB f32 + 12.8 GB bf16
+    shadow), streaming auto-link ingest — batches of 64 and 500 new rows linked against the whole shard
+    (cx_autolink_pass_timed).  The filter streams the bf16 shadow once per batch: HBM-bound at 64, MFMA-bound at 500."""
+    import cortex_amd
+    ix = cortex_amd.HipIndex(d, device=device)
+    ix.reserve(n)
+    chunk = 1_000_000
+    for lo in range(0, n, chunk):
+        m = min(chunk, n - lo)
+        gen = torch.empty((m, d), dtype=torch.float32, device=dev)
+        assert L.cx_synth_fill_dev(device, gen.data_ptr(), SEED_CORPUS, SEED_CORPUS, SEED_DUP, n // 50, lo, m, d, 1) == 0
+        ix.insert_batch_dev(synth_ids(lo, m), gen.data_ptr(), m, d)
+        del gen
+    t = float(np.float32(thr))
+    ix.autolink_pass_timed(100, t, 50, np.arange(n - 64, n, dtype=np.uint32))   # builds the shadow
+    out = {"workload": f"streaming auto-link ingest against a {n} x {d} shard (bf16 shadow {n * d * 2 / 1e9:.1f} GB), threshold {thr}, top-100, 50 edges/node"}
+    for b in (64, 500):
+        scan = np.arange(n - b, n, dtype=np.uint32)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            ne, ph = ix.autolink_pass_timed(100, t, 50, scan)
+            w = time.perf_counter() - t0
+            if best is None or w < best[0]:
+                best = (w, ph, ne)
+        w, ph, ne = best
+        gbs = n * d * 2 / (ph[1] * 1e-3) / 1e9
+        tf = 2.0 * (-(-b // 128) * 128) * n * d / (ph[1] * 1e-3) / 1e12
+        out[f"batch_{b}"] = {"wall_ms": w * 1e3, "filter_ms": ph[1], "rescore_ms": ph[2], "edges": int(ne), "pairs_per_s": b * n / w,
+                             "roofline": ({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
+                                          if b <= 128 else
+                                          {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0})}
+    ix.close()
+    return out
 
 
 def config2_leg(L, device: int, dev, n: int = 1_000_000, d: int = 384, k: int = 10, steps: int = 300):
