@@ -531,3 +531,45 @@ def test_search_batch_modes_with_filter_and_tombstones(hip, oracle, d, k, nq):
     # and twice the same call gives the same bytes
     b2 = h.search_batch_arrays(qs, k, hf)
     assert np.array_equal(bi, b2[0]) and np.array_equal(bs, b2[1]) and np.array_equal(bc, b2[3])
+
+
+def test_more_than_4G_elements(hip, oracle):
+    """5.7M x 768 = 4.4e9 elements (17.5 GB): element offsets no longer fit 32 bits.  Rows near the end of the store
+    must find themselves through the single-query scan, the batched kernel (split store) and the wide lists, and the
+    oracle's exact answer over the last rows' neighbourhood must match."""
+    import torch
+    from cortex_amd import _lib
+    L = _lib.load()
+    n, d = 5_700_000, 768
+    h = hip.HipIndex(d)
+    h.reserve(n)
+    chunk = 950_000
+    keep = {}
+    for lo in range(0, n, chunk):
+        m = min(chunk, n - lo)
+        gen = torch.empty((m, d), dtype=torch.float32, device="cuda:0")
+        assert L.cx_synth_fill_dev(0, gen.data_ptr(), oracle.SEED_CORPUS, oracle.SEED_CORPUS, oracle.SEED_DUP, n // 50, lo, m, d, 1) == 0
+        ids = np.zeros((m, 16), np.uint8)
+        ids[:, 8:] = (np.arange(m, dtype=np.uint64) + np.uint64(lo)).astype(">u8").view(np.uint8).reshape(m, 8)
+        h.insert_batch_dev(ids, gen.data_ptr(), m, d)
+        for r in (0, m // 2, m - 1):
+            keep[lo + r] = gen[r].cpu().numpy()
+        del gen
+    assert h.len() == n
+    probes = sorted(keep)
+    q = np.stack([keep[r] for r in probes])
+
+    def row_of(id16):
+        return int(np.frombuffer(id16.tobytes()[8:], dtype=">u8")[0])
+
+    for r, v in zip(probes, q):
+        gi, gs, gd = h.search_arrays(v, 5)
+        assert gs[0] >= 1.0 - SCORE_TOL and r in [row_of(x) for x in gi[:2]], f"row {r} (single)"
+        assert np.all(np.diff(gs) <= 0)
+    for k in (10, 100):
+        bi, bs, bd, bc = h.search_batch_arrays(np.concatenate([q] * 3)[:40], k)     # 40 queries: batched / wide (64-query) kernels
+        for j in range(40):
+            r = probes[j % len(probes)]
+            assert int(bc[j]) == k and bs[j, 0] >= 1.0 - SCORE_TOL and r in [row_of(x) for x in bi[j, :2]], f"row {r} (batch k={k})"
+            gi, gs, gd = h.search_arrays(q[j % len(probes)], k)
+            assert_topk_parity(np.array([row_of(x) for x in bi[j, :k]]), bs[j, :k], np.array([row_of(x) for x in gi]), gs, what=f"batch vs single k={k} q{j}")
