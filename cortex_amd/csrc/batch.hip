@@ -289,7 +289,16 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
         // hold cosines of k DIFFERENT rows, so their minimum is a valid lower bound of the query's global k-th best
         // cosine whichever blocks contributed — rows below it can be skipped by everyone.  Results do not depend
         // on timing: the bound only removes rows that cannot be in the top k.
-        unsigned long long n_pcompact = 0;
+        unsigned long long n_pcompact = 0, n_tie = 0, cp[6] = {0, 0, 0, 0, 0, 0}, cp_t = 0;
+        auto cstamp = [&](int i) {
+            if constexpr (DIAG) {
+                __builtin_amdgcn_sched_barrier(0);
+                unsigned long long t;
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+                __builtin_amdgcn_sched_barrier(0);
+                cp[i] += t - cp_t; cp_t = t;
+            }
+        };
         // E = 1: 4 lanes per query, all 16 queries of the group per refresh, slots at stride 32;
         // wide (E = 4): 8 lanes per query, the 8 queries this producer owns per refresh, stride 128
         constexpr uint32_t LPQ = E == 1 ? 4u : 8u, NG = E == 1 ? 4u : 7u, GSTRIDE = E == 1 ? 32u : 128u;
@@ -339,7 +348,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
             while (need) {
                 const int l = __ffsll((unsigned long long)need) - 1;
                 need &= need - 1;
-                if constexpr (DIAG) n_pcompact++;
+                if constexpr (DIAG) { n_pcompact++; cstamp(5); }
                 const uint32_t qs = own_grp * 16u + (uint32_t)l;
                 uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)pubv, l);
                 n = n < 64u * E ? n : 64u * E;
@@ -361,6 +370,8 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
                         ord[e] = score_ord(score_of(distance_of(sim[e])));
                     }
                 }
+                if constexpr (DIAG) asm volatile("s_nop 0" :: "v"(ord[0]), "v"(ord[E - 1]));
+                cstamp(0);   // entries read, norms gathered, cosines formed
                 auto count_ge = [&](uint32_t t) {
                     uint32_t c = 0;
 #pragma unroll
@@ -384,6 +395,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
                     b = __builtin_amdgcn_readfirstlane(b - 1);
                 }
                 const bool exact_k = c_at_T == k;
+                cstamp(1);   // radix walk
                 uint64_t gt[E], eq[E], keep[E];
                 uint32_t n_gt = 0, n_eq = 0;
 #pragma unroll
@@ -395,21 +407,40 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
                     keep[e] = gt[e] | eq[e];
                 }
                 if (!exact_k && n_eq != k - n_gt) {   // equal scores straddle the cut: lower rows win
+                    if constexpr (DIAG) n_tie++;
                     const uint32_t want_eq = k - n_gt;
-                    uint32_t rk[E];
+                    if (n_eq > 24u) {
+                        // many equal scores (a wide list's first compaction: half of the first rows have a non-positive
+                        // cosine, i.e. score 0): the want_eq lowest rows among them by a radix walk over the row index —
+                        // rows are unique, so exactly want_eq survive — instead of ranking each against all the others
+                        uint32_t R = 0;
+#pragma unroll 1
+                        for (int rb = 31 - __builtin_clz(n_rows | 1u); rb >= 0; rb--) {
+                            const uint32_t cand = R | (1u << rb);
+                            uint32_t c = 0;
 #pragma unroll
-                    for (int e = 0; e < E; e++) rk[e] = 0;
-#pragma unroll
-                    for (int f = 0; f < E; f++)
-                        for (uint64_t m = eq[f]; m; m &= m - 1) {
-                            const uint32_t ro = (uint32_t)__builtin_amdgcn_readlane((int)r0[f], __ffsll((unsigned long long)m) - 1);
-#pragma unroll
-                            for (int e = 0; e < E; e++) rk[e] += ro < r0[e] ? 1u : 0u;
+                            for (int e = 0; e < E; e++) c += (uint32_t)__popcll(__ballot(valid[e] && ord[e] == T && r0[e] < cand));
+                            R = (uint32_t)__builtin_amdgcn_readfirstlane((int)(c < want_eq ? cand : R));
                         }
 #pragma unroll
-                    for (int e = 0; e < E; e++) keep[e] = gt[e] | __ballot(valid[e] && ord[e] == T && rk[e] < want_eq);
+                        for (int e = 0; e < E; e++) keep[e] = gt[e] | __ballot(valid[e] && ord[e] == T && r0[e] <= R);
+                    } else {
+                        uint32_t rk[E];
+#pragma unroll
+                        for (int e = 0; e < E; e++) rk[e] = 0;
+#pragma unroll
+                        for (int f = 0; f < E; f++)
+                            for (uint64_t m = eq[f]; m; m &= m - 1) {
+                                const uint32_t ro = (uint32_t)__builtin_amdgcn_readlane((int)r0[f], __ffsll((unsigned long long)m) - 1);
+#pragma unroll
+                                for (int e = 0; e < E; e++) rk[e] += ro < r0[e] ? 1u : 0u;
+                            }
+#pragma unroll
+                        for (int e = 0; e < E; e++) keep[e] = gt[e] | __ballot(valid[e] && ord[e] == T && rk[e] < want_eq);
+                    }
                 }
                 // the k-th best = the smallest kept score order, and among equal ones the largest row
+                cstamp(2);   // keep masks and ties
                 uint32_t mine = 0xFFFFFFFFu;
 #pragma unroll
                 for (int e = 0; e < E; e++) mine = (((keep[e] >> lane) & 1ull) && ord[e] < mine) ? ord[e] : mine;
@@ -422,6 +453,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
                         const uint32_t ro = (uint32_t)__builtin_amdgcn_readlane((int)r0[e], le);
                         if (ro >= trow) { trow = ro; tsim = readlane_f32(sim[e], le); }
                     }
+                cstamp(4);   // k-th entry (wave min, its row)
                 // survivors to [0, k): rank in (slot, lane) order <= the entry's old index, and every lane read first
                 uint32_t base = 0;
 #pragma unroll
@@ -438,9 +470,14 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
                     if (((keep[e] >> lane) & 1ull) && sim[e] > 0.0f)
                         __hip_atomic_fetch_max(a.gslots + qs * GSTRIDE + ((r0[e] * 2654435761u) >> 16) % k, __float_as_uint(sim[e]),
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cstamp(3);   // survivors written, slot atomics issued
                 if (lane == 0) {
                     c_tau[qs] = cand_key(trow, tsim);
-                    const float t = tsim > 0.0f ? tsim * tsim * (1.0f - 1.0e-4f) : -1.0f;
+                    // k-th best score is 0 (a clamped non-positive cosine): every later row with dot <= 0 ties with it
+                    // at a higher row and loses, so from here on only positive dots are candidates (t = 0); without
+                    // this the list kept refilling with score-0 rows and every compaction ran the tie rule over ~100 of
+                    // them.  A NaN k-th score (fewer than k comparable rows yet) leaves the door open (t = -1).
+                    const float t = tsim > 0.0f ? tsim * tsim * (1.0f - 1.0e-4f) : (tsim == tsim ? 0.0f : -1.0f);
                     if (t > c_tsq[qs]) c_tsq[qs] = t;
                     c_shr[qs] = n;
                 }
@@ -501,6 +538,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
             if (lane == 0) {
                 unsigned long long *o = a.diag + ((size_t)blockIdx.x * 8 + wave) * 8;
                 o[0] = t_stage; o[3] = t_bar; o[5] = t_wait; o[6] = t_write; o[7] = n_pcompact;
+                if (blockIdx.x == 7 && wave == 5 && n_pcompact) printf("[batch2 diag] block 7 producer 1: %llu compactions; cycles each: load+gather+cos %llu, radix %llu, keep masks+ties %llu, k-th entry %llu, scatter+atomics %llu; tie branches %llu\n", n_pcompact, cp[0] / n_pcompact, cp[1] / n_pcompact, cp[2] / n_pcompact, cp[4] / n_pcompact, cp[3] / n_pcompact, n_tie);
             }
         }
         __syncthreads();   // the consumers have slid their last appends into place
