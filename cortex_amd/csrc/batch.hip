@@ -1,6 +1,7 @@
 // batch.hip — batched exact search: many queries per pass over the corpus (VectorIndex::search_batch,
 // vector/index.rs:390-410; BASELINE config 4's inner loop; the auto-linker's top-100 lists).  The reference runs B
-// independent scans (rayon, one per query); here the row store is read ONCE per 64 (or 32) queries.
+// independent scans (rayon, one per query); here the row store is read ONCE per 64 queries (32 for the wide lists of a
+// call with no more than 32 queries).
 //
 // At B = 64 the contraction needs 32 flop per corpus byte — past what f32 VALU FMAs sustain next to an 8 TB/s
 // stream — so the dot products run on the matrix cores.  An exact-f32 MFMA (v_mfma_f32_16x16x4_f32) version of this
@@ -13,7 +14,7 @@
 //    (build_split_kernel, cx_index::d_split) and their |row|^2 (d_norms);
 //  - 512-thread block per CU: 4 consumer waves (16 queries each in registers, MFMA loop, per-tile test, appends)
 //    and 4 producer waves (move the next tiles HBM -> registers -> LDS, compact the candidate lists, share a
-//    score bound with the other blocks); one block barrier per 16-row tile;
+//    score bound with the other blocks); one block barrier per 16-row tile (two in the single-buffer wide mode, MODE 8);
 //  - per-block lists go to HBM, one merge block per query finishes (merge_small_kernel / merge_radix_kernel).
 #include <vector>
 
@@ -96,7 +97,8 @@ __device__ inline float wave_sum_dpp(float v) {
 }
 
 // E = candidate-list entries a lane holds in a compaction: 1 for k <= 32 (64 queries per pass, lists of 80),
-// 4 for k <= 104 ("wide": 32 queries per pass — the auto-linker's top-100 lists — lists of up to 272).
+// 4 for k <= 104 ("wide": the auto-linker's top-100 lists — 32 queries per pass with lists of up to 272, or all 64 with
+// lists of 216 / 264 beside a single tile buffer when the call has more than 32 queries).
 // A list entry is (row, dot) plus, for E = 1, |row|^2 — 12 bytes, so that no compaction and no final ordering goes
 // back to HBM for the norm (the wide lists spend that LDS on length and gather it from the index's norm cache,
 // a.norms); the producers copy the norms per tile into LDS for the consumers' per-tile test.
