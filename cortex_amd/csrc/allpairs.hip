@@ -384,9 +384,195 @@ __global__ __launch_bounds__(256) void rescore_kernel(const RescoreArgs a) {
     }
 }
 
+// ---- symmetric pass: each pair scored once ------------------------------------------------------------------
+// The rescore is bound by bytes: 1.5M candidate rows x 3 KiB of scattered reads per 100k x 768 pass.  In the symmetric
+// pass (i, j) is in list i exactly when (j, i) is in list j (the filter emits both from one accumulator; on diagonal
+// tiles both accumulators hold the same sum), and the exact cosine is symmetric bit for bit: the same products in the
+// same order, |q|^2 and |row|^2 summed by the same chain, and a commutative product of the two roots.  So row i sums
+// only its entries j >= i — and those whose own list overflowed and will be redone — and writes the result into its
+// own slot and into the slot list j holds for i.  A second kernel then orders each list from the stored cosines.
+constexpr uint32_t PAIR_SIM_UNSET = 0xFFFFFFFFu;   // a NaN no cosine_from_sums result has: "nobody wrote this entry"
+
+__global__ __launch_bounds__(256) void pair_sims_clear_kernel(const RescoreArgs a) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t i = wave; i < a.n_scan; i += n_waves) {
+        const uint32_t total = a.cand_cnt[i], cnt = total < a.cap ? total : a.cap;
+        for (uint32_t c = lane; c < cnt; c += 64u) reinterpret_cast<uint32_t *>(a.pair_sims)[(size_t)i * a.cap + c] = PAIR_SIM_UNSET;
+    }
+}
+
+__global__ __launch_bounds__(256) void pair_score_kernel(const RescoreArgs a) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t dim = a.dim;
+    const bool vec4 = (dim & 3u) == 0;
+    for (uint32_t i = wave; i < a.n_scan; i += n_waves) {
+        const uint32_t total = a.cand_cnt[i];
+        if (total > a.cap) continue;                       // overflowed: redone on the exact path, nobody waits for it
+        const uint32_t cnt = total;
+        const float *q = a.rows + (size_t)i * dim;
+        float qq = 0.0f;
+        if (vec4) {
+            const f32x4 *q4 = reinterpret_cast<const f32x4 *>(q);
+            for (uint32_t j = lane; j < dim / 4u; j += 64u) {
+                const f32x4 x = q4[j];
+                qq = fmaf(x.w, x.w, fmaf(x.z, x.z, fmaf(x.y, x.y, fmaf(x.x, x.x, qq))));
+            }
+        } else {
+            for (uint32_t j = lane; j < dim; j += 64u) qq = fmaf(q[j], q[j], qq);
+        }
+        qq = wave_sum(qq);
+        // 64 list entries at a time, one per lane; the ones this row has to sum are then taken four at a time (their
+        // row reads and reductions overlap), so no step runs with idle slots
+        for (uint32_t c0 = 0; c0 < cnt; c0 += 64u) {
+            const uint32_t c = c0 + lane;
+            const bool in = c < cnt;
+            const uint32_t jl = in ? a.cand[(size_t)i * a.cap + c] : 0u;
+            const bool partner_redone = in && a.cand_cnt[jl] > a.cap;
+            uint64_t todo = __ballot(in && (jl >= i || partner_redone));
+            const uint64_t mirrored = __ballot(in && jl > i && !partner_redone);
+            while (todo) {
+                uint32_t jrow[4], slot[4];
+                bool need[4];
+                float d0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, n0[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    need[u] = todo != 0ull;
+                    const int l = need[u] ? __ffsll((unsigned long long)todo) - 1 : 0;
+                    if (need[u]) todo &= todo - 1ull;
+                    slot[u] = (uint32_t)l;
+                    jrow[u] = (uint32_t)__builtin_amdgcn_readlane((int)jl, l);
+                }
+                // the same fixed-order chains as rescore_kernel: a pair scores the same through either kernel
+                if (vec4) {
+                    const f32x4 *q4 = reinterpret_cast<const f32x4 *>(q);
+                    for (uint32_t j = lane; j < dim / 4u; j += 64u) {
+                        const f32x4 y = q4[j];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            if (!need[u]) continue;
+                            const f32x4 x = reinterpret_cast<const f32x4 *>(a.rows + (size_t)jrow[u] * dim)[j];
+                            d0[u] = fmaf(x.w, y.w, fmaf(x.z, y.z, fmaf(x.y, y.y, fmaf(x.x, y.x, d0[u]))));
+                            n0[u] = fmaf(x.w, x.w, fmaf(x.z, x.z, fmaf(x.y, x.y, fmaf(x.x, x.x, n0[u]))));
+                        }
+                    }
+                } else {
+                    for (uint32_t j = lane; j < dim; j += 64u) {
+                        const float y = q[j];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            if (!need[u]) continue;
+                            const float x = a.rows[(size_t)jrow[u] * dim + j];
+                            d0[u] = fmaf(x, y, d0[u]);
+                            n0[u] = fmaf(x, x, n0[u]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (!need[u]) continue;
+                    const float sim = cosine_from_sums(wave_sum(d0[u]), qq, wave_sum(n0[u]));
+                    if (lane == 0) a.pair_sims[(size_t)i * a.cap + c0 + slot[u]] = sim;
+                    if ((mirrored >> slot[u]) & 1ull) {   // the slot list j keeps for i
+                        const uint32_t cj = a.cand_cnt[jrow[u]];
+                        for (uint32_t t = lane; t < cj; t += 64u)
+                            if (a.cand[(size_t)jrow[u] * a.cap + t] == i) a.pair_sims[(size_t)jrow[u] * a.cap + t] = sim;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void select_lists_kernel(const RescoreArgs a) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t i = wave; i < a.n_scan; i += n_waves) {
+        const uint32_t total = a.cand_cnt[i];
+        const uint32_t cnt = total < a.cap ? total : a.cap;
+        bool redo = total > a.cap;
+        if (cnt <= 64u && !redo) {
+            // the usual case, one entry per lane: order by rank counting (cnt x (2 v_readlane + compare)) instead of
+            // cnt serial insertions into the register list
+            const bool in = lane < cnt;
+            const uint32_t jr = in ? a.cand[(size_t)i * a.cap + lane] : 0u;
+            const uint32_t sb = in ? reinterpret_cast<const uint32_t *>(a.pair_sims)[(size_t)i * a.cap + lane] : 0u;
+            const uint32_t mt = in ? a.meta[jr] : META_REMOVED;
+            if (__ballot(in && sb == PAIR_SIM_UNSET)) {
+                if (lane == 0) { a.overflow[i] = 1u; a.out_cnt[i] = 0u; }
+                continue;
+            }
+            const float sim = __uint_as_float(sb);
+            const float score = score_of(distance_of(sim));
+            const bool ok = in && score >= a.threshold && !(mt & META_REMOVED);   // NaN fails the comparison
+            const uint64_t key = ok ? make_key(score, jr) : 0ull;
+            uint32_t rank = 0;
+            const uint32_t n_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt);
+            for (uint32_t f = 0; f < n_u; f++) rank += readlane_u64(key, (int)f) > key ? 1u : 0u;
+            const bool valid = ok && rank < a.topk;
+            if (valid) {
+                a.out_rows[(size_t)i * a.topk + rank] = jr;
+                a.out_scores[(size_t)i * a.topk + rank] = score;
+                if (a.out_dists) a.out_dists[(size_t)i * a.topk + rank] = distance_of(sim);
+            }
+            const uint32_t n_out = (uint32_t)__popcll(__ballot(valid));
+            if (lane == 0) { a.overflow[i] = 0u; a.out_cnt[i] = n_out; }
+            continue;
+        }
+        WaveTopK<KS> top;
+        top.init(a.topk);
+        for (uint32_t c0 = 0; c0 < cnt && !redo; c0 += 64u) {
+            const uint32_t c = c0 + lane;
+            const uint32_t jr = c < cnt ? a.cand[(size_t)i * a.cap + c] : 0u;
+            const uint32_t sb = c < cnt ? reinterpret_cast<const uint32_t *>(a.pair_sims)[(size_t)i * a.cap + c] : 0u;
+            if (__ballot(c < cnt && sb == PAIR_SIM_UNSET)) { redo = true; break; }   // an entry nobody scored: exact path
+            const uint32_t mt = c < cnt ? a.meta[jr] : META_REMOVED;
+            const uint32_t m = cnt - c0 < 64u ? cnt - c0 : 64u;
+            for (uint32_t l = 0; l < m; l++) {
+                const float sim = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)sb, (int)l));
+                const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)jr, (int)l);
+                const uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)mt, (int)l);
+                const float score = score_of(distance_of(sim));
+                if (!(score >= a.threshold)) continue;              // rules.rs:50 / index.rs:386 (NaN fails)
+                if (meta & META_REMOVED) continue;                  // removed from the index
+                const uint64_t key = make_key(score, row);
+                if (key > top.tau) top.insert(key, sim);
+            }
+        }
+        if (lane == 0) a.overflow[i] = redo ? 1u : 0u;
+        uint32_t n_out = 0;
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            const uint32_t r = (uint32_t)s * 64u + lane;
+            const bool valid = !redo && r < a.topk && top.key[s] != 0ull;
+            if (valid) {
+                a.out_rows[(size_t)i * a.topk + r] = key_row(top.key[s]);
+                a.out_scores[(size_t)i * a.topk + r] = score_of(distance_of(top.sim[s]));
+                if (a.out_dists) a.out_dists[(size_t)i * a.topk + r] = distance_of(top.sim[s]);
+            }
+            n_out += (uint32_t)__popcll(__ballot(valid));
+        }
+        if (lane == 0) a.out_cnt[i] = n_out;
+    }
+}
+
 int launch_rescore(const RescoreArgs &a, hipStream_t stream) {
     if (!a.n_scan) return CX_OK;
     if (a.topk > TOPK_MAX) return set_err(CX_ERR_VALIDATION, "rescore: topk=%u exceeds %u", a.topk, TOPK_MAX);
+    if (a.pair_sims) {
+        if (a.q_rows || a.scan_rows) return set_err(CX_ERR_VALIDATION, "rescore: pair scratch is for the symmetric pass only");
+        uint32_t g = (a.n_scan + 3u) / 4u;
+        if (g > 16384u) g = 16384u;
+        hipLaunchKernelGGL(pair_sims_clear_kernel, dim3(g), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(pair_score_kernel, dim3(g), dim3(256), 0, stream, a);
+        if (a.topk <= 64) hipLaunchKernelGGL((select_lists_kernel<1>), dim3(g), dim3(256), 0, stream, a);
+        else if (a.topk <= 128) hipLaunchKernelGGL((select_lists_kernel<2>), dim3(g), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((select_lists_kernel<4>), dim3(g), dim3(256), 0, stream, a);
+        CX_HIP(hipGetLastError());
+        return CX_OK;
+    }
     uint32_t grid = (a.n_scan + 3u) / 4u;
     if (grid > 16384u) grid = 16384u;
     if (a.topk <= 64) hipLaunchKernelGGL((rescore_kernel<1>), dim3(grid), dim3(256), 0, stream, a);

@@ -59,7 +59,8 @@ struct PassScratch {
     RedoScratch redo;
     uint32_t *d_scan = nullptr, *d_cand_cnt = nullptr, *d_cand = nullptr, *d_overflow = nullptr;
     uint32_t *d_list_rows = nullptr, *d_list_cnt = nullptr, *d_counts = nullptr, *d_ident = nullptr;
-    float *d_list_scores = nullptr, *d_list_dists = nullptr;
+    float *d_list_scores = nullptr, *d_list_dists = nullptr, *d_pair_sims = nullptr;
+    size_t c_pair_sims = 0;
     uint64_t *d_offsets = nullptr;
     uint8_t *d_deleted = nullptr;
     char *d_temp = nullptr;
@@ -71,7 +72,7 @@ struct PassScratch {
     ~PassScratch() {
         (void)hipFree(d_scan); (void)hipFree(d_cand_cnt); (void)hipFree(d_cand); (void)hipFree(d_overflow);
         (void)hipFree(d_list_rows); (void)hipFree(d_list_cnt); (void)hipFree(d_counts); (void)hipFree(d_ident);
-        (void)hipFree(d_list_scores); (void)hipFree(d_list_dists); (void)hipFree(d_offsets);
+        (void)hipFree(d_list_scores); (void)hipFree(d_list_dists); (void)hipFree(d_offsets); (void)hipFree(d_pair_sims);
         (void)hipFree(d_deleted); (void)hipFree(d_temp); (void)hipFree(d_from); (void)hipFree(d_to); (void)hipFree(d_w);
     }
 };
@@ -268,6 +269,11 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
             r.out_scores = ps.d_list_scores + (size_t)lo * topk;
             r.out_cnt = ps.d_list_cnt + lo;
             r.overflow = ps.d_overflow + lo;
+            static const int sym_rescore = getenv("CX_RESCORE_SYMMETRIC") ? atoi(getenv("CX_RESCORE_SYMMETRIC")) : 1;
+            if (f.symmetric && sym_rescore) {   // every list of the store is present: each pair is scored once (allpairs.hip)
+                if (int rc = ensure_dev(ps.d_pair_sims, ps.c_pair_sims, (size_t)m * cap)) return rc;
+                r.pair_sims = ps.d_pair_sims;
+            }
             if (int rc = launch_rescore(r, s)) return rc;
         }
         if (phase_ms && n_scan > chunk) CX_HIP(hipEventRecord(ev[2], s));  // multi-chunk: only the total is meaningful

@@ -132,6 +132,10 @@ struct RescoreArgs {
     float *out_scores;     // [n_scan][topk]
     uint32_t *out_cnt;     // [n_scan]
     uint32_t *overflow;    // [n_scan] 1 = candidate list overflowed, redo on the exact path
+    // Symmetric pass only (scan set == all rows in order, every list present): scratch [n_scan][cap] for the exact
+    // cosine of each list entry.  score(i, j) == score(j, i) bit for bit, so each pair is summed once — by the row
+    // with the lower index — and written into both lists; null = every list scores its own entries.
+    float *pair_sims;
 };
 int launch_rescore(const RescoreArgs &a, hipStream_t stream);
 

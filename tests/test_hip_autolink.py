@@ -287,3 +287,41 @@ def test_small_scan_sets_take_the_stream_filter(hip, oracle, n, d, n_scan):
             assert abs(sc - float(thr)) <= SCORE_TOL, f"node {node} neighbour {nb} score {sc}"
         for nb in set(gs) & set(es):
             assert abs(gs[nb] - es[nb]) <= SCORE_TOL
+
+
+def test_symmetric_rescore_is_bit_identical(hip):
+    """In the symmetric pass each pair is scored once and written into both lists (allpairs.hip: pair_score_kernel).
+    score(i, j) == score(j, i) bit for bit, so the edges — ids, order and weights — must be the bytes the one-sided
+    rescore produces.  The switch is read once per process, hence two child processes."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, hashlib, numpy as np
+sys.path.insert(0, %r)
+import torch, cortex_amd
+from cortex_amd import _lib
+L = _lib.load()
+out = []
+for n, d, cap_thr in ((30000, 768, 0.85), (12000, 384, 0.3)):
+    gen = torch.empty((n, d), dtype=torch.float32, device="cuda:0")
+    assert L.cx_synth_fill_dev(0, gen.data_ptr(), 20260313, 20260313, 20260315, n // 50, 0, n, d, 1) == 0
+    ids = np.zeros((n, 16), np.uint8); ids[:, 8:] = np.arange(n, dtype=np.uint64).astype(">u8").view(np.uint8).reshape(n, 8)
+    h = cortex_amd.HipIndex(d); h.insert_batch_dev(ids, gen.data_ptr(), n, d)
+    for r in (5, 77, 1234): h.remove(ids[r].tobytes())
+    fr, to, w = h.autolink_pass_rows(None, 100, cap_thr, 50)     # 0.3: candidate lists overflow, rows take the exact path
+    m = hashlib.sha256(); m.update(fr.tobytes()); m.update(to.tobytes()); m.update(w.tobytes())
+    out.append("%%d %%s" %% (len(fr), m.hexdigest()))
+print("|".join(out))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    # candidate capacity 512 (default) and 24: with 24 most lists overflow and are redone on the exact path, so the
+    # "partner's list will be redone, score it yourself" rule of the symmetric kernels is exercised too; the edges do
+    # not depend on the capacity either
+    for sym, cap in (("1", "512"), ("0", "512"), ("1", "24"), ("0", "24")):
+        env = dict(os.environ, CX_RESCORE_SYMMETRIC=sym, CX_PAIR_CAND_CAP=cap)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(r.stdout.strip().splitlines()[-1])
+    assert res[0] == res[1] == res[2] == res[3] and int(res[0].split()[0]) > 100000, res
