@@ -280,13 +280,50 @@ TEST(test_search_decayed_reranks) {
     CHECK(cx_apply_score_decay(&off, 0.8f, 0.15f, now, 0, 0, now, 0, 0) == 0.8f);
 }
 
+// One process, several shards (here: three shards on the one device of the test box): results must be those of a
+// single index over the same insertions — ids, order (ties by global insertion order) and scores.
+TEST(test_sharded_single_process) {
+    const size_t dim = 384, n = 3000;
+    std::mt19937 rng(7);
+    std::normal_distribution<float> g(0.0f, 1.0f);
+    std::vector<NodeId> ids(n);
+    std::vector<Embedding> rows(n, Embedding(dim));
+    for (size_t i = 0; i < n; i++) { ids[i] = now_v7(); for (auto &x : rows[i]) x = g(rng); }
+    for (size_t i = 10; i < n; i += 97) rows[i] = rows[i - 7];       // exact duplicates: the tie order is checked too
+    HipIndex one(dim);
+    ShardedHipIndex many(dim, {0, 0, 0}, 128);
+    for (size_t i = 0; i < n; i++) { one.insert(ids[i], rows[i]); many.insert(ids[i], rows[i]); }
+    one.insert(ids[5], rows[6]); many.insert(ids[5], rows[6]);        // upsert of a known id keeps its place
+    for (size_t i = 0; i < n; i += 11) { one.remove(ids[i]); many.remove(ids[i]); }
+    CHECK(many.len() == one.len() && many.n_shards() == 3);
+    auto same = [&](const std::vector<SimilarityResult> &a, const std::vector<SimilarityResult> &b) {
+        if (a.size() != b.size()) return false;
+        for (size_t i = 0; i < a.size(); i++) if (!(a[i].node_id == b[i].node_id) || a[i].score != b[i].score) return false;
+        return true;
+    };
+    for (size_t qi : {1u, 17u, 107u, 2999u}) {
+        CHECK(same(many.search(rows[qi], 10), one.search(rows[qi], 10)));
+        CHECK(same(many.search(rows[qi], 200), one.search(rows[qi], 200)));
+        CHECK(same(many.search_threshold(rows[qi], 0.2f), one.search_threshold(rows[qi], 0.2f)));
+    }
+    VectorFilter f = VectorFilter::new_().excluding({ids[17], ids[18]});
+    CHECK(same(many.search(rows[17], 5, &f), one.search(rows[17], 5, &f)));
+    one.rebuild(); many.rebuild();
+    CHECK(many.len() == one.len());
+    CHECK(same(many.search(rows[107], 50), one.search(rows[107], 50)));
+    one.insert(now_v7(), rows[3]); 
+    bool threw = false;
+    try { many.insert(now_v7(), Embedding(3)); } catch (const CortexError &) { threw = true; }
+    CHECK(threw);
+}
+
 int main() {
     if (cx_device_count() <= 0) { std::fprintf(stderr, "no HIP device: %s\n", "this test needs a GPU"); return 2; }
     run_test_index_insert_and_search(); run_test_threshold_search(); run_test_index_persistence();
     run_test_dimension_mismatch_rejected(); run_test_empty_index_search(); run_test_brute_force_fallback();
     run_test_filter_by_kind(); run_test_filter_exclude(); run_test_remove_doesnt_crash_search(); run_test_search_batch();
     run_test_similarity_score_range(); run_test_threshold_returns_only_above(); run_test_config();
-    run_test_linker_similarity_edges_and_dedup(); run_test_bulk_load_nodes(); run_test_search_decayed_reranks();
+    run_test_linker_similarity_edges_and_dedup(); run_test_bulk_load_nodes(); run_test_search_decayed_reranks(); run_test_sharded_single_process();
     std::printf("%d tests run, %d checks failed\n", g_run, g_failed);
     return g_failed ? 1 : 0;
 }
