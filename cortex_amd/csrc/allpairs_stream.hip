@@ -162,7 +162,7 @@ __global__ __launch_bounds__(512) void pair_filter_stream_kernel(const PairFilte
 
 bool pair_filter_stream_supported(const PairFilterArgs &a) {
     return a.n_scan >= 1 && a.n_scan <= pstream::MAX_SCAN && !a.symmetric && a.n_rows >= pstream::ROWS &&
-           (a.dim == 768 || a.dim == 1024);
+           (a.dim == 384 || a.dim == 512 || a.dim == 768 || a.dim == 1024);
 }
 
 template <int D>
@@ -181,6 +181,8 @@ static int launch_stream_d(const PairFilterArgs &a, hipStream_t stream) {
 
 int launch_pair_filter_stream(const PairFilterArgs &a, hipStream_t stream) {
     if (!pair_filter_stream_supported(a)) return set_err(CX_ERR_VALIDATION, "stream pair filter: unsupported shape (n_scan %u, dim %u)", a.n_scan, a.dim);
+    if (a.dim == 384) return launch_stream_d<384>(a, stream);
+    if (a.dim == 512) return launch_stream_d<512>(a, stream);
     if (a.dim == 768) return launch_stream_d<768>(a, stream);
     return launch_stream_d<1024>(a, stream);
 }

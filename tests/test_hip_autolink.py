@@ -258,9 +258,9 @@ def test_topk_lists_and_generic_walk(hip, oracle):
     assert [(a, b, r) for a, b, r, _ in walk2] == exp
 
 
-@pytest.mark.parametrize("n,d,n_scan", [(5003, 1024, 64), (2000, 768, 17), (1031, 1024, 1), (4096, 768, 64)])
+@pytest.mark.parametrize("n,d,n_scan", [(5003, 1024, 64), (2000, 768, 17), (1031, 1024, 1), (4096, 768, 64), (3001, 384, 64), (2500, 512, 33)])
 def test_small_scan_sets_take_the_stream_filter(hip, oracle, n, d, n_scan):
-    """Scan sets of <= 64 rows at dim 768 / 1024 (streaming ingest, config 5) run pair_filter_stream_kernel: ragged
+    """Scan sets of <= 64 rows at dim 384 / 512 / 768 / 1024 (streaming ingest, config 5) run pair_filter_stream_kernel: ragged
     last tile (n not a multiple of 16), fewer scanned rows than a consumer wave holds, scanned rows anywhere."""
     rows = oracle.synth_rows(n, d)
     ids = ids_for(n)
