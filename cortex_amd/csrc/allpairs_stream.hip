@@ -8,7 +8,8 @@
 //    (two register sets; store, then reload into the same register), one XOR swizzle on the LDS address;
 //  - per tile a consumer runs dim/32 v_mfma_f32_16x16x32_bf16 (tile rows x its 16 scanned rows) and screens the 16x16
 //    scores against thr - eps; hits go to the scanned row's candidate list (rare);
-//  - one raw barrier per tile (lgkmcnt(0) + s_barrier: the prefetched loads stay in flight).
+//  - one raw barrier per tile (lgkmcnt(0) + s_barrier: the prefetched loads stay in flight); a tile is one 16-row image,
+//    or two for dims <= 512, where one image alone is too little work per barrier.
 // Same contract as pair_filter_kernel (allpairs.hip): candidate columns out, no score matrix.
 #include "kernels.hpp"
 
@@ -18,7 +19,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace pstream {
-constexpr uint32_t ROWS = 16, MAX_SCAN = 64;
+constexpr uint32_t IMG_ROWS = 16, MAX_SCAN = 64;   // a tile is one or two 16-row images (rows_per_tile)
+// tile rows per barrier: narrow rows make a 16-row tile so small (12 KiB at 384-d) that the barrier and the loop
+// overhead weigh as much as its MFMAs; two images per step halve that
+constexpr uint32_t rows_per_tile(uint32_t dim) { return dim <= 512 ? 32u : 16u; }
 // byte offset of 16-byte piece p of tile row i: pieces XOR-swizzled with the row inside each 256-byte segment, so the 16
 // lanes of a ds_read_b128 group (rows 0..15, same piece) hit 16 different bank groups
 template <int D>
@@ -28,7 +32,8 @@ __device__ inline uint32_t t_off(uint32_t i, uint32_t p) { return i * (uint32_t)
 template <int D>
 __global__ __launch_bounds__(512) void pair_filter_stream_kernel(const PairFilterArgs a) {
     using namespace pstream;
-    constexpr uint32_t ROW_BYTES = D * 2, TILE_BYTES = ROWS * ROW_BYTES, LOADS = TILE_BYTES / 4 / 1024, KS = D / 32;
+    constexpr uint32_t ROWS = rows_per_tile(D), NIMG = ROWS / IMG_ROWS;
+    constexpr uint32_t ROW_BYTES = D * 2, IMG_BYTES = IMG_ROWS * ROW_BYTES, TILE_BYTES = ROWS * ROW_BYTES, LOADS = TILE_BYTES / 4 / 1024, KS = D / 32;
     static_assert(D % 128 == 0, "dim must be a multiple of 128 (whole KiB per producer wave)");
     extern __shared__ __attribute__((aligned(16))) char smem[];   // two tile buffers
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, pw = wave & 3u;
@@ -49,7 +54,8 @@ __global__ __launch_bounds__(512) void pair_filter_stream_kernel(const PairFilte
 #pragma unroll
         for (uint32_t e = 0; e < LOADS; e++) {
             const uint32_t o = (pw * LOADS + e) * 1024u + lane * 16u;   // byte offset inside the (row-major) tile
-            dst_off[e] = t_off<D>(o / ROW_BYTES, (o % ROW_BYTES) >> 4);
+            const uint32_t row = o / ROW_BYTES;                          // 0 .. ROWS-1: image row / 16, swizzled inside its image
+            dst_off[e] = (row / IMG_ROWS) * IMG_BYTES + t_off<D>(row % IMG_ROWS, (o % ROW_BYTES) >> 4);
         }
         const uint32_t my_src = pw * LOADS * 1024u + lane * 16u;
         const char *shadow = reinterpret_cast<const char *>(a.shadow);
@@ -120,38 +126,41 @@ __global__ __launch_bounds__(512) void pair_filter_stream_kernel(const PairFilte
     uint32_t buf = 0;
     for (uint32_t st = 0, tile = blockIdx.x; st < my_steps; st++, tile += gridDim.x) {
         if (!wave_live || tile >= n_tiles) { tile_barrier(); buf ^= 1u; continue; }
-        const char *T = smem + buf * TILE_BYTES;
-        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-        constexpr int CH = 4;
-        static_assert(KS % CH == 0, "dim/32 must be a multiple of 4");
-        auto rd = [&](uint32_t ks) { return *reinterpret_cast<const bf16x8 *>(T + a_off[ks & 3u] + (ks >> 2) * 256u); };
-        bf16x8 fa[CH], fb[CH];
+        // a ragged last tile was read shifted up (src_of): its row 0 is row n_rows - ROWS
+        const size_t row0 = (size_t)tile * ROWS + ROWS <= a.n_rows ? (size_t)tile * ROWS : (size_t)a.n_rows - ROWS;
+        const size_t first_new = (size_t)tile * ROWS;   // rows below this were already covered by the previous tile
 #pragma unroll
-        for (int u = 0; u < CH; u++) fa[u] = rd(u);
+        for (uint32_t img = 0; img < NIMG; img++) {
+            const char *T = smem + buf * TILE_BYTES + img * IMG_BYTES;
+            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+            constexpr int CH = 4;
+            static_assert(KS % CH == 0, "dim/32 must be a multiple of 4");
+            auto rd = [&](uint32_t ks) { return *reinterpret_cast<const bf16x8 *>(T + a_off[ks & 3u] + (ks >> 2) * 256u); };
+            bf16x8 fa[CH], fb[CH];
 #pragma unroll
-        for (uint32_t c = 0; c < KS / CH; c++) {
-            bf16x8 *cur = (c & 1u) ? fb : fa, *nxt = (c & 1u) ? fa : fb;
-            if (c + 1 < KS / CH) {
+            for (int u = 0; u < CH; u++) fa[u] = rd(u);
 #pragma unroll
-                for (int u = 0; u < CH; u++) nxt[u] = rd((c + 1) * CH + u);
+            for (uint32_t c = 0; c < KS / CH; c++) {
+                bf16x8 *cur = (c & 1u) ? fb : fa, *nxt = (c & 1u) ? fa : fb;
+                if (c + 1 < KS / CH) {
+#pragma unroll
+                    for (int u = 0; u < CH; u++) nxt[u] = rd((c + 1) * CH + u);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < CH; u++) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u], qf[c * CH + u], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            // C[image row 4 kq + e][scanned row j]: screen, then emit the rare hits
+            const float mx = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
+            if (__ballot(mx >= a.thr_lo) != 0ull) {
 #pragma unroll
-            for (int u = 0; u < CH; u++) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u], qf[c * CH + u], acc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // C[tile row 4 kq + e][scanned row j]: screen, then emit the rare hits
-        const float mx = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
-        if (__ballot(mx >= a.thr_lo) != 0ull) {
-            // a ragged last tile was read shifted up (src_of): its row 0 is row n_rows - 16
-            const size_t row0 = (size_t)tile * ROWS + ROWS <= a.n_rows ? (size_t)tile * ROWS : (size_t)a.n_rows - ROWS;
-            const size_t first_new = (size_t)tile * ROWS;   // rows below this were already covered by the previous tile
-#pragma unroll
-            for (uint32_t e = 0; e < 4; e++) {
-                const size_t row = row0 + 4u * kq + e;
-                if (acc[e] >= a.thr_lo && si < a.n_scan && row >= first_new && row < a.n_rows) {
-                    const uint32_t slot = atomicAdd(a.cand_cnt + si, 1u);
-                    if (slot < a.cap) a.cand[(size_t)si * a.cap + slot] = (uint32_t)row;
+                for (uint32_t e = 0; e < 4; e++) {
+                    const size_t row = row0 + img * IMG_ROWS + 4u * kq + e;
+                    if (acc[e] >= a.thr_lo && si < a.n_scan && row >= first_new && row < a.n_rows) {
+                        const uint32_t slot = atomicAdd(a.cand_cnt + si, 1u);
+                        if (slot < a.cap) a.cand[(size_t)si * a.cap + slot] = (uint32_t)row;
+                    }
                 }
             }
         }
@@ -161,17 +170,17 @@ __global__ __launch_bounds__(512) void pair_filter_stream_kernel(const PairFilte
 }
 
 bool pair_filter_stream_supported(const PairFilterArgs &a) {
-    return a.n_scan >= 1 && a.n_scan <= pstream::MAX_SCAN && !a.symmetric && a.n_rows >= pstream::ROWS &&
+    return a.n_scan >= 1 && a.n_scan <= pstream::MAX_SCAN && !a.symmetric && a.n_rows >= pstream::rows_per_tile(a.dim) &&
            (a.dim == 384 || a.dim == 512 || a.dim == 768 || a.dim == 1024);
 }
 
 template <int D>
 static int launch_stream_d(const PairFilterArgs &a, hipStream_t stream) {
-    constexpr size_t lds = 2 * (size_t)pstream::ROWS * D * 2;
+    constexpr size_t lds = 2 * (size_t)pstream::rows_per_tile(D) * D * 2;
     static std::atomic<uint64_t> attr_devices{0};
     if (first_use_on_device(attr_devices))
         CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_filter_stream_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const uint32_t n_tiles = (a.n_rows + pstream::ROWS - 1) / pstream::ROWS;
+    const uint32_t n_tiles = (a.n_rows + pstream::rows_per_tile(D) - 1) / pstream::rows_per_tile(D);
     const uint32_t cus = device_cus();
     const uint32_t grid = n_tiles < cus ? n_tiles : cus;
     hipLaunchKernelGGL(pair_filter_stream_kernel<D>, dim3(grid), dim3(512), lds, stream, a);
