@@ -265,6 +265,9 @@ def test_concurrent_readers(hip, oracle):
     (777, 768, 32, 7),       # k = 32 (largest fused k), fewer queries than one wave's share
     (40, 384, 10, 3),        # fewer rows than blocks
     (2000, 768, 100, 5),     # k > 32: falls back to one scan per query
+    (40, 384, 40, 70),       # wide lists for all 64 queries over fewer rows than one block's first tiles (k == n)
+    (300, 768, 100, 64),     # the same at 768-d (single tile buffer), one full group
+    (17, 768, 17, 33),       # a corpus of one ragged tile
 ])
 def test_search_batch_matches_oracle(hip, oracle, n, d, k, nq):
     rows = oracle.synth_rows(n, d)
