@@ -595,7 +595,8 @@ __global__ __launch_bounds__(256) void link_rules_kernel(const LinkArgs a) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_scan) return;
     const uint32_t self = a.scan_rows ? a.scan_rows[i] : i;
-    const uint32_t cnt = a.list_cnt[i];
+    // auto_linker.rs:217-218: a node without an embedding is skipped — a row removed from the index is exactly that
+    const uint32_t cnt = (a.meta && (a.meta[self] & META_REMOVED)) ? 0u : a.list_cnt[i];
     uint32_t n = 0;
     const uint64_t base = MODE == 1 ? a.offsets[i] : 0ull;
     for (uint32_t r = 0; r < cnt && n < a.max_edges; r++) {

@@ -308,6 +308,7 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
     l.list_scores = ps.d_list_scores;
     l.list_cnt = ps.d_list_cnt;
     l.deleted = d_deleted;
+    l.meta = ix->d_meta;
     l.n_scan = n_scan;
     l.topk = topk;
     l.max_edges = dedup ? 0xFFFFFFFFu : max_edges;

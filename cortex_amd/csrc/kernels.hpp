@@ -145,6 +145,7 @@ struct LinkArgs {
     const float *list_scores;
     const uint32_t *list_cnt;
     const uint8_t *deleted;   // [n_rows] storage tombstones (quirk Q2) or null
+    const uint32_t *meta;     // [n_rows] index metadata: a scanned row that was removed from the index has no embedding and proposes nothing
     uint32_t n_scan, topk, max_edges, dedup;
     float threshold;
     uint32_t *counts;         // [n_scan]  (count pass)

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Randomised differential run of the auto-link pass (all rows / a scan subset, thresholds, per-node caps, storage
+tombstones, removed rows, several dims) and of the dedup scan against the CPU oracle's restatement of the reference loop
+(test infrastructure).  Exits non-zero on the first unexplained difference."""
+import argparse, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import cortex_amd as hip
+from oracle import oracle as O
+from conftest import ids_for
+from test_hip_autolink import compare_edges, per_node, oracle_scores
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=120.0)
+ap.add_argument("--seed", type=int, default=1)
+a = ap.parse_args()
+O.build()
+rng = np.random.default_rng(a.seed)
+t_end = time.time() + a.seconds
+cases = 0
+while time.time() < t_end:
+    d = int(rng.choice([768, 384, 768, 384, 1024, 512, 128, 100]))
+    n = int(rng.choice([rng.integers(2, 300), rng.integers(300, 1500), rng.integers(1500, 3500)]))
+    thr = float(np.float32(rng.choice([0.85, 0.75, 0.92, 0.5, 0.3])))
+    cap_e = int(rng.choice([50, 50, 5, 1, 200]))
+    topk = int(rng.choice([100, 100, 10, 256]))
+    rows = O.synth_rows(n, d, seed_rows=int(rng.integers(1, 1 << 30)))
+    ids = ids_for(n)
+    h = hip.HipIndex(d); h.insert_batch(ids, rows)
+    o = O.OracleIndex(d); o.insert_batch(ids, rows)
+    for r in rng.integers(0, n, int(rng.integers(0, 4))):
+        h.remove(ids[r].tobytes()); o.remove(ids[r].tobytes())
+    deleted = None
+    if rng.random() < 0.4:
+        deleted = (rng.random(n) < 0.1).astype(np.uint8)
+    mode = rng.random()
+    if mode < 0.5:
+        scan = None
+    elif mode < 0.8:
+        scan = np.unique(rng.integers(0, n, int(rng.integers(1, 65)))).astype(np.uint32)       # stream / small kernels
+    else:
+        scan = np.unique(rng.integers(0, n, int(rng.integers(65, 600)))).astype(np.uint32)     # 128 / 256 tiles, asymmetric
+    what = f"case n={n} d={d} thr={thr} cap={cap_e} topk={topk} scan={'all' if scan is None else len(scan)} deleted={deleted is not None}"
+    try:
+        fr, to, w = h.autolink_pass_rows(scan, topk, thr, cap_e, deleted)
+        want = o.autolink_pass(np.arange(n, dtype=np.uint32) if scan is None else scan, topk, np.float32(thr), cap_e, deleted, n_threads=8)
+        compare_edges(per_node(fr, to, w), per_node(want["from_row"], want["to_row"], want["weight"]), thr, oracle_scores(o, rows), what)
+        order = [int(x) for x in fr]
+        scan_list = list(range(n)) if scan is None else [int(x) for x in scan]
+        pos = {r: i for i, r in enumerate(scan_list)}
+        assert all(pos[order[i]] <= pos[order[i + 1]] for i in range(len(order) - 1)), f"{what}: edges not in scan order"
+    except AssertionError as err:
+        print("MISMATCH", what, "seed", a.seed, "after", cases, "cases:", err)
+        sys.exit(1)
+    cases += 1
+print(f"{cases} random auto-link cases agree with the oracle (seed {a.seed}, {a.seconds:.0f} s)")

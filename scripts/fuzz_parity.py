@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Randomised differential run of the search paths against the CPU oracle (test infrastructure): random corpus
+sizes, dims, k, query counts, tombstones and filters through search / search_batch for a given number of seconds.
+Exits non-zero on the first disagreement, printing the case so that it can be added to the parity tests."""
+import argparse, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import cortex_amd as hip
+from oracle import oracle as O
+from conftest import assert_topk_parity, ids_for
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=120.0)
+ap.add_argument("--seed", type=int, default=1)
+a = ap.parse_args()
+O.build()
+rng = np.random.default_rng(a.seed)
+t_end = time.time() + a.seconds
+cases = 0
+while time.time() < t_end:
+    d = int(rng.choice([384, 768, 384, 768, 128, 100, 1024, 64]))
+    n = int(rng.choice([rng.integers(1, 200), rng.integers(200, 5000), rng.integers(5000, 40000)]))
+    k = int(rng.choice([1, 5, 10, 16, 32, 33, 64, 100, 104, 105, 300]))
+    nq = int(rng.choice([1, 2, 3, 17, 32, 33, 64, 65, 130]))
+    rows = O.synth_rows(n, d, seed_rows=int(rng.integers(1, 1 << 30)))
+    if rng.random() < 0.2 and n > 4:
+        rows = rows.copy(); rows[rng.integers(0, n, 3)] = 0.0                  # zero-norm rows (NaN scores)
+    if rng.random() < 0.2 and n > 10:
+        rows = rows.copy(); rows[n // 2:] = rows[: n - n // 2]                # every row twice: ties everywhere
+    ids = ids_for(n)
+    h = hip.HipIndex(d); h.insert_batch(ids, rows)
+    o = O.OracleIndex(d); o.insert_batch(ids, rows)
+    for r in rng.integers(0, n, int(rng.integers(0, 6))):
+        h.remove(ids[r].tobytes()); o.remove(ids[r].tobytes())
+    hf = of = None
+    if rng.random() < 0.3:
+        for r in range(0, n, 2):
+            h.set_metadata(ids[r].tobytes(), "fact" if r % 4 else "event", "kai"); o.set_metadata(ids[r].tobytes(), "fact" if r % 4 else "event", "kai")
+        ex = [ids[int(i)].tobytes() for i in rng.integers(0, n, 4)]
+        hf, of = hip.VectorFilter(kinds=["fact"], exclude=ex), O.Filter(kinds=["fact"], exclude=ex)
+    qs = O.synth_queries(max(n, 64), d, nq, seed_centres=int(rng.integers(1, 1 << 30)))
+    lut = {ids[i].tobytes(): i for i in range(n)}
+    what = f"case n={n} d={d} k={k} nq={nq} filter={hf is not None}"
+    try:
+        bi, bs, bd, bc = h.search_batch_arrays(qs, k, hf)
+        for i in range(nq):
+            e = o.search(qs[i], k, of)
+            m = int(bc[i])
+            assert m == len(e["row"]), f"{what}: q{i} count {m} != {len(e['row'])}"
+            assert_topk_parity(np.array([lut[x.tobytes()] for x in bi[i, :m]]), bs[i, :m], e["row"], e["score"], what=f"{what} batch q{i}")
+        for i in range(min(nq, 3)):
+            gi, gs, gd = h.search_arrays(qs[i], k, hf)
+            e = o.search(qs[i], k, of)
+            assert_topk_parity(np.array([lut[x.tobytes()] for x in gi]), gs, e["row"], e["score"], what=f"{what} single q{i}")
+    except AssertionError as err:
+        print("MISMATCH", what, "seed", a.seed, "after", cases, "cases:", err)
+        sys.exit(1)
+    cases += 1
+print(f"{cases} random cases agree with the oracle (seed {a.seed}, {a.seconds:.0f} s)")

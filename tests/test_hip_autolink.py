@@ -325,3 +325,24 @@ print("|".join(out))
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(r.stdout.strip().splitlines()[-1])
     assert res[0] == res[1] == res[2] == res[3] and int(res[0].split()[0]) > 100000, res
+
+
+def test_removed_rows_are_not_scanned(hip, oracle):
+    """A row removed from the index has no embedding any more: as a scanned node it proposes nothing
+    (auto_linker.rs:217-218 skips nodes without an embedding), whether every row is scanned or it is named in the
+    scan list; as a neighbour it never shows up.  Found by scripts/fuzz_autolink.py."""
+    n, d = 600, 128
+    rows = oracle.synth_rows(n, d)
+    h, o, ids = build(hip, oracle, rows)
+    gone = [2, 21, 26, 599]
+    for r in gone:
+        h.remove(ids[r].tobytes()); o.remove(ids[r].tobytes())
+    thr = float(np.float32(0.75))
+    for scan in (None, np.array([1, 2, 3, 21, 300, 599], dtype=np.uint32)):
+        fr, to, w = h.autolink_pass_rows(scan, 100, thr, 50)
+        assert not set(fr.tolist()) & set(gone) and not set(to.tolist()) & set(gone)
+        want = o.autolink_pass(np.arange(n, dtype=np.uint32) if scan is None else scan, 100, np.float32(thr), 50)
+        compare_edges(per_node(fr, to, w), per_node(want["from_row"], want["to_row"], want["weight"]), thr, oracle_scores(o, rows), "removed")
+    pairs = h.dedup_scan_rows(0.9) if hasattr(h, "dedup_scan_rows") else None
+    if pairs is not None:
+        assert not (set(np.asarray(pairs[0]).tolist()) | set(np.asarray(pairs[1]).tolist())) & set(gone)
