@@ -50,6 +50,23 @@ while time.time() < t_end:
         scan_list = list(range(n)) if scan is None else [int(x) for x in scan]
         pos = {r: i for i, r in enumerate(scan_list)}
         assert all(pos[order[i]] <= pos[order[i + 1]] for i in range(len(order) - 1)), f"{what}: edges not in scan order"
+        if rng.random() < 0.4:   # DedupScanner::scan (dedup.rs:65-127) over the same index
+            dthr = float(np.float32(rng.choice([0.92, 0.85, 0.97])))
+            try:
+                pa, pb, psim = h.dedup_scan_rows(dthr, deleted)
+            except hip.CortexError as ce:
+                if "or more neighbours above the threshold" not in str(ce):
+                    raise
+                pa = None          # a row with >= 256 duplicates: the pass asks for cx_search_threshold, by contract
+            if pa is not None:
+                wd = o.dedup_scan(np.float32(dthr), deleted)
+                got_p = {(int(x), int(y)): float(z) for x, y, z in zip(pa, pb, psim)}
+                exp_p = {(int(e["from_row"]), int(e["to_row"])): float(e["weight"]) for e in wd}
+                for key in set(got_p) ^ set(exp_p):
+                    sc = got_p.get(key, exp_p.get(key))
+                    assert abs(sc - dthr) <= 5e-5, f"{what}: dedup pair {key} score {sc} (thr {dthr})"
+                for key in set(got_p) & set(exp_p):
+                    assert abs(got_p[key] - exp_p[key]) <= 5e-5, f"{what}: dedup pair {key} similarity"
     except AssertionError as err:
         print("MISMATCH", what, "seed", a.seed, "after", cases, "cases:", err)
         sys.exit(1)
