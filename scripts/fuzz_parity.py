@@ -13,6 +13,7 @@ from conftest import assert_topk_parity, ids_for
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=120.0)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--big", action="store_true", help="corpora of 50k-300k rows at 384/768-d: many compactions per list, several query groups")
 a = ap.parse_args()
 O.build()
 rng = np.random.default_rng(a.seed)
@@ -39,13 +40,26 @@ while time.time() < t_end:
             h.set_metadata(ids[r].tobytes(), "fact" if r % 4 else "event", "kai"); o.set_metadata(ids[r].tobytes(), "fact" if r % 4 else "event", "kai")
         ex = [ids[int(i)].tobytes() for i in rng.integers(0, n, 4)]
         hf, of = hip.VectorFilter(kinds=["fact"], exclude=ex), O.Filter(kinds=["fact"], exclude=ex)
+    if a.big:
+        d = int(rng.choice([384, 768]))
+        n = int(rng.integers(50_000, 300_000))
+        k = int(rng.choice([1, 10, 32, 33, 100, 104]))
+        nq = int(rng.choice([33, 64, 65, 130]))
+        rows = O.synth_rows(n, d, seed_rows=int(rng.integers(1, 1 << 30)))
+        ids = ids_for(n)
+        h = hip.HipIndex(d); h.insert_batch(ids, rows)
+        o = O.OracleIndex(d); o.insert_batch(ids, rows)
+        for r in rng.integers(0, n, 5):
+            h.remove(ids[r].tobytes()); o.remove(ids[r].tobytes())
+        hf = of = None
     qs = O.synth_queries(max(n, 64), d, nq, seed_centres=int(rng.integers(1, 1 << 30)))
     lut = {ids[i].tobytes(): i for i in range(n)}
     what = f"case n={n} d={d} k={k} nq={nq} filter={hf is not None}"
     try:
         bi, bs, bd, bc = h.search_batch_arrays(qs, k, hf)
+        exp_all = o.search_batch(qs, k, of, n_threads=16) if a.big else None
         for i in range(nq):
-            e = o.search(qs[i], k, of)
+            e = exp_all[i] if exp_all is not None else o.search(qs[i], k, of)
             m = int(bc[i])
             assert m == len(e["row"]), f"{what}: q{i} count {m} != {len(e['row'])}"
             assert_topk_parity(np.array([lut[x.tobytes()] for x in bi[i, :m]]), bs[i, :m], e["row"], e["score"], what=f"{what} batch q{i}")
