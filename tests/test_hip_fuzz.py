@@ -1,0 +1,23 @@
+"""Short runs of the randomised differential scripts (scripts/fuzz_*.py) as part of the GPU suite: random sizes, dims,
+k, query counts, filters, tombstones, mutation histories and auto-link passes against the CPU oracle.  The scripts run
+longer by hand (`--seconds`); the long runs of this round are recorded in profiles/r01/tuning.md."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("script,args", [
+    ("fuzz_parity.py", ["--seconds", "10", "--seed", "101"]),
+    ("fuzz_parity.py", ["--big", "--seconds", "12", "--seed", "102"]),
+    ("fuzz_autolink.py", ["--seconds", "12", "--seed", "103"]),
+    ("fuzz_stateful.py", ["--seconds", "10", "--seed", "104"]),
+])
+def test_randomised_differential_run(hip, script, args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", script)] + args, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "agree with the oracle" in r.stdout
