@@ -77,6 +77,7 @@ SIGNATURES = {
     "cx_dimension": (_U32, [_P]),
     "cx_row_count": (_U64, [_P]),
     "cx_row_id": (C.c_int, [_P, _U64, _P]),
+    "cx_rows_alive": (C.c_int, [_P, _U64, _U64, _P]),
     "cx_rows_of": (C.c_int, [_P, _U64, _P, _P]),
     "cx_search": (C.c_int, [_P, _P, _U64, _U64, _P, _P, _P, _P, _P]),
     "cx_search_threshold": (C.c_int, [_P, _P, _U64, C.c_float, _P, _U64, _P, _P, _P, _P, _P]),

@@ -701,6 +701,14 @@ int cx_row_id(const cx_index *ix, uint64_t row, uint8_t out_id[16]) try {
     return CX_OK;
 } catch (...) { return cx::on_exception(); }
 
+int cx_rows_alive(const cx_index *ix, uint64_t row_lo, uint64_t n, uint8_t *out_alive) try {
+    if (!ix || (n && !out_alive)) return set_err(CX_ERR_VALIDATION, "null argument");
+    if (row_lo + n > ix->n_rows) return set_err(CX_ERR_VALIDATION, "rows %llu..%llu beyond the %llu rows of the index",
+                                                (unsigned long long)row_lo, (unsigned long long)(row_lo + n), (unsigned long long)ix->n_rows);
+    for (uint64_t i = 0; i < n; i++) out_alive[i] = (ix->h_meta[(size_t)(row_lo + i)] & META_REMOVED) ? 0 : 1;
+    return CX_OK;
+} catch (...) { return cx::on_exception(); }
+
 int cx_rows_of(const cx_index *ix, uint64_t n, const uint8_t *ids, uint32_t *out_rows) try {
     if (!ix || (n && (!ids || !out_rows))) return set_err(CX_ERR_VALIDATION, "null argument");
     for (uint64_t i = 0; i < n; i++) {

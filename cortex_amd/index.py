@@ -388,6 +388,13 @@ class HipIndex:
             self._check(rc)
             return a[:n.value], b[:n.value], s[:n.value]
 
+    def rows_alive(self, row_lo: int = 0, n: Optional[int] = None) -> np.ndarray:
+        """cx_rows_alive: bool per row of [row_lo, row_lo + n): False = removed (a tombstone until rebuild)."""
+        n = self.row_count() - row_lo if n is None else n
+        out = np.zeros(max(1, n), np.uint8)
+        self._check(self._L.cx_rows_alive(self._h, row_lo, n, out.ctypes.data))
+        return out[:n].astype(bool)
+
     def rows_of(self, ids) -> np.ndarray:
         """cx_rows_of: insertion rows of ids (u8 [n,16] or a sequence of 16-byte ids); UINT32_MAX = not indexed."""
         arr = ids if isinstance(ids, np.ndarray) else np.frombuffer(b"".join(_id16(i) for i in ids), dtype=np.uint8)

@@ -150,12 +150,14 @@ class ShardedAutolink:
     block buffer.  Both are injectable (CPU gloo tests); hip_lists_fn / hip_rows_fn are the product paths."""
 
     def __init__(self, rank: int, world: int, shard_rows: Sequence[int], dim: int, topk: int, device: torch.device,
-                 lists_fn: Callable, rows_fn: Callable, merge_fn=None, group=None, block: int = 2048):
+                 lists_fn: Callable, rows_fn: Callable, merge_fn=None, group=None, block: int = 2048,
+                 alive_fn: Optional[Callable] = None):
         self.rank, self.world, self.dim, self.topk, self.block = rank, world, dim, topk, block
         self.shard_rows = [int(x) for x in shard_rows]
         self.bases = np.concatenate([[0], np.cumsum(self.shard_rows)[:-1]]).astype(np.int64)
         self.device, self.group = device, group
         self.rows_fn = rows_fn
+        self.alive_fn = alive_fn   # alive_fn(row_lo, n) -> bool[n] over OWN rows: removed rows are not scanned (auto_linker.rs:217-218)
         self.knn = ShardedKnn(rank, world, self.bases.tolist(), block, topk, device, lists_fn, merge_fn=merge_fn, group=group)
         self.buf = torch.zeros((block, dim), dtype=torch.float32, device=device)
 
@@ -193,6 +195,8 @@ class ShardedAutolink:
                 valid = np.arange(self.topk)[None, :] < counts[:, None]
                 safe_rows = np.where(valid, rows, 0)
                 ok = valid & (rows != self_g[:, None]) & (scores >= thr)
+                if self.alive_fn is not None:
+                    ok &= np.asarray(self.alive_fn(lo, m), dtype=bool)[:, None]
                 if deleted is not None:
                     ok &= ~deleted[safe_rows].astype(bool)
                 ok &= np.cumsum(ok, axis=1) <= max_edges_per_node
@@ -210,6 +214,11 @@ def hip_lists_fn(index, threshold: float) -> Callable:
         stream = torch.cuda.current_stream(s.device).cuda_stream
         index.autolink_lists_dev(queries.data_ptr(), nq, s.k, threshold, base, base + 4 * n, base + 8 * n, base + 12 * n, stream)
     return fn
+
+
+def hip_alive_fn(index) -> Callable:
+    """alive_fn for a cortex_amd.HipIndex shard."""
+    return lambda row_lo, n: index.rows_alive(row_lo, n)
 
 
 def hip_rows_fn(index) -> Callable:

@@ -52,6 +52,7 @@ extern "C" {
     fn cx_dedup_scan_rows(ix: *const c_void, dedup_threshold: f32, deleted: *const u8, cap: u64, out_a: *mut u32,
                           out_b: *mut u32, out_similarity: *mut f32, n_out: *mut u64, n_needed: *mut u64) -> c_int;
     fn cx_row_id(ix: *const c_void, row: u64, out_id16: *mut u8) -> c_int;
+    fn cx_rows_alive(ix: *const c_void, row_lo: u64, n: u64, out_alive: *mut u8) -> c_int;
     fn cx_save(ix: *const c_void, path: *const c_char) -> c_int;
     fn cx_load(path: *const c_char, device: c_int) -> *mut c_void;
     // query-time score decay + re-rank

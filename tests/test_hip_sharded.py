@@ -148,14 +148,19 @@ def test_sharded_autolink_equals_single_index_pass(hip, oracle, n, d, parts, thr
 
 
 def test_sharded_autolink_world_one_run(hip, oracle):
-    from cortex_amd.sharded import ShardedAutolink, hip_lists_fn, hip_rows_fn
+    from cortex_amd.sharded import ShardedAutolink, hip_alive_fn, hip_lists_fn, hip_rows_fn
     dev = torch.device("cuda", 0)
     n, d = 1500, 768
     rows = oracle.synth_rows(n, d)
     h = hip.HipIndex(d)
-    h.insert_batch(ids_for(n), rows)
+    ids = ids_for(n)
+    h.insert_batch(ids, rows)
+    for r in (3, 700, 1499):             # removed rows are neither neighbours nor scanned (auto_linker.rs:217-218)
+        h.remove(ids[r].tobytes())
+    assert not h.rows_alive(3, 1)[0] and h.rows_alive(4, 1)[0] and int(h.rows_alive().sum()) == n - 3
     thr32 = float(np.float32(0.85))
-    sa = ShardedAutolink(0, 1, [n], d, 100, dev, hip_lists_fn(h, thr32), hip_rows_fn(h), block=512)
+    sa = ShardedAutolink(0, 1, [n], d, 100, dev, hip_lists_fn(h, thr32), hip_rows_fn(h), block=512, alive_fn=hip_alive_fn(h))
     f, t, w = sa.run(thr32, 50)
+    assert not set(f.tolist()) & {3, 700, 1499}
     fr, to, ww = h.autolink_pass_rows(None, 100, thr32, 50)
     assert np.array_equal(f, fr.astype(np.int64)) and np.array_equal(t, to.astype(np.int64)) and np.array_equal(w, ww)
