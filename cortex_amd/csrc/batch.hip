@@ -647,6 +647,10 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
             __builtin_amdgcn_sched_barrier(0);
         }
         stamp(t_mfma);
+        // single tile buffer: the tile is no longer needed once the MFMA loop has read it, so the hand-back barrier
+        // comes BEFORE the epilogue and the producers write the next tile while the consumers test and append (the
+        // epilogue touches only registers and the candidate lists)
+        if constexpr (NBUF == 1) tile_barrier();
 
         // epilogue: lane (j, kq) holds rows 4 kq + r of query j.  All four tests first, one wave-level branch:
         // after warm-up no lane has a survivor and the wave falls through
@@ -682,9 +686,8 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
             if (kq == 0u) c_pub[qslot] = c_cnt[qslot];
         }
         stamp(t_epi);
-        tile_barrier();
+        tile_barrier();        // two buffers: the tile's only barrier; single buffer: the next tile is in place
         if constexpr (NBUF == 2) buf ^= 1u;
-        else tile_barrier();   // single buffer: the producers write the next tile between the two barriers
         stamp(t_bar);
     }
     apply_shrink();
