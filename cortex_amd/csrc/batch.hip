@@ -760,7 +760,7 @@ static bool batch_wide_k(uint32_t k) {
 }
 uint32_t batch_queries_per_pass(uint32_t dim, uint32_t k, uint64_t nq) {
     static const int full = getenv("CX_BATCH_WIDE_FULL") ? atoi(getenv("CX_BATCH_WIDE_FULL")) : 1;   // 0: wide lists always 32 queries per pass
-    return (!batch_wide_k(k) || (full && nq > 32)) ? 64u : 32u;
+    return (!batch_wide_k(k) || (full && nq > 32) || full == 2) ? 64u : 32u;   // 2: the 64-query wide mode for any query count
 }
 
 // launch shape for nq queries over n_rows rows: chunks x groups blocks.  A block should see >= 256 tiles (4096
