@@ -529,6 +529,15 @@ def autolink_leg(L, device: int, d: int, skip_cpu: bool, n: int = 100_000, thr: 
                              "algorithmic rate (the contract's figure) is ~2x the executed MFMA rate; profiles/r01 holds the "
                              "PMC MFMA-busy measurement of the kernel"},
     }
+    # the ordered top-100 neighbour lists of every row (SURVEY a14': what the linker needs when the reference's legacy
+    # structural rules are on — its default): the batched search in its wide mode over the same corpus, host API
+    ix.topk_lists_rows(100, np.arange(2048, dtype=np.uint32))
+    t0 = time.perf_counter()
+    lr, ls, lc = ix.topk_lists_rows(100, None)
+    t_lists = time.perf_counter() - t0
+    res["top100_lists_all_rows"] = {"seconds": t_lists, "lists_per_s": n / t_lists, "full_lists": int((lc == 100).sum()),
+                                    "kernel": "cx::batch2_kernel (wide lists, 64 queries per pass)"}
+    del lr, ls, lc
     if not skip_cpu:
         from oracle import oracle as O
         o = O.OracleIndex(d)
