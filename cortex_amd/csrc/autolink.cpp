@@ -569,6 +569,12 @@ int cx_topk_lists_rows(const cx_index *ix, uint64_t n_scan64, const uint32_t *sc
                                 (size_t)k_eff * 4, m, hipMemcpyDeviceToHost, s));
         CX_HIP(hipMemcpyAsync(out_counts + lo, ps.d_list_cnt, (size_t)m * 4, hipMemcpyDeviceToHost, s));
         CX_HIP(hipStreamSynchronize(s));
+        // a scanned row that was removed from the index has no embedding: like the passes, it gets no list
+        // (auto_linker.rs:217-218)
+        for (uint32_t i = 0; i < m; i++) {
+            const uint32_t r = scan_rows ? scan_rows[lo + i] : (uint32_t)(lo + i);
+            if (ix->h_meta[r] & META_REMOVED) out_counts[lo + i] = 0;
+        }
     }
     return CX_OK;
 } catch (...) { return cx::on_exception(); }

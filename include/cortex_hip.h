@@ -213,8 +213,8 @@ uint64_t cx_row_count(const cx_index *ix);
 /* id of a row (for callers that work with row indices); 0 ok */
 int cx_row_id(const cx_index *ix, uint64_t row, uint8_t out_id[16]);
 /* out_alive[i] = 1 if row row_lo + i holds a vector, 0 if it was removed (a tombstone until cx_rebuild compacts).  The
- * linker passes skip removed rows when they scan (auto_linker.rs:217-218: a node without an embedding); callers that
- * walk lists themselves (cx_topk_lists_rows) use this to do the same.  0 ok. */
+ * linker passes skip removed rows when they scan (auto_linker.rs:217-218: a node without an embedding) and
+ * cx_topk_lists_rows returns an empty list for them.  0 ok. */
 int cx_rows_alive(const cx_index *ix, uint64_t row_lo, uint64_t n, uint8_t *out_alive);
 /* rows of n ids (the linker passes take row indices): out_rows[i] = row of ids[16 i ..], or UINT32_MAX if the id
  * is not in the index (a node without an embedding: auto_linker.rs:217-218 skips it).  0 ok. */

@@ -343,6 +343,8 @@ def test_removed_rows_are_not_scanned(hip, oracle):
         assert not set(fr.tolist()) & set(gone) and not set(to.tolist()) & set(gone)
         want = o.autolink_pass(np.arange(n, dtype=np.uint32) if scan is None else scan, 100, np.float32(thr), 50)
         compare_edges(per_node(fr, to, w), per_node(want["from_row"], want["to_row"], want["weight"]), thr, oracle_scores(o, rows), "removed")
+    lr, ls, lc = h.topk_lists_rows(100, np.array([1, 2, 21, 300], dtype=np.uint32))
+    assert lc[1] == 0 and lc[2] == 0 and lc[0] == 100 and lc[3] == 100 and not set(lr[0, :100].tolist()) & set(gone)
     pairs = h.dedup_scan_rows(0.9) if hasattr(h, "dedup_scan_rows") else None
     if pairs is not None:
         assert not (set(np.asarray(pairs[0]).tolist()) | set(np.asarray(pairs[1]).tolist())) & set(gone)
