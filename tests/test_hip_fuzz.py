@@ -11,13 +11,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("script,args", [
-    ("fuzz_parity.py", ["--seconds", "10", "--seed", "101"]),
-    ("fuzz_parity.py", ["--big", "--seconds", "12", "--seed", "102"]),
-    ("fuzz_autolink.py", ["--seconds", "12", "--seed", "103"]),
-    ("fuzz_stateful.py", ["--seconds", "10", "--seed", "104"]),
+@pytest.mark.parametrize("script,args,env", [
+    ("fuzz_parity.py", ["--seconds", "10", "--seed", "101"], {}),
+    ("fuzz_parity.py", ["--big", "--seconds", "12", "--seed", "102"], {}),
+    ("fuzz_parity.py", ["--seconds", "8", "--seed", "105"], {"CX_BATCH_WIDE_MIN_K": "8"}),     # wide lists from k = 8
+    ("fuzz_autolink.py", ["--seconds", "12", "--seed", "103"], {}),
+    ("fuzz_autolink.py", ["--seconds", "10", "--seed", "106"], {"CX_PAIR_CAND_CAP": "24"}),     # most rows on the exact path
+    ("fuzz_stateful.py", ["--seconds", "10", "--seed", "104"], {}),
 ])
-def test_randomised_differential_run(hip, script, args):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", script)] + args, capture_output=True, text=True, timeout=600)
+def test_randomised_differential_run(hip, script, args, env):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", script)] + args, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, **env))
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert "agree with the oracle" in r.stdout
