@@ -65,6 +65,8 @@ SIGNATURES = {
     "cx_set_metadata": (C.c_int, [_P, _P, _U32, _U32]),
     "cx_set_metadata_batch": (C.c_int, [_P, _U64, _P, _P, _P]),
     "cx_intern": (_U32, [_P, C.c_char_p, _U64]),
+    "cx_lookup": (_U32, [_P, C.c_char_p, _U64]),
+    "cx_debug_check_result_block": (C.c_int, [_P, _P, _U64, _U64, _U64, _U64]),
     "cx_node_decode": (C.c_int, [_P, _U64, _P]),
     "cx_bulk_load_nodes": (C.c_int, [_P, _U64, _P, _P, _U32, _P]),
     "cx_set_node_stats_batch": (C.c_int, [_P, _U64, _P, _P, _P, _P, _P]),
@@ -82,10 +84,10 @@ SIGNATURES = {
     "cx_search": (C.c_int, [_P, _P, _U64, _U64, _P, _P, _P, _P, _P]),
     "cx_search_threshold": (C.c_int, [_P, _P, _U64, C.c_float, _P, _U64, _P, _P, _P, _P, _P]),
     "cx_search_batch": (C.c_int, [_P, _U64, _P, _U64, _U64, _P, _P, _P, _P, _P]),
-    "cx_autolink_pass_rows": (C.c_int, [_P, _U64, _P, _U64, C.c_float, _U64, _P, _U64, _P, _P, _P, _P, _P]),
+    "cx_autolink_pass_rows": (C.c_int, [_P, _U64, _P, _U64, C.c_float, _U64, _U64, _P, _P, _P, _U64, _P, _P, _P, _P, _P]),
     "cx_dedup_scan_rows": (C.c_int, [_P, C.c_float, _P, _U64, _P, _P, _P, _P, _P]),
     "cx_topk_lists_rows": (C.c_int, [_P, _U64, _P, _U64, _P, _P, _P]),
-    "cx_autolink_pass_timed": (C.c_int, [_P, _U64, _P, _U64, C.c_float, _U64, _P, _P]),
+    "cx_autolink_pass_timed": (C.c_int, [_P, _U64, _P, _U64, C.c_float, _U64, _U64, _P, _P, _P, _P]),
     "cx_autolink_lists_dev": (C.c_int, [_P, _U64, _P, _U64, C.c_float, _P, _P, _P, _P, _P]),
     "cx_copy_rows_dev": (C.c_int, [_P, _U64, _U64, _P, _P]),
     "cx_search_dev": (C.c_int, [_P, _P, _U64, _P, _P, _P, _P, _P, _P]),

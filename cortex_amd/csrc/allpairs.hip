@@ -587,9 +587,24 @@ int launch_rescore(const RescoreArgs &a, hipStream_t stream) {
 // linker/auto_linker.rs:233-264 with SimilarityLinkRule (rules.rs:42-62) as the
 // only rule: walk the ordered list; skip self (:235-237); skip neighbours the
 // storage has tombstoned (:240-243); score >= threshold -> edge (weight =
-// score); stop once max_edges_per_node edges were proposed (:261-263).
+// score) unless the node already has that edge (existing_set, :226-231,
+// :249-258: dropped without counting, the walk goes on); after each neighbour
+// that was not skipped, stop once max_edges_per_node edges were proposed
+// (:261-263 — tested AFTER the push, so max_edges = 0 still lets the first
+// neighbour's edge through, as the reference does).
 // With a.dedup the same walk emits DedupScanner::scan's pairs instead (dedup.rs:65-127).
-// MODE 0 counts, MODE 1 writes at the exclusive-scan offsets.
+// MODE 0 counts, MODE 1 writes at the exclusive-scan offsets (positions >= max_total dropped: :284-287).
+__device__ __forceinline__ bool edge_exists(const uint32_t *seg, uint32_t n, uint32_t j) {
+    uint32_t lo = 0, hi = n;   // segment sorted ascending
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint32_t v = seg[mid];
+        if (v == j) return true;
+        if (v < j) lo = mid + 1; else hi = mid;
+    }
+    return false;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void link_rules_kernel(const LinkArgs a) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -599,7 +614,14 @@ __global__ __launch_bounds__(256) void link_rules_kernel(const LinkArgs a) {
     const uint32_t cnt = (a.meta && (a.meta[self] & META_REMOVED)) ? 0u : a.list_cnt[i];
     uint32_t n = 0;
     const uint64_t base = MODE == 1 ? a.offsets[i] : 0ull;
-    for (uint32_t r = 0; r < cnt && n < a.max_edges; r++) {
+    const uint32_t *have = nullptr;
+    uint32_t n_have = 0;
+    if (a.existing_offsets) {
+        const uint64_t lo = a.existing_offsets[i];
+        have = a.existing_to + lo;
+        n_have = (uint32_t)(a.existing_offsets[i + 1] - lo);
+    }
+    for (uint32_t r = 0; r < cnt; r++) {
         const uint32_t j = a.list_rows[(size_t)i * a.topk + r];
         if (j == self) continue;
         if (a.dedup) {
@@ -611,14 +633,15 @@ __global__ __launch_bounds__(256) void link_rules_kernel(const LinkArgs a) {
             continue;
         }
         const float s = a.list_scores[(size_t)i * a.topk + r];
-        if (s >= a.threshold) {
-            if (MODE == 1) {
+        if (s >= a.threshold && !(n_have && edge_exists(have, n_have, j))) {
+            if (MODE == 1 && base + n < a.max_total) {
                 a.out_from[base + n] = self;
                 a.out_to[base + n] = j;
                 a.out_weight[base + n] = s;
             }
             n++;
         }
+        if (n >= a.max_edges) break;
     }
     if (MODE == 0) a.counts[i] = n;
 }

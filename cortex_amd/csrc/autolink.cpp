@@ -61,7 +61,9 @@ struct PassScratch {
     uint32_t *d_list_rows = nullptr, *d_list_cnt = nullptr, *d_counts = nullptr, *d_ident = nullptr;
     float *d_list_scores = nullptr, *d_list_dists = nullptr, *d_pair_sims = nullptr;
     size_t c_pair_sims = 0;
-    uint64_t *d_offsets = nullptr;
+    uint64_t *d_offsets = nullptr, *d_exist_off = nullptr;
+    uint32_t *d_exist_to = nullptr;
+    size_t c_exist_off = 0, c_exist_to = 0;
     uint8_t *d_deleted = nullptr;
     char *d_temp = nullptr;
     uint32_t *d_from = nullptr, *d_to = nullptr;
@@ -74,6 +76,7 @@ struct PassScratch {
         (void)hipFree(d_list_rows); (void)hipFree(d_list_cnt); (void)hipFree(d_counts); (void)hipFree(d_ident);
         (void)hipFree(d_list_scores); (void)hipFree(d_list_dists); (void)hipFree(d_offsets); (void)hipFree(d_pair_sims);
         (void)hipFree(d_deleted); (void)hipFree(d_temp); (void)hipFree(d_from); (void)hipFree(d_to); (void)hipFree(d_w);
+        (void)hipFree(d_exist_off); (void)hipFree(d_exist_to);
     }
 };
 
@@ -155,9 +158,16 @@ static int redo_lists(const cx_index *ix, Ctx *c, PassScratch &ps, hipStream_t s
     return CX_OK;
 }
 
+// The reference's per-cycle inputs besides the thresholds (auto_linker.rs:226-231, :284-287).
+struct CycleInputs {
+    const uint64_t *existing_offsets = nullptr;   // host CSR over the scanned nodes, [n_scan + 1]; null = no edges yet
+    const uint32_t *existing_to = nullptr;
+    uint64_t max_edges_per_cycle = ~0ull;
+};
+
 int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, const uint32_t *scan_rows,
               uint32_t topk, float threshold, uint32_t max_edges, const uint8_t *deleted, bool dedup,
-              uint64_t *total, double *phase_ms /* optional [4] */) {
+              const CycleInputs &cyc, uint64_t *total, double *phase_ms /* optional [4] */) {
     const uint32_t n_rows = (uint32_t)ix->n_rows;
     const uint32_t n_scan = (uint32_t)n_scan64;
     hipStream_t s = c->stream;
@@ -182,6 +192,23 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
         if (int rc = ensure_dev(ps.d_deleted, ps.c_deleted, (size_t)n_rows)) return rc;
         CX_HIP(hipMemcpyAsync(ps.d_deleted, deleted, n_rows, hipMemcpyHostToDevice, s));
         d_deleted = ps.d_deleted;
+    }
+    // existing edges of the scanned nodes: validated, each node's segment sorted (the rules kernel bisects it)
+    std::vector<uint32_t> exist_sorted;
+    if (cyc.existing_offsets) {
+        const uint64_t *eo = cyc.existing_offsets;
+        if (eo[0] != 0) return set_err(CX_ERR_VALIDATION, "autolink: existing_offsets[0] must be 0");
+        for (uint32_t i = 0; i < n_scan; i++)
+            if (eo[i + 1] < eo[i]) return set_err(CX_ERR_VALIDATION, "autolink: existing_offsets decrease at node %u", i);
+        const uint64_t n_exist = eo[n_scan];
+        if (n_exist && !cyc.existing_to) return set_err(CX_ERR_VALIDATION, "autolink: existing_to is null");
+        exist_sorted.assign(cyc.existing_to, cyc.existing_to + n_exist);
+        for (uint32_t i = 0; i < n_scan; i++)
+            if (eo[i + 1] - eo[i] > 1) std::sort(exist_sorted.begin() + eo[i], exist_sorted.begin() + eo[i + 1]);
+        if (int rc = ensure_dev(ps.d_exist_off, ps.c_exist_off, (size_t)n_scan + 1)) return rc;
+        if (int rc = ensure_dev(ps.d_exist_to, ps.c_exist_to, (size_t)std::max<uint64_t>(n_exist, 1))) return rc;
+        CX_HIP(hipMemcpyAsync(ps.d_exist_off, eo, ((size_t)n_scan + 1) * 8, hipMemcpyHostToDevice, s));
+        if (n_exist) CX_HIP(hipMemcpyAsync(ps.d_exist_to, exist_sorted.data(), (size_t)n_exist * 4, hipMemcpyHostToDevice, s));
     }
     if (int rc = ensure_dev(ps.d_list_rows, ps.c_list_rows, (size_t)n_scan * topk)) return rc;
     if (int rc = ensure_dev(ps.d_list_scores, ps.c_list_scores, (size_t)n_scan * topk)) return rc;
@@ -312,6 +339,11 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
     l.n_scan = n_scan;
     l.topk = topk;
     l.max_edges = dedup ? 0xFFFFFFFFu : max_edges;
+    l.max_total = dedup ? ~0ull : cyc.max_edges_per_cycle;
+    if (cyc.existing_offsets && !dedup) {
+        l.existing_offsets = ps.d_exist_off;
+        l.existing_to = ps.d_exist_to;
+    }
     l.dedup = dedup ? 1u : 0u;
     l.threshold = threshold;
     l.counts = ps.d_counts;
@@ -322,7 +354,7 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
     CX_HIP(hipMemcpyAsync(&last_off, ps.d_offsets + (n_scan - 1), 8, hipMemcpyDeviceToHost, s));
     CX_HIP(hipMemcpyAsync(&last_cnt, ps.d_counts + (n_scan - 1), 4, hipMemcpyDeviceToHost, s));
     CX_HIP(hipStreamSynchronize(s));
-    const uint64_t n_edges = last_off + last_cnt;
+    const uint64_t n_edges = std::min<uint64_t>(last_off + last_cnt, l.max_total);   // :284-287
     if (n_edges) {
         if (int rc = ensure_dev(ps.d_from, ps.c_from, (size_t)n_edges)) return rc;
         if (int rc = ensure_dev(ps.d_to, ps.c_to, (size_t)n_edges)) return rc;
@@ -360,7 +392,7 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
     return CX_OK;
 }
 
-int copy_edges_rows(Ctx *c, PassScratch &ps, uint64_t total, uint64_t cap, uint32_t *out_from, uint32_t *out_to,
+int copy_edges_rows(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t total, uint64_t cap, uint32_t *out_from, uint32_t *out_to,
                     float *out_w, uint64_t *n_out, uint64_t *n_needed) {
     if (n_needed) *n_needed = total;
     const uint64_t take = std::min(total, cap);
@@ -370,6 +402,11 @@ int copy_edges_rows(Ctx *c, PassScratch &ps, uint64_t total, uint64_t cap, uint3
         CX_HIP(hipMemcpyAsync(out_to, ps.d_to, take * 4, hipMemcpyDeviceToHost, c->stream));
         CX_HIP(hipMemcpyAsync(out_w, ps.d_w, take * 4, hipMemcpyDeviceToHost, c->stream));
         CX_HIP(hipStreamSynchronize(c->stream));
+        // the caller maps these rows to ids (cx_row_id) and indexes its own arrays with them: check before handing over
+        for (uint64_t i = 0; i < take; i++)
+            if (out_from[i] >= ix->n_rows || out_to[i] >= ix->n_rows)
+                return set_err(CX_ERR_DEVICE, "device edge list is corrupt: edge %llu is %u -> %u in an index of %llu rows",
+                               (unsigned long long)i, out_from[i], out_to[i], (unsigned long long)ix->n_rows);
     }
     *n_out = take;
     if (total > cap) return set_err(CX_ERR_CAPACITY, "%llu edges, buffer holds %llu", (unsigned long long)total, (unsigned long long)cap);
@@ -381,8 +418,9 @@ int copy_edges_rows(Ctx *c, PassScratch &ps, uint64_t total, uint64_t cap, uint3
 extern "C" {
 
 int cx_autolink_pass_rows(const cx_index *ix, uint64_t n_scan, const uint32_t *scan_rows, uint64_t topk,
-                          float threshold, uint64_t max_edges_per_node, const uint8_t *deleted, uint64_t cap,
-                          uint32_t *out_from, uint32_t *out_to, float *out_weight, uint64_t *n_out,
+                          float threshold, uint64_t max_edges_per_node, uint64_t max_edges_per_cycle,
+                          const uint8_t *deleted, const uint64_t *existing_offsets, const uint32_t *existing_to,
+                          uint64_t cap, uint32_t *out_from, uint32_t *out_to, float *out_weight, uint64_t *n_out,
                           uint64_t *n_needed) try {
     if (!ix || !n_out) return set_err(CX_ERR_VALIDATION, "null argument");
     *n_out = 0;
@@ -394,10 +432,14 @@ int cx_autolink_pass_rows(const cx_index *ix, uint64_t n_scan, const uint32_t *s
     if (!lease.c) return CX_ERR_DEVICE;
     PassScratch &ps = scratch_of(lease.c);
     uint64_t total = 0;
+    CycleInputs cyc;
+    cyc.existing_offsets = existing_offsets;
+    cyc.existing_to = existing_to;
+    cyc.max_edges_per_cycle = max_edges_per_cycle;
     if (int rc = pass_core(ix, lease.c, ps, n_scan, scan_rows, (uint32_t)std::min<uint64_t>(topk, 0xFFFFFFFFull), threshold,
-                           (uint32_t)std::min<uint64_t>(max_edges_per_node, 0xFFFFFFFFull), deleted, false, &total, nullptr))
+                           (uint32_t)std::min<uint64_t>(max_edges_per_node, 0xFFFFFFFFull), deleted, false, cyc, &total, nullptr))
         return rc;
-    return copy_edges_rows(lease.c, ps, total, cap, out_from, out_to, out_weight, n_out, n_needed);
+    return copy_edges_rows(ix, lease.c, ps, total, cap, out_from, out_to, out_weight, n_out, n_needed);
 } catch (...) { return cx::on_exception(); }
 
 int cx_dedup_scan_rows(const cx_index *ix, float dedup_threshold, const uint8_t *deleted, uint64_t cap,
@@ -416,21 +458,28 @@ int cx_dedup_scan_rows(const cx_index *ix, float dedup_threshold, const uint8_t 
     if (!lease.c) return CX_ERR_DEVICE;
     PassScratch &ps = scratch_of(lease.c);
     uint64_t total = 0;
-    if (int rc = pass_core(ix, lease.c, ps, scan.size(), scan.data(), TOPK_MAX, dedup_threshold, 0, deleted, true, &total, nullptr))
+    if (int rc = pass_core(ix, lease.c, ps, scan.size(), scan.data(), TOPK_MAX, dedup_threshold, 0, deleted, true, CycleInputs(), &total, nullptr))
         return rc;
-    return copy_edges_rows(lease.c, ps, total, cap, out_a, out_b, out_similarity, n_out, n_needed);
+    return copy_edges_rows(ix, lease.c, ps, total, cap, out_a, out_b, out_similarity, n_out, n_needed);
 } catch (...) { return cx::on_exception(); }
 
 int cx_autolink_pass_timed(const cx_index *ix, uint64_t n_scan, const uint32_t *scan_rows, uint64_t topk,
-                           float threshold, uint64_t max_edges_per_node, uint64_t *n_edges, double *phase_ms) try {
+                           float threshold, uint64_t max_edges_per_node, uint64_t max_edges_per_cycle,
+                           const uint64_t *existing_offsets, const uint32_t *existing_to, uint64_t *n_edges,
+                           double *phase_ms) try {
     if (!ix || !n_edges || !phase_ms) return set_err(CX_ERR_VALIDATION, "null argument");
     if (!scan_rows) n_scan = ix->n_rows;
+    if (n_scan > 0xFFFFFFF0ull) return set_err(CX_ERR_VALIDATION, "too many scanned rows");
     if (int rc = use_device(ix)) return rc;
     CtxLease lease(ix);
     if (!lease.c) return CX_ERR_DEVICE;
     PassScratch &ps = scratch_of(lease.c);
-    return pass_core(ix, lease.c, ps, n_scan, scan_rows, (uint32_t)topk, threshold, (uint32_t)max_edges_per_node, nullptr,
-                     false, n_edges, phase_ms);
+    CycleInputs cyc;
+    cyc.existing_offsets = existing_offsets;
+    cyc.existing_to = existing_to;
+    cyc.max_edges_per_cycle = max_edges_per_cycle;
+    return pass_core(ix, lease.c, ps, n_scan, scan_rows, (uint32_t)std::min<uint64_t>(topk, 0xFFFFFFFFull), threshold,
+                     (uint32_t)std::min<uint64_t>(max_edges_per_node, 0xFFFFFFFFull), nullptr, false, cyc, n_edges, phase_ms);
 } catch (...) { return cx::on_exception(); }
 
 /* Ordered neighbour lists of nq external vectors against this shard (the multi-GPU building block of the
@@ -569,6 +618,10 @@ int cx_topk_lists_rows(const cx_index *ix, uint64_t n_scan64, const uint32_t *sc
                                 (size_t)k_eff * 4, m, hipMemcpyDeviceToHost, s));
         CX_HIP(hipMemcpyAsync(out_counts + lo, ps.d_list_cnt, (size_t)m * 4, hipMemcpyDeviceToHost, s));
         CX_HIP(hipStreamSynchronize(s));
+        if (int rc = check_result_block(out_counts + lo, out_rows + (size_t)lo * topk, m, topk, k_eff, n_rows)) {
+            memset(out_counts + lo, 0, (size_t)m * 4);
+            return rc;
+        }
         // a scanned row that was removed from the index has no embedding: like the passes, it gets no list
         // (auto_linker.rs:217-218)
         for (uint32_t i = 0; i < m; i++) {

@@ -39,7 +39,7 @@ float decayed(const cx_decay_config &cfg, float raw, float rb, int64_t now_s, ui
     const double days_idle = (double)idle_s / 86400.0;
     double kind_rate = cfg.daily_rate;
     for (uint32_t i = 0; i < cfg.n_by_kind; i++)
-        if (cfg.kind_codes[i] == st.kind) { kind_rate = cfg.kind_rates[i]; break; }
+        if (cfg.kind_codes[i] != 0 && cfg.kind_codes[i] == st.kind) { kind_rate = cfg.kind_rates[i]; break; }   // 0 = cx_lookup's "never interned"
     const double effective_days = std::min(days_idle, cfg.max_age_days);
     const float temporal = (float)std::max(std::exp(-kind_rate * effective_days), cfg.min_factor);
     const float echo = (float)std::min(1.0 + (double)st.access * cfg.echo_weight, cfg.echo_cap);

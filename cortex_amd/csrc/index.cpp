@@ -46,6 +46,21 @@ int use_device(const cx_index *ix) {
     return CX_OK;
 }
 
+int check_result_block(const uint32_t *counts, const uint32_t *rows, uint64_t nq, uint64_t stride, uint64_t k_max,
+                       uint64_t n_rows) {
+    for (uint64_t i = 0; i < nq; i++) {
+        const uint32_t cnt = counts[i];
+        if (cnt > k_max)
+            return set_err(CX_ERR_DEVICE, "device result block is corrupt: list %llu holds %u entries, at most %llu possible",
+                           (unsigned long long)i, cnt, (unsigned long long)k_max);
+        for (uint32_t j = 0; j < cnt; j++)
+            if (rows[i * stride + j] >= n_rows)
+                return set_err(CX_ERR_DEVICE, "device result block is corrupt: list %llu entry %u names row %u of %llu",
+                               (unsigned long long)i, j, rows[i * stride + j], (unsigned long long)n_rows);
+    }
+    return CX_OK;
+}
+
 Ctx *acquire_ctx(const cx_index *ix) {
     {
         std::lock_guard<std::mutex> g(ix->mu);
@@ -131,6 +146,7 @@ int upsert_impl(cx_index *ix, uint64_t n, const uint8_t *ids, const float *embs,
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     const size_t row_bytes = (size_t)ix->dim * sizeof(float);
     uint64_t i = 0;
+    uint64_t meta_lo = UINT64_MAX, meta_hi = 0;   // new rows that took pending metadata: [meta_lo, meta_hi)
     while (i < n) {
         const IdKey key = id_key(ids + 16 * i);
         auto it = ix->map.find(key);
@@ -150,8 +166,19 @@ int upsert_impl(cx_index *ix, uint64_t n, const uint8_t *ids, const float *embs,
             if (ix->map.find(kk) != ix->map.end()) break;
             ix->map.emplace(kk, (uint32_t)ix->n_rows);
             ix->ids.insert(ix->ids.end(), ids + 16 * i, ids + 16 * i + 16);
-            ix->h_meta.push_back(0);
-            ix->h_agent.push_back(0);
+            uint32_t meta0 = 0, agent0 = 0;
+            if (!ix->pending_meta.empty()) {   // metadata that arrived before the vector (vector/tests.rs:65-66)
+                auto pm = ix->pending_meta.find(kk);
+                if (pm != ix->pending_meta.end()) {
+                    meta0 = META_HAS | (pm->second.first << 8);
+                    agent0 = pm->second.second;
+                    ix->pending_meta.erase(pm);
+                    meta_lo = std::min<uint64_t>(meta_lo, ix->n_rows);
+                    meta_hi = std::max<uint64_t>(meta_hi, ix->n_rows + 1);
+                }
+            }
+            ix->h_meta.push_back(meta0);
+            ix->h_agent.push_back(agent0);
             ix->n_rows++;
             ix->n_alive++;
             i++;
@@ -159,6 +186,10 @@ int upsert_impl(cx_index *ix, uint64_t n, const uint8_t *ids, const float *embs,
         if (row_bytes)
             CX_HIP(hipMemcpyAsync(ix->d_rows + (size_t)first_row * ix->dim, embs + run_start * len,
                                   (i - run_start) * row_bytes, kind, ix->up_stream));
+    }
+    if (meta_lo < meta_hi) {
+        CX_HIP(hipMemcpyAsync(ix->d_meta + meta_lo, &ix->h_meta[meta_lo], (size_t)(meta_hi - meta_lo) * 4, hipMemcpyHostToDevice, ix->up_stream));
+        CX_HIP(hipMemcpyAsync(ix->d_agent + meta_lo, &ix->h_agent[meta_lo], (size_t)(meta_hi - meta_lo) * 4, hipMemcpyHostToDevice, ix->up_stream));
     }
     CX_HIP(hipStreamSynchronize(ix->up_stream));
     return CX_OK;
@@ -536,6 +567,7 @@ int cx_upsert_batch_dev(cx_index *ix, uint64_t n, const uint8_t *ids, const floa
 
 int cx_remove(cx_index *ix, const uint8_t id[16]) try {
     if (!ix || !id) return set_err(CX_ERR_VALIDATION, "null argument");
+    ix->pending_meta.erase(id_key(id));     // vector/index.rs:318: metadata goes whether or not a vector exists
     auto it = ix->map.find(id_key(id));
     if (it == ix->map.end()) return CX_OK;  // vector/index.rs:317 — HashMap::remove of a missing key
     if (int rc = use_device(ix)) return rc;
@@ -552,9 +584,12 @@ int cx_set_metadata(cx_index *ix, const uint8_t id[16], uint32_t kind_code, uint
     if (!ix || !id) return set_err(CX_ERR_VALIDATION, "null argument");
     if (kind_code >= (1u << 24)) return set_err(CX_ERR_VALIDATION, "kind code out of range");
     auto it = ix->map.find(id_key(id));
-    // The reference keeps metadata in its own map and only consults it for ids
-    // that have a vector (:234); metadata for an unknown id has no effect.
-    if (it == ix->map.end()) return CX_OK;
+    // The reference keeps metadata in its own map (:219-222) and consults it for ids that have a
+    // vector (:234): metadata for an id without a vector waits for the insert (vector/tests.rs:65-66).
+    if (it == ix->map.end()) {
+        ix->pending_meta[id_key(id)] = {kind_code, agent_code};
+        return CX_OK;
+    }
     if (int rc = use_device(ix)) return rc;
     const uint32_t row = it->second;
     ix->h_meta[row] = META_HAS | (kind_code << 8);
@@ -571,7 +606,10 @@ int cx_set_metadata_batch(cx_index *ix, uint64_t n, const uint8_t *ids, const ui
     uint32_t lo = UINT32_MAX, hi = 0;
     for (uint64_t i = 0; i < n; i++) {
         auto it = ix->map.find(id_key(ids + 16 * i));
-        if (it == ix->map.end()) continue;  // as cx_set_metadata: no vector, no effect
+        if (it == ix->map.end()) {           // as cx_set_metadata: kept until the id gets its vector
+            ix->pending_meta[id_key(ids + 16 * i)] = {kind_codes[i], agent_codes[i]};
+            continue;
+        }
         const uint32_t row = it->second;
         ix->h_meta[row] = META_HAS | (kind_codes[i] << 8);
         ix->h_agent[row] = agent_codes[i];
@@ -587,15 +625,24 @@ int cx_set_metadata_batch(cx_index *ix, uint64_t n, const uint8_t *ids, const ui
     return CX_OK;
 } catch (...) { return cx::on_exception(); }
 
-uint32_t cx_intern(cx_index *ix, const char *utf8, uint64_t len) {
+uint32_t cx_intern(cx_index *ix, const char *utf8, uint64_t len) try {
     if (!ix || (!utf8 && len)) return 0;
     std::string s(utf8 ? utf8 : "", (size_t)len);
+    std::lock_guard<std::mutex> g(ix->intern_mu);
     auto it = ix->interned.find(s);
     if (it != ix->interned.end()) return it->second;
     const uint32_t code = (uint32_t)ix->interned.size() + 1;
     ix->interned.emplace(std::move(s), code);
     return code;
-}
+} catch (...) { cx::on_exception(); return 0; }
+
+uint32_t cx_lookup(const cx_index *ix, const char *utf8, uint64_t len) try {
+    if (!ix || (!utf8 && len)) return 0;
+    const std::string s(utf8 ? utf8 : "", (size_t)len);
+    std::lock_guard<std::mutex> g(ix->intern_mu);
+    auto it = ix->interned.find(s);
+    return it == ix->interned.end() ? 0u : it->second;   // 0: a string no row was ever tagged with matches no row
+} catch (...) { cx::on_exception(); return 0; }
 
 int cx_rebuild(cx_index *ix) try {
     if (!ix) return set_err(CX_ERR_VALIDATION, "null index");
@@ -607,42 +654,46 @@ int cx_rebuild(cx_index *ix) try {
         if (!(ix->h_meta[r] & META_REMOVED)) keep.push_back((uint32_t)r);
     const uint64_t n_new = keep.size();
     const uint64_t ncap = std::max<uint64_t>(n_new, 1024);
-    float *nr = nullptr;
-    uint32_t *nm = nullptr, *na = nullptr, *d_keep = nullptr;
-    CX_HIP(hipMalloc((void **)&nr, (ncap + 16) * ix->dim * sizeof(float) + 64));  // + one batch tile of padding (batch.hip)
-    CX_HIP(hipMalloc((void **)&nm, ncap * sizeof(uint32_t)));
-    CX_HIP(hipMalloc((void **)&na, ncap * sizeof(uint32_t)));
-    CX_HIP(hipMemsetAsync(nm, 0, ncap * sizeof(uint32_t), ix->up_stream));
-    CX_HIP(hipMemsetAsync(na, 0, ncap * sizeof(uint32_t), ix->up_stream));
+    // Everything new is built beside the live state and swapped in only after the last device operation succeeded:
+    // a failure on the way (allocation, gather, copy) leaves the index exactly as it was.
+    struct NewStore {
+        float *rows = nullptr;
+        uint32_t *meta = nullptr, *agent = nullptr, *keep = nullptr;
+        ~NewStore() { (void)hipFree(rows); (void)hipFree(meta); (void)hipFree(agent); (void)hipFree(keep); }
+    } ns;
+    CX_HIP(hipMalloc((void **)&ns.rows, (ncap + 16) * ix->dim * sizeof(float) + 64));  // + one batch tile of padding (batch.hip)
+    CX_HIP(hipMalloc((void **)&ns.meta, ncap * sizeof(uint32_t)));
+    CX_HIP(hipMalloc((void **)&ns.agent, ncap * sizeof(uint32_t)));
+    CX_HIP(hipMemsetAsync(ns.meta, 0, ncap * sizeof(uint32_t), ix->up_stream));
+    CX_HIP(hipMemsetAsync(ns.agent, 0, ncap * sizeof(uint32_t), ix->up_stream));
     std::vector<uint8_t> nids(n_new * 16);
     std::vector<uint32_t> nmeta(n_new), nagent(n_new);
     std::vector<NodeStats> nstats(ix->h_stats.empty() ? 0 : n_new);
-    ix->map.clear();
+    std::unordered_map<IdKey, uint32_t, IdHash> nmap;
+    nmap.reserve(n_new);
     for (uint64_t i = 0; i < n_new; i++) {
         const uint32_t r = keep[i];
         memcpy(&nids[16 * i], &ix->ids[16 * (size_t)r], 16);
         nmeta[i] = ix->h_meta[r];
         nagent[i] = ix->h_agent[r];
         if (!nstats.empty() && r < ix->h_stats.size()) nstats[i] = ix->h_stats[r];
-        ix->map.emplace(id_key(&nids[16 * i]), (uint32_t)i);
+        nmap.emplace(id_key(&nids[16 * i]), (uint32_t)i);
     }
     if (n_new) {
-        CX_HIP(hipMalloc((void **)&d_keep, n_new * 4));
-        CX_HIP(hipMemcpyAsync(d_keep, keep.data(), n_new * 4, hipMemcpyHostToDevice, ix->up_stream));
+        CX_HIP(hipMalloc((void **)&ns.keep, n_new * 4));
+        CX_HIP(hipMemcpyAsync(ns.keep, keep.data(), n_new * 4, hipMemcpyHostToDevice, ix->up_stream));
         if (ix->dim)
-            if (int rc = launch_gather_rows(ix->d_rows, nr, d_keep, (uint32_t)n_new, ix->dim, ix->up_stream)) return rc;
-        CX_HIP(hipMemcpyAsync(nm, nmeta.data(), n_new * 4, hipMemcpyHostToDevice, ix->up_stream));
-        CX_HIP(hipMemcpyAsync(na, nagent.data(), n_new * 4, hipMemcpyHostToDevice, ix->up_stream));
+            if (int rc = launch_gather_rows(ix->d_rows, ns.rows, ns.keep, (uint32_t)n_new, ix->dim, ix->up_stream)) return rc;
+        CX_HIP(hipMemcpyAsync(ns.meta, nmeta.data(), n_new * 4, hipMemcpyHostToDevice, ix->up_stream));
+        CX_HIP(hipMemcpyAsync(ns.agent, nagent.data(), n_new * 4, hipMemcpyHostToDevice, ix->up_stream));
     }
     CX_HIP(hipStreamSynchronize(ix->up_stream));
-    if (d_keep) CX_HIP(hipFree(d_keep));
-    CX_HIP(hipFree(ix->d_rows));
-    CX_HIP(hipFree(ix->d_meta));
-    CX_HIP(hipFree(ix->d_agent));
-    ix->d_rows = nr;
-    ix->d_meta = nm;
-    ix->d_agent = na;
+    // commit: nothing below can fail
+    std::swap(ix->d_rows, ns.rows);      // the old buffers leave with ns
+    std::swap(ix->d_meta, ns.meta);
+    std::swap(ix->d_agent, ns.agent);
     ix->cap = ncap;
+    ix->map.swap(nmap);
     ix->ids.swap(nids);
     ix->h_meta.swap(nmeta);
     ix->h_agent.swap(nagent);
@@ -655,6 +706,12 @@ int cx_rebuild(cx_index *ix) try {
     ix->norms_rows = 0;   // and so are the row norms
     ix->norms_stale.clear();
     return CX_OK;
+} catch (...) { return cx::on_exception(); }
+
+int cx_debug_check_result_block(const uint32_t *counts, const uint32_t *rows, uint64_t nq, uint64_t stride, uint64_t k_max,
+                                uint64_t n_rows) try {
+    if (nq && (!counts || !rows)) return set_err(CX_ERR_VALIDATION, "null argument");
+    return check_result_block(counts, rows, nq, stride, k_max, n_rows);
 } catch (...) { return cx::on_exception(); }
 
 int cx_profile_enable(cx_index *ix, int on) try {
@@ -749,6 +806,12 @@ int cx_search_batch(const cx_index *ix, uint64_t nq, const float *queries, uint6
         return rc;
     if (direct) CX_HIP(hipStreamSynchronize(c->stream));
     else if (int rc = fetch_block(c, dv, hv)) return rc;
+    // nothing read back from the device is used as an index or a length before it was checked: a kernel bug must
+    // surface as CX_ERR_DEVICE, never as a fault on the caller's side of the FFI
+    if (int rc = check_result_block(hv.counts, hv.rows, nq, k_eff, k_eff, ix->n_rows)) {
+        for (uint64_t i = 0; i < nq; i++) out_counts[i] = 0;
+        return rc;
+    }
     for (uint64_t i = 0; i < nq; i++) {
         const uint32_t cnt = hv.counts[i];
         out_counts[i] = cnt;
@@ -792,6 +855,7 @@ int cx_search_threshold(const cx_index *ix, const float *query, uint64_t len, fl
     CX_HIP(hipMemcpyAsync(hv.counts, dv.counts, 4, hipMemcpyDeviceToHost, c->stream));
     CX_HIP(hipStreamSynchronize(c->stream));
     const uint64_t total = hv.counts[0];
+    if (total > n) return set_err(CX_ERR_DEVICE, "search_threshold: device reported %llu results for %u rows", (unsigned long long)total, n);
     if (n_needed) *n_needed = total;
     const uint64_t take = std::min<uint64_t>(total, cap);
     if (take) {
@@ -800,6 +864,8 @@ int cx_search_threshold(const cx_index *ix, const float *query, uint64_t len, fl
         CX_HIP(hipMemcpyAsync(hv.scores, dv.scores, take * 4, hipMemcpyDeviceToHost, c->stream));
         CX_HIP(hipMemcpyAsync(hv.dists, dv.dists, take * 4, hipMemcpyDeviceToHost, c->stream));
         CX_HIP(hipStreamSynchronize(c->stream));
+        const uint32_t one = (uint32_t)take;
+        if (int rc = check_result_block(&one, hv.rows, 1, take, take, ix->n_rows)) return rc;
         for (uint64_t j = 0; j < take; j++) {
             memcpy(out_ids + 16 * j, &ix->ids[16 * (size_t)hv.rows[j]], 16);
             out_scores[j] = hv.scores[j];

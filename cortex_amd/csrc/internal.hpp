@@ -121,7 +121,14 @@ struct cx_index {
     std::vector<uint32_t> h_meta, h_agent;
     std::vector<NodeStats> h_stats;   // empty until cx_set_node_stats_batch; rows beyond its size read as defaults
     std::unordered_map<IdKey, uint32_t, IdHash> map;
+    // string -> code table of kinds / agents.  cx_intern (&mut self paths) adds, cx_lookup (&self: filters) only reads;
+    // intern_mu makes the two safe against each other whatever lock the caller holds.
     std::unordered_map<std::string, uint32_t> interned;
+    mutable std::mutex intern_mu;
+    // set_metadata for an id that has no vector yet (the reference keeps metadata in a map of its own,
+    // vector/index.rs:219-222; its integration test sets it before insert, vector/tests.rs:65-66): (kind, agent)
+    // codes waiting for the id's row; applied by the upsert that creates the row, dropped by cx_remove (:318)
+    std::unordered_map<IdKey, std::pair<uint32_t, uint32_t>, IdHash> pending_meta;
     hipStream_t up_stream = nullptr;
     mutable std::mutex mu;
     mutable std::vector<Ctx *> pool;
@@ -165,6 +172,10 @@ struct CtxLease {
     CtxLease(const CtxLease &) = delete;
     CtxLease &operator=(const CtxLease &) = delete;
 };
+// counts[i] <= k_max and every listed row < n_rows, or CX_ERR_DEVICE: guards every host-side use of a result block
+// read back from the device (rows of list i start at rows + i * stride)
+int check_result_block(const uint32_t *counts, const uint32_t *rows, uint64_t nq, uint64_t stride, uint64_t k_max,
+                       uint64_t n_rows);
 bool use_nontemporal(const cx_index *ix);
 // nq single-query scans (query i = d_queries + i*dim) enqueued on s; results at [i*k_eff, ...)
 int ensure_norms(const cx_index *ix, hipStream_t s);   // index.cpp

@@ -146,7 +146,13 @@ struct LinkArgs {
     const uint32_t *list_cnt;
     const uint8_t *deleted;   // [n_rows] storage tombstones (quirk Q2) or null
     const uint32_t *meta;     // [n_rows] index metadata: a scanned row that was removed from the index has no embedding and proposes nothing
+    // auto_linker.rs:226-231: per scanned node (scan order) the rows it already has a related_to edge to, CSR, each
+    // node's segment sorted ascending (the host sorts its copy); null = no edges yet.  Such neighbours are skipped
+    // WITHOUT counting towards max_edges (:249-258).
+    const uint64_t *existing_offsets;   // [n_scan + 1]
+    const uint32_t *existing_to;
     uint32_t n_scan, topk, max_edges, dedup;
+    uint64_t max_total;       // emit pass: edges at positions >= max_total are dropped (:284-287 take(max_edges_per_cycle))
     float threshold;
     uint32_t *counts;         // [n_scan]  (count pass)
     const uint64_t *offsets;  // [n_scan]  (emit pass)

@@ -85,9 +85,10 @@ int cx_save(const cx_index *ix, const char *path) try {
         }
     }
     // metadata
+    std::lock_guard<std::mutex> intern_guard(ix->intern_mu);
     std::vector<const std::string *> names(ix->interned.size() + 1, nullptr);
     for (auto &kv : ix->interned) names[kv.second] = &kv.first;
-    uint64_t n_meta = 0;
+    uint64_t n_meta = ix->pending_meta.size();   // metadata of ids without a vector is part of the map too (:438)
     for (uint64_t r = 0; r < ix->n_rows; r++)
         if (!(ix->h_meta[r] & META_REMOVED) && (ix->h_meta[r] & META_HAS)) n_meta++;
     w.u64(n_meta);
@@ -97,6 +98,15 @@ int cx_save(const cx_index *ix, const char *path) try {
         if ((m & META_REMOVED) || !(m & META_HAS)) continue;
         const uint32_t kc = m >> 8, ac = ix->h_agent[r];
         w.uuid(&ix->ids[16 * (size_t)r]);
+        w.str(kc < names.size() && names[kc] ? *names[kc] : empty);
+        w.str(ac < names.size() && names[ac] ? *names[ac] : empty);
+    }
+    for (auto &kv : ix->pending_meta) {
+        uint8_t id[16];
+        memcpy(id, &kv.first.a, 8);
+        memcpy(id + 8, &kv.first.b, 8);
+        const uint32_t kc = kv.second.first, ac = kv.second.second;
+        w.uuid(id);
         w.str(kc < names.size() && names[kc] ? *names[kc] : empty);
         w.str(ac < names.size() && names[ac] ? *names[ac] : empty);
     }

@@ -129,16 +129,22 @@ class HipIndex:
             keep.append(cb)
             cf.has_exclude, cf.n_exclude, cf.exclude_ids = 1, len(f.exclude), C.cast(cb, C.c_void_p)
         if f.kinds is not None:
-            codes = np.array([self.intern(k) for k in f.kinds], dtype=np.uint32)
+            codes = np.array([self.lookup(k) for k in f.kinds], dtype=np.uint32)
             keep.append(codes)
             cf.has_kinds, cf.n_kinds, cf.kind_codes = 1, len(f.kinds), codes.ctypes.data
         if f.source_agent is not None:
-            cf.has_agent, cf.agent_code = 1, self.intern(f.source_agent)
+            cf.has_agent, cf.agent_code = 1, self.lookup(f.source_agent)
         return cf, keep
 
     def intern(self, s: str) -> int:
+        """cx_intern: code of a kind / agent string, added if new — the &mut self paths (set_metadata, bulk load)."""
         b = s.encode()
         return self._L.cx_intern(self._h, b, len(b))
+
+    def lookup(self, s: str) -> int:
+        """cx_lookup: read-only (&self) — what filters use; 0 for a string no row was ever tagged with."""
+        b = s.encode()
+        return self._L.cx_lookup(self._h, b, len(b))
 
     # -- VectorIndex: mutation --------------------------------------------
     def insert(self, node_id: NodeId, embedding) -> None:
@@ -218,7 +224,7 @@ class HipIndex:
         cl = scoring.http_candidate_limit(limit, config, rb) if candidate_limit is None else candidate_limit
         now = scoring.now_utc() if now is None else now
         q = _f32(query).reshape(-1)
-        c, keep = config._c(self.intern)
+        c, keep = config._c(self.lookup)
         cap = max(1, limit)
         ids = np.zeros((cap, 16), np.uint8)
         sc = np.zeros(cap, np.float32)
@@ -348,23 +354,40 @@ class HipIndex:
         return out
 
     # -- the auto-linker's similarity pass, batched ---------------------------
+    @staticmethod
+    def _existing_csr(existing, n_scan: int):
+        """(offsets u64 [n_scan+1], to_rows u32) -> contiguous arrays for the ABI; None passes through."""
+        if existing is None:
+            return None, None
+        eo = np.ascontiguousarray(existing[0], dtype=np.uint64)
+        et = np.ascontiguousarray(existing[1], dtype=np.uint32)
+        if eo.size != n_scan + 1 or int(eo[-1]) != et.size:
+            raise ValidationError("existing: offsets must have n_scan + 1 entries and end at len(to_rows)")
+        return eo, et
+
     def autolink_pass_rows(self, scan_rows, topk: int, threshold: float, max_edges_per_node: int,
-                           deleted: Optional[np.ndarray] = None):
+                           deleted: Optional[np.ndarray] = None, existing=None,
+                           max_edges_per_cycle: Optional[int] = None):
         """cx_autolink_pass_rows: (from_rows u32, to_rows u32, weights f32), scan order then score order.
-        scan_rows=None scans every row."""
+        scan_rows=None scans every row.  existing = (offsets [n_scan+1], to_rows) CSR of the related_to edges the
+        scanned nodes already have (auto_linker.rs:226-231); max_edges_per_cycle: :284-287, None = no truncation."""
         sr = None if scan_rows is None else np.ascontiguousarray(scan_rows, dtype=np.uint32)
         n_scan = self.row_count() if sr is None else sr.size
         dl = None if deleted is None else np.ascontiguousarray(deleted, dtype=np.uint8)
         if dl is not None and dl.size != self.row_count():
             raise ValidationError("deleted must have one flag per row")
+        eo, et = self._existing_csr(existing, n_scan)
+        cyc = 0xFFFFFFFFFFFFFFFF if max_edges_per_cycle is None else int(max_edges_per_cycle)
         cap = max(1024, n_scan * 4)
         while True:
             fr, to = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
             w = np.zeros(cap, np.float32)
             n, need = C.c_uint64(0), C.c_uint64(0)
             rc = self._L.cx_autolink_pass_rows(self._h, n_scan, sr.ctypes.data if sr is not None else None, int(topk),
-                                               float(threshold), int(max_edges_per_node),
-                                               dl.ctypes.data if dl is not None else None, cap, fr.ctypes.data,
+                                               float(threshold), int(max_edges_per_node), cyc,
+                                               dl.ctypes.data if dl is not None else None,
+                                               eo.ctypes.data if eo is not None else None,
+                                               et.ctypes.data if et is not None else None, cap, fr.ctypes.data,
                                                to.ctypes.data, w.ctypes.data, C.byref(n), C.byref(need))
             if rc == 4 and need.value > cap:
                 cap = int(need.value)
@@ -415,14 +438,19 @@ class HipIndex:
                                                rows.ctypes.data, scores.ctypes.data, counts.ctypes.data))
         return rows, scores, counts
 
-    def autolink_pass_timed(self, topk: int, threshold: float, max_edges_per_node: int, scan_rows=None):
+    def autolink_pass_timed(self, topk: int, threshold: float, max_edges_per_node: int, scan_rows=None,
+                            existing=None, max_edges_per_cycle: Optional[int] = None):
         """(n_edges, [shadow_ms, filter_ms, rescore_ms, rules_ms]) with the edges left in HBM."""
         sr = None if scan_rows is None else np.ascontiguousarray(scan_rows, dtype=np.uint32)
         n_scan = self.row_count() if sr is None else sr.size
+        eo, et = self._existing_csr(existing, n_scan)
+        cyc = 0xFFFFFFFFFFFFFFFF if max_edges_per_cycle is None else int(max_edges_per_cycle)
         ne = C.c_uint64(0)
         ph = (C.c_double * 4)()
         self._check(self._L.cx_autolink_pass_timed(self._h, n_scan, sr.ctypes.data if sr is not None else None,
-                                                   int(topk), float(threshold), int(max_edges_per_node),
+                                                   int(topk), float(threshold), int(max_edges_per_node), cyc,
+                                                   eo.ctypes.data if eo is not None else None,
+                                                   et.ctypes.data if et is not None else None,
                                                    C.byref(ne), ph))
         return ne.value, list(ph)
 

@@ -88,11 +88,17 @@ int cx_upsert_batch_dev(cx_index *ix, uint64_t n, const uint8_t *ids, const floa
 int cx_remove(cx_index *ix, const uint8_t id[16]);
 /* HnswIndex::set_metadata — vector/index.rs:219-222 (kind, source_agent interned) */
 int cx_set_metadata(cx_index *ix, const uint8_t id[16], uint32_t kind_code, uint32_t agent_code);
-/* n set_metadata calls in one (ids n*16 bytes); ids without a vector are ignored like above */
+/* n set_metadata calls in one (ids n*16 bytes).  Like the reference's separate metadata map, metadata set for an id
+ * that has no vector yet is kept and binds when the vector is inserted (vector/tests.rs:65-66 does exactly that);
+ * cx_remove drops it (:318). */
 int cx_set_metadata_batch(cx_index *ix, uint64_t n, const uint8_t *ids, const uint32_t *kind_codes,
                           const uint32_t *agent_codes);
-/* string -> stable code for cx_set_metadata / cx_filter (NodeKind / agent names) */
+/* string -> stable code for cx_set_metadata (NodeKind / agent names); adds the string if it is new (&mut self) */
 uint32_t cx_intern(cx_index *ix, const char *utf8, uint64_t len);
+/* &self: the code of a string for a cx_filter, 0 if it was never interned — no row carries code 0, so a kind or
+ * agent nobody was tagged with matches no row that has metadata, as in matches_filter (vector/index.rs:225-251).
+ * Safe to call concurrently with searches and with cx_intern. */
+uint32_t cx_lookup(const cx_index *ix, const char *utf8, uint64_t len);
 /* VectorIndex::rebuild — vector/index.rs:416-435.  The exact engine needs no
  * graph: this compacts removed rows out of HBM (order preserved). Never
  * required for correctness. */
@@ -253,17 +259,26 @@ int cx_search_batch(const cx_index *ix, uint64_t nq, const float *queries, uint6
  * rows in score order (search(emb, topk), self included in the ranks), skip
  * self, skip rows flagged in `deleted` (nodes the storage has tombstoned but
  * that are still indexed), propose an edge for score >=
- * threshold with weight = score, stop after max_edges_per_node.  scan_rows =
- * row index of each scanned node (NULL = every row, n_scan ignored);
- * deleted = cx_row_count() flags or NULL.  Rows are insertion rows
- * (cx_row_id maps them to ids).  Edges come out in scan order, then score
- * order.  Writes min(cap, n) edges, *n_needed = n; CX_ERR_CAPACITY if n > cap.
- * topk <= 256.  Structural / config rules stay on the host: they need the
- * ordered neighbour lists only (cx_search_batch with k = 100). */
+ * threshold with weight = score UNLESS the node already has that edge
+ * (`existing_set`, :226-231: dropped without counting, :249-258, and the walk
+ * goes on down the list), stop once max_edges_per_node were proposed (:261-263;
+ * the test follows the push, so 0 still lets a node's first neighbour through,
+ * as in the reference); of all proposals, in scan order, the first
+ * max_edges_per_cycle are kept (:284-287; UINT64_MAX = no truncation).
+ * scan_rows = row index of each scanned node (NULL = every row, n_scan
+ * ignored); deleted = cx_row_count() flags or NULL.  existing_offsets
+ * [n_scan + 1] / existing_to: CSR over the scanned nodes, in scan order, of
+ * the rows each already has an outgoing related_to edge to (cx_rows_of maps
+ * ids; targets without a row can be left out); NULL = no edges yet.  Rows are
+ * insertion rows (cx_row_id maps them to ids).  Edges come out in scan order,
+ * then score order.  Writes min(cap, n) edges, *n_needed = n; CX_ERR_CAPACITY
+ * if n > cap.  topk <= 256.  Structural / config rules stay on the host: they
+ * need the ordered neighbour lists only (cx_topk_lists_rows). */
 int cx_autolink_pass_rows(const cx_index *ix, uint64_t n_scan, const uint32_t *scan_rows, uint64_t topk,
-                          float threshold, uint64_t max_edges_per_node, const uint8_t *deleted,
-                          uint64_t cap, uint32_t *out_from, uint32_t *out_to, float *out_weight,
-                          uint64_t *n_out, uint64_t *n_needed);
+                          float threshold, uint64_t max_edges_per_node, uint64_t max_edges_per_cycle,
+                          const uint8_t *deleted, const uint64_t *existing_offsets,
+                          const uint32_t *existing_to, uint64_t cap, uint32_t *out_from, uint32_t *out_to,
+                          float *out_weight, uint64_t *n_out, uint64_t *n_needed);
 
 /* The auto-linker's neighbour query for a set of nodes at once (auto_linker.rs:221: `search(&emb, 100, None)`
  * per scanned node; SURVEY §8 a14': "ordered top-100 (j, score) per i" is the engine's contract, every rule —
@@ -287,8 +302,9 @@ int cx_dedup_scan_rows(const cx_index *ix, float dedup_threshold, const uint8_t 
  * number and the device time of the four phases (ms: shadow refresh, MFMA
  * filter, exact rescore, link rules) are returned.  bench.py's auto-link leg. */
 int cx_autolink_pass_timed(const cx_index *ix, uint64_t n_scan, const uint32_t *scan_rows, uint64_t topk,
-                           float threshold, uint64_t max_edges_per_node, uint64_t *n_edges,
-                           double *phase_ms);
+                           float threshold, uint64_t max_edges_per_node, uint64_t max_edges_per_cycle,
+                           const uint64_t *existing_offsets, const uint32_t *existing_to,
+                           uint64_t *n_edges, double *phase_ms);
 
 /* Multi-GPU building block of the all-pairs pass: the ordered neighbour lists of nq
  * EXTERNAL vectors (d_queries: nq x dimension f32 in HBM, e.g. a block of another shard's rows) against this
@@ -329,7 +345,14 @@ int cx_merge_topk_dev(int device, uint64_t n_parts, uint64_t nq, uint64_t k, uin
                       float *d_out_scores, float *d_out_distances, uint32_t *d_out_counts,
                       void *stream);
 
-/* ---- measurement ------------------------------------------------------ */
+/* ---- measurement and diagnostics -------------------------------------- */
+
+/* The check every host entry point applies to a result block it read back from the device before using any of it
+ * as an index or a length ("nothing aborts across the boundary" also when a kernel misbehaves): counts[i] <= k_max
+ * and rows[i * stride + j] < n_rows for j < counts[i], else CX_ERR_DEVICE with a message.  Exported so the guard
+ * itself can be tested without a GPU. */
+int cx_debug_check_result_block(const uint32_t *counts, const uint32_t *rows, uint64_t nq, uint64_t stride,
+                                uint64_t k_max, uint64_t n_rows);
 
 /* When on, every launch of the dominant scan kernel is bracketed by HIP
  * events on the stream it runs on (bench.py's roofline leg). */

@@ -86,7 +86,8 @@ class HipIndex final : public VectorIndex {
         std::vector<uint32_t> kinds;
         cx_filter c{};
     };
-    uint32_t intern(const std::string &s) const { return cx_intern(h_, s.data(), s.size()); }
+    uint32_t intern(const std::string &s) { return cx_intern(h_, s.data(), s.size()); }            // &mut self: adds
+    uint32_t lookup(const std::string &s) const { return cx_lookup(h_, s.data(), s.size()); }      // &self: filters
     bool marshal(const VectorFilter *f, FilterBuf &b) const {
         if (!f) return false;
         if (f->exclude) {
@@ -94,10 +95,10 @@ class HipIndex final : public VectorIndex {
             b.c.has_exclude = 1; b.c.n_exclude = f->exclude->size(); b.c.exclude_ids = b.ex.data();
         }
         if (f->kinds) {
-            for (auto &k : *f->kinds) b.kinds.push_back(intern(k));
+            for (auto &k : *f->kinds) b.kinds.push_back(lookup(k));
             b.c.has_kinds = 1; b.c.n_kinds = f->kinds->size(); b.c.kind_codes = b.kinds.data();
         }
-        if (f->source_agent) { b.c.has_agent = 1; b.c.agent_code = intern(*f->source_agent); }
+        if (f->source_agent) { b.c.has_agent = 1; b.c.agent_code = lookup(*f->source_agent); }
         return true;
     }
     static std::vector<SimilarityResult> collect(const uint8_t *ids, const float *s, const float *d, size_t n) {
@@ -196,10 +197,10 @@ public:
     }
     // the HTTP search handler's candidates -> decay -> stable re-rank -> truncate (routes.rs:889-947)
     std::vector<DecayedResult> search_decayed(const Embedding &q, size_t limit, const ScoreDecayConfig &cfg, float recency_bias,
-                                              int64_t now_s, uint32_t now_ns = 0, const VectorFilter *filter = nullptr) {
+                                              int64_t now_s, uint32_t now_ns = 0, const VectorFilter *filter = nullptr) const {
         std::vector<uint32_t> codes;
         std::vector<double> rates;
-        for (auto &kv : cfg.by_kind) { codes.push_back(intern(kv.first)); rates.push_back(kv.second); }
+        for (auto &kv : cfg.by_kind) { codes.push_back(lookup(kv.first)); rates.push_back(kv.second); }
         cx_decay_config c{cfg.enabled ? 1 : 0, cfg.daily_rate, cfg.max_age_days, cfg.min_factor, cfg.echo_weight, cfg.echo_cap,
                           cfg.recency_weight, (uint32_t)codes.size(), codes.data(), rates.data()};
         const size_t cand = cfg.enabled && recency_bias > 0.0f ? std::max<size_t>(3 * limit, 30) : limit;   // :899-903
@@ -394,24 +395,46 @@ class Linker {
 public:
     explicit Linker(const HipIndex &ix) : ix_(ix) {}
 
-    /// The edges `run_cycle` proposes from SimilarityLinkRule for the scanned nodes (scan order, then score order),
-    /// before its existing-edge and per-cycle filters.  scan = nullptr scans every node.
+    /// The edges `run_cycle` proposes from SimilarityLinkRule for the scanned nodes (scan order, then score order).
+    /// scan = nullptr scans every node.  existing = per scanned node (scan order; with scan = nullptr: row order) the
+    /// targets of its outgoing related_to edges — `storage.edges_from(node.id)` restricted to the relation this rule
+    /// proposes (auto_linker.rs:226-231); such neighbours are dropped without counting towards max_edges_per_node
+    /// (:249-258).  max_edges_per_cycle: :284-287 (SIZE_MAX = no truncation).
     std::vector<ProposedEdge> similarity_edges(const std::vector<NodeId> *scan, const SimilarityConfig &cfg,
                                                size_t max_edges_per_node = 50, const std::vector<NodeId> *deleted = nullptr,
-                                               size_t topk = 100) const {
+                                               size_t topk = 100, const std::vector<std::vector<NodeId>> *existing = nullptr,
+                                               size_t max_edges_per_cycle = SIZE_MAX) const {
         cfg.validate();
         std::vector<uint32_t> scan_rows;
         if (scan) scan_rows = rows_of(*scan);
         const std::vector<uint8_t> del = deleted_flags(deleted);
         const uint64_t n_scan = scan ? scan_rows.size() : cx_row_count(ix_.raw());
+        std::vector<uint64_t> ex_off;
+        std::vector<uint32_t> ex_to;
+        if (existing) {
+            if (existing->size() != n_scan) throw CortexError(CX_ERR_VALIDATION, "existing: one entry per scanned node");
+            ex_off.assign(1, 0);
+            for (auto &targets : *existing) {
+                if (!targets.empty()) {
+                    std::vector<uint8_t> flat;
+                    for (auto &id : targets) flat.insert(flat.end(), id.begin(), id.end());
+                    std::vector<uint32_t> rows(targets.size());
+                    check(cx_rows_of(ix_.raw(), targets.size(), flat.data(), rows.data()));
+                    for (uint32_t r : rows)
+                        if (r != 0xFFFFFFFFu) ex_to.push_back(r);   // a target without an embedding never shows up in a list
+                }
+                ex_off.push_back(ex_to.size());
+            }
+        }
         uint64_t cap = std::max<uint64_t>(1024, n_scan * 4), n = 0, need = 0;
         std::vector<uint32_t> from, to;
         std::vector<float> w;
         for (;;) {
             from.resize(cap); to.resize(cap); w.resize(cap);
             const int rc = cx_autolink_pass_rows(ix_.raw(), n_scan, scan ? scan_rows.data() : nullptr, topk, cfg.auto_link_threshold,
-                                                 max_edges_per_node, del.empty() ? nullptr : del.data(), cap, from.data(), to.data(),
-                                                 w.data(), &n, &need);
+                                                 max_edges_per_node, max_edges_per_cycle == SIZE_MAX ? UINT64_MAX : max_edges_per_cycle,
+                                                 del.empty() ? nullptr : del.data(), existing ? ex_off.data() : nullptr,
+                                                 existing ? ex_to.data() : nullptr, cap, from.data(), to.data(), w.data(), &n, &need);
             if (rc == CX_ERR_CAPACITY && need > cap) { cap = need; continue; }
             check(rc);
             break;

@@ -33,6 +33,7 @@ extern "C" {
     fn cx_remove(ix: *mut c_void, id: *const u8) -> c_int;
     fn cx_set_metadata(ix: *mut c_void, id: *const u8, kind: u32, agent: u32) -> c_int;
     fn cx_intern(ix: *mut c_void, s: *const c_char, len: u64) -> u32;
+    fn cx_lookup(ix: *const c_void, s: *const c_char, len: u64) -> u32;
     fn cx_rebuild(ix: *mut c_void) -> c_int;
     fn cx_len(ix: *const c_void) -> u64;
     fn cx_row_count(ix: *const c_void) -> u64;
@@ -45,8 +46,10 @@ extern "C" {
                        ids: *mut u8, scores: *mut f32, dists: *mut f32, counts: *mut u64) -> c_int;
     // auto-linker / dedup passes
     fn cx_autolink_pass_rows(ix: *const c_void, n_scan: u64, scan_rows: *const u32, topk: u64, threshold: f32,
-                             max_edges_per_node: u64, deleted: *const u8, cap: u64, out_from: *mut u32,
+                             max_edges_per_node: u64, max_edges_per_cycle: u64, deleted: *const u8,
+                             existing_offsets: *const u64, existing_to: *const u32, cap: u64, out_from: *mut u32,
                              out_to: *mut u32, out_weight: *mut f32, n_out: *mut u64, n_needed: *mut u64) -> c_int;
+    fn cx_rows_of(ix: *const c_void, n: u64, ids: *const u8, out_rows: *mut u32) -> c_int;
     fn cx_topk_lists_rows(ix: *const c_void, n_scan: u64, scan_rows: *const u32, topk: u64, out_rows: *mut u32,
                           out_scores: *mut f32, out_counts: *mut u32) -> c_int;
     fn cx_dedup_scan_rows(ix: *const c_void, dedup_threshold: f32, deleted: *const u8, cap: u64, out_a: *mut u32,
@@ -119,7 +122,10 @@ impl HipIndex {
         let h = unsafe { cx_create(dimension as u32, device) };
         if h.is_null() { Err(last_error()) } else { Ok(Self { h, dimension }) }
     }
-    fn intern(&self, s: &str) -> u32 { unsafe { cx_intern(self.h, s.as_ptr() as *const c_char, s.len() as u64) } }
+    // adds the string if new: only from &mut self (set_metadata, bulk load)
+    fn intern(&mut self, s: &str) -> u32 { unsafe { cx_intern(self.h, s.as_ptr() as *const c_char, s.len() as u64) } }
+    // read-only: filters on the concurrent &self path; 0 = never interned = matches no row that has metadata
+    fn lookup(&self, s: &str) -> u32 { unsafe { cx_lookup(self.h, s.as_ptr() as *const c_char, s.len() as u64) } }
     /// serve.rs:105-123 / api.rs:56-70 in one call: `values` are the raw bincode values of the nodes table
     /// (a `RedbStorage::raw_node_values()` iterator a maintainer adds next to `list_nodes`), handed over
     /// without deserialising a `Node` per row.  `strict` = Cortex::open's `?` on a wrong-length embedding.
@@ -143,7 +149,7 @@ impl HipIndex {
     pub fn search_decayed(&self, q: &Vec<f32>, limit: usize, cfg: &ScoreDecayConfig, recency_bias: f32,
                           now: DateTime<Utc>) -> Result<Vec<(NodeId, f32, f32)>> {
         let (codes, rates): (Vec<u32>, Vec<f64>) = cfg.by_kind.iter()
-            .map(|(k, r)| (unsafe { cx_intern(self.h, k.as_ptr() as *const c_char, k.len() as u64) }, *r)).unzip();
+            .map(|(k, r)| (self.lookup(k), *r)).unzip();
         let c = CxDecayConfig { enabled: cfg.enabled as i32, daily_rate: cfg.daily_rate, max_age_days: cfg.max_age_days,
             min_factor: cfg.min_factor, echo_weight: cfg.echo_weight, echo_cap: cfg.echo_cap, recency_weight: cfg.recency_weight,
             n_by_kind: codes.len() as u32, kind_codes: codes.as_ptr(), kind_rates: rates.as_ptr() };
@@ -154,6 +160,55 @@ impl HipIndex {
             recency_bias, now.timestamp(), now.timestamp_subsec_nanos(), ids.as_mut_ptr(), sc.as_mut_ptr(), raw.as_mut_ptr(), &mut n) };
         if rc != 0 { return Err(last_error()); }
         Ok((0..n as usize).map(|i| (Uuid::from_slice(&ids[16 * i..16 * i + 16]).unwrap(), sc[i], raw[i])).collect())
+    }
+
+    fn rows_of(&self, ids: &[NodeId]) -> Result<Vec<u32>> {
+        let mut flat = Vec::with_capacity(16 * ids.len());
+        for id in ids { flat.extend_from_slice(id.as_bytes()); }
+        let mut rows = vec![0u32; ids.len()];
+        check(unsafe { cx_rows_of(self.h, ids.len() as u64, flat.as_ptr(), rows.as_mut_ptr()) })?;
+        Ok(rows)
+    }
+
+    /// The kNN loop of `AutoLinker::run_cycle` (auto_linker.rs:215-264) for SimilarityLinkRule, one call per cycle:
+    /// `nodes` = the cycle's batch in scan order (nodes without a row in the index are skipped like :217-218 would
+    /// after a failed `ensure_embedding`), `existing[i]` = targets of `storage.edges_from(nodes[i].id)` whose relation
+    /// is related_to (:226-231), `deleted` = tombstoned-but-indexed neighbours (:240-243).  Returns (from, to, score)
+    /// in proposal order, already truncated to `max_edges_per_cycle` (:284-287).
+    pub fn similarity_edges(&self, nodes: &[NodeId], existing: &[Vec<NodeId>], cfg: &SimilarityConfig,
+                            max_edges_per_node: usize, max_edges_per_cycle: usize, deleted: &[NodeId])
+        -> Result<Vec<(NodeId, NodeId, f32)>> {
+        const NO_ROW: u32 = u32::MAX;
+        let all = self.rows_of(nodes)?;
+        let (mut scan, mut ex_off, mut ex_to): (Vec<u32>, Vec<u64>, Vec<u32>) = (Vec::new(), vec![0], Vec::new());
+        for (i, &r) in all.iter().enumerate() {
+            if r == NO_ROW { continue; }
+            scan.push(r);
+            if let Some(t) = existing.get(i) { ex_to.extend(self.rows_of(t)?.into_iter().filter(|&x| x != NO_ROW)); }
+            ex_off.push(ex_to.len() as u64);
+        }
+        let n_rows = unsafe { cx_row_count(self.h) } as usize;
+        let mut del = vec![0u8; if deleted.is_empty() { 0 } else { n_rows }];
+        for r in self.rows_of(deleted)? { if r != NO_ROW { del[r as usize] = 1; } }
+        let mut cap = (scan.len() * 4).max(1024);
+        loop { // count-then-fill
+            let (mut fr, mut to, mut w) = (vec![0u32; cap], vec![0u32; cap], vec![0f32; cap]);
+            let (mut n, mut need) = (0u64, 0u64);
+            let rc = unsafe { cx_autolink_pass_rows(self.h, scan.len() as u64, scan.as_ptr(), 100, cfg.auto_link_threshold,
+                max_edges_per_node as u64, max_edges_per_cycle as u64, if del.is_empty() { std::ptr::null() } else { del.as_ptr() },
+                ex_off.as_ptr(), ex_to.as_ptr(), cap as u64, fr.as_mut_ptr(), to.as_mut_ptr(), w.as_mut_ptr(), &mut n, &mut need) };
+            if rc == CX_ERR_CAPACITY && need as usize > cap { cap = need as usize; continue; }
+            check(rc)?;
+            let mut id = [0u8; 16];
+            let mut out = Vec::with_capacity(n as usize);
+            for i in 0..n as usize {
+                check(unsafe { cx_row_id(self.h, fr[i] as u64, id.as_mut_ptr()) })?;
+                let a = NodeId::from_slice(&id).unwrap();
+                check(unsafe { cx_row_id(self.h, to[i] as u64, id.as_mut_ptr()) })?;
+                out.push((a, NodeId::from_slice(&id).unwrap(), w[i]));
+            }
+            return Ok(out);
+        }
     }
 
     pub fn set_metadata(&mut self, id: NodeId, kind: NodeKind, source_agent: String) {
@@ -168,10 +223,10 @@ impl HipIndex {
             b.c.has_exclude = 1; b.c.n_exclude = ex.len() as u64; b.c.exclude_ids = b.ex.as_ptr();
         }
         if let Some(kinds) = &f.kinds {
-            b.kinds = kinds.iter().map(|k| self.intern(k.as_str())).collect();
+            b.kinds = kinds.iter().map(|k| self.lookup(k.as_str())).collect();
             b.c.has_kinds = 1; b.c.n_kinds = kinds.len() as u64; b.c.kind_codes = b.kinds.as_ptr();
         }
-        if let Some(agent) = &f.source_agent { b.c.has_agent = 1; b.c.agent_code = self.intern(agent); }
+        if let Some(agent) = &f.source_agent { b.c.has_agent = 1; b.c.agent_code = self.lookup(agent); }
         Some(b)
     }
     fn collect(ids: &[u8], scores: &[f32], dists: &[f32], n: usize) -> Vec<SimilarityResult> {

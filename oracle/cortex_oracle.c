@@ -43,7 +43,23 @@ struct cxo_index {
     /* open-addressing id -> row+1 */
     uint32_t *slots;
     size_t n_slots;
+    /* the part of `metadata: HashMap<NodeId, NodeMetadata>` (index.rs:189) whose ids have no vector (yet): the
+     * two maps are independent (set_metadata :219-222 never looks at `vectors`; the reference's own integration
+     * test sets metadata BEFORE insert, vector/tests.rs:65-66).  A plain list: test infrastructure, small. */
+    struct cxo_pending { uint8_t id[16]; char *kind, *agent; } *pending;
+    size_t n_pending, cap_pending;
 };
+
+static long pending_find(const cxo_index *ix, const uint8_t id[16]) {
+    for (size_t i = 0; i < ix->n_pending; i++)
+        if (memcmp(ix->pending[i].id, id, 16) == 0) return (long)i;
+    return -1;
+}
+static void pending_drop(cxo_index *ix, long i, int free_strings) {
+    if (free_strings) { free(ix->pending[i].kind); free(ix->pending[i].agent); }
+    ix->pending[i] = ix->pending[ix->n_pending - 1];
+    ix->n_pending--;
+}
 
 static uint64_t id_hash(const uint8_t id[16]) {
     uint64_t h = 1469598103934665603ull;
@@ -86,6 +102,8 @@ void cxo_index_free(cxo_index *ix) {
     for (size_t r = 0; r < ix->n_rows; r++) {
         free(ix->rows[r].vec); free(ix->rows[r].kind); free(ix->rows[r].agent);
     }
+    for (size_t i = 0; i < ix->n_pending; i++) { free(ix->pending[i].kind); free(ix->pending[i].agent); }
+    free(ix->pending);
     free(ix->rows); free(ix->slots); free(ix);
 }
 
@@ -118,6 +136,8 @@ int cxo_insert(cxo_index *ix, const uint8_t id[16], const float *emb, size_t len
     row->vec = (float *)malloc((len ? len : 1) * sizeof(float));
     memcpy(row->vec, emb, len * sizeof(float));
     row->alive = 1;
+    long pm = pending_find(ix, id);   /* metadata.get(id) now finds what set_metadata stored earlier */
+    if (pm >= 0) { row->kind = ix->pending[pm].kind; row->agent = ix->pending[pm].agent; pending_drop(ix, pm, 0); }
     ix->n_rows++; ix->n_alive++;
     if ((ix->n_rows + 1) * 2 > ix->n_slots) map_rebuild(ix, ix->n_slots * 2);
     else {
@@ -136,6 +156,8 @@ int cxo_insert_batch(cxo_index *ix, size_t n, const uint8_t *ids, const float *e
 
 /* vector/index.rs:316-323 — drop vector and metadata; never an error */
 int cxo_remove(cxo_index *ix, const uint8_t id[16]) {
+    long pm = pending_find(ix, id);   /* self.metadata.remove(&id) :318, vector or not */
+    if (pm >= 0) pending_drop(ix, pm, 1);
     long r = map_find(ix, id);
     if (r < 0) return 0;
     cxo_row *row = &ix->rows[r];
@@ -148,11 +170,26 @@ int cxo_remove(cxo_index *ix, const uint8_t id[16]) {
     return 0;
 }
 
-/* vector/index.rs:219-222 — metadata map is independent of the vector map,
- * but matches_filter only ever looks it up for ids that are in `vectors`. */
+/* vector/index.rs:219-222 — metadata map is independent of the vector map;
+ * matches_filter only ever looks it up for ids that are in `vectors`, so an
+ * entry for an id without a vector waits in `pending` until the insert. */
 void cxo_set_metadata(cxo_index *ix, const uint8_t id[16], const char *kind, const char *agent) {
     long r = map_find(ix, id);
-    if (r < 0) return;
+    if (r < 0) {
+        long pm = pending_find(ix, id);
+        if (pm >= 0) { free(ix->pending[pm].kind); free(ix->pending[pm].agent); }
+        else {
+            if (ix->n_pending == ix->cap_pending) {
+                ix->cap_pending = ix->cap_pending ? ix->cap_pending * 2 : 16;
+                ix->pending = (struct cxo_pending *)realloc(ix->pending, ix->cap_pending * sizeof *ix->pending);
+            }
+            pm = (long)ix->n_pending++;
+            memcpy(ix->pending[pm].id, id, 16);
+        }
+        ix->pending[pm].kind = strdup(kind);
+        ix->pending[pm].agent = strdup(agent);
+        return;
+    }
     free(ix->rows[r].kind); free(ix->rows[r].agent);
     ix->rows[r].kind = strdup(kind);
     ix->rows[r].agent = strdup(agent);
@@ -340,13 +377,20 @@ int cxo_config_validate(const cxo_similarity_config *c) { /* vector/config.rs:66
 
 /* ------------------------------------------------------------ auto-linker */
 
-/* linker/auto_linker.rs:215-264 with linker/rules.rs:42-62 as the only rule. */
+/* linker/auto_linker.rs:215-264 with linker/rules.rs:42-62 as the only rule, then the per-cycle
+ * truncation of :284-287.  existing_offsets/existing_to: CSR over the scanned nodes (scan order) of the
+ * rows each already has an outgoing related_to edge to — the `existing_set` of :226-231 restricted to the
+ * one relation this rule proposes; such neighbours are skipped WITHOUT counting (:249-258) and the walk
+ * goes on down the top-k list.  NULL = no edges yet. */
 size_t cxo_autolink_pass(const cxo_index *ix, size_t n_scan, const uint32_t *scan_rows,
-                         size_t topk, float threshold, size_t max_edges_per_node,
-                         const uint8_t *deleted, int n_threads,
-                         cxo_edge *out, size_t cap, size_t *n_needed) {
+                         size_t topk, float threshold, size_t max_edges_per_node, size_t max_edges_per_cycle,
+                         const uint8_t *deleted, const uint64_t *existing_offsets, const uint32_t *existing_to,
+                         int n_threads, cxo_edge *out, size_t cap, size_t *n_needed) {
+    /* the cap is tested after a neighbour's edges were pushed (:259-262): a node proposes at most
+     * max(max_edges_per_node, 1) edges with this one rule */
+    const size_t per_node = max_edges_per_node ? max_edges_per_node : 1;
     size_t *cnt = (size_t *)calloc(n_scan ? n_scan : 1, sizeof(size_t));
-    cxo_edge *tmp = (cxo_edge *)malloc((n_scan ? n_scan : 1) * (max_edges_per_node ? max_edges_per_node : 1) * sizeof *tmp);
+    cxo_edge *tmp = (cxo_edge *)malloc((n_scan ? n_scan : 1) * per_node * sizeof *tmp);
     long i;
     (void)n_threads;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads > 0 ? n_threads : 1)
@@ -357,14 +401,21 @@ size_t cxo_autolink_pass(const cxo_index *ix, size_t n_scan, const uint32_t *sca
         size_t kk = topk < ix->n_alive ? topk : ix->n_alive;
         cxo_result *similar = (cxo_result *)malloc((kk ? kk : 1) * sizeof *similar);
         size_t n = cxo_search(ix, emb, topk, NULL, similar);          /* :220-221 */
-        size_t node_edge_count = 0;
+        size_t node_edge_count = 0;                                   /* :224 */
+        const uint32_t *have = existing_offsets ? existing_to + existing_offsets[i] : NULL;   /* :226-231 */
+        const size_t n_have = existing_offsets ? (size_t)(existing_offsets[i + 1] - existing_offsets[i]) : 0;
         for (size_t j = 0; j < n; j++) {
             if (similar[j].row == r) continue;                         /* :235-237 skip self */
             if (deleted && deleted[similar[j].row]) continue;          /* :240-243 */
             if (similar[j].score >= threshold) {                       /* rules.rs:50 */
-                cxo_edge *e = &tmp[(size_t)i * max_edges_per_node + node_edge_count];
-                e->from_row = r; e->to_row = similar[j].row; e->weight = similar[j].score;
-                node_edge_count++;                                     /* :255 */
+                int exists = 0;                                        /* :253-254 existing_set.contains(&key) */
+                for (size_t e = 0; e < n_have; e++)
+                    if (have[e] == similar[j].row) { exists = 1; break; }
+                if (!exists) {
+                    cxo_edge *e = &tmp[(size_t)i * per_node + node_edge_count];
+                    e->from_row = r; e->to_row = similar[j].row; e->weight = similar[j].score;
+                    node_edge_count++;                                 /* :255-256 */
+                }
             }
             if (node_edge_count >= max_edges_per_node) break;          /* :261-263 */
         }
@@ -374,7 +425,8 @@ size_t cxo_autolink_pass(const cxo_index *ix, size_t n_scan, const uint32_t *sca
     size_t total = 0;
     for (size_t s = 0; s < n_scan; s++)
         for (size_t j = 0; j < cnt[s]; j++) {
-            if (total < cap) out[total] = tmp[s * max_edges_per_node + j];
+            if (total >= max_edges_per_cycle) break;                   /* :284-287 take(max_edges_per_cycle) */
+            if (total < cap) out[total] = tmp[s * per_node + j];
             total++;
         }
     free(cnt); free(tmp);

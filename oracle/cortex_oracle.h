@@ -106,14 +106,18 @@ typedef struct cxo_edge {
 /* The auto-linker's per-node kNN loop — linker/auto_linker.rs:215-264 with
  * only SimilarityLinkRule active (legacy structural rules off, no config
  * rules): search(emb, topk=100), skip self, skip deleted neighbours, keep
- * score >= threshold, count, stop once max_edges_per_node reached.
+ * score >= threshold, drop edges that already exist WITHOUT counting them
+ * (:226-231, :249-258), count, stop once max_edges_per_node reached; then
+ * the first max_edges_per_cycle proposals of the cycle (:284-287).
  * rows: the scanned nodes, in scan order.  deleted: optional per-row flags
  * (nodes tombstoned in storage but still indexed, quirk Q2).
+ * existing_offsets [n_scan+1] / existing_to: CSR, per scanned node the rows it
+ * already has a related_to edge to (NULL = none).
  * Returns the number of edges written (at most cap; *n_needed gets the total). */
 size_t cxo_autolink_pass(const cxo_index *ix, size_t n_scan, const uint32_t *scan_rows,
-                         size_t topk, float threshold, size_t max_edges_per_node,
-                         const uint8_t *deleted, int n_threads,
-                         cxo_edge *out, size_t cap, size_t *n_needed);
+                         size_t topk, float threshold, size_t max_edges_per_node, size_t max_edges_per_cycle,
+                         const uint8_t *deleted, const uint64_t *existing_offsets, const uint32_t *existing_to,
+                         int n_threads, cxo_edge *out, size_t cap, size_t *n_needed);
 
 /* DedupScanner::scan pair emission — linker/dedup.rs:65-127: per live row,
  * search_threshold(dedup_threshold), skip self, canonical unordered pair,

@@ -87,8 +87,8 @@ def lib():
         L.cxo_config_validate.restype = C.c_int
         L.cxo_config_validate.argtypes = [C.c_void_p]
         L.cxo_autolink_pass.restype = C.c_size_t
-        L.cxo_autolink_pass.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_float, C.c_size_t,
-                                        C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.cxo_autolink_pass.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_float, C.c_size_t, C.c_size_t,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
         L.cxo_dedup_scan.restype = C.c_size_t
         L.cxo_dedup_scan.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.cxo_last_error.restype = C.c_char_p
@@ -219,14 +219,25 @@ class OracleIndex:
         return [out[i, :counts[i]] for i in range(nq)]
 
     def autolink_pass(self, scan_rows, topk: int, threshold: float, max_edges_per_node: int,
-                      deleted: Optional[np.ndarray] = None, n_threads: int = 1) -> np.ndarray:
+                      deleted: Optional[np.ndarray] = None, n_threads: int = 1, existing=None,
+                      max_edges_per_cycle: Optional[int] = None) -> np.ndarray:
+        """existing: (offsets u64 [n_scan+1], to_rows u32) CSR of the related_to edges each scanned node already
+        has (auto_linker.rs:226-231); max_edges_per_cycle: :284-287 (None = no truncation)."""
         rows = np.ascontiguousarray(scan_rows, dtype=np.uint32)
-        cap = max(1, rows.size * max_edges_per_node)
+        cap = max(1, rows.size * max(max_edges_per_node, 1))
         out = np.zeros(cap, dtype=EDGE_DTYPE)
         need = C.c_size_t(0)
         d = np.ascontiguousarray(deleted, dtype=np.uint8) if deleted is not None else None
-        n = self._L.cxo_autolink_pass(self._h, rows.size, rows.ctypes.data, topk, threshold, max_edges_per_node,
-                                      d.ctypes.data if d is not None else None, n_threads,
+        eo = et = None
+        if existing is not None:
+            eo = np.ascontiguousarray(existing[0], dtype=np.uint64)
+            et = np.ascontiguousarray(existing[1], dtype=np.uint32)
+            assert eo.size == rows.size + 1 and int(eo[-1]) == et.size
+        cyc = (1 << 63) if max_edges_per_cycle is None else int(max_edges_per_cycle)
+        n = self._L.cxo_autolink_pass(self._h, rows.size, rows.ctypes.data, topk, threshold, max_edges_per_node, cyc,
+                                      d.ctypes.data if d is not None else None,
+                                      eo.ctypes.data if eo is not None else None,
+                                      et.ctypes.data if et is not None else None, n_threads,
                                       out.ctypes.data, cap, C.byref(need))
         return out[:n]
 

@@ -66,3 +66,26 @@ def test_similarity_config_mirror():  # vector/config.rs:93-135
         bad.validate()
     c = SimilarityConfig.new().with_auto_link_threshold(1.5).with_dedup_threshold(-0.5)
     assert c.auto_link_threshold == 1.0 and c.dedup_threshold == 0.0
+
+
+def test_poisoned_result_block_is_an_error_not_an_index():
+    """Every host entry point checks a result block it read back from the device before using it (a
+    kernel bug once became a SIGSEGV in the caller).  The guard itself, fed a poisoned block: no GPU needed."""
+    import ctypes as C
+    import numpy as np
+    from cortex_amd import _lib
+    L = _lib.load()
+    nq, k, n_rows = 3, 4, 100
+    counts = np.array([4, 2, 0], np.uint32)
+    rows = np.zeros((nq, k), np.uint32)
+    rows[0] = [5, 99, 0, 7]
+    rows[1] = [1, 2, 0xFFFFFFFF, 0xFFFFFFFF]      # beyond counts[1]: never looked at
+    chk = lambda: L.cx_debug_check_result_block(counts.ctypes.data, rows.ctypes.data, nq, k, k, n_rows)
+    assert chk() == 0
+    rows[0, 1] = 100                               # a row index one past the store
+    assert chk() == 2 and b"row 100" in L.cx_last_error()
+    rows[0, 1] = 99
+    counts[2] = 5                                  # a list longer than k (the `lane < k` writer bug of round 1)
+    assert chk() == 2 and b"5 entries" in L.cx_last_error()
+    counts[2] = 0xFFFFFFFF
+    assert chk() == 2

@@ -102,6 +102,78 @@ def test_scan_subset_order_and_deleted_neighbours(hip, oracle):
                   oracle_scores(o, rows), "subset+deleted")
 
 
+def _csr(lists):
+    off = np.zeros(len(lists) + 1, np.uint64)
+    off[1:] = np.cumsum([len(x) for x in lists])
+    return off, np.array([t for x in lists for t in x], dtype=np.uint32)
+
+
+@pytest.mark.parametrize("n,d,scan_all", [(3000, 768, True), (2500, 384, False), (700, 100, True)])
+def test_rescan_with_existing_edges_matches_oracle(hip, oracle, n, d, scan_all):
+    """The rescan after a threshold/model change (auto_linker.rs:137-182): ~30 % of the scanned nodes already have
+    outgoing related_to edges.  The reference drops those WITHOUT counting them towards max_edges_per_node
+    (:226-231, :249-258) and keeps walking its top-100 list; then take(max_edges_per_cycle) (:284-287).
+    The fused pass must agree with the oracle edge for edge."""
+    rows = oracle.synth_rows(n, d)
+    h, o, ids = build(hip, oracle, rows)
+    rng = np.random.default_rng(11)
+    thr_old, thr_new, cap = float(np.float32(0.85)), float(np.float32(0.75)), 10
+    scan = None if scan_all else rng.permutation(n)[:600].astype(np.uint32)
+    scan_o = np.arange(n, dtype=np.uint32) if scan is None else scan
+    first = o.autolink_pass(scan_o, 100, thr_old, cap, n_threads=8)       # what an earlier cycle created
+    have = {}
+    for e in first:
+        have.setdefault(int(e["from_row"]), []).append(int(e["to_row"]))
+    lists, with_edges = [], 0
+    for s in scan_o:
+        mine = have.get(int(s), [])
+        if mine and rng.random() < 0.3:
+            keep = mine if rng.random() < 0.5 else mine[: max(1, len(mine) // 2)]
+            extra = [int(x) for x in rng.integers(0, n, 3)]               # edges to unrelated nodes (other cycles' work)
+            lists.append(list(rng.permutation(keep + extra)))            # unsorted on purpose
+            with_edges += 1
+        else:
+            lists.append([])
+    assert with_edges > 0.1 * len(scan_o) * (len(have) / len(scan_o))
+    existing = _csr(lists)
+    fr, to, w = h.autolink_pass_rows(scan, 100, thr_new, cap, existing=existing)
+    e = o.autolink_pass(scan_o, 100, thr_new, cap, n_threads=8, existing=existing)
+    got, exp = per_node(fr, to, w), per_node(e["from_row"], e["to_row"], e["weight"])
+    compare_edges(got, exp, thr_new, oracle_scores(o, rows), f"rescan n={n} d={d}")
+    # on this corpus nothing sits near the threshold or a cap boundary: the lists are identical, in order
+    assert list(zip(fr.tolist(), to.tolist())) == list(zip(e["from_row"].tolist(), e["to_row"].tolist()))
+    assert np.max(np.abs(w - e["weight"])) <= SCORE_TOL
+    sets = {int(s): set(l) for s, l in zip(scan_o, lists)}
+    assert all(int(b) not in sets[int(a)] for a, b in zip(fr, to))        # never proposed again
+    # the pass without `existing` differs (it spends its cap on edges the node already has)
+    fr0, to0, _ = h.autolink_pass_rows(scan, 100, thr_new, cap)
+    assert list(zip(fr0.tolist(), to0.tolist())) != list(zip(fr.tolist(), to.tolist()))
+    # per-cycle cap: the first max_edges_per_cycle proposals in scan order
+    frc, toc, wc = h.autolink_pass_rows(scan, 100, thr_new, cap, existing=existing, max_edges_per_cycle=2000)
+    m = min(2000, len(fr))
+    assert len(frc) == m and np.array_equal(frc, fr[:m]) and np.array_equal(toc, to[:m]) and np.array_equal(wc, w[:m])
+    ne, _ = h.autolink_pass_timed(100, thr_new, cap, scan, existing=existing, max_edges_per_cycle=2000)
+    assert ne == m
+
+
+def test_existing_edges_validation_and_cap_semantics(hip, oracle):
+    n, d = 600, 128
+    rows = oracle.synth_rows(n, d)
+    h, o, ids = build(hip, oracle, rows)
+    scan = np.array([9, 20, 33], dtype=np.uint32)
+    with pytest.raises(hip.ValidationError):
+        h.autolink_pass_rows(scan, 100, 0.5, 5, existing=(np.array([0, 1], np.uint64), np.array([1], np.uint32)))
+    with pytest.raises(hip.ValidationError):                    # offsets must not decrease
+        h.autolink_pass_rows(scan, 100, 0.5, 5, existing=(np.array([0, 2, 1, 2], np.uint64), np.array([1, 2], np.uint32)))
+    # the cap is tested after the push (:259-262): 0 behaves like 1, as in the reference
+    fr0, to0, w0 = h.autolink_pass_rows(scan, 100, 0.0, 0)
+    fr1, to1, w1 = h.autolink_pass_rows(scan, 100, 0.0, 1)
+    e0 = o.autolink_pass(scan, 100, np.float32(0.0), 0)
+    assert np.array_equal(fr0, fr1) and np.array_equal(to0, to1) and len(fr0) == 3
+    assert list(zip(fr0.tolist(), to0.tolist())) == list(zip(e0["from_row"].tolist(), e0["to_row"].tolist()))
+    assert len(h.autolink_pass_rows(scan, 100, 0.0, 5, max_edges_per_cycle=0)[0]) == 0
+
+
 def test_candidate_overflow_takes_the_exact_path(hip, oracle, monkeypatch):
     monkeypatch.setenv("CX_PAIR_CAND_CAP", "16")                # clusters hold ~50 rows: most lists overflow
     n, d, thr = 1500, 768, float(np.float32(0.75))

@@ -71,6 +71,32 @@ def test_filter_by_kind(hip):  # :609-627
     assert results[0].node_id == id2
 
 
+def test_metadata_set_before_insert_binds(hip, tmp_path):  # vector/tests.rs:65-66: set_metadata, THEN insert
+    index = hip.HipIndex.new(3)
+    id1, id2, id3, id4 = now_v7(), now_v7(), now_v7(), now_v7()
+    index.set_metadata(id1, "fact", "test")
+    index.insert(id1, [1.0, 0.0, 0.0])
+    index.set_metadata(id2, "decision", "test")
+    index.insert(id2, [0.9, 0.1, 0.0])
+    index.set_metadata(id3, "decision", "test")   # never gets a vector
+    index.set_metadata(id4, "fact", "other")      # gets its vector after a save/load round trip
+    f = hip.VectorFilter.new().with_kinds(["decision"])
+    assert [r.node_id for r in index.search([1.0, 0.0, 0.0], 5, f)] == [id2]
+    # a kind nobody was tagged with: rows with metadata fail, and the lookup does not grow the table (&self)
+    assert index.search([1.0, 0.0, 0.0], 5, hip.VectorFilter.new().with_kinds(["never-seen"])) == []
+    assert index.lookup("never-seen") == 0 and index.lookup("decision") == index.intern("decision") != 0
+    # metadata of ids without a vector is part of the saved map (index.rs:438) and binds after load
+    path = tmp_path / "meta.hnsw"
+    index.save(path)
+    loaded = hip.HipIndex.load(path)
+    loaded.insert(id4, [0.7, 0.3, 0.0])
+    fa = hip.VectorFilter.new().with_source_agent("other")
+    assert [r.node_id for r in loaded.search([1.0, 0.0, 0.0], 5, fa)] == [id4]
+    index.remove(id3)                              # metadata.remove without a vector (:318)
+    index.insert(id3, [0.8, 0.2, 0.0])             # now a node without metadata: passes every kind filter (Q3)
+    assert [r.node_id for r in index.search([1.0, 0.0, 0.0], 5, f)] == [id2, id3]
+
+
 def test_filter_exclude(hip):  # :630-646
     index = hip.HipIndex.new(3)
     id1, id2 = now_v7(), now_v7()

@@ -87,3 +87,57 @@ def test_walk_skips_existing_edges_without_counting_them(setup):
     have = {(order[0], "related_to"), (order[2], "related_to")}
     walk = linker.autolink_walk(ix, [ids[20].tobytes()], [always], max_edges_per_node=3, existing=lambda node: have)
     assert [b for _, b, _, _ in walk] == [order[1], order[3], order[4]]
+
+
+def _csr(lists):
+    off = np.zeros(len(lists) + 1, np.uint64)
+    off[1:] = np.cumsum([len(x) for x in lists])
+    to = np.array([t for x in lists for t in x], dtype=np.uint32)
+    return off, to
+
+
+def test_oracle_pass_with_existing_edges_equals_the_walk(setup):
+    """auto_linker.rs:226-231, :249-263, :284-287 in the oracle's pass: an edge the node already has is dropped
+    WITHOUT counting towards max_edges_per_node (the walk goes deeper into the top-100 list), and the cycle keeps
+    the first max_edges_per_cycle proposals.  Checked against the line-for-line Python walk over the oracle's lists."""
+    oracle, rows, ids, ix = setup
+    from cortex_amd import linker
+    from cortex_amd.config import SimilarityConfig
+    cfg = SimilarityConfig(auto_link_threshold=0.6, dedup_threshold=0.95, contradiction_threshold=0.8)
+    rng = np.random.default_rng(3)
+    scan = rng.permutation(len(rows))[:120].astype(np.uint32)
+    first = ix.o.autolink_pass(scan, 100, np.float32(0.6), 4)            # a first cycle: 4 edges per node
+    have = {int(s): [] for s in scan}
+    for e in first:
+        have[int(e["from_row"])].append(int(e["to_row"]))
+    lists = []
+    for p, s in enumerate(scan):
+        if p % 3 == 0:
+            lists.append(have[int(s)] + [int(x) for x in rng.integers(0, len(rows), 2)])   # its edges + unrelated ones
+        elif p % 3 == 1:
+            lists.append(have[int(s)][:2])                                                  # some of them
+        else:
+            lists.append([])
+    off, to = _csr(lists)
+    want = ix.o.autolink_pass(scan, 100, np.float32(0.6), 4, existing=(off, to))
+    sets = {int(s): {(t, "related_to") for t in l} for s, l in zip(scan, lists)}
+    walk = linker.autolink_walk(ix, [ids[i].tobytes() for i in scan], [linker.similarity_rule(cfg)], max_edges_per_node=4,
+                                existing=lambda node: sets[node])
+    assert [(a, b) for a, b, _, _ in walk] == [(int(e["from_row"]), int(e["to_row"])) for e in want]
+    # nothing the node already has is proposed again, and nodes with all 4 first-cycle edges existing walk deeper
+    for e in want:
+        assert (int(e["to_row"]), "related_to") not in sets[int(e["from_row"])]
+    deeper = [int(s) for p, s in enumerate(scan) if p % 3 == 0 and len(have[int(s)]) == 4]
+    assert deeper and any(int(e["from_row"]) in deeper for e in want)
+    # per-cycle truncation = the first max_edges_per_cycle proposals, in scan order
+    cut = ix.o.autolink_pass(scan, 100, np.float32(0.6), 4, existing=(off, to), max_edges_per_cycle=37)
+    assert len(cut) == 37 and np.array_equal(cut, want[:37])
+
+
+def test_oracle_pass_cap_is_tested_after_the_push(setup):
+    """:259-262 follows the push: with max_edges_per_node = 0 the first neighbour's edge still gets through."""
+    oracle, rows, ids, ix = setup
+    scan = np.array([9, 20], dtype=np.uint32)
+    e0 = ix.o.autolink_pass(scan, 100, np.float32(0.0), 0)
+    e1 = ix.o.autolink_pass(scan, 100, np.float32(0.0), 1)
+    assert len(e0) == 2 and np.array_equal(e0, e1)

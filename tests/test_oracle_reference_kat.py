@@ -71,6 +71,24 @@ def test_filter_by_kind(oracle):  # vector/index.rs:609-627
     assert bytes(r[0]["node_id"]) == id2.bytes
 
 
+def test_metadata_set_before_insert_binds(oracle):  # vector/tests.rs:65-66: set_metadata, THEN insert
+    """`metadata` is a map of its own (index.rs:189, :219-222): an entry made before the vector exists is found by
+    matches_filter (:234) once the vector is there; remove drops it (:318) even if no vector ever came."""
+    ix = oracle.OracleIndex(3)
+    id1, id2, id3 = new_id(), new_id(), new_id()
+    ix.set_metadata(id1, "fact", "test")
+    ix.insert(id1, [1.0, 0.0, 0.0])
+    ix.set_metadata(id2, "decision", "test")
+    ix.insert(id2, [0.9, 0.1, 0.0])
+    ix.set_metadata(id3, "decision", "test")     # never gets a vector
+    r = ix.search([1.0, 0.0, 0.0], 5, oracle.Filter(kinds=["decision"]))
+    assert [bytes(x["node_id"]) for x in r] == [id2.bytes]
+    ix.remove(id3)                                # metadata.remove without a vector
+    ix.insert(id3, [0.8, 0.2, 0.0])               # now a node without metadata: passes every kind filter (Q3)
+    r = ix.search([1.0, 0.0, 0.0], 5, oracle.Filter(kinds=["decision"]))
+    assert [bytes(x["node_id"]) for x in r] == [id2.bytes, id3.bytes]
+
+
 def test_filter_exclude(oracle):  # vector/index.rs:630-646
     ix = oracle.OracleIndex(3)
     id1, id2 = new_id(), new_id()
