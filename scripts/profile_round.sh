@@ -14,11 +14,13 @@ step knn-trace; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-form
 step knn-fetch; timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/knn_fetch -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-autolink > $O/knn_fetch.json 2> $O/knn_fetch.err || { tail -5 $O/knn_fetch.err; exit 1; }
 step knn-write; timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/knn_write -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-autolink > $O/knn_write.json 2> $O/knn_write.err || { tail -5 $O/knn_write.err; exit 1; }
 step autolink-trace; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/al_trace -- python3 $R/scripts/bench_autolink.py > $O/autolink.json 2> $O/al_trace.err || { tail -5 $O/al_trace.err; exit 1; }
+# MFMA pipe utilisation of the all-pairs filter GEMM (north_star: ">= 50 % MFMA utilisation"): counters only, program directly after `--`
+step autolink-mfma; timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/al_mfma -- python3 $R/scripts/bench_autolink.py --reps 2 > $O/al_mfma.json 2> $O/al_mfma.err || { tail -5 $O/al_mfma.err; exit 1; }
 step batch-trace; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/batch_trace -- python3 $R/scripts/bench_batch.py > $O/batch.json 2> $O/batch_trace.err || { tail -5 $O/batch_trace.err; exit 1; }
 step batch-fetch; timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/batch_fetch -- python3 $R/scripts/bench_batch.py --steps 5 > $O/batch_fetch.json 2> $O/batch_fetch.err || { tail -5 $O/batch_fetch.err; exit 1; }
 # keep only the summaries (traces are large)
 for d in knn_trace al_trace batch_trace; do f=$(ls -t $O/$d/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/${d}_kernel_stats.csv; done
-for d in knn_fetch knn_write batch_fetch; do f=$(ls -t $O/$d/*/*counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && python3 - "$f" > $O/${d}_summary.json <<'PY'
+for d in knn_fetch knn_write batch_fetch al_mfma; do f=$(ls -t $O/$d/*/*counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && python3 - "$f" > $O/${d}_summary.json <<'PY'
 import csv, sys, json, collections
 agg = collections.defaultdict(lambda: [0.0, 0])
 for r in csv.DictReader(open(sys.argv[1])):
@@ -27,5 +29,25 @@ for r in csv.DictReader(open(sys.argv[1])):
 print(json.dumps([{"kernel": k[0], "counter": k[1], "sum": v[0], "dispatches": v[1], "per_dispatch": v[0] / v[1]} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]], indent=1))
 PY
 done
-rm -rf $O/knn_trace $O/al_trace $O/batch_trace $O/knn_fetch $O/knn_write $O/batch_fetch
+# MFMA utilisation of pair_filter256_kernel: busy cycles (summed over all SIMDs) / (kernel cycles x 256 CUs x 4 SIMDs);
+# GRBM_GUI_ACTIVE is reported per XCD and summed over the 8 of them
+python3 - $O/al_mfma_summary.json > $O/autolink_mfma_utilisation.json <<'PY'
+import json, sys
+rows = json.load(open(sys.argv[1]))
+def per(kern, ctr):
+    for r in rows:
+        if kern in r["kernel"] and r["counter"] == ctr:
+            return r["per_dispatch"], r["dispatches"]
+    return None, 0
+busy, nb = per("pair_filter256_kernel", "SQ_VALU_MFMA_BUSY_CYCLES")
+act, na = per("pair_filter256_kernel", "GRBM_GUI_ACTIVE")
+out = {"command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -- python3 scripts/bench_autolink.py --reps 2",
+       "kernel": "cx::pair_filter256_kernel", "dispatches": nb,
+       "per_launch": {"SQ_VALU_MFMA_BUSY_CYCLES": busy, "GRBM_GUI_ACTIVE_sum_over_8_XCDs": act}}
+if busy and act:
+    cyc = act / 8.0
+    out["derived"] = {"kernel_cycles": cyc, "mfma_pipe_utilisation": busy / (cyc * 256 * 4)}
+print(json.dumps(out, indent=1))
+PY
+rm -rf $O/knn_trace $O/al_trace $O/batch_trace $O/knn_fetch $O/knn_write $O/batch_fetch $O/al_mfma
 ls -la $O; cat $O/bench.json

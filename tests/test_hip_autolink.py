@@ -140,9 +140,11 @@ def test_rescan_with_existing_edges_matches_oracle(hip, oracle, n, d, scan_all):
     e = o.autolink_pass(scan_o, 100, thr_new, cap, n_threads=8, existing=existing)
     got, exp = per_node(fr, to, w), per_node(e["from_row"], e["to_row"], e["weight"])
     compare_edges(got, exp, thr_new, oracle_scores(o, rows), f"rescan n={n} d={d}")
-    # on this corpus nothing sits near the threshold or a cap boundary: the lists are identical, in order
-    assert list(zip(fr.tolist(), to.tolist())) == list(zip(e["from_row"].tolist(), e["to_row"].tolist()))
-    assert np.max(np.abs(w - e["weight"])) <= SCORE_TOL
+    # compare_edges tolerates near-ties (two neighbours whose scores differ by less than SCORE_TOL may swap and, at a
+    # cap boundary, replace each other); they must stay the exception: nearly every node's list is identical, in order
+    same = sum(1 for node in exp if [x[0] for x in got.get(node, [])] == [x[0] for x in exp[node]])
+    assert same >= 0.98 * len(exp), f"only {same} of {len(exp)} nodes have the oracle's exact list"
+    assert len(fr) == len(e)
     sets = {int(s): set(l) for s, l in zip(scan_o, lists)}
     assert all(int(b) not in sets[int(a)] for a, b in zip(fr, to))        # never proposed again
     # the pass without `existing` differs (it spends its cap on edges the node already has)
