@@ -93,6 +93,30 @@ SIGNATURES = {
     "cx_search_dev": (C.c_int, [_P, _P, _U64, _P, _P, _P, _P, _P, _P]),
     "cx_search_batch_dev": (C.c_int, [_P, _U64, _P, _U64, _P, _P, _P, _P, _P, _P]),
     "cx_merge_topk_dev": (C.c_int, [C.c_int, _U64, _U64, _U64, _U64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    # one index over several GPUs (sharded.cpp)
+    "cx_sharded_create": (_P, [_U32, _U32, _P]),
+    "cx_sharded_destroy": (None, [_P]),
+    "cx_sharded_n_shards": (_U32, [_P]),
+    "cx_sharded_shard": (_P, [_P, _U32]),
+    "cx_sharded_peer_to_peer": (C.c_int, [_P]),
+    "cx_sharded_upsert": (C.c_int, [_P, _P, _P, _U64]),
+    "cx_sharded_upsert_batch": (C.c_int, [_P, _U64, _P, _P, _U64]),
+    "cx_sharded_upsert_batch_dev": (C.c_int, [_P, _U64, _P, _P, _U64]),
+    "cx_sharded_remove": (C.c_int, [_P, _P]),
+    "cx_sharded_set_metadata": (C.c_int, [_P, _P, _U32, _U32]),
+    "cx_sharded_intern": (_U32, [_P, C.c_char_p, _U64]),
+    "cx_sharded_lookup": (_U32, [_P, C.c_char_p, _U64]),
+    "cx_sharded_len": (_U64, [_P]),
+    "cx_sharded_dimension": (_U32, [_P]),
+    "cx_sharded_row_count": (_U64, [_P]),
+    "cx_sharded_row_id": (C.c_int, [_P, _U64, _P]),
+    "cx_sharded_rows_of": (C.c_int, [_P, _U64, _P, _P]),
+    "cx_sharded_rebuild": (C.c_int, [_P]),
+    "cx_sharded_search": (C.c_int, [_P, _P, _U64, _U64, _P, _P, _P, _P, _P]),
+    "cx_sharded_search_batch": (C.c_int, [_P, _U64, _P, _U64, _U64, _P, _P, _P, _P, _P]),
+    "cx_sharded_search_threshold": (C.c_int, [_P, _P, _U64, C.c_float, _P, _U64, _P, _P, _P, _P, _P]),
+    "cx_sharded_autolink_pass_rows": (C.c_int, [_P, _U64, _P, _U64, C.c_float, _U64, _U64, _P, _P, _P, _U64, _P, _P, _P, _P, _P]),
+    "cx_sharded_dedup_scan_rows": (C.c_int, [_P, C.c_float, _P, _U64, _P, _P, _P, _P, _P]),
     "cx_profile_enable": (C.c_int, [_P, C.c_int]),
     "cx_profile_read": (C.c_int, [_P, _P, _P, C.c_int]),
     "cx_device_rows": (_P, [_P]),

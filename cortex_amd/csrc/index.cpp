@@ -195,11 +195,8 @@ int upsert_impl(cx_index *ix, uint64_t n, const uint8_t *ids, const float *embs,
     return CX_OK;
 }
 
-struct FilterUpload {
-    DevFilter f;
-    bool needs_sync = false;
-};
-
+}  // namespace
+namespace cx {
 // VectorFilter -> device view.  Exclude ids that are not in the index cannot
 // match any row and are dropped.
 int build_filter(const cx_index *ix, Ctx *c, const cx_filter *filter, hipStream_t s, FilterUpload &out) {
@@ -244,8 +241,6 @@ int build_filter(const cx_index *ix, Ctx *c, const cx_filter *filter, hipStream_
     return CX_OK;
 }
 
-}  // namespace
-namespace cx {
 bool use_nontemporal(const cx_index *ix) {
     static int forced = -1;
     if (forced == -1) {
@@ -433,9 +428,6 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
     return CX_OK;
 }
 
-}  // namespace cx
-namespace {
-
 // Host queries -> pinned staging, zero-padded / truncated to dim; the sum of
 // squares of any elements beyond dim still belongs to |q| (the reference
 // zips for the dot but takes the norm over the whole query, index.rs:172-173).
@@ -457,6 +449,9 @@ int stage_queries(const cx_index *ix, Ctx *c, uint64_t nq, const float *queries,
     if (dim) CX_HIP(hipMemcpyAsync(c->d_query, c->h_query, (size_t)nq * dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
     return CX_OK;
 }
+
+}  // namespace cx
+namespace {
 
 // Results of a host-API call live in ONE device block [counts nq | pad][rows][scores][dists] mirrored by one
 // pinned host block, so they come back with a single D2H copy (four separate copies cost ~10 us of a ~40 us

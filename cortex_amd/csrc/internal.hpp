@@ -176,6 +176,14 @@ struct CtxLease {
 // read back from the device (rows of list i start at rows + i * stride)
 int check_result_block(const uint32_t *counts, const uint32_t *rows, uint64_t nq, uint64_t stride, uint64_t k_max,
                        uint64_t n_rows);
+struct FilterUpload {
+    DevFilter f;
+    bool needs_sync = false;
+};
+// VectorFilter -> its device view in c's scratch (index.cpp); exclude ids that are not in the index are dropped
+int build_filter(const cx_index *ix, Ctx *c, const cx_filter *filter, hipStream_t s, FilterUpload &out);
+// host queries -> c->d_query (dim floats each, zero-padded / truncated; tails[i] = sum of squares beyond dim), on c->stream
+int stage_queries(const cx_index *ix, Ctx *c, uint64_t nq, const float *queries, uint64_t len, std::vector<float> &tails);
 bool use_nontemporal(const cx_index *ix);
 // nq single-query scans (query i = d_queries + i*dim) enqueued on s; results at [i*k_eff, ...)
 int ensure_norms(const cx_index *ix, hipStream_t s);   // index.cpp

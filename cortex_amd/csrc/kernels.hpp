@@ -63,6 +63,18 @@ int launch_merge_parts(uint32_t n_parts, uint32_t nq, uint32_t k, uint64_t part_
                        const uint32_t *d_counts, uint64_t *out_rows, float *out_scores, float *out_dists,
                        uint32_t *out_counts, hipStream_t stream);
 
+// single-process sharded index (sharded.cpp): rows are global insertion sequence numbers, ties resolve by them
+int launch_merge_parts_seq(uint32_t n_parts, uint32_t nq, uint32_t k, uint64_t part_stride, const uint32_t *d_seq_rows,
+                           const float *d_scores, const float *d_dists, const uint32_t *d_counts, uint32_t *out_seq_rows,
+                           float *out_scores, float *out_dists, uint32_t *out_counts, hipStream_t stream);
+// a shard's lists -> its part of the root's gather buffer (peer writes), local rows -> sequence numbers
+int launch_publish_part(const uint32_t *rows, const float *scores, const float *dists, const uint32_t *counts,
+                        const uint32_t *gseq, uint32_t nq, uint32_t k_src, uint32_t k_dst, uint32_t n_rows, uint32_t *dst,
+                        hipStream_t stream);
+// rows of this shard -> given vectors of a query block (possibly on a peer device)
+int launch_scatter_rows(const float *src, float *dst, const uint32_t *d_src_rows, const uint32_t *d_dst_pos, uint32_t n,
+                        uint32_t dim, hipStream_t stream);
+
 // ---- batched search (batch.hip) ----
 struct BatchArgs {
     const float *rows;      // [n_rows][dim]

@@ -22,6 +22,8 @@
 //  - rows beyond 256 MiB are streamed with non-temporal loads: they cannot
 //    stay in the 256 MiB Infinity Cache between queries anyway.
 //  - per-block lists are merged by a second, tiny kernel (merge_kernel).
+#include <algorithm>
+
 #include "kernels.hpp"
 #include "topk.hpp"
 
@@ -569,11 +571,16 @@ __global__ __launch_bounds__(1024) void merge_radix_kernel(const MergeArgs m0) {
     if (tid == 0) *m.out_count = S < k ? S : k;
 }
 
-template <int KS>
+// SEQ = false: shard p's rows are local, part_base[p] makes them global and ties resolve by (part, slot) — parts are
+// ordered by row range (the multi-process path, sharded.py).  SEQ = true (the single-process sharded index,
+// sharded.cpp): rows already ARE global insertion sequence numbers (< 2^32, unique), shards interleave, so the key's
+// row field holds the sequence number itself — ties resolve by insertion order exactly as in one index — and the
+// payload carries the candidate's index instead of its distance; out_rows is then u32.
+template <int KS, bool SEQ>
 __global__ __launch_bounds__(256) void merge_parts_kernel(uint32_t n_parts, uint32_t nq, uint32_t k, uint64_t lstride, uint64_t cstride,
                                                           const PartBase part_base, const uint32_t *rows,
                                                           const float *scores, const float *dists,
-                                                          const uint32_t *counts, uint64_t *out_rows,
+                                                          const uint32_t *counts, void *out_rows_v,
                                                           float *out_scores, float *out_dists,
                                                           uint32_t *out_counts) {
     // a 64-bit global row does not fit the 32-bit row field of a key, so the
@@ -596,8 +603,13 @@ __global__ __launch_bounds__(256) void merge_parts_kernel(uint32_t n_parts, uint
             const uint32_t p = i / k, slot = i % k;
             if (slot < counts[(size_t)p * cstride + qi]) {
                 const size_t src = (size_t)p * lstride + (size_t)qi * k + slot;
-                kg = make_key(scores[src], i);
-                sg = dists[src];  // payload: the shard's distance, carried through unchanged
+                if (SEQ) {
+                    kg = make_key(scores[src], rows[src]);
+                    sg = __uint_as_float(i);   // payload: where the candidate sits (only ever moved, never computed with)
+                } else {
+                    kg = make_key(scores[src], i);
+                    sg = dists[src];  // payload: the shard's distance, carried through unchanged
+                }
             }
         }
         top.offer_lanes(kg, sg, [](uint32_t) { return true; });
@@ -621,12 +633,13 @@ __global__ __launch_bounds__(256) void merge_parts_kernel(uint32_t n_parts, uint
             const uint64_t ki = top.key[s];
             const bool valid = i < k && ki != 0ull;
             if (valid) {
-                const uint32_t idx = key_row(ki);
+                const uint32_t idx = SEQ ? __float_as_uint(top.sim[s]) : key_row(ki);
                 const uint32_t p = idx / k, slot = idx % k;
                 const size_t src = (size_t)p * lstride + (size_t)qi * k + slot;
-                out_rows[(size_t)qi * k + i] = part_base.base[p] + rows[src];
+                if (SEQ) static_cast<uint32_t *>(out_rows_v)[(size_t)qi * k + i] = key_row(ki);
+                else static_cast<uint64_t *>(out_rows_v)[(size_t)qi * k + i] = part_base.base[p] + rows[src];
                 out_scores[(size_t)qi * k + i] = scores[src];
-                out_dists[(size_t)qi * k + i] = top.sim[s];
+                out_dists[(size_t)qi * k + i] = SEQ ? dists[src] : top.sim[s];
             }
             count += (uint32_t)__popcll(__ballot(valid));
         }
@@ -634,21 +647,103 @@ __global__ __launch_bounds__(256) void merge_parts_kernel(uint32_t n_parts, uint
     }
 }
 
-int launch_merge_parts(uint32_t n_parts, uint32_t nq, uint32_t k, uint64_t part_stride, const PartBase &part_base,
-                       const uint32_t *d_rows, const float *d_scores, const float *d_dists,
-                       const uint32_t *d_counts, uint64_t *out_rows, float *out_scores, float *out_dists,
-                       uint32_t *out_counts, hipStream_t stream) {
+static int launch_merge_parts_impl(bool seq, uint32_t n_parts, uint32_t nq, uint32_t k, uint64_t part_stride, const PartBase &part_base,
+                                   const uint32_t *d_rows, const float *d_scores, const float *d_dists,
+                                   const uint32_t *d_counts, void *out_rows, float *out_scores, float *out_dists,
+                                   uint32_t *out_counts, hipStream_t stream) {
     if (k > TOPK_MAX) return set_err(CX_ERR_VALIDATION, "merge: k=%u exceeds %u", k, TOPK_MAX);
     if (nq == 0 || k == 0) return CX_OK;
     const uint64_t lstride = part_stride ? part_stride : (uint64_t)nq * k;
     const uint64_t cstride = part_stride ? part_stride : (uint64_t)nq;
-#define CX_MP(KS_) hipLaunchKernelGGL((merge_parts_kernel<KS_>), dim3(nq), dim3(256), 0, stream, n_parts, nq, k, lstride, cstride, \
-                                      part_base, d_rows, d_scores, d_dists, d_counts, out_rows, out_scores,       \
-                                      out_dists, out_counts)
-    if (k <= 64) CX_MP(1);
-    else if (k <= 128) CX_MP(2);
-    else CX_MP(4);
+#define CX_MP(KS_, SEQ_) hipLaunchKernelGGL((merge_parts_kernel<KS_, SEQ_>), dim3(nq), dim3(256), 0, stream, n_parts, nq, k, lstride, cstride, \
+                                            part_base, d_rows, d_scores, d_dists, d_counts, out_rows, out_scores,       \
+                                            out_dists, out_counts)
+    if (seq) {
+        if (k <= 64) CX_MP(1, true);
+        else if (k <= 128) CX_MP(2, true);
+        else CX_MP(4, true);
+    } else {
+        if (k <= 64) CX_MP(1, false);
+        else if (k <= 128) CX_MP(2, false);
+        else CX_MP(4, false);
+    }
 #undef CX_MP
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+
+int launch_merge_parts(uint32_t n_parts, uint32_t nq, uint32_t k, uint64_t part_stride, const PartBase &part_base,
+                       const uint32_t *d_rows, const float *d_scores, const float *d_dists,
+                       const uint32_t *d_counts, uint64_t *out_rows, float *out_scores, float *out_dists,
+                       uint32_t *out_counts, hipStream_t stream) {
+    return launch_merge_parts_impl(false, n_parts, nq, k, part_stride, part_base, d_rows, d_scores, d_dists, d_counts, out_rows,
+                                   out_scores, out_dists, out_counts, stream);
+}
+
+int launch_merge_parts_seq(uint32_t n_parts, uint32_t nq, uint32_t k, uint64_t part_stride, const uint32_t *d_seq_rows,
+                           const float *d_scores, const float *d_dists, const uint32_t *d_counts, uint32_t *out_seq_rows,
+                           float *out_scores, float *out_dists, uint32_t *out_counts, hipStream_t stream) {
+    PartBase pb;
+    memset(&pb, 0, sizeof pb);
+    return launch_merge_parts_impl(true, n_parts, nq, k, part_stride, pb, d_seq_rows, d_scores, d_dists, d_counts, out_seq_rows,
+                                   out_scores, out_dists, out_counts, stream);
+}
+
+// One shard's lists of a call -> its part of the root's gather buffer (possibly peer memory: posted xGMI writes),
+// local rows translated to global insertion sequence numbers on the way.  Part layout = sharded.py's packed chunk:
+// rows[nq*k] | scores[nq*k] | dists[nq*k] | counts[nq].
+// The shard's lists are k_src wide (its own k_eff), the part k_dst wide (the call's k).
+__global__ __launch_bounds__(256) void publish_part_kernel(const uint32_t *rows, const float *scores, const float *dists,
+                                                           const uint32_t *counts, const uint32_t *gseq, uint32_t nq, uint32_t k_src,
+                                                           uint32_t k_dst, uint32_t n_rows, uint32_t *dst) {
+    const uint32_t n = nq * k_dst;
+    uint32_t *d_rows = dst;
+    float *d_scores = reinterpret_cast<float *>(dst + n), *d_dists = reinterpret_cast<float *>(dst + 2 * (size_t)n);
+    uint32_t *d_counts = dst + 3 * (size_t)n;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t q = i / k_dst, slot = i % k_dst;
+        if (slot < k_src && slot < counts[q]) {
+            const size_t src = (size_t)q * k_src + slot;
+            const uint32_t r = rows[src];
+            d_rows[i] = r < n_rows ? gseq[r] : 0xFFFFFFFFu;   // an impossible row stays impossible: the host check reports it
+            d_scores[i] = scores[src];
+            d_dists[i] = dists[src];
+        }
+    }
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x)
+        d_counts[q] = counts[q] <= k_src ? counts[q] : 0xFFFFFFFFu;
+}
+
+int launch_publish_part(const uint32_t *rows, const float *scores, const float *dists, const uint32_t *counts,
+                        const uint32_t *gseq, uint32_t nq, uint32_t k_src, uint32_t k_dst, uint32_t n_rows, uint32_t *dst,
+                        hipStream_t stream) {
+    if (!nq) return CX_OK;
+    const uint32_t n = std::max(nq * k_dst, nq);
+    const uint32_t grid = std::min<uint32_t>((n + 255u) / 256u, 1024u);
+    hipLaunchKernelGGL(publish_part_kernel, dim3(grid), dim3(256), 0, stream, rows, scores, dists, counts, gseq, nq, k_src, k_dst,
+                       n_rows, dst);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+
+// rows src_rows[i] of this shard -> vector dst_pos[i] of a query block that may live on another device
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float *src, float *dst, const uint32_t *src_rows,
+                                                           const uint32_t *dst_pos, uint32_t n, uint32_t dim) {
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t r = wave; r < n; r += n_waves) {
+        const float *s = src + (size_t)src_rows[r] * dim;
+        float *d = dst + (size_t)dst_pos[r] * dim;
+        for (uint32_t j = lane; j < dim; j += 64u) d[j] = s[j];
+    }
+}
+
+int launch_scatter_rows(const float *src, float *dst, const uint32_t *d_src_rows, const uint32_t *d_dst_pos, uint32_t n,
+                        uint32_t dim, hipStream_t stream) {
+    if (!n || !dim) return CX_OK;
+    const uint32_t blocks = std::min<uint32_t>((n + 3u) / 4u, 2048u);
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(blocks), dim3(256), 0, stream, src, dst, d_src_rows, d_dst_pos, n, dim);
     CX_HIP(hipGetLastError());
     return CX_OK;
 }

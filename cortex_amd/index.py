@@ -479,3 +479,62 @@ class HipIndex:
         cf, keep = self._filter(filter)
         self._check(self._L.cx_search_batch_dev(self._h, nq, d_queries, int(k), C.byref(cf) if cf else None,
                                                 d_rows, d_scores, d_dists, d_counts, stream))
+
+
+class _ShardedAbi:
+    """Presents the cx_sharded_* entry points under the names of their single-index counterparts, so that
+    ShardedHipIndex IS HipIndex with a different handle: every method that has a sharded form runs unchanged; one
+    that has none fails loudly instead of reaching a shard behind the index's back."""
+    _HAVE = {"upsert", "upsert_batch", "upsert_batch_dev", "remove", "set_metadata", "intern", "lookup", "len", "dimension",
+             "row_count", "row_id", "rows_of", "rebuild", "search", "search_batch", "search_threshold",
+             "autolink_pass_rows", "dedup_scan_rows"}
+
+    def __init__(self, L):
+        self._L = L
+
+    def __getattr__(self, name):
+        if name.startswith("cx_") and name[3:] in self._HAVE:
+            return getattr(self._L, "cx_sharded_" + name[3:])
+        if name in ("cx_last_error", "cx_device_count") or name.startswith("cx_sharded_"):
+            return getattr(self._L, name)
+        raise ValidationError(f"{name} has no sharded form: call it on a shard (ShardedHipIndex.shard(i)) or on a HipIndex")
+
+
+class ShardedHipIndex(HipIndex):
+    """One index over several GPUs of the node behind the same interface (include/cortex_hip.h: cx_sharded).
+    devices: one entry per shard; a device may repeat.  Rows in the linker interfaces (autolink_pass_rows,
+    dedup_scan_rows, rows_of, row_id, row_count) are GLOBAL rows = insertion sequence numbers, i.e. exactly the rows of
+    a single HipIndex that saw the same calls."""
+
+    def __init__(self, dimension: int, devices: Sequence[int]):
+        L = _lib.load()
+        self._L = _ShardedAbi(L)
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        self._h = L.cx_sharded_create(dimension, len(devices), devs)
+        if not self._h:
+            raise CortexError(self._err())
+        self.dimension = dimension
+        self.devices = list(devices)
+        self.device = self.devices[0]
+
+    @classmethod
+    def new(cls, dimension: int, devices: Sequence[int] = (0,)) -> "ShardedHipIndex":
+        return cls(dimension, devices)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._L.cx_sharded_destroy(self._h)
+            self._h = None
+
+    @property
+    def n_shards(self) -> int:
+        return int(self._L.cx_sharded_n_shards(self._h))
+
+    @property
+    def peer_to_peer(self) -> bool:
+        return bool(self._L.cx_sharded_peer_to_peer(self._h))
+
+    def shard_len(self, i: int) -> int:
+        """rows held by shard i (live ones)"""
+        L = _lib.load()
+        return int(L.cx_len(L.cx_sharded_shard(self._h, i)))

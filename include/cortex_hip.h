@@ -345,6 +345,74 @@ int cx_merge_topk_dev(int device, uint64_t n_parts, uint64_t nq, uint64_t k, uin
                       float *d_out_scores, float *d_out_distances, uint32_t *d_out_counts,
                       void *stream);
 
+/* ---- one index over several GPUs of the node, behind the same boundary ------------------
+ *
+ * `cx_sharded` is the multi-device form of `cx_index` for a host that is ONE process (the reference's shape:
+ * serve.rs:101 holds one Arc<RwLock<index>>): one shard (a cx_index) per entry of device_ids, one stream per
+ * shard, nothing for the caller to orchestrate.  New ids are placed block-round-robin (4096 consecutive new ids per
+ * shard, SURVEY §8e "append-only ingest round-robins by block"), a known id keeps its shard and row (HashMap insert
+ * semantics, vector/index.rs:307).  Every row carries its GLOBAL insertion sequence number ("global row"): result
+ * order, tie order (score desc, global row asc) and every row-indexed interface below are those of ONE index that
+ * saw the same sequence of calls — the sharded index is checked against exactly that.
+ * A search runs the shard scans concurrently; each shard publishes its partial top-k straight into the gather
+ * buffer on the first shard's device (peer-to-peer writes over xGMI: single hop, no ring — the payload is KBs and
+ * latency-bound), the root merges the parts (merge_parts_kernel) and hands the result to the host.
+ * A device may be listed more than once (several shards on one GPU; how the tests run on a one-GPU box).
+ * Threading: as for cx_index — `const cx_sharded*` entry points are re-entrant, the others need exclusivity. */
+typedef struct cx_sharded cx_sharded;
+
+cx_sharded *cx_sharded_create(uint32_t dimension, uint32_t n_shards, const int *device_ids);   /* NULL on failure */
+void cx_sharded_destroy(cx_sharded *h);
+uint32_t cx_sharded_n_shards(const cx_sharded *h);
+/* shard i as a plain index (read-only uses: cx_len, cx_row_count, cx_device_rows ...) */
+const cx_index *cx_sharded_shard(const cx_sharded *h, uint32_t i);
+/* 1 if every shard can write the root's memory directly (xGMI / same device), 0 if parts travel through pinned host memory */
+int cx_sharded_peer_to_peer(const cx_sharded *h);
+
+/* VectorIndex::insert / remove / set_metadata / len / rebuild (vector/index.rs:298-323, :219-222, :412-435) */
+int cx_sharded_upsert(cx_sharded *h, const uint8_t id[16], const float *embedding, uint64_t len);
+int cx_sharded_upsert_batch(cx_sharded *h, uint64_t n, const uint8_t *ids, const float *embeddings, uint64_t len);
+/* same, embeddings resident in HBM of any device of the node (copied device to device into the owning shards) */
+int cx_sharded_upsert_batch_dev(cx_sharded *h, uint64_t n, const uint8_t *ids, const float *d_embeddings, uint64_t len);
+int cx_sharded_remove(cx_sharded *h, const uint8_t id[16]);
+int cx_sharded_set_metadata(cx_sharded *h, const uint8_t id[16], uint32_t kind_code, uint32_t agent_code);
+uint32_t cx_sharded_intern(cx_sharded *h, const char *utf8, uint64_t len);          /* same code on every shard */
+uint32_t cx_sharded_lookup(const cx_sharded *h, const char *utf8, uint64_t len);
+uint64_t cx_sharded_len(const cx_sharded *h);
+uint32_t cx_sharded_dimension(const cx_sharded *h);
+/* global rows ever assigned (removed ones included until cx_sharded_rebuild renumbers) */
+uint64_t cx_sharded_row_count(const cx_sharded *h);
+int cx_sharded_row_id(const cx_sharded *h, uint64_t global_row, uint8_t out_id[16]);
+/* out_rows[i] = global row of ids[16 i ..] or UINT32_MAX */
+int cx_sharded_rows_of(const cx_sharded *h, uint64_t n, const uint8_t *ids, uint32_t *out_rows);
+/* compacts every shard and renumbers the global rows (order preserved) */
+int cx_sharded_rebuild(cx_sharded *h);
+
+/* VectorIndex::search / search_batch / search_threshold over all shards — same contracts as cx_search,
+ * cx_search_batch, cx_search_threshold */
+int cx_sharded_search(const cx_sharded *h, const float *query, uint64_t len, uint64_t k, const cx_filter *filter,
+                      uint8_t *out_ids, float *out_scores, float *out_distances, uint64_t *n_out);
+int cx_sharded_search_batch(const cx_sharded *h, uint64_t nq, const float *queries, uint64_t len, uint64_t k,
+                            const cx_filter *filter, uint8_t *out_ids, float *out_scores, float *out_distances,
+                            uint64_t *out_counts);
+int cx_sharded_search_threshold(const cx_sharded *h, const float *query, uint64_t len, float threshold,
+                                const cx_filter *filter, uint64_t cap, uint8_t *out_ids, float *out_scores,
+                                float *out_distances, uint64_t *n_out, uint64_t *n_needed);
+
+/* cx_autolink_pass_rows / cx_dedup_scan_rows over all shards; every row argument and result is a GLOBAL row
+ * (scan_rows, deleted[cx_sharded_row_count()], existing_to, out_from / out_to).  Per block of scanned nodes the
+ * owners scatter the nodes' vectors into every shard's query block (peer writes), every shard produces the block's
+ * ordered neighbour lists against its own rows (cx_autolink_lists_dev: MFMA filter + exact rescore), the lists are
+ * published to the root and merged like partial top-k lists, and the root walks the reference's rules. */
+int cx_sharded_autolink_pass_rows(const cx_sharded *h, uint64_t n_scan, const uint32_t *scan_rows, uint64_t topk,
+                                  float threshold, uint64_t max_edges_per_node, uint64_t max_edges_per_cycle,
+                                  const uint8_t *deleted, const uint64_t *existing_offsets,
+                                  const uint32_t *existing_to, uint64_t cap, uint32_t *out_from, uint32_t *out_to,
+                                  float *out_weight, uint64_t *n_out, uint64_t *n_needed);
+int cx_sharded_dedup_scan_rows(const cx_sharded *h, float dedup_threshold, const uint8_t *deleted, uint64_t cap,
+                               uint32_t *out_a, uint32_t *out_b, float *out_similarity, uint64_t *n_out,
+                               uint64_t *n_needed);
+
 /* ---- measurement and diagnostics -------------------------------------- */
 
 /* The check every host entry point applies to a result block it read back from the device before using any of it

@@ -218,117 +218,104 @@ public:
     cx_index *raw() const { return h_; }
 };
 
-// One process, several GPUs (SURVEY §8e for a server that is a single process, like the reference's): one HipIndex
-// per device, each holding a share of the rows; a search runs on every shard at once (one host thread per shard, the
-// &self entry points are re-entrant) and the k-way merge of <= n_shards * k candidates happens on the host.  Rows are
-// dealt to the shards in blocks of `block_rows` insertions; ties between equal scores resolve by global insertion
-// order exactly as in a single index (each shard row remembers its global sequence number).  The multi-process variant
-// with an RCCL all-gather is cortex_amd/sharded.py; this one needs no collective: the partial lists are KB-sized and
-// already on the host.
+// One process, several GPUs (SURVEY §8b/§8e for a server that is a single process, like the reference's): the same
+// trait over `cx_sharded` (cortex_hip.h) — one shard per listed device, shard scans concurrent, partial top-k lists
+// published peer-to-peer into the root device's gather buffer and merged there, ties by global insertion order exactly
+// as in a single index.  Everything happens behind the C ABI; this class only marshals.  (The multi-PROCESS variant with
+// an RCCL all-gather is cortex_amd/sharded.py.)
 class ShardedHipIndex final : public VectorIndex {
-    std::vector<std::unique_ptr<HipIndex>> shards_;
-    std::vector<std::vector<uint64_t>> seq_;   // [shard][row] -> global insertion sequence
-    uint64_t next_seq_ = 0;
-    size_t block_rows_;
-    struct Hit { SimilarityResult r; uint64_t seq; };
-    static bool better(const Hit &a, const Hit &b) {   // score descending, NaN last, then insertion order
-        const bool an = a.r.score != a.r.score, bn = b.r.score != b.r.score;
-        if (an != bn) return bn;
-        if (!an && a.r.score != b.r.score) return a.r.score > b.r.score;
-        return a.seq < b.seq;
+    cx_sharded *h_;
+    static void check(int rc) {
+        if (rc != CX_OK) throw CortexError(rc, cx_last_error());
     }
-    int shard_of(const NodeId &id) const {
-        for (size_t s = 0; s < shards_.size(); s++) {
-            uint32_t row = 0;
-            if (cx_rows_of(shards_[s]->raw(), 1, id.data(), &row) == CX_OK && row != UINT32_MAX) return (int)s;
+    struct FilterBuf {
+        std::vector<uint8_t> ex;
+        std::vector<uint32_t> kinds;
+        cx_filter c{};
+    };
+    bool marshal(const VectorFilter *f, FilterBuf &b) const {
+        if (!f) return false;
+        if (f->exclude) {
+            for (auto &id : *f->exclude) b.ex.insert(b.ex.end(), id.begin(), id.end());
+            b.c.has_exclude = 1; b.c.n_exclude = f->exclude->size(); b.c.exclude_ids = b.ex.data();
         }
-        return -1;
+        if (f->kinds) {
+            for (auto &k : *f->kinds) b.kinds.push_back(cx_sharded_lookup(h_, k.data(), k.size()));
+            b.c.has_kinds = 1; b.c.n_kinds = f->kinds->size(); b.c.kind_codes = b.kinds.data();
+        }
+        if (f->source_agent) { b.c.has_agent = 1; b.c.agent_code = cx_sharded_lookup(h_, f->source_agent->data(), f->source_agent->size()); }
+        return true;
     }
-    template <class F>
-    std::vector<SimilarityResult> fan_out(size_t keep, bool truncate, F &&per_shard) const {
-        std::vector<std::vector<Hit>> parts(shards_.size());
-        std::vector<std::thread> pool;
-        std::vector<std::exception_ptr> errs(shards_.size());
-        for (size_t s = 0; s < shards_.size(); s++)
-            pool.emplace_back([&, s] {
-                try {
-                    auto res = per_shard(*shards_[s]);
-                    std::vector<uint8_t> ids(16 * std::max<size_t>(1, res.size()));
-                    std::vector<uint32_t> rows(std::max<size_t>(1, res.size()));
-                    for (size_t i = 0; i < res.size(); i++) std::memcpy(&ids[16 * i], res[i].node_id.data(), 16);
-                    if (!res.empty() && cx_rows_of(shards_[s]->raw(), res.size(), ids.data(), rows.data()) != CX_OK)
-                        throw CortexError(CX_ERR_VALIDATION, cx_last_error());
-                    for (size_t i = 0; i < res.size(); i++) parts[s].push_back({res[i], rows[i] < seq_[s].size() ? seq_[s][rows[i]] : ~0ull});
-                } catch (...) { errs[s] = std::current_exception(); }
-            });
-        for (auto &t : pool) t.join();
-        for (auto &e : errs) if (e) std::rethrow_exception(e);
-        std::vector<Hit> all;
-        for (auto &p : parts) all.insert(all.end(), p.begin(), p.end());
-        std::stable_sort(all.begin(), all.end(), better);
-        if (truncate && all.size() > keep) all.resize(keep);
-        std::vector<SimilarityResult> out;
-        for (auto &h : all) out.push_back(h.r);
+    static std::vector<SimilarityResult> collect(const uint8_t *ids, const float *s, const float *d, size_t n) {
+        std::vector<SimilarityResult> out(n);
+        for (size_t i = 0; i < n; i++) {
+            std::memcpy(out[i].node_id.data(), ids + 16 * i, 16);
+            out[i].score = s[i];
+            out[i].distance = d[i];
+        }
         return out;
     }
 
 public:
-    ShardedHipIndex(size_t dimension, const std::vector<int> &devices, size_t block_rows = 4096) : block_rows_(std::max<size_t>(1, block_rows)) {
-        if (devices.empty()) throw CortexError(CX_ERR_VALIDATION, "no devices");
-        for (int d : devices) shards_.push_back(std::make_unique<HipIndex>(dimension, d));
-        seq_.resize(shards_.size());
+    ShardedHipIndex(size_t dimension, const std::vector<int> &devices) : h_(cx_sharded_create((uint32_t)dimension, (uint32_t)devices.size(), devices.data())) {
+        if (!h_) throw CortexError(CX_ERR_DEVICE, cx_last_error());
     }
-    size_t n_shards() const { return shards_.size(); }
-    HipIndex &shard(size_t s) { return *shards_[s]; }
-    void insert(const NodeId &id, const Embedding &e) override {
-        int s = shard_of(id);                                  // HashMap::insert semantics: a known id keeps its place
-        const bool fresh = s < 0;
-        if (fresh) s = (int)((next_seq_ / block_rows_) % shards_.size());
-        const uint64_t before = cx_row_count(shards_[s]->raw());
-        shards_[s]->insert(id, e);                             // throws on a dimension mismatch: nothing recorded
-        if (fresh) {
-            if (seq_[s].size() <= before) seq_[s].resize(before + 1);
-            seq_[s][before] = next_seq_++;
-        }
-    }
-    void remove(const NodeId &id) override { const int s = shard_of(id); if (s >= 0) shards_[s]->remove(id); }
+    ShardedHipIndex(const ShardedHipIndex &) = delete;
+    ~ShardedHipIndex() override { if (h_) cx_sharded_destroy(h_); }
+    size_t n_shards() const { return cx_sharded_n_shards(h_); }
+    cx_sharded *raw() const { return h_; }
+    void insert(const NodeId &id, const Embedding &e) override { check(cx_sharded_upsert(h_, id.data(), e.data(), e.size())); }
+    void remove(const NodeId &id) override { check(cx_sharded_remove(h_, id.data())); }
     void set_metadata(const NodeId &id, const std::string &kind, const std::string &agent) {
-        const int s = shard_of(id); if (s >= 0) shards_[s]->set_metadata(id, kind, agent);
+        check(cx_sharded_set_metadata(h_, id.data(), cx_sharded_intern(h_, kind.data(), kind.size()), cx_sharded_intern(h_, agent.data(), agent.size())));
     }
     std::vector<SimilarityResult> search(const Embedding &q, size_t k, const VectorFilter *f = nullptr) const override {
-        if (k == 0) return {};
-        return fan_out(k, true, [&](const HipIndex &ix) { return ix.search(q, k, f); });
+        const size_t cap = std::max<size_t>(1, std::min<size_t>(k, cx_sharded_row_count(h_)));
+        std::vector<uint8_t> ids(16 * cap);
+        std::vector<float> sc(cap), di(cap);
+        uint64_t n = 0;
+        FilterBuf fb;
+        const cx_filter *cf = marshal(f, fb) ? &fb.c : nullptr;
+        check(cx_sharded_search(h_, q.data(), q.size(), k, cf, ids.data(), sc.data(), di.data(), &n));
+        return collect(ids.data(), sc.data(), di.data(), n);
     }
     std::vector<SimilarityResult> search_threshold(const Embedding &q, float thr, const VectorFilter *f = nullptr) const override {
-        return fan_out(0, false, [&](const HipIndex &ix) { return ix.search_threshold(q, thr, f); });
+        FilterBuf fb;
+        const cx_filter *cf = marshal(f, fb) ? &fb.c : nullptr;
+        uint64_t cap = 256;
+        for (;;) {
+            std::vector<uint8_t> ids(16 * cap);
+            std::vector<float> sc(cap), di(cap);
+            uint64_t n = 0, need = 0;
+            const int rc = cx_sharded_search_threshold(h_, q.data(), q.size(), thr, cf, cap, ids.data(), sc.data(), di.data(), &n, &need);
+            if (rc == CX_ERR_CAPACITY && need > cap) { cap = need; continue; }
+            check(rc);
+            return collect(ids.data(), sc.data(), di.data(), n);
+        }
     }
     std::map<NodeId, std::vector<SimilarityResult>> search_batch(const std::vector<std::pair<NodeId, Embedding>> &queries, size_t k,
                                                                 const VectorFilter *f = nullptr) const override {
-        std::map<NodeId, std::vector<SimilarityResult>> out;   // index.rs:390-410: one search per query
-        for (auto &q : queries) out[q.first] = search(q.second, k, f);
+        std::map<NodeId, std::vector<SimilarityResult>> out;
+        if (queries.empty()) return out;
+        const size_t nq = queries.size(), len = queries[0].second.size(), kk = std::max<size_t>(1, k);
+        std::vector<float> flat;
+        flat.reserve(nq * len);
+        for (auto &q : queries) {
+            if (q.second.size() != len) throw CortexError(CX_ERR_VALIDATION, "search_batch: queries of different lengths");
+            flat.insert(flat.end(), q.second.begin(), q.second.end());
+        }
+        std::vector<uint8_t> ids(16 * nq * kk);
+        std::vector<float> sc(nq * kk), di(nq * kk);
+        std::vector<uint64_t> counts(nq);
+        FilterBuf fb;
+        const cx_filter *cf = marshal(f, fb) ? &fb.c : nullptr;
+        check(cx_sharded_search_batch(h_, nq, flat.data(), len, k, cf, ids.data(), sc.data(), di.data(), counts.data()));
+        for (size_t i = 0; i < nq; i++) out[queries[i].first] = collect(&ids[16 * i * kk], &sc[i * kk], &di[i * kk], counts[i]);
         return out;
     }
-    size_t len() const override { size_t n = 0; for (auto &s : shards_) n += s->len(); return n; }
-    void rebuild() override {
-        // compaction moves rows: the sequence numbers move with them (rows keep their order inside a shard)
-        for (size_t s = 0; s < shards_.size(); s++) {
-            const uint64_t n = cx_row_count(shards_[s]->raw());
-            std::vector<NodeId> ids((size_t)n);
-            for (uint64_t r = 0; r < n; r++) cx_row_id(shards_[s]->raw(), r, ids[(size_t)r].data());
-            std::vector<uint64_t> old = seq_[s];
-            shards_[s]->rebuild();
-            std::vector<uint64_t> fresh;
-            for (uint64_t r = 0; r < n; r++) {
-                uint32_t row = 0;
-                if (cx_rows_of(shards_[s]->raw(), 1, ids[(size_t)r].data(), &row) == CX_OK && row != UINT32_MAX) {
-                    if (fresh.size() <= row) fresh.resize(row + 1);
-                    fresh[row] = r < old.size() ? old[(size_t)r] : 0;
-                }
-            }
-            seq_[s].swap(fresh);
-        }
-    }
-    void save(const std::string &) const override { throw CortexError(CX_ERR_VALIDATION, "a sharded index is saved shard by shard (shard(i).save)"); }
+    size_t len() const override { return cx_sharded_len(h_); }
+    void rebuild() override { check(cx_sharded_rebuild(h_)); }
+    void save(const std::string &) const override { throw CortexError(CX_ERR_VALIDATION, "a sharded index is not saved as one file: rebuild it from the nodes table (serve.rs:105-123)"); }
 };
 
 struct SimilarityConfig {  // vector/config.rs:3-87

@@ -64,6 +64,33 @@ extern "C" {
     fn cx_search_decayed(ix: *const c_void, q: *const f32, len: u64, limit: u64, candidate_limit: u64, f: *const CxFilter,
                          cfg: *const CxDecayConfig, recency_bias: f32, now_s: i64, now_ns: u32, ids: *mut u8,
                          scores: *mut f32, raw_scores: *mut f32, n_out: *mut u64) -> c_int;
+    // one index over several GPUs of the node: same contracts, `cx_sharded` handle
+    fn cx_sharded_create(dimension: u32, n_shards: u32, device_ids: *const c_int) -> *mut c_void;
+    fn cx_sharded_destroy(h: *mut c_void);
+    fn cx_sharded_upsert(h: *mut c_void, id: *const u8, emb: *const f32, len: u64) -> c_int;
+    fn cx_sharded_upsert_batch(h: *mut c_void, n: u64, ids: *const u8, embs: *const f32, len: u64) -> c_int;
+    fn cx_sharded_remove(h: *mut c_void, id: *const u8) -> c_int;
+    fn cx_sharded_set_metadata(h: *mut c_void, id: *const u8, kind: u32, agent: u32) -> c_int;
+    fn cx_sharded_intern(h: *mut c_void, s: *const c_char, len: u64) -> u32;
+    fn cx_sharded_lookup(h: *const c_void, s: *const c_char, len: u64) -> u32;
+    fn cx_sharded_len(h: *const c_void) -> u64;
+    fn cx_sharded_row_count(h: *const c_void) -> u64;
+    fn cx_sharded_rebuild(h: *mut c_void) -> c_int;
+    fn cx_sharded_search(h: *const c_void, q: *const f32, len: u64, k: u64, f: *const CxFilter,
+                         ids: *mut u8, scores: *mut f32, dists: *mut f32, n_out: *mut u64) -> c_int;
+    fn cx_sharded_search_threshold(h: *const c_void, q: *const f32, len: u64, thr: f32, f: *const CxFilter,
+                                   cap: u64, ids: *mut u8, scores: *mut f32, dists: *mut f32,
+                                   n_out: *mut u64, n_needed: *mut u64) -> c_int;
+    fn cx_sharded_search_batch(h: *const c_void, nq: u64, qs: *const f32, len: u64, k: u64, f: *const CxFilter,
+                               ids: *mut u8, scores: *mut f32, dists: *mut f32, counts: *mut u64) -> c_int;
+    fn cx_sharded_rows_of(h: *const c_void, n: u64, ids: *const u8, out_rows: *mut u32) -> c_int;
+    fn cx_sharded_row_id(h: *const c_void, global_row: u64, out_id16: *mut u8) -> c_int;
+    fn cx_sharded_autolink_pass_rows(h: *const c_void, n_scan: u64, scan_rows: *const u32, topk: u64, threshold: f32,
+                                     max_edges_per_node: u64, max_edges_per_cycle: u64, deleted: *const u8,
+                                     existing_offsets: *const u64, existing_to: *const u32, cap: u64, out_from: *mut u32,
+                                     out_to: *mut u32, out_weight: *mut f32, n_out: *mut u64, n_needed: *mut u64) -> c_int;
+    fn cx_sharded_dedup_scan_rows(h: *const c_void, dedup_threshold: f32, deleted: *const u8, cap: u64, out_a: *mut u32,
+                                  out_b: *mut u32, out_similarity: *mut f32, n_out: *mut u64, n_needed: *mut u64) -> c_int;
     // start-up bulk load from the nodes table
     fn cx_bulk_load_nodes(ix: *mut c_void, n: u64, blob: *const u8, offsets: *const u64, flags: u32,
                           stats: *mut CxBulkStats) -> c_int;
@@ -305,5 +332,149 @@ impl VectorIndex for HipIndex {
         let h = unsafe { cx_load(p.as_ptr(), 0) };
         if h.is_null() { return Err(last_error()); }
         Ok(Self { h, dimension: 0 })
+    }
+}
+
+
+/// The same index over several MI355X of the node (`cx_sharded`, cortex_hip.h): one shard per device, shard scans
+/// concurrent, partial top-k lists merged on the first device; results, tie order and rows are those of ONE index.
+/// serve.rs:101 becomes `Arc::new(RwLock::new(ShardedHipIndex::new(dim, &[0, 1, 2, 3, 4, 5, 6, 7])?))`.
+pub struct ShardedHipIndex { h: *mut c_void }
+unsafe impl Send for ShardedHipIndex {}
+unsafe impl Sync for ShardedHipIndex {}
+impl Drop for ShardedHipIndex { fn drop(&mut self) { unsafe { cx_sharded_destroy(self.h) } } }
+
+impl ShardedHipIndex {
+    pub fn new(dimension: usize, devices: &[i32]) -> Result<Self> {
+        let h = unsafe { cx_sharded_create(dimension as u32, devices.len() as u32, devices.as_ptr()) };
+        if h.is_null() { Err(last_error()) } else { Ok(Self { h }) }
+    }
+    pub fn set_metadata(&mut self, id: NodeId, kind: NodeKind, source_agent: String) {
+        let k = unsafe { cx_sharded_intern(self.h, kind.as_str().as_ptr() as *const c_char, kind.as_str().len() as u64) };
+        let a = unsafe { cx_sharded_intern(self.h, source_agent.as_ptr() as *const c_char, source_agent.len() as u64) };
+        unsafe { cx_sharded_set_metadata(self.h, id.as_bytes().as_ptr(), k, a) };
+    }
+    /// n inserts in one call (the start-up loop of serve.rs:105-123 without N FFI round trips)
+    pub fn insert_batch(&mut self, ids: &[NodeId], embeddings: &[f32], len: usize) -> Result<()> {
+        let mut flat = Vec::with_capacity(16 * ids.len());
+        for id in ids { flat.extend_from_slice(id.as_bytes()); }
+        check(unsafe { cx_sharded_upsert_batch(self.h, ids.len() as u64, flat.as_ptr(), embeddings.as_ptr(), len as u64) })
+    }
+    fn lookup(&self, s: &str) -> u32 { unsafe { cx_sharded_lookup(self.h, s.as_ptr() as *const c_char, s.len() as u64) } }
+    fn filter(&self, f: Option<&VectorFilter>) -> Option<Box<FilterBuf>> {
+        let f = f?;
+        let mut b = Box::new(FilterBuf { ex: Vec::new(), kinds: Vec::new(), c: unsafe { std::mem::zeroed() } });
+        if let Some(ex) = &f.exclude {
+            for id in ex { b.ex.extend_from_slice(id.as_bytes()); }
+            b.c.has_exclude = 1; b.c.n_exclude = ex.len() as u64; b.c.exclude_ids = b.ex.as_ptr();
+        }
+        if let Some(kinds) = &f.kinds {
+            b.kinds = kinds.iter().map(|k| self.lookup(k.as_str())).collect();
+            b.c.has_kinds = 1; b.c.n_kinds = kinds.len() as u64; b.c.kind_codes = b.kinds.as_ptr();
+        }
+        if let Some(agent) = &f.source_agent { b.c.has_agent = 1; b.c.agent_code = self.lookup(agent); }
+        Some(b)
+    }
+    /// AutoLinker::run_cycle's kNN loop for SimilarityLinkRule over all shards — HipIndex::similarity_edges with
+    /// global rows underneath (cx_sharded_rows_of / cx_sharded_row_id instead of cx_rows_of / cx_row_id).
+    pub fn similarity_edges(&self, nodes: &[NodeId], existing: &[Vec<NodeId>], cfg: &SimilarityConfig,
+                            max_edges_per_node: usize, max_edges_per_cycle: usize) -> Result<Vec<(NodeId, NodeId, f32)>> {
+        const NO_ROW: u32 = u32::MAX;
+        let rows_of = |ids: &[NodeId]| -> Result<Vec<u32>> {
+            let mut flat = Vec::with_capacity(16 * ids.len());
+            for id in ids { flat.extend_from_slice(id.as_bytes()); }
+            let mut rows = vec![0u32; ids.len()];
+            check(unsafe { cx_sharded_rows_of(self.h, ids.len() as u64, flat.as_ptr(), rows.as_mut_ptr()) })?;
+            Ok(rows)
+        };
+        let all = rows_of(nodes)?;
+        let (mut scan, mut ex_off, mut ex_to): (Vec<u32>, Vec<u64>, Vec<u32>) = (Vec::new(), vec![0], Vec::new());
+        for (i, &r) in all.iter().enumerate() {
+            if r == NO_ROW { continue; }
+            scan.push(r);
+            if let Some(t) = existing.get(i) { ex_to.extend(rows_of(t)?.into_iter().filter(|&x| x != NO_ROW)); }
+            ex_off.push(ex_to.len() as u64);
+        }
+        let mut cap = (scan.len() * 4).max(1024);
+        loop {
+            let (mut fr, mut to, mut w) = (vec![0u32; cap], vec![0u32; cap], vec![0f32; cap]);
+            let (mut n, mut need) = (0u64, 0u64);
+            let rc = unsafe { cx_sharded_autolink_pass_rows(self.h, scan.len() as u64, scan.as_ptr(), 100, cfg.auto_link_threshold,
+                max_edges_per_node as u64, max_edges_per_cycle as u64, std::ptr::null(), ex_off.as_ptr(), ex_to.as_ptr(),
+                cap as u64, fr.as_mut_ptr(), to.as_mut_ptr(), w.as_mut_ptr(), &mut n, &mut need) };
+            if rc == CX_ERR_CAPACITY && need as usize > cap { cap = need as usize; continue; }
+            check(rc)?;
+            let mut id = [0u8; 16];
+            let mut out = Vec::with_capacity(n as usize);
+            for i in 0..n as usize {
+                check(unsafe { cx_sharded_row_id(self.h, fr[i] as u64, id.as_mut_ptr()) })?;
+                let a = NodeId::from_slice(&id).unwrap();
+                check(unsafe { cx_sharded_row_id(self.h, to[i] as u64, id.as_mut_ptr()) })?;
+                out.push((a, NodeId::from_slice(&id).unwrap(), w[i]));
+            }
+            return Ok(out);
+        }
+    }
+}
+
+impl VectorIndex for ShardedHipIndex {
+    fn insert(&mut self, id: NodeId, embedding: &Embedding) -> Result<()> {
+        check(unsafe { cx_sharded_upsert(self.h, id.as_bytes().as_ptr(), embedding.as_ptr(), embedding.len() as u64) })
+    }
+    fn remove(&mut self, id: NodeId) -> Result<()> { check(unsafe { cx_sharded_remove(self.h, id.as_bytes().as_ptr()) }) }
+    fn search(&self, query: &Embedding, k: usize, filter: Option<&VectorFilter>) -> Result<Vec<SimilarityResult>> {
+        let cap = k.min(unsafe { cx_sharded_row_count(self.h) } as usize).max(1);
+        let (mut ids, mut sc, mut di) = (vec![0u8; 16 * cap], vec![0f32; cap], vec![0f32; cap]);
+        let mut n = 0u64;
+        let fb = self.filter(filter);
+        let fp = fb.as_ref().map_or(std::ptr::null(), |b| &b.c as *const CxFilter);
+        check(unsafe { cx_sharded_search(self.h, query.as_ptr(), query.len() as u64, k as u64, fp,
+                                         ids.as_mut_ptr(), sc.as_mut_ptr(), di.as_mut_ptr(), &mut n) })?;
+        Ok(HipIndex::collect(&ids, &sc, &di, n as usize))
+    }
+    fn search_threshold(&self, query: &Embedding, threshold: f32, filter: Option<&VectorFilter>)
+        -> Result<Vec<SimilarityResult>> {
+        let fb = self.filter(filter);
+        let fp = fb.as_ref().map_or(std::ptr::null(), |b| &b.c as *const CxFilter);
+        let mut cap = 256usize;
+        loop {
+            let (mut ids, mut sc, mut di) = (vec![0u8; 16 * cap], vec![0f32; cap], vec![0f32; cap]);
+            let (mut n, mut need) = (0u64, 0u64);
+            let rc = unsafe { cx_sharded_search_threshold(self.h, query.as_ptr(), query.len() as u64, threshold, fp,
+                                                          cap as u64, ids.as_mut_ptr(), sc.as_mut_ptr(), di.as_mut_ptr(),
+                                                          &mut n, &mut need) };
+            if rc == CX_ERR_CAPACITY { cap = need as usize; continue; }
+            check(rc)?;
+            return Ok(HipIndex::collect(&ids, &sc, &di, n as usize));
+        }
+    }
+    fn search_batch(&self, queries: &[(NodeId, Embedding)], k: usize, filter: Option<&VectorFilter>)
+        -> Result<HashMap<NodeId, Vec<SimilarityResult>>> {
+        let nq = queries.len();
+        if nq == 0 { return Ok(HashMap::new()); }
+        let len = queries[0].1.len();
+        let mut flat = Vec::with_capacity(nq * len);
+        for (_, e) in queries { flat.extend_from_slice(e); }
+        let kk = k.max(1);
+        let (mut ids, mut sc, mut di) = (vec![0u8; 16 * nq * kk], vec![0f32; nq * kk], vec![0f32; nq * kk]);
+        let mut counts = vec![0u64; nq];
+        let fb = self.filter(filter);
+        let fp = fb.as_ref().map_or(std::ptr::null(), |b| &b.c as *const CxFilter);
+        check(unsafe { cx_sharded_search_batch(self.h, nq as u64, flat.as_ptr(), len as u64, k as u64, fp,
+                                               ids.as_mut_ptr(), sc.as_mut_ptr(), di.as_mut_ptr(), counts.as_mut_ptr()) })?;
+        let mut map = HashMap::with_capacity(nq);
+        for (i, (qid, _)) in queries.iter().enumerate() {
+            let o = i * kk;
+            map.insert(*qid, HipIndex::collect(&ids[16 * o..], &sc[o..], &di[o..], counts[i] as usize));
+        }
+        Ok(map)
+    }
+    fn len(&self) -> usize { unsafe { cx_sharded_len(self.h) as usize } }
+    fn rebuild(&mut self) -> Result<()> { check(unsafe { cx_sharded_rebuild(self.h) }) }
+    fn save(&self, _path: &Path) -> Result<()> {
+        Err(CortexError::Validation("a sharded index is rebuilt from the nodes table at start-up (serve.rs:105-123), not saved".into()))
+    }
+    fn load(_path: &Path) -> Result<Self> {
+        Err(CortexError::Validation("a sharded index is rebuilt from the nodes table at start-up (serve.rs:105-123), not loaded".into()))
     }
 }

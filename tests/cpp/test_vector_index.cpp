@@ -284,6 +284,7 @@ TEST(test_search_decayed_reranks) {
 // single index over the same insertions — ids, order (ties by global insertion order) and scores.
 TEST(test_sharded_single_process) {
     const size_t dim = 384, n = 3000;
+    setenv("CX_SHARD_PLACEMENT_BLOCK", "128", 1);   // 24 placement blocks over the three shards instead of one
     std::mt19937 rng(7);
     std::normal_distribution<float> g(0.0f, 1.0f);
     std::vector<NodeId> ids(n);
@@ -291,7 +292,7 @@ TEST(test_sharded_single_process) {
     for (size_t i = 0; i < n; i++) { ids[i] = now_v7(); for (auto &x : rows[i]) x = g(rng); }
     for (size_t i = 10; i < n; i += 97) rows[i] = rows[i - 7];       // exact duplicates: the tie order is checked too
     HipIndex one(dim);
-    ShardedHipIndex many(dim, {0, 0, 0}, 128);
+    ShardedHipIndex many(dim, {0, 0, 0});
     for (size_t i = 0; i < n; i++) { one.insert(ids[i], rows[i]); many.insert(ids[i], rows[i]); }
     one.insert(ids[5], rows[6]); many.insert(ids[5], rows[6]);        // upsert of a known id keeps its place
     for (size_t i = 0; i < n; i += 11) { one.remove(ids[i]); many.remove(ids[i]); }

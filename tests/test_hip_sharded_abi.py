@@ -1,0 +1,214 @@
+"""The multi-GPU index behind the C ABI (cx_sharded_*): one process, one shard per listed device.
+A one-GPU box lists device 0 several times (P shards on one GPU — same code path: per-shard streams, publish into
+the root's gather buffer, merge_parts_kernel, host hand-over).
+
+Bar: a sharded index is indistinguishable from a SINGLE HipIndex that saw the same sequence of calls — same ids in the
+same order (ties: global insertion order), scores equal, and the row-indexed linker passes return the same edges in
+global rows — and therefore matches the oracle wherever the single index does."""
+import threading
+import uuid
+
+import numpy as np
+import pytest
+
+from conftest import SCORE_TOL, assert_topk_parity, ids_for
+
+pytestmark = pytest.mark.gpu
+
+
+def build(hip, rows, ids, shards=3):
+    d = rows.shape[1]
+    one = hip.HipIndex(d)
+    sh = hip.ShardedHipIndex(d, [0] * shards)
+    # several calls of different sizes: runs are cut at the 4096-row placement blocks
+    cuts = [0, 1, 5000, 5003, len(rows)]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        one.insert_batch(ids[a:b], rows[a:b])
+        sh.insert_batch(ids[a:b], rows[a:b])
+    return one, sh
+
+
+def same_lists(a, b, what):
+    ai, asc, ad = a
+    bi, bsc, bd = b
+    assert len(asc) == len(bsc), f"{what}: {len(asc)} vs {len(bsc)} results"
+    assert np.array_equal(ai, bi), f"{what}: ids differ"
+    assert np.allclose(asc, bsc, rtol=0, atol=1e-6) and np.allclose(ad, bd, rtol=0, atol=1e-6), f"{what}: scores differ"
+
+
+@pytest.fixture(scope="module")
+def corpus(oracle):
+    n, d = 13_000, 384
+    rows = oracle.synth_rows(n, d)
+    # six exact duplicates of one vector spread over the placement blocks (= over the shards): ties by insertion order
+    for r in (10, 4200, 4300, 8500, 9000, 12999):
+        rows[r] = rows[10]
+    return rows, ids_for(n), oracle.synth_queries(n, d, 70)
+
+
+def test_sharded_equals_single_index_and_oracle(hip, oracle, corpus):
+    rows, ids, qs = corpus
+    n, d = rows.shape
+    one, sh = build(hip, rows, ids)
+    assert sh.n_shards == 3 and len(sh) == len(one) == n and sh.row_count() == n
+    assert [sh.shard_len(i) for i in range(3)] == [4096 + 712, 4096, 4096]      # placement blocks of 4096 new ids, round robin
+    o = oracle.OracleIndex(d)
+    o.insert_batch(ids, rows)
+    # single query, k = 10 and the linker's 100; the duplicate vector as a query: six ties in insertion order
+    for k in (1, 10, 100):
+        for q in list(qs[:6]) + [rows[10]]:
+            same_lists(sh.search_arrays(q, k), one.search_arrays(q, k), f"search k={k}")
+    gi, gs, _ = sh.search_arrays(rows[10], 6)
+    assert [int(x) for x in gi[:, 8:].copy().view(">u8").reshape(-1)] == [10, 4200, 4300, 8500, 9000, 12999]
+    e = o.search(qs[0], 10)
+    gi, gs, _ = sh.search_arrays(qs[0], 10)
+    assert_topk_parity(gi[:, 8:].copy().view(">u8").reshape(-1).astype(np.int64), gs, e["row"], e["score"], what="sharded vs oracle")
+    # batches: the MFMA kernel per shard (k = 10, wide lists k = 100), a ragged second pass
+    for k in (10, 100):
+        a = sh.search_batch_arrays(qs, k)
+        b = one.search_batch_arrays(qs, k)
+        assert np.array_equal(a[3], b[3])
+        for j in range(len(qs)):
+            c = int(a[3][j])
+            same_lists((a[0][j, :c], a[1][j, :c], a[2][j, :c]), (b[0][j, :c], b[1][j, :c], b[2][j, :c]), f"batch k={k} q{j}")
+    # k beyond the in-register lists (host merge of the shards' sort paths), and k beyond the corpus
+    same_lists(sh.search_arrays(qs[1], 700), one.search_arrays(qs[1], 700), "k=700")
+    assert len(sh.search_arrays(qs[1], 50_000)[1]) == n
+    # threshold search: variable length, merged on the host
+    for thr in (0.9, 0.6):
+        same_lists(sh.search_threshold_arrays(qs[2], thr), one.search_threshold_arrays(qs[2], thr), f"threshold {thr}")
+    # a query longer than the dimension (the reference zips, index.rs:172): dot over the prefix, |q| over all of it
+    ql = np.concatenate([qs[3], np.float32([0.5, -0.25])])
+    same_lists(sh.search_arrays(ql, 10), one.search_arrays(ql, 10), "long query")
+
+
+def test_sharded_mutations_filters_and_rebuild(hip, oracle, corpus):
+    rows, ids, qs = corpus
+    n, d = rows.shape
+    one, sh = build(hip, rows, ids)
+    new = oracle.synth_queries(n, d, 4)
+    extra_ids = ids_for(n + 300)[n:]
+    extra = oracle.synth_rows(n + 300, d, n, 300)
+    for ix in (one, sh):
+        for i, r in enumerate((3, 4100, 9000, 12000)):               # in-place upserts keep shard and row
+            ix.insert(ids[r].tobytes(), new[i])
+        for r in (7, 4097, 8200, 8201, 12998):
+            ix.remove(ids[r].tobytes())
+        ix.remove(uuid.uuid4().bytes)                                 # unknown id: not an error
+        ix.set_metadata(extra_ids[5].tobytes(), "decision", "kai")    # metadata BEFORE the vector (vector/tests.rs:65-66)
+        ix.insert_batch(extra_ids, extra)
+        for r in range(0, 3000, 2):
+            ix.set_metadata(ids[r].tobytes(), ("fact", "decision", "event")[r % 3], ("kai", "test")[(r // 2) % 2])
+        ix.insert(ids[7].tobytes(), rows[7])                          # a removed id comes back as a NEW row at the end
+    assert len(sh) == len(one) and sh.row_count() == one.row_count()
+    with pytest.raises(hip.ValidationError):
+        sh.insert(uuid.uuid4().bytes, np.zeros(d + 1, np.float32))
+    top = one.search_arrays(qs[0], 5)[0]
+    filters = [None, hip.VectorFilter(kinds=["decision"]), hip.VectorFilter(kinds=["fact", "event"], source_agent="kai"),
+               hip.VectorFilter(exclude=[top[0].tobytes(), top[2].tobytes(), uuid.uuid4().bytes]),
+               hip.VectorFilter(kinds=["never-seen"], source_agent="nobody")]
+    for f in filters:
+        for k in (10, 100):
+            for q in (qs[0], qs[5], extra[5], rows[7]):
+                same_lists(sh.search_arrays(q, k, f), one.search_arrays(q, k, f), f"filter {f} k={k}")
+        a, b = sh.search_batch_arrays(qs[:40], 10, f), one.search_batch_arrays(qs[:40], 10, f)
+        assert np.array_equal(a[3], b[3]) and np.array_equal(a[0], b[0])
+    # global rows are the single index's rows
+    probe = [ids[0].tobytes(), ids[4096].tobytes(), extra_ids[299].tobytes(), ids[7].tobytes(), uuid.uuid4().bytes]
+    assert np.array_equal(sh.rows_of(probe), one.rows_of(probe))
+    for r in (0, 4096, 9999, one.row_count() - 1):
+        assert sh.row_id(r) == one.row_id(r)
+    # rebuild compacts every shard and renumbers the global rows in order — like the single index's compaction
+    one.rebuild(); sh.rebuild()
+    assert sh.row_count() == one.row_count() == len(one)
+    assert np.array_equal(sh.rows_of(probe), one.rows_of(probe))
+    for k in (10, 100):
+        for q in (qs[1], rows[10], extra[5]):
+            same_lists(sh.search_arrays(q, k), one.search_arrays(q, k), f"after rebuild k={k}")
+    sh.insert_batch(ids_for(n + 400)[n + 300:], oracle.synth_rows(n + 400, d, n + 300, 100))
+    one.insert_batch(ids_for(n + 400)[n + 300:], oracle.synth_rows(n + 400, d, n + 300, 100))
+    same_lists(sh.search_arrays(qs[2], 50), one.search_arrays(qs[2], 50), "append after rebuild")
+
+
+def _csr(lists):
+    off = np.zeros(len(lists) + 1, np.uint64)
+    off[1:] = np.cumsum([len(x) for x in lists])
+    return off, np.array([t for x in lists for t in x], dtype=np.uint32)
+
+
+@pytest.mark.parametrize("n,d,shards", [(9000, 768, 3), (6000, 100, 2)])
+def test_sharded_linker_passes_equal_single_index(hip, oracle, n, d, shards):
+    """cx_sharded_autolink_pass_rows / cx_sharded_dedup_scan_rows: scanned vectors scattered to every shard, per-shard
+    neighbour lists merged on the root, the reference's walk (self, deleted, existing edges, caps) in global rows —
+    edge for edge what one index over the same rows returns, hence what the oracle returns."""
+    rows = oracle.synth_rows(n, d)
+    ids = ids_for(n)
+    one = hip.HipIndex(d); one.insert_batch(ids, rows)
+    sh = hip.ShardedHipIndex(d, [0] * shards); sh.insert_batch(ids, rows)
+    for ix in (one, sh):
+        ix.remove(ids[11].tobytes()); ix.remove(ids[4100].tobytes())
+    rng = np.random.default_rng(4)
+    thr = float(np.float32(0.75))
+    deleted = (rng.random(n) < 0.05).astype(np.uint8)
+    # whole store, then an arbitrary-order subset with existing edges and a per-cycle cap
+    a = sh.autolink_pass_rows(None, 100, thr, 50, deleted)
+    b = one.autolink_pass_rows(None, 100, thr, 50, deleted)
+    assert len(b[0]) > 1000
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    scan = rng.permutation(n)[:2500].astype(np.uint32)              # crosses a 2048-node block of the sharded pass
+    first = one.autolink_pass_rows(scan, 100, float(np.float32(0.85)), 10)
+    have = {}
+    for f, t in zip(first[0], first[1]):
+        have.setdefault(int(f), []).append(int(t))
+    lists = [list(rng.permutation(have.get(int(s), []) + [int(x) for x in rng.integers(0, n, 2)])) if rng.random() < 0.3 else [] for s in scan]
+    ex = _csr(lists)
+    for cyc in (None, 2000):
+        a = sh.autolink_pass_rows(scan, 100, thr, 10, deleted, existing=ex, max_edges_per_cycle=cyc)
+        b = one.autolink_pass_rows(scan, 100, thr, 10, deleted, existing=ex, max_edges_per_cycle=cyc)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), f"cycle cap {cyc}"
+    o = oracle.OracleIndex(d); o.insert_batch(ids, rows)
+    o.remove(ids[11].tobytes()); o.remove(ids[4100].tobytes())
+    keep = np.array([s for s in scan[:300] if s not in (11, 4100)], dtype=np.uint32)
+    e = o.autolink_pass(keep, 100, thr, 10, deleted, n_threads=8)
+    g = sh.autolink_pass_rows(keep, 100, thr, 10, deleted)
+    same = sum(1 for x, y in zip(zip(g[0].tolist(), g[1].tolist()), zip(e["from_row"].tolist(), e["to_row"].tolist())) if x == y)
+    assert len(g[0]) == len(e) and same >= 0.97 * len(e)
+    # dedup: pairs reported once, by the node scanned first, in global row order
+    a = sh.dedup_scan_rows(float(np.float32(0.92)), deleted)
+    b = one.dedup_scan_rows(float(np.float32(0.92)), deleted)
+    assert len(b[0]) > 0 and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def test_sharded_concurrent_readers_and_empty_shards(hip, oracle):
+    d = 384
+    sh = hip.ShardedHipIndex(d, [0, 0, 0, 0])
+    assert sh.search_arrays(np.ones(d, np.float32), 5)[1].size == 0     # empty index
+    rows = oracle.synth_rows(5000, d)
+    ids = ids_for(5000)
+    sh.insert_batch(ids[:100], rows[:100])                                # three of the four shards still empty
+    one = hip.HipIndex(d); one.insert_batch(ids[:100], rows[:100])
+    same_lists(sh.search_arrays(rows[3], 10), one.search_arrays(rows[3], 10), "one populated shard")
+    same_lists(sh.search_arrays(rows[3], 150), one.search_arrays(rows[3], 150), "k > rows")
+    sh.insert_batch(ids[100:], rows[100:]); one.insert_batch(ids[100:], rows[100:])
+    qs = oracle.synth_queries(5000, d, 12)
+    want = [one.search_arrays(q, 10) for q in qs]
+    wantb = one.search_batch_arrays(qs, 10)
+    errs = []
+
+    def work(t):
+        try:
+            for rep in range(5):
+                if t % 2:
+                    for i in range(len(qs)):
+                        same_lists(sh.search_arrays(qs[i], 10), want[i], f"thread {t}")
+                else:
+                    a = sh.search_batch_arrays(qs, 10)
+                    assert np.array_equal(a[0], wantb[0]) and np.array_equal(a[3], wantb[3])
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs[0]
+    with pytest.raises(hip.ValidationError):
+        sh.save("/tmp/x")                                                 # no sharded form: fails loudly
