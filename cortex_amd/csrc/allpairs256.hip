@@ -14,12 +14,25 @@
 //    are no ordinary global loads in the loop, so hipcc adds no vmcnt(0) of its own (checked in the ISA).
 //  - RAW: slot t+2 is read (in step t+1) one barrier after the wait that retired it.  WAR: slot (t+3)%4 was
 //    last read in step t-2; those ds_reads retired before the MFMAs of step t-1 that consumed them.
+//  - Round 2: the shadow is read from a copy cut into the DMA's own pieces (launch_tile_shadow: one instruction = one
+//    contiguous, pre-swizzled KiB = 8 whole cache lines, SGPR base + lane * 16 addressing), fragment offsets are two
+//    VGPRs + immediates, and the epilogue collects hits in LDS and pays ONE round trip of slot atomics per wave.
+//    Measured on the way (100k x 768, symmetric; CX_PAIR_SCHED arms): loads only (MFMAs removed) 2.88 ms, MFMAs only
+//    3.87 ms at the sustained clock, the kernel 6.75 ms = their SUM — an in-order wave that is issuing an LDS-DMA
+//    (100-185 cycles each: the CU's one texture-address path moves ~43 B/clk) feeds the matrix pipe nothing, and its SIMD
+//    partner is in the same place.  Tried against that and rejected, all slower than the lockstep interleave: ping-pong
+//    between the SIMD partners with a second barrier per K-step (7.07 ms against 6.45), the same with the load half at
+//    s_setprio 1 (7.18) or no priorities (7.03), DMA issue slots staggered by wave & 3 (7.3) or between partners only
+//    (7.24), a 5-slot ring (6.78).  What is left is bytes per flop: a 256x256 tile moves 32 KiB per K-step through that
+//    path whatever the schedule.
 //  - 16-byte pieces of a 64-byte row are stored at piece ^ (row >> 3 & 3): with rows at a 64-byte stride this
 //    makes every ds_read_b128 lane group (MI355X_MICROARCH.md §LDS) of the 32-row x 2-piece operand pattern hit
 //    16 different 16-byte bank groups (SQ_LDS_BANK_CONFLICT stays 0).
 #include "kernels.hpp"
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <type_traits>
 #include <vector>
 
 namespace cx {
@@ -29,20 +42,24 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace p256 {
-constexpr int BM = 256, BN = 256, BK = 32, NS = 4;
+constexpr int BM = 256, BN = 256, BK = 32;
 constexpr int OP_BYTES = BM * BK * 2;          // 16 KiB per operand per slot
 constexpr int SLOT_BYTES = 2 * OP_BYTES;       // 32 KiB
-constexpr int LDS_BYTES = NS * SLOT_BYTES;     // 128 KiB
+// ring of NS slots: NS - 1 K-steps of DMA in flight (NS = 4: 128 KiB; NS = 5: 160 KiB, the whole LDS of a CU)
 // 16-byte piece p of a 64-byte row sits at slot p ^ (row >> 3 & 3): a ds_read_b128 lane group (16 lanes, 256 B of
 // banks) of the 32-row x 2-piece MFMA operand pattern then covers all sixteen 16-byte bank groups
 __device__ inline uint32_t off(uint32_t row, uint32_t piece) { return row * 64u + ((piece ^ ((row >> 3) & 3u)) << 4); }
 }  // namespace p256
 
-template <bool DIAG, bool IL>
+// TA: the A operand (scanned rows) comes from the tiled shadow too — the symmetric pass and any pass that scans the rows
+// of this shard in order; otherwise (a subset / a permutation of rows, or external vectors) A is gathered row by row from
+// a row-major shadow with per-lane addresses.  The B operand (this shard's rows) is always read from the tiled shadow.
+template <bool DIAG, int SCHED, bool TA, int NS>
 __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArgs a) {
     using namespace p256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const uint32_t wm = wave >> 2, wn = wave & 3u;   // 2 x 4 waves: rows wm*128.., cols wn*64..
 
     const uint32_t tiles_i = (a.n_scan + BM - 1) / BM, tiles_j = (a.n_rows + BN - 1) / BN;
@@ -66,32 +83,56 @@ __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArg
     }
     const uint32_t i0 = ti * BM, j0 = tj * BN;
     unsigned long long c_vm = 0, c_bar = 0;
+    const uint32_t KT = a.dim / BK;
+    constexpr uint32_t PF = NS - 1;                       // K-steps of DMA in flight
+    // the counted wait: all but the (PF - 2) youngest K-steps' DMAs (4 instructions each) of this wave have landed
+    auto wait_ring = [&]() {
+        if constexpr (PF == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    };
+    static_assert(NS == 4 || NS == 5, "ring of 4 or 5 slots");
 
-    // loader: one LDS-DMA = 16 rows x 64 B; 16 per operand per slot, 2 per wave
-    const uint32_t lrow = lane >> 2, lpos = lane & 3u;
-    const uint16_t *srcA[2], *srcB[2];
+    // loader: one LDS-DMA instruction = 16 rows x 64 B = 1 KiB; 16 per operand per slot, 2 per wave (groups 2 wave, + 1).
+    // Tiled source (a.shadow_t): the KiB is ONE contiguous, pre-swizzled piece — 8 whole cache lines per instruction
+    // instead of 16 half lines, no line fetched twice by consecutive K-steps — addressed as a wave-uniform base (SGPRs)
+    // plus lane * 16: no per-lane 64-bit pointers in the loop (the kernel sits at the 256-VGPR cap).
+    const uint32_t last_blk = (a.n_rows - 1u) / 16u;
+    const uint32_t voff = lane * 16u;
+    const char *sB[2], *sA[2];
+    const uint16_t *srcA[2] = {nullptr, nullptr};   // per-lane row pointers, row-major A only
 #pragma unroll
     for (int q = 0; q < 2; q++) {
-        const uint32_t r = (wave * 2u + (uint32_t)q) * 16u + lrow;
-        const uint32_t piece = lpos ^ ((r >> 3) & 3u);
-        uint32_t gi = i0 + r;
-        gi = gi < a.n_scan ? gi : a.n_scan - 1u;
-        const uint32_t ga = a.scan_rows ? a.scan_rows[gi] : gi;
-        uint32_t gb = j0 + r;
-        gb = gb < a.n_rows ? gb : a.n_rows - 1u;
-        srcA[q] = (a.shadow_q ? a.shadow_q : a.shadow) + (size_t)ga * a.dim + piece * 8u;
-        srcB[q] = a.shadow + (size_t)gb * a.dim + piece * 8u;
-    }
-    auto stage = [&](uint32_t slot, uint32_t kt) {
-        char *A = smem + slot * SLOT_BYTES, *B = A + OP_BYTES;
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const uint32_t o = (wave * 2u + (uint32_t)q) * 1024u;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcA[q] + kt * BK),
-                                             (__attribute__((address_space(3))) void *)(A + o), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcB[q] + kt * BK),
-                                             (__attribute__((address_space(3))) void *)(B + o), 16, 0, 0);
+        uint32_t bb = j0 / 16u + wave * 2u + (uint32_t)q;
+        bb = bb < last_blk ? bb : last_blk;
+        sB[q] = reinterpret_cast<const char *>(a.shadow_t) + (size_t)bb * KT * 1024u;
+        if constexpr (TA) {
+            uint32_t ba = i0 / 16u + wave * 2u + (uint32_t)q;
+            ba = ba < last_blk ? ba : last_blk;
+            sA[q] = reinterpret_cast<const char *>(a.shadow_t) + (size_t)ba * KT * 1024u;
+        } else {
+            const uint32_t lrow = lane >> 2, lpos = lane & 3u;
+            const uint32_t r = (wave * 2u + (uint32_t)q) * 16u + lrow;
+            const uint32_t piece = lpos ^ ((r >> 3) & 3u);
+            uint32_t gi = i0 + r;
+            gi = gi < a.n_scan ? gi : a.n_scan - 1u;
+            const uint32_t ga = a.scan_rows ? a.scan_rows[gi] : gi;
+            srcA[q] = (a.shadow_q ? a.shadow_q : a.shadow) + (size_t)ga * a.dim + piece * 8u;
+            sA[q] = nullptr;
         }
+    }
+    auto dma = [&](uint32_t slot, uint32_t kt, int which) {   // which: 0 A q0, 1 B q0, 2 A q1, 3 B q1
+        const int q = which >> 1;
+        char *dst = smem + slot * SLOT_BYTES + ((which & 1) ? OP_BYTES : 0) + (wave * 2u + (uint32_t)q) * 1024u;
+        const void *src;
+        if (which & 1) src = sB[q] + (size_t)kt * 1024u + voff;
+        else if constexpr (TA) src = sA[q] + (size_t)kt * 1024u + voff;
+        else src = srcA[q] + kt * BK;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    };
+    auto stage = [&](uint32_t slot, uint32_t kt) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) dma(slot, kt, w);
     };
 
     // 128x64 per wave = 4 x 2 tiles of v_mfma_f32_32x32x16_bf16 (16 accumulator registers each): half the MFMA
@@ -105,19 +146,14 @@ __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArg
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[m][n][e] = 0.0f;
 
-    const uint32_t KT = a.dim / BK;
     const uint32_t fr = lane & 31u, fq = lane >> 5;
-    // fragment read offsets inside an operand image (loop invariant): [32-row block][k half h]: lane (fr, fq)
-    // reads piece 2 h + fq of row fr
-    uint32_t offA[4][2], offB[2][2];
+    // fragment read offsets: lane (fr, fq) reads piece 2 h + fq of row fr of a 32-row block.  The swizzle depends on
+    // (row >> 3) & 3 only, i.e. on fr — the same for every 32-row block — so two VGPRs serve all of A and B; the block
+    // (m * 2048, n * 2048) is an immediate offset of the ds_read and the slot / wave part is scalar.
+    uint32_t fo[2];
 #pragma unroll
-    for (uint32_t m = 0; m < 4; m++)
-#pragma unroll
-        for (uint32_t h = 0; h < 2; h++) offA[m][h] = off(wm * 128u + m * 32u + fr, 2u * h + fq);
-#pragma unroll
-    for (uint32_t n = 0; n < 2; n++)
-#pragma unroll
-        for (uint32_t h = 0; h < 2; h++) offB[n][h] = OP_BYTES + off(wn * 64u + n * 32u + fr, 2u * h + fq);
+    for (uint32_t h = 0; h < 2; h++) fo[h] = off(fr, 2u * h + fq);
+    const uint32_t baseA = wm * 128u * 64u, baseB = OP_BYTES + wn * 64u * 64u;
 
     // Software pipeline.  Fragment registers are double buffered (statically indexed: the K loop is unrolled
     // by two): in step kt a wave first issues the DMA of step kt+3 and the ds_reads of step kt+1, then the 32
@@ -125,21 +161,24 @@ __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArg
     // in lockstep (one block per CU), so a stream that loads, then computes, then waits leaves the matrix pipe
     // idle while both load; a stream whose loads sit under its own MFMAs keeps it fed.
     bf16x8 fa0[8], fb0[4], fa1[8], fb1[4];
+    auto rdA = [&](uint32_t slot, int m, int h) { return *reinterpret_cast<const bf16x8 *>(smem + (slot * SLOT_BYTES + baseA + fo[h]) + m * 2048); };
+    auto rdB = [&](uint32_t slot, int n, int h) { return *reinterpret_cast<const bf16x8 *>(smem + (slot * SLOT_BYTES + baseB + fo[h]) + n * 2048); };
     auto read_frags = [&](uint32_t kt, bf16x8 *fa, bf16x8 *fb) {
-        const char *S = smem + (kt & 3u) * SLOT_BYTES;
+        const uint32_t slot = kt % NS;
 #pragma unroll
         for (int n = 0; n < 2; n++)
 #pragma unroll
-            for (int h = 0; h < 2; h++) fb[n * 2 + h] = *reinterpret_cast<const bf16x8 *>(S + offB[n][h]);
+            for (int h = 0; h < 2; h++) fb[n * 2 + h] = rdB(slot, n, h);
 #pragma unroll
         for (int m = 0; m < 4; m++)
 #pragma unroll
-            for (int h = 0; h < 2; h++) fa[m * 2 + h] = *reinterpret_cast<const bf16x8 *>(S + offA[m][h]);
+            for (int h = 0; h < 2; h++) fa[m * 2 + h] = rdA(slot, m, h);
     };
     // FULL = steady state (steps kt+1 and kt+3 exist): no branches in the body, so hipcc keeps counted
     // lgkmcnt waits; with the conditions inside it joins control flow and falls back to lgkmcnt(0) right
     // after issuing the prefetch reads.
     auto mfmas = [&](const bf16x8 *fa, const bf16x8 *fb) {
+        if constexpr (SCHED == 3) { asm volatile("" :: "v"(fa[0]), "v"(fa[7]), "v"(fb[0]), "v"(fb[3])); return; }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -157,12 +196,16 @@ __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArg
     // issue time (an LDS-DMA holds the wave's issue for 60-185 cycles) runs under this wave's own MFMAs instead
     // of in front of them.  As [stage][reads][MFMAs] a wave's non-MFMA issue took ~790 cycles per step against
     // the 512 its SIMD partner computes for, and the pipe idled the difference (tuning.md).
-    auto step_full = [&](uint32_t kt, const bf16x8 *fa, const bf16x8 *fb, bf16x8 *na, bf16x8 *nb) {
-        char *SA = smem + ((kt + 3) & 3u) * SLOT_BYTES, *SB = SA + OP_BYTES;   // slot (kt-1)&3: last read in step kt-2
-        const char *S = smem + ((kt + 1) & 3u) * SLOT_BYTES;                    // landed before the barrier of step kt-1
-        const uint32_t ko = (kt + 3) * BK;
-        if constexpr (!IL) {   // A/B arm (CX_PAIR_INTERLEAVE=0): the same work as [stage][reads][MFMAs]
-            stage((kt + 3) & 3u, kt + 3);
+    // P (0..3): the MFMA slots after which this wave issues its four DMAs are P, P + 4, P + 8, P + 12.  With every wave at
+    // P = 0 the eight waves of the block hit the CU's one texture-address path with 8 KiB at the same four moments of
+    // a step and each issue then waits its turn (100-185 cycles of issue time per DMA, during which the in-order wave
+    // feeds the matrix pipe nothing); P = wave & 3 spreads the block's 32 DMAs of a step over all sixteen MFMA slots.
+    auto step_full = [&](uint32_t kt, const bf16x8 *fa, const bf16x8 *fb, bf16x8 *na, bf16x8 *nb, auto pc) {
+        constexpr int P = decltype(pc)::value;
+        const uint32_t dslot = (kt + PF) % NS;   // = slot of step kt-1: last read in step kt-2
+        const uint32_t rslot = (kt + 1) % NS;    // landed before the barrier of step kt-1
+        if constexpr (SCHED == 0 || SCHED == 3 || SCHED == 4) {   // A/B arms (CX_PAIR_SCHED): [stage][reads][MFMAs]; 3 = no MFMAs, 4 = no DMA
+            if constexpr (SCHED != 4) stage(dslot, kt + PF);
             read_frags(kt + 1, na, nb);
             mfmas(fa, fb);
         } else {
@@ -171,35 +214,28 @@ __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArg
         for (int idx = 0; idx < 16; idx++) {
             const int h = idx >> 3, m = (idx >> 1) & 3, n = idx & 1;
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m * 2 + h], fb[n * 2 + h], acc[m][n], 0, 0, 0);
-            if ((idx & 3) == 0) {
-                const int d = idx >> 2, q = d >> 1;
-                const uint32_t o = (wave * 2u + (uint32_t)q) * 1024u;
-                if ((d & 1) == 0)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcA[q] + ko),
-                                                     (__attribute__((address_space(3))) void *)(SA + o), 16, 0, 0);
-                else
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcB[q] + ko),
-                                                     (__attribute__((address_space(3))) void *)(SB + o), 16, 0, 0);
+            if ((idx & 3) == P) {
+                dma(dslot, kt + PF, idx >> 2);
             } else {
-                const int r = idx - (idx >> 2) - 1;   // 0..11: B fragments first, then A
-                if (r < 4) nb[r] = *reinterpret_cast<const bf16x8 *>(S + offB[r >> 1][r & 1]);
-                else na[r - 4] = *reinterpret_cast<const bf16x8 *>(S + offA[(r - 4) >> 1][(r - 4) & 1]);
+                const int r = idx - (idx >> 2) - ((idx & 3) > P ? 1 : 0);   // 0..11: B fragments first, then A
+                if (r < 4) nb[r] = rdB(rslot, r >> 1, r & 1);
+                else na[r - 4] = rdA(rslot, (r - 4) >> 1, (r - 4) & 1);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         }
         unsigned long long w0 = 0, w1 = 0;
         if constexpr (DIAG) { asm volatile("s_nop 0" :: "v"(acc[3][1][15])); w0 = __builtin_readcyclecounter(); }
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // step kt+2 landed (read next step); kt+3 stays in flight
+        wait_ring();  // step kt+2 landed (read next step); the younger ones stay in flight
         if constexpr (DIAG) w1 = __builtin_readcyclecounter();
         __builtin_amdgcn_s_barrier();
         if constexpr (DIAG) { const unsigned long long w2 = __builtin_readcyclecounter(); c_vm += w1 - w0; c_bar += w2 - w1; }
     };
     auto step_tail = [&](uint32_t kt, const bf16x8 *fa, const bf16x8 *fb, bf16x8 *na, bf16x8 *nb) {
-        if (kt + 3 < KT) stage((kt + 3) & 3u, kt + 3);
+        if (kt + PF < KT) stage((kt + PF) % NS, kt + PF);
         if (kt + 1 < KT) read_frags(kt + 1, na, nb);
         mfmas(fa, fb);
-        if (kt + 3 < KT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (kt + PF < KT) wait_ring();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     };
@@ -207,18 +243,18 @@ __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArg
     unsigned long long t0 = 0, t1 = 0, t2 = 0;
     if constexpr (DIAG) t0 = __builtin_readcyclecounter();
     // prologue: steps 0..2 in flight; 0 and 1 must land (0 is read now, 1 during step 0)
-    stage(0, 0);
-    if (KT > 1) stage(1, 1);
-    if (KT > 2) stage(2, 2);
-    if (KT > 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#pragma unroll
+    for (uint32_t st = 0; st < PF; st++)
+        if (st < KT) stage(st, st);
+    if (KT >= PF) wait_ring();
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if constexpr (DIAG) t1 = __builtin_readcyclecounter();
     read_frags(0, fa0, fb0);
     uint32_t kt = 0;
-    for (; kt + 5 <= KT; kt += 2) {          // both steps of the pair have their kt+3 inside the K range
-        step_full(kt, fa0, fb0, fa1, fb1);
-        step_full(kt + 1, fa1, fb1, fa0, fb0);
+    for (; kt + PF + 2 <= KT; kt += 2) {     // both steps of the pair have their kt+3 inside the K range
+        step_full(kt, fa0, fb0, fa1, fb1, std::integral_constant<int, 0>{});
+        step_full(kt + 1, fa1, fb1, fa0, fb0, std::integral_constant<int, 0>{});
     }
     for (; kt < KT; kt += 2) {
         step_tail(kt, fa0, fb0, fa1, fb1);
@@ -228,16 +264,29 @@ __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArg
     if constexpr (DIAG) { asm volatile("s_nop 0" :: "v"(acc[3][1][15])); t2 = __builtin_readcyclecounter(); }
     // epilogue: C[row][col], col = lane & 15 (j), row = 4*(lane >> 4) + e (i)
     const bool mirror = a.symmetric && ti != tj;
-    // One hit position: both directions' slot atomics are issued before either result is waited for (one round
-    // trip to L2 per position instead of two).
-    auto emit = [&](uint32_t i, uint32_t j) {
-        const bool fwd = i < a.n_scan && j < a.n_rows;
-        const bool rev = mirror && fwd;   // symmetric pass: n_scan == n_rows
-        uint32_t s_f = a.cap, s_r = a.cap;
-        if (fwd) s_f = atomicAdd(a.cand_cnt + i, 1u);
-        if (rev) s_r = atomicAdd(a.cand_cnt + j, 1u);
-        if (s_f < a.cap) a.cand[(size_t)i * a.cap + s_f] = j;
-        if (s_r < a.cap) a.cand[(size_t)j * a.cap + s_r] = i;
+    // Hits are first collected — (row, column) pairs appended to a per-wave list in LDS (the ring is free: every wave is
+    // past the last K-step's barrier), positions from a ballot prefix, no atomics — and only then turned into candidate
+    // slots: every lane takes entries of the list, all their slot atomics go out back to back and are waited for ONCE.
+    // Before, each hit position paid its own round trip to L2 (atomicAdd -> slot -> store), 600-3000 cycles apiece and
+    // one after the other: a wave with five hit positions kept its whole block (and the CU) for ~5k cycles.
+    constexpr uint32_t HL_CAP = 256;                                    // pairs per wave; flushed when full
+    uint32_t *hl = reinterpret_cast<uint32_t *>(smem) + wave * (2u * HL_CAP);
+    uint32_t nh = 0;                                                     // wave-uniform
+    auto flush = [&]() {
+        uint32_t slot[HL_CAP / 64], ii[HL_CAP / 64], jj[HL_CAP / 64];
+#pragma unroll
+        for (uint32_t t = 0; t < HL_CAP / 64; t++) {
+            const uint32_t idx = lane + 64u * t;
+            slot[t] = a.cap;
+            if (idx < nh) {
+                ii[t] = hl[2u * idx]; jj[t] = hl[2u * idx + 1u];
+                slot[t] = atomicAdd(a.cand_cnt + ii[t], 1u);
+            }
+        }
+#pragma unroll
+        for (uint32_t t = 0; t < HL_CAP / 64; t++)
+            if (slot[t] < a.cap) a.cand[(size_t)ii[t] * a.cap + slot[t]] = jj[t];
+        nh = 0;
     };
     // Hits are rare (a handful per 128x64 wave tile), so the 128 accumulator values are screened 16 at a time
     // with a running maximum and ONE wave-uniform branch per 16x64 strip; only strips with a hit somewhere in
@@ -265,19 +314,55 @@ __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArg
             const uint32_t j = j0 + wn * 64u + n * 32u + fr;
 #pragma unroll
             for (uint32_t e = 0; e < 16; e++) {
-                const bool hit = acc[m][n][e] >= a.thr_lo;
-                if (__ballot(hit) == 0ull) continue;
-                if (hit) {
-                    const uint32_t i = i0 + wm * 128u + m * 32u + 8u * (e >> 2) + 4u * fq + (e & 3u);
-                    emit(i, j);
+                const uint32_t i = i0 + wm * 128u + m * 32u + 8u * (e >> 2) + 4u * fq + (e & 3u);
+                const bool hit = acc[m][n][e] >= a.thr_lo && i < a.n_scan && j < a.n_rows;
+                const uint64_t bm = __ballot(hit);
+                if (bm == 0ull) continue;
+                const uint32_t per = mirror ? 2u : 1u;   // symmetric pass (n_scan == n_rows): (i, j) also stands for (j, i)
+                const uint32_t cnt = (uint32_t)__popcll(bm) * per;
+                if (nh + cnt <= HL_CAP) {
+                    if (hit) {
+                        const uint32_t pos = nh + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull)) * per;
+                        hl[2u * pos] = i; hl[2u * pos + 1u] = j;
+                        if (mirror) { hl[2u * pos + 2u] = j; hl[2u * pos + 3u] = i; }
+                    }
+                    nh += cnt;
+                } else if (hit) {   // list full (a block of near-duplicates): this position pays its own round trip
+                    const uint32_t s_f = atomicAdd(a.cand_cnt + i, 1u);
+                    uint32_t s_r = a.cap;
+                    if (mirror) s_r = atomicAdd(a.cand_cnt + j, 1u);
+                    if (s_f < a.cap) a.cand[(size_t)i * a.cap + s_f] = j;
+                    if (s_r < a.cap) a.cand[(size_t)j * a.cap + s_r] = i;
                 }
             }
         }
+    if (nh) flush();
     if constexpr (DIAG) {
         const unsigned long long t3 = __builtin_readcyclecounter();
         if (lane == 0) { unsigned long long *o = a.diag + ((size_t)blockIdx.x * 8 + wave) * 4; o[0] = t1 - t0; o[1] = t2 - t1; o[2] = t3 - t2; o[3] = t3 - t0;
             if (blockIdx.x % 9000 == 5017 % 9000 && wave == 5) printf("[pair256] tile %u: main-loop waits vmcnt %llu barrier %llu; epilogue: screen %llu walk %llu\n", blockIdx.x, c_vm, c_bar, t2b - t2, t3 - t2b); }
     }
+}
+
+__global__ __launch_bounds__(256) void tile_shadow_kernel(const uint16_t *shadow, uint16_t *shadow_t, uint32_t row_lo, uint32_t row_hi, uint32_t dim) {
+    const uint32_t ppr = dim / 8u;   // 16-byte pieces per row
+    const uint64_t n = (uint64_t)(row_hi - row_lo) * ppr;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t r = row_lo + (uint32_t)(t / ppr), p = (uint32_t)(t % ppr);
+        const uint4 v = *reinterpret_cast<const uint4 *>(shadow + (size_t)r * dim + p * 8u);
+        const size_t tile = ((size_t)(r / 16u) * (dim / 32u) + p / 4u) * 512u;
+        *reinterpret_cast<uint4 *>(shadow_t + tile + (r % 16u) * 32u + (((p & 3u) ^ ((r >> 3) & 3u)) << 3)) = v;
+    }
+}
+
+int launch_tile_shadow(const uint16_t *shadow, uint16_t *shadow_t, uint32_t row_lo, uint32_t row_hi, uint32_t dim, hipStream_t stream) {
+    if (row_hi <= row_lo) return CX_OK;
+    if (dim % 32u) return set_err(CX_ERR_VALIDATION, "tiled shadow needs dim %% 32 == 0 (got %u)", dim);
+    const uint64_t n = (uint64_t)(row_hi - row_lo) * (dim / 8u);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 255u) / 256u, 16384u);
+    hipLaunchKernelGGL(tile_shadow_kernel, dim3(grid), dim3(256), 0, stream, shadow, shadow_t, row_lo, row_hi, dim);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
 }
 
 void pair_filter256_tile_list(uint32_t n_rows, std::vector<uint32_t> &out) {
@@ -291,29 +376,29 @@ void pair_filter256_tile_list(uint32_t n_rows, std::vector<uint32_t> &out) {
     }
 }
 
-int launch_pair_filter256(const PairFilterArgs &a, hipStream_t stream) {
+template <bool DIAG, int SCHED, bool TA, int NS>
+static int launch256(const PairFilterArgs &a, uint32_t tiles, hipStream_t stream) {
     using namespace p256;
-    if (a.dim % BK != 0 || a.dim == 0) return set_err(CX_ERR_VALIDATION, "pair filter 256 needs dim %% 32 == 0 (got %u)", a.dim);
-    if (!a.n_scan || !a.n_rows) return CX_OK;
-    if (a.symmetric && (!a.tile_list || (a.n_rows + BM - 1) / BM > 0xFFFFu))
-        return set_err(CX_ERR_VALIDATION, "pair filter 256: symmetric pass needs a tile list");
-    const uint64_t tiles = a.symmetric ? a.n_tiles : (uint64_t)((a.n_scan + BM - 1) / BM) * ((a.n_rows + BN - 1) / BN);
-    if (tiles > 0x7FFFFFFFull) return set_err(CX_ERR_VALIDATION, "pair filter 256: too many tiles");
+    constexpr int lds = NS * SLOT_BYTES;
     static std::atomic<uint64_t> attr_devices{0};
-    if (first_use_on_device(attr_devices)) {
-        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_filter256_kernel<false, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_filter256_kernel<true, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_filter256_kernel<false, false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    }
-    static const int il = getenv("CX_PAIR_INTERLEAVE") ? atoi(getenv("CX_PAIR_INTERLEAVE")) : 1;
+    if (first_use_on_device(attr_devices))
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_filter256_kernel<DIAG, SCHED, TA, NS>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL((pair_filter256_kernel<DIAG, SCHED, TA, NS>), dim3(tiles), dim3(512), lds, stream, a);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+
+template <bool TA, int NS>
+static int launch256_sched(const PairFilterArgs &a, uint32_t tiles, hipStream_t stream) {
+    // K-step schedule: 1 = every wave interleaves its DMAs and fragment reads with its own MFMAs (the product);
+    // 0 / 3 / 4 = measurement arms ([DMA][reads][MFMAs]; loads only; MFMAs + reads only)
+    static const int sched = getenv("CX_PAIR_SCHED") ? atoi(getenv("CX_PAIR_SCHED")) : 1;
     if (getenv("CX_PAIR_DIAG")) {   // diagnostic build: per-phase cycles per tile on stderr, results still valid
         PairFilterArgs d = a;
         const size_t n = (size_t)tiles * 8 * 4;
         CX_HIP(hipMalloc((void **)&d.diag, n * 8));
-        hipLaunchKernelGGL((pair_filter256_kernel<true, true>), dim3((uint32_t)tiles), dim3(512), LDS_BYTES, stream, d);
+        if (int rc = launch256<true, 1, TA, NS>(d, tiles, stream)) return rc;
         CX_HIP(hipStreamSynchronize(stream));
         std::vector<unsigned long long> h(n);
         CX_HIP(hipMemcpy(h.data(), d.diag, n * 8, hipMemcpyDeviceToHost));
@@ -325,10 +410,27 @@ int launch_pair_filter256(const PairFilterArgs &a, hipStream_t stream) {
                 (unsigned long long)tiles, s[0] / nw, s[1] / nw, s[2] / nw, s[3] / nw);
         return CX_OK;
     }
-    if (il) hipLaunchKernelGGL((pair_filter256_kernel<false, true>), dim3((uint32_t)tiles), dim3(512), LDS_BYTES, stream, a);
-    else hipLaunchKernelGGL((pair_filter256_kernel<false, false>), dim3((uint32_t)tiles), dim3(512), LDS_BYTES, stream, a);
-    CX_HIP(hipGetLastError());
-    return CX_OK;
+    switch (sched) {
+        case 0: return launch256<false, 0, TA, NS>(a, tiles, stream);
+        case 3: return launch256<false, 3, TA, NS>(a, tiles, stream);
+        case 4: return launch256<false, 4, TA, NS>(a, tiles, stream);
+        default: return launch256<false, 1, TA, NS>(a, tiles, stream);
+    }
+}
+
+int launch_pair_filter256(const PairFilterArgs &a, hipStream_t stream) {
+    using namespace p256;
+    if (a.dim % BK != 0 || a.dim == 0) return set_err(CX_ERR_VALIDATION, "pair filter 256 needs dim %% 32 == 0 (got %u)", a.dim);
+    if (!a.n_scan || !a.n_rows) return CX_OK;
+    if (!a.shadow_t) return set_err(CX_ERR_VALIDATION, "pair filter 256 needs the tiled shadow");
+    if (a.symmetric && (!a.tile_list || (a.n_rows + BM - 1) / BM > 0xFFFFu))
+        return set_err(CX_ERR_VALIDATION, "pair filter 256: symmetric pass needs a tile list");
+    const uint64_t tiles = a.symmetric ? a.n_tiles : (uint64_t)((a.n_scan + BM - 1) / BM) * ((a.n_rows + BN - 1) / BN);
+    if (tiles > 0x7FFFFFFFull) return set_err(CX_ERR_VALIDATION, "pair filter 256: too many tiles");
+    const bool tiled_a = !a.shadow_q && !a.scan_rows;   // the scanned rows are this shard's rows, in order
+    static const int ns = getenv("CX_PAIR_RING") ? atoi(getenv("CX_PAIR_RING")) : 4;   // LDS ring slots: 4 or 5
+    if (ns == 5) return tiled_a ? launch256_sched<true, 5>(a, (uint32_t)tiles, stream) : launch256_sched<false, 5>(a, (uint32_t)tiles, stream);
+    return tiled_a ? launch256_sched<true, 4>(a, (uint32_t)tiles, stream) : launch256_sched<false, 4>(a, (uint32_t)tiles, stream);
 }
 
 }  // namespace cx

@@ -21,22 +21,35 @@ constexpr float FILTER_EPS = 2.0f / 256.0f + 1.0f / 65536.0f + 1.0e-4f;
 int ensure_shadow(const cx_index *ix, hipStream_t s) {
     std::lock_guard<std::mutex> g(ix->shadow_mu);
     const uint64_t n = ix->n_rows;
+    const bool tiled = ix->dim % 32 == 0;
     if (ix->shadow_cap < n) {
         if (ix->d_shadow) CX_HIP(hipFree(ix->d_shadow));
+        if (ix->d_shadow_t) CX_HIP(hipFree(ix->d_shadow_t));
         ix->d_shadow = nullptr;
+        ix->d_shadow_t = nullptr;
         ix->shadow_cap = 0;
         const uint64_t cap = std::max<uint64_t>(n, ix->cap);
         CX_HIP(hipMalloc((void **)&ix->d_shadow, cap * ix->dim * sizeof(uint16_t) + 64));
+        if (tiled) {   // whole 16-row blocks, zero beyond the last row
+            const size_t bytes = (size_t)((cap + 15) / 16) * 16 * ix->dim * sizeof(uint16_t);
+            CX_HIP(hipMalloc((void **)&ix->d_shadow_t, bytes));
+            CX_HIP(hipMemsetAsync(ix->d_shadow_t, 0, bytes, s));
+        }
         ix->shadow_cap = cap;
         ix->shadow_rows = 0;
         ix->shadow_stale.clear();
     }
     for (uint32_t r : ix->shadow_stale)
-        if (r < ix->shadow_rows)
+        if (r < ix->shadow_rows) {
             if (int rc = launch_build_shadow(ix->d_rows, ix->d_shadow, r, r + 1, ix->dim, s)) return rc;
+            if (tiled)
+                if (int rc = launch_tile_shadow(ix->d_shadow, ix->d_shadow_t, r, r + 1, ix->dim, s)) return rc;
+        }
     ix->shadow_stale.clear();
     if (ix->shadow_rows < n) {
         if (int rc = launch_build_shadow(ix->d_rows, ix->d_shadow, (uint32_t)ix->shadow_rows, (uint32_t)n, ix->dim, s)) return rc;
+        if (tiled)
+            if (int rc = launch_tile_shadow(ix->d_shadow, ix->d_shadow_t, (uint32_t)ix->shadow_rows, (uint32_t)n, ix->dim, s)) return rc;
         ix->shadow_rows = n;
     }
     CX_HIP(hipStreamSynchronize(s));
@@ -232,6 +245,7 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
             PairFilterArgs f;
             memset(&f, 0, sizeof f);
             f.shadow = ix->d_shadow;
+            f.shadow_t = ix->d_shadow_t;
             f.scan_rows = d_scan ? d_scan + lo : nullptr;
             f.n_scan = m;
             f.n_rows = n_rows;
@@ -517,6 +531,7 @@ int cx_autolink_lists_dev(const cx_index *ix, uint64_t nq64, const float *d_quer
         PairFilterArgs f;
         memset(&f, 0, sizeof f);
         f.shadow = ix->d_shadow;
+        f.shadow_t = ix->d_shadow_t;
         f.shadow_q = d_qsh;
         f.n_scan = nq;
         f.n_rows = n_rows;

@@ -537,6 +537,7 @@ void cx_destroy(cx_index *ix) {
     (void)hipFree(ix->d_meta);
     (void)hipFree(ix->d_agent);
     (void)hipFree(ix->d_shadow);
+    (void)hipFree(ix->d_shadow_t);
     (void)hipFree(ix->d_norms);
     (void)hipFree(ix->d_split);
     (void)hipFree(ix->d_tile_list);

@@ -106,8 +106,13 @@ int launch_merge_batch(const MergeArgs &m, uint32_t nq, hipStream_t stream);
 int launch_build_shadow(const float *rows, uint16_t *shadow, uint32_t row_lo, uint32_t row_hi, uint32_t dim,
                         hipStream_t stream);
 
+// rows [row_lo, row_hi) of a row-major bf16 shadow -> the piece-tiled copy the 256-tile kernel's LDS-DMA reads:
+// element (r, k) -> tile (r / 16, k / 32) of 512 elements, inside at (r % 16) * 32 + (((k % 32) / 8) ^ ((r >> 3) & 3)) * 8 + k % 8
+int launch_tile_shadow(const uint16_t *shadow, uint16_t *shadow_t, uint32_t row_lo, uint32_t row_hi, uint32_t dim, hipStream_t stream);
+
 struct PairFilterArgs {
     const uint16_t *shadow;     // [n_rows][dim] bf16, L2-normalised rows (the J operand)
+    const uint16_t *shadow_t;   // the J operand again, cut into 1 KiB LDS-DMA pieces (launch_tile_shadow); null = read `shadow`
     const uint16_t *shadow_q;   // I operand if the scanned vectors are not rows of this shard ([n_scan][dim]); null = shadow
     const uint32_t *scan_rows;  // [n_scan] row of each scanned node, or null = identity
     uint32_t n_scan, n_rows, dim;
