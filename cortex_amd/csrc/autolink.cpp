@@ -176,6 +176,11 @@ struct CycleInputs {
     const uint64_t *existing_offsets = nullptr;   // host CSR over the scanned nodes, [n_scan + 1]; null = no edges yet
     const uint32_t *existing_to = nullptr;
     uint64_t max_edges_per_cycle = ~0ull;
+    // cx_topk_lists_rows' use of the pass: stop once the ordered lists stand in the scratch (no rule walk), and send
+    // every scanned row whose thresholded list holds fewer than min_count entries down the exact path as well
+    bool lists_only = false;
+    uint32_t min_count = 0;
+    uint32_t cand_cap = 0;      // candidate slots per scanned row; 0 = cand_cap()
 };
 
 int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, const uint32_t *scan_rows,
@@ -189,7 +194,7 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
     if (topk == 0 || topk > TOPK_MAX) return set_err(CX_ERR_VALIDATION, "autolink: topk must be in 1..%u", TOPK_MAX);
     for (uint32_t i = 0; scan_rows && i < n_scan; i++)
         if (scan_rows[i] >= n_rows) return set_err(CX_ERR_VALIDATION, "autolink: scan row %u out of range", scan_rows[i]);
-    const uint32_t cap = cand_cap();
+    const uint32_t cap = cyc.cand_cap ? cyc.cand_cap : cand_cap();
     const bool mfma_path = ix->dim % 64 == 0 && ix->dim > 0;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (phase_ms) for (auto &e : ev) CX_HIP(hipEventCreate(&e));
@@ -322,6 +327,13 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
         std::vector<uint32_t> of(n_scan);
         CX_HIP(hipMemcpyAsync(of.data(), ps.d_overflow, (size_t)n_scan * 4, hipMemcpyDeviceToHost, s));
         CX_HIP(hipStreamSynchronize(s));
+        if (cyc.min_count) {   // short lists: the threshold hid part of this row's top-k
+            std::vector<uint32_t> cnt(n_scan);
+            CX_HIP(hipMemcpyAsync(cnt.data(), ps.d_list_cnt, (size_t)n_scan * 4, hipMemcpyDeviceToHost, s));
+            CX_HIP(hipStreamSynchronize(s));
+            for (uint32_t i = 0; i < n_scan; i++)
+                if (!of[i] && cnt[i] < cyc.min_count) of[i] = 1u;
+        }
         for (uint32_t i = 0; i < n_scan; i++)
             if (of[i]) redo.push_back(i);
     } else {
@@ -337,6 +349,11 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
                                 ps.d_list_cnt))
             return rc;
 
+    if (cyc.lists_only) {
+        CX_HIP(hipStreamSynchronize(s));
+        *total = redo.size();   // how many lists came from the exact path (diagnostics)
+        return CX_OK;
+    }
     // link rules: count, exclusive scan, emit
     if (int rc = ensure_dev(ps.d_counts, ps.c_counts, (size_t)n_scan)) return rc;
     if (int rc = ensure_dev(ps.d_offsets, ps.c_offsets, (size_t)n_scan)) return rc;
@@ -579,8 +596,105 @@ int cx_autolink_lists_dev(const cx_index *ix, uint64_t nq64, const float *d_quer
     return CX_OK;
 } catch (...) { return cx::on_exception(); }
 
-/* Ordered top-k lists of the scanned rows (see cortex_hip.h): gather the scanned vectors on the device, run the
- * batched search over them block by block, copy the lists out. */
+}  // extern "C"
+
+namespace {
+
+// Ordered top-k lists of MANY scanned rows through the all-pairs machinery instead of the batched search: the bf16
+// filter GEMM + exact rescore produce, per scanned row, every neighbour with score >= tau, best first; a row whose
+// list holds k entries has its exact top k there (every row scoring >= its k-th best scores >= tau, and the filter
+// loses no pair with exact score >= tau); a row with fewer — tau hid part of its top k — or with an overflowed
+// candidate list goes down the exact path (redo_lists).  tau comes from a sample of the scanned rows: the smallest
+// k-th best score among 64 of them, searched exactly, minus a margin.  Exactness never depends on tau; only the share
+// of rows that take the slow path does (1/65 of them in expectation for scores without ties).
+// 100k x 768, k = 100, every row: 0.196 s through the batched search's wide lists -> see profiles/r02/tuning.md.
+// Returns false when this path does not apply (the caller's batched-search loop runs); true with *rc otherwise.
+bool lists_by_filter(const cx_index *ix, Ctx *c, PassScratch &ps, uint32_t n_scan, const uint32_t *scan_rows, uint32_t topk,
+                     uint32_t *out_rows, float *out_scores, uint32_t *out_counts, int *rc) {
+    static const int min_scan = getenv("CX_LISTS_FILTER_MIN") ? atoi(getenv("CX_LISTS_FILTER_MIN")) : 256;
+    const uint32_t n_rows = (uint32_t)ix->n_rows;
+    if ((int64_t)n_scan < min_scan || ix->dim % 64 != 0 || ix->dim == 0 || ix->n_alive < 4ull * topk || topk > TOPK_MAX) return false;
+    hipStream_t s = c->stream;
+    auto fail = [&](int e) { *rc = e; return true; };
+    // 1. tau from a sample
+    const uint32_t S = std::min<uint32_t>(64u, n_scan);
+    std::vector<uint32_t> samp(S);
+    for (uint32_t i = 0; i < S; i++) {
+        const uint64_t pos = (uint64_t)i * n_scan / S;
+        samp[i] = scan_rows ? scan_rows[pos] : (uint32_t)pos;
+    }
+    if (int e = ensure_dev(ps.d_w, ps.c_w, (size_t)S * ix->dim)) return fail(e);
+    if (int e = ensure_dev(ps.d_scan, ps.c_scan, (size_t)std::max(S, n_scan))) return fail(e);
+    if (int e = ensure_dev(ps.d_list_rows, ps.c_list_rows, (size_t)S * topk)) return fail(e);
+    if (int e = ensure_dev(ps.d_list_scores, ps.c_list_scores, (size_t)S * topk)) return fail(e);
+    if (int e = ensure_dev(ps.d_list_dists, ps.c_list_dists, (size_t)S * topk)) return fail(e);
+    if (int e = ensure_dev(ps.d_list_cnt, ps.c_list_cnt, (size_t)S)) return fail(e);
+    if (hipMemcpyAsync(ps.d_scan, samp.data(), (size_t)S * 4, hipMemcpyHostToDevice, s) != hipSuccess) return fail(set_err(CX_ERR_DEVICE, "copy failed"));
+    if (int e = launch_gather_rows(ix->d_rows, ps.d_w, ps.d_scan, S, ix->dim, s)) return fail(e);
+    DevFilter flt;
+    memset(&flt, 0, sizeof flt);
+    flt.meta = ix->d_meta;
+    flt.agent = ix->d_agent;
+    if (int e = search_core(ix, c, ps.d_w, nullptr, S, topk, flt, 0.0f, false, ps.d_list_rows, ps.d_list_scores, ps.d_list_dists,
+                            ps.d_list_cnt, s))
+        return fail(e);
+    std::vector<float> sc((size_t)S * topk);
+    std::vector<uint32_t> cn(S);
+    if (hipMemcpyAsync(sc.data(), ps.d_list_scores, sc.size() * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipMemcpyAsync(cn.data(), ps.d_list_cnt, (size_t)S * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess)
+        return fail(set_err(CX_ERR_DEVICE, "copy failed"));
+    float tau = 2.0f;
+    for (uint32_t i = 0; i < S; i++) {
+        if (ix->h_meta[samp[i]] & META_REMOVED) continue;
+        if (cn[i] < topk) return false;                 // fewer than k comparable rows: nothing for a threshold to do
+        const float kth = sc[(size_t)i * topk + (topk - 1)];
+        if (!(kth == kth)) return false;
+        tau = std::min(tau, kth);
+    }
+    static const float margin = getenv("CX_LISTS_MARGIN") ? (float)atof(getenv("CX_LISTS_MARGIN")) : 0.003f;
+    tau -= margin;
+    // a k-th best score near 0 is a clamped non-positive cosine: no useful bound, and thr - eps <= 0 would make every pair a candidate
+    if (!(tau >= 0.05f) || tau > 1.0f) {
+        if (getenv("CX_LISTS_DIAG")) fprintf(stderr, "[lists] sampled threshold %.4f: no use, batched search instead\n", tau);
+        return false;
+    }
+    // 2. the pass, lists only
+    CycleInputs cyc;
+    cyc.lists_only = true;
+    cyc.min_count = topk;
+    // at a k-th-best threshold (far below a link threshold) the filter's rigorous bf16 slack (0.008) lets several times k
+    // candidates through per row: wider candidate lists than the link passes' 512, unless the environment pins them
+    static const int lcap = getenv("CX_LISTS_CAND_CAP") ? atoi(getenv("CX_LISTS_CAND_CAP")) : 1024;
+    if (!getenv("CX_PAIR_CAND_CAP")) cyc.cand_cap = (uint32_t)std::max(lcap, 16);
+    uint64_t n_exact = 0;
+    if (int e = pass_core(ix, c, ps, n_scan, scan_rows, topk, tau, 0, nullptr, false, cyc, &n_exact, nullptr)) return fail(e);
+    if (getenv("CX_LISTS_DIAG")) fprintf(stderr, "[lists] tau %.4f, %llu of %u lists from the exact path\n", tau, (unsigned long long)n_exact, n_scan);
+    // 3. out
+    if (hipMemcpyAsync(out_rows, ps.d_list_rows, (size_t)n_scan * topk * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipMemcpyAsync(out_scores, ps.d_list_scores, (size_t)n_scan * topk * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipMemcpyAsync(out_counts, ps.d_list_cnt, (size_t)n_scan * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess)
+        return fail(set_err(CX_ERR_DEVICE, "copy failed"));
+    if (int e = check_result_block(out_counts, out_rows, n_scan, topk, topk, n_rows)) {
+        memset(out_counts, 0, (size_t)n_scan * 4);
+        return fail(e);
+    }
+    for (uint32_t i = 0; i < n_scan; i++) {
+        const uint32_t r = scan_rows ? scan_rows[i] : i;
+        if (ix->h_meta[r] & META_REMOVED) out_counts[i] = 0;   // no embedding, no list (auto_linker.rs:217-218)
+    }
+    *rc = CX_OK;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+/* Ordered top-k lists of the scanned rows (see cortex_hip.h): for many scanned rows the all-pairs machinery
+ * (lists_by_filter above); else gather the scanned vectors on the device, run the batched search over them block by
+ * block, copy the lists out. */
 int cx_topk_lists_rows(const cx_index *ix, uint64_t n_scan64, const uint32_t *scan_rows, uint64_t topk64,
                        uint32_t *out_rows, float *out_scores, uint32_t *out_counts) try {
     if (!ix || !out_rows || !out_scores || !out_counts) return set_err(CX_ERR_VALIDATION, "null argument");
@@ -598,6 +712,10 @@ int cx_topk_lists_rows(const cx_index *ix, uint64_t n_scan64, const uint32_t *sc
     hipStream_t s = c->stream;
     PassScratch &ps = scratch_of(c);
     const uint32_t k_eff = std::min<uint32_t>(topk, n_rows);
+    {
+        int rc = CX_OK;
+        if (lists_by_filter(ix, c, ps, (uint32_t)n_scan, scan_rows, topk, out_rows, out_scores, out_counts, &rc)) return rc;
+    }
     const uint32_t BLOCK = 16384;
     const uint32_t blk = (uint32_t)std::min<uint64_t>(BLOCK, n_scan);
     // scratch: gathered vectors (d_w), their row indices (d_scan), lists (d_list_*)

@@ -422,3 +422,53 @@ def test_removed_rows_are_not_scanned(hip, oracle):
     pairs = h.dedup_scan_rows(0.9) if hasattr(h, "dedup_scan_rows") else None
     if pairs is not None:
         assert not (set(np.asarray(pairs[0]).tolist()) | set(np.asarray(pairs[1]).tolist())) & set(gone)
+
+
+@pytest.mark.parametrize("n,d,topk", [(6000, 768, 100), (5000, 384, 100), (3000, 1024, 20)])
+def test_topk_lists_of_many_rows_filter_path(hip, oracle, n, d, topk, monkeypatch):
+    """cx_topk_lists_rows for >= 256 scanned rows runs the all-pairs machinery (bf16 filter GEMM at a sampled threshold
+    + exact rescore; rows whose list comes out short or overflowed take the exact path).  The lists must be the exact
+    ordered top-k all the same: against the single-query scan for a sample of rows, against the oracle for a few, and —
+    with a candidate cap so small that most rows take the exact path — against themselves."""
+    rows = oracle.synth_rows(n, d)
+    h, o, ids = build(hip, oracle, rows)
+    for r in (7, 1500):
+        h.remove(ids[r].tobytes()); o.remove(ids[r].tobytes())
+    rng = np.random.default_rng(9)
+    row_of = lambda gi: gi[:, 8:].copy().view(">u8").reshape(-1).astype(np.int64)
+
+    def check(scan, lr, ls, lc, sample):
+        scan_o = np.arange(n, dtype=np.uint32) if scan is None else scan
+        assert lr.shape == (len(scan_o), topk)
+        for p in sample:
+            node = int(scan_o[p])
+            m = int(lc[p])
+            if node in (7, 1500):
+                assert m == 0                                  # a removed row has no embedding: no list
+                continue
+            assert m == topk
+            gi, gs, _ = h.search_arrays(rows[node], topk)
+            assert_topk_parity(lr[p, :m].astype(np.int64), ls[p, :m], row_of(gi), gs, what=f"lists row {node}")
+            assert np.all(np.diff(ls[p, :m]) <= 0) and len(set(lr[p, :m].tolist())) == m
+            assert not ({7, 1500} & set(lr[p, :m].tolist()))
+        for p in sample[:4]:
+            node = int(scan_o[p])
+            if node in (7, 1500):
+                continue
+            e = o.search(rows[node], topk)
+            assert_topk_parity(lr[p, :topk].astype(np.int64), ls[p, :topk], e["row"], e["score"], what=f"lists row {node} vs oracle")
+
+    lr, ls, lc = h.topk_lists_rows(topk, None)                    # every row: the symmetric pass
+    check(None, lr, ls, lc, [0, 7, 8, 1499, 1500, n - 1] + rng.choice(n, 60, replace=False).tolist())
+    scan = rng.permutation(n)[:700].astype(np.uint32)             # a cycle's batch, arbitrary order
+    scan[3] = 7
+    lr2, ls2, lc2 = h.topk_lists_rows(topk, scan)
+    check(scan, lr2, ls2, lc2, list(range(0, 700, 9)))
+    # the same lists whichever path produced them: subset vs whole store
+    for p in range(0, 700, 13):
+        if int(scan[p]) != 7:
+            assert np.array_equal(lr2[p], lr[int(scan[p])]) and np.array_equal(ls2[p], ls[int(scan[p])])
+    # ... and with a candidate cap of 16 (most rows overflow -> exact path): identical lists
+    monkeypatch.setenv("CX_PAIR_CAND_CAP", "16")
+    lr3, ls3, lc3 = h.topk_lists_rows(topk, scan)
+    assert np.array_equal(lc3, lc2) and np.array_equal(lr3, lr2) and np.array_equal(ls3, ls2)
