@@ -1,0 +1,290 @@
+// batchg.hip — batched exact search for the row widths batch2_kernel (batch.hip) has no instance for.
+//
+// VectorIndex::search_batch (vector/index.rs:390-410) is dimension-agnostic and the reference ships 1024-d embeddings
+// (BGE-large, embedding.rs:43-50: BASELINE config 5's width).  batch2_kernel keeps 64 queries, split into bf16 hi + lo,
+// in the consumer waves' REGISTERS — dim/4 VGPRs per wave: 192 at 768-d, 256 at 1024-d, the whole budget of a wave at two
+// waves per SIMD — so round 1 sent every other width to one scan per query: B times the HBM traffic.  Here the roles of
+// the operands swap: the queries (pre-split once per call into the MFMA B-operand layout, batchg_split_queries_kernel)
+// are staged K-block by K-block through LDS, and the ROWS go straight from HBM into registers, are split there
+// (hi = bf16(a), lo = bf16(a - hi): the same three-product scheme as batch.hip, |cos error| <= 1e-6) and multiplied
+// as the MFMA A operand.  Any dim % 128 == 0 up to 4096; no split store, no shadow: the f32 rows are read once per
+// 64 queries.
+//
+//   block = 4 waves, row tile = 128 rows (wave w: rows 32 w .. 32 w + 31 = two 16-row A fragments m = 0, 1)
+//   K-block = 128 k = 4 MFMA steps of 32; per step and wave: 4 x global_load_dwordx4 (2 per fragment: whole 128-byte
+//     lines per row), 8 v_cvt_pk_bf16 pairs, 4 query groups x 2 fragments x 3 mfma_f32_16x16x32_bf16
+//   queries: K-block kb+1 is fetched into registers while K-block kb is computed, written to the other LDS buffer at
+//     the top of the next iteration; ONE raw barrier per K-block
+//   epilogue: cosine with the scan kernel's arithmetic (cosine_from_sums), dense scores [query][row] to HBM
+//     (256 B per row against the row's dim * 4: + 6 % traffic at 1024-d); launch_dense_topk (scan.hip) then takes
+//     the top k per query with the register lists of the single-query scan and the usual merge.
+// Bound: HBM.  Algorithmic bytes per launch = n_rows * dim * 4.
+#include <algorithm>
+
+#include "kernels.hpp"
+#include "topk.hpp"
+
+namespace cx {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+namespace bg {
+constexpr int TILE_ROWS = 128;      // rows per block tile
+constexpr int KB = 128;             // k per K-block
+constexpr int STEPS = KB / 32;      // MFMA steps per K-block
+constexpr int NQ = 64;              // queries per pass
+constexpr int STEP_BYTES = 2 * NQ * 4 * 16;   // one step's query image: hi [64][4 kq][8 bf16] | lo = 8 KiB
+constexpr int KB_BYTES = STEPS * STEP_BYTES;  // 32 KiB
+constexpr int LDS_BYTES = 2 * KB_BYTES;       // double buffered: 64 KiB -> two blocks per CU
+
+__device__ inline void split4g(const f32x4 v, bf16x4_t &hi, bf16x4_t &lo) {   // as batch.hip's split4
+    const uint32_t p01 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v.x, v.y}, bf16x2_t));
+    const uint32_t p23 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v.z, v.w}, bf16x2_t));
+    const f32x2 b01 = {__uint_as_float(p01 << 16), __uint_as_float(p01 & 0xFFFF0000u)};
+    const f32x2 b23 = {__uint_as_float(p23 << 16), __uint_as_float(p23 & 0xFFFF0000u)};
+    const f32x2 d01 = (f32x2){v.x, v.y} - b01, d23 = (f32x2){v.z, v.w} - b23;
+    const uint32_t q01 = __builtin_bit_cast(uint32_t, __builtin_convertvector(d01, bf16x2_t));
+    const uint32_t q23 = __builtin_bit_cast(uint32_t, __builtin_convertvector(d23, bf16x2_t));
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    hi = __builtin_bit_cast(bf16x4_t, (u32x2){p01, p23});
+    lo = __builtin_bit_cast(bf16x4_t, (u32x2){q01, q23});
+}
+}  // namespace bg
+
+// queries [nq][dim] f32 -> qimg: per MFMA step s (32 k): hi image [64 queries][4 kq][8 bf16] | lo image, 8 KiB a step.
+// Lane kq of the MFMA holds the k values {32 s + 4 kq .. + 3} and {32 s + 16 + 4 kq .. + 3} (the row side loads the
+// same two float4 per lane: 64 contiguous bytes per row per load instruction); queries beyond nq are zero.
+// Also |q|^2 per query.
+__global__ __launch_bounds__(256) void batchg_split_queries_kernel(const float *queries, uint32_t nq, uint32_t dim, char *qimg, float *qq) {
+    const uint32_t n_steps = dim / 32u;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_steps * bg::NQ * 4u; t += gridDim.x * blockDim.x) {
+        const uint32_t s = t / (bg::NQ * 4u), j = (t / 4u) % bg::NQ, kq = t % 4u;
+        f32x4 v0 = {0.0f, 0.0f, 0.0f, 0.0f}, v1 = v0;
+        if (j < nq) {
+            const f32x4 *q4 = reinterpret_cast<const f32x4 *>(queries + (size_t)j * dim + 32u * s);
+            v0 = q4[kq];
+            v1 = q4[4u + kq];
+        }
+        bf16x4_t h0, l0, h1, l1;
+        bg::split4g(v0, h0, l0);
+        bg::split4g(v1, h1, l1);
+        char *base = qimg + (size_t)s * bg::STEP_BYTES + (j * 4u + kq) * 16u;
+        *reinterpret_cast<bf16x8_t *>(base) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+        *reinterpret_cast<bf16x8_t *>(base + bg::STEP_BYTES / 2) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+    // |q|^2: one wave per query (blocks of 4 waves stride over the queries)
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u, n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t j = wave; j < bg::NQ; j += n_waves) {
+        float sacc = 0.0f;
+        if (j < nq)
+            for (uint32_t c = lane; c < dim; c += 64u) { const float x = queries[(size_t)j * dim + c]; sacc = fmaf(x, x, sacc); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 64);
+        if (lane == 0) qq[j] = sacc;
+    }
+}
+
+struct BatchGArgs {
+    const float *rows;     // [n_rows][dim]
+    const float *norms;    // |row|^2 (cx_index::d_norms)
+    const char *qimg;      // split query images, dim / 32 steps of 8 KiB
+    const float *qq;       // [64] |q|^2
+    float *dense;          // [64][stride] cosines out
+    uint32_t n_rows, dim, nq, stride;
+};
+
+template <int PROBE>   // 0 = the product; 1 = loads only (no split, no MFMA); 2 = no row loads (MFMAs on stale registers)
+__global__ __launch_bounds__(256, 2) void batchg_kernel(const BatchGArgs a) {
+    using namespace bg;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t j = lane & 15u, kq = lane >> 4;
+    const uint32_t n_tiles = (a.n_rows + TILE_ROWS - 1) / TILE_ROWS;
+    const uint32_t n_kb = a.dim / KB;
+    if (blockIdx.x >= n_tiles) return;
+    const uint32_t my_tiles = (n_tiles - 1u - blockIdx.x) / gridDim.x + 1u;
+    const uint32_t total_kb = my_tiles * n_kb;   // K-blocks this block walks: the query images cycle once per tile
+
+    auto tile_barrier = [&]() {   // raw barrier: __syncthreads() would drain the rows in flight (vmcnt(0))
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    // query staging: a K-block image is 32 KiB = 8 x 16 B per thread
+    f32x4 qr[8];
+    auto q_fetch = [&](uint32_t kb) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(a.qimg + (size_t)(kb % n_kb) * KB_BYTES) + tid;
+#pragma unroll
+        for (int e = 0; e < 8; e++) qr[e] = src[e * 256];
+    };
+    auto q_store = [&](uint32_t buf) {
+        f32x4 *dst = reinterpret_cast<f32x4 *>(smem + buf * KB_BYTES) + tid;
+#pragma unroll
+        for (int e = 0; e < 8; e++) dst[e * 256] = qr[e];
+    };
+
+    // row side: lane (j, kq) of fragment m loads row 32 wave + 16 m + j, two float4 per step
+    f32x4 acc[2][4];
+    const f32x4 *rp[2], *rpn[2];
+    auto tile_ptrs = [&](uint32_t tile, const f32x4 *(&p)[2]) {
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            uint32_t r = tile * TILE_ROWS + wave * 32u + (uint32_t)m * 16u + j;
+            r = r < a.n_rows ? r : a.n_rows - 1u;   // tail: re-read the last row, never stored
+            p[m] = reinterpret_cast<const f32x4 *>(a.rows + (size_t)r * a.dim) + kq;
+        }
+    };
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) acc[m][g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    };
+    // two register sets of HALF a K-block each (2 steps x 2 fragments x 2 float4 = 32 VGPRs): while one half is
+    // multiplied the other is in flight, and each set is re-requested for the next K-block the moment it has been used
+    constexpr int HS = STEPS / 2;
+    f32x4 ra[HS][2][2], rb[HS][2][2];
+    auto r_fetch = [&](f32x4 (&dst)[HS][2][2], const f32x4 *const (&p)[2], uint32_t step0) {   // step0: first MFMA step inside the row
+#pragma unroll
+        for (int s = 0; s < HS; s++)
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                const f32x4 *q = p[m] + (size_t)(step0 + (uint32_t)s) * 8u;
+                if constexpr (PROBE == 2) { asm volatile("" : "+v"(dst[s][m][0]), "+v"(dst[s][m][1])); continue; }
+                dst[s][m][0] = __builtin_nontemporal_load(q);
+                dst[s][m][1] = __builtin_nontemporal_load(q + 4);
+            }
+    };
+    auto compute = [&](const f32x4 (&src)[HS][2][2], uint32_t buf, uint32_t half) {
+        const char *Q = smem + buf * KB_BYTES + half * (HS * STEP_BYTES) + (j * 4u + kq) * 16u;
+        if constexpr (PROBE == 1) {
+#pragma unroll
+            for (int s = 0; s < HS; s++)
+#pragma unroll
+                for (int m = 0; m < 2; m++) acc[m][0] += src[s][m][0] + src[s][m][1];
+            return;
+        }
+#pragma unroll
+        for (int s = 0; s < HS; s++) {
+            s16x8 ah[2], al[2];
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                bf16x4_t h0, l0, h1, l1;
+                split4g(src[s][m][0], h0, l0);
+                split4g(src[s][m][1], h1, l1);
+                ah[m] = __builtin_bit_cast(s16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+                al[m] = __builtin_bit_cast(s16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const s16x8 qh = *reinterpret_cast<const s16x8 *>(Q + s * STEP_BYTES + g * 1024);
+                const s16x8 ql = *reinterpret_cast<const s16x8 *>(Q + s * STEP_BYTES + STEP_BYTES / 2 + g * 1024);
+#pragma unroll
+                for (int m = 0; m < 2; m++) {
+                    acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], qh, acc[m][g], 0, 0, 0);   // small terms first
+                    acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], ql, acc[m][g], 0, 0, 0);
+                    acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], qh, acc[m][g], 0, 0, 0);
+                }
+            }
+        }
+    };
+    // C layout: lane (j, kq) holds rows 4 kq + e (e = 0..3) of query j of group g: four consecutive rows -> one float4
+    auto epilogue = [&](uint32_t tile) {
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            const uint32_t r0 = tile * TILE_ROWS + wave * 32u + (uint32_t)m * 16u + 4u * kq;
+            if (r0 >= a.n_rows) continue;
+            f32x4 rr = {1.0f, 1.0f, 1.0f, 1.0f};
+            if (r0 + 3u < a.n_rows) rr = *reinterpret_cast<const f32x4 *>(a.norms + r0);
+            else { for (uint32_t e = 0; e < 4u; e++) if (r0 + e < a.n_rows) rr[e] = a.norms[r0 + e]; }
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const uint32_t q = (uint32_t)g * 16u + j;
+                if (q >= a.nq) continue;
+                const float qq = a.qq[q];
+                f32x4 c;
+#pragma unroll
+                for (int e = 0; e < 4; e++) c[e] = cosine_from_sums(acc[m][g][e], qq, rr[e]);
+                float *dst = a.dense + (size_t)q * a.stride + r0;
+                if (r0 + 3u < a.n_rows) *reinterpret_cast<f32x4 *>(dst) = c;
+                else { for (uint32_t e = 0; e < 4u; e++) if (r0 + e < a.n_rows) dst[e] = c[e]; }
+            }
+        }
+    };
+
+    // Pipeline over the block's K-blocks, tile by tile.  K-block `it` reads its query image from LDS buffer it & 1;
+    // the image of it + 1 (fetched during it - 1) is written to the other buffer at the top of the iteration and the
+    // image of it + 2 requested.  Rows: half a K-block per register set, each set re-requested (for the next K-block,
+    // which may open the next tile) right after it has been multiplied.  One barrier per K-block.
+    uint32_t tile = blockIdx.x, it = 0;
+    tile_ptrs(tile, rp);
+    rpn[0] = rp[0]; rpn[1] = rp[1];
+    zero_acc();
+    q_fetch(0);
+    q_store(0);
+    if (total_kb > 1u) q_fetch(1);
+    r_fetch(ra, rp, 0);
+    r_fetch(rb, rp, HS);
+    tile_barrier();
+    for (uint32_t t = 0; t < my_tiles; t++) {
+        const bool more_tiles = t + 1u < my_tiles;
+        if (more_tiles) tile_ptrs(tile + gridDim.x, rpn);
+        for (uint32_t kbl = 0; kbl < n_kb; kbl++, it++) {
+            const uint32_t buf = it & 1u;
+            const bool last = kbl + 1u == n_kb;
+            if (it + 1u < total_kb) q_store(buf ^ 1u);
+            if (it + 2u < total_kb) q_fetch(it + 2u);
+            compute(ra, buf, 0);
+            if (!last) r_fetch(ra, rp, (kbl + 1u) * STEPS);
+            else if (more_tiles) r_fetch(ra, rpn, 0);
+            compute(rb, buf, 1);
+            if (!last) r_fetch(rb, rp, (kbl + 1u) * STEPS + HS);
+            else if (more_tiles) r_fetch(rb, rpn, HS);
+            if (last) {
+                epilogue(tile);
+                tile += gridDim.x;
+                rp[0] = rpn[0]; rp[1] = rpn[1];
+                zero_acc();
+            }
+            tile_barrier();
+        }
+    }
+}
+
+bool batchg_supported(uint32_t dim, uint32_t k) { return dim % bg::KB == 0 && dim <= 4096 && k >= 1 && k <= TOPK_MAX; }
+size_t batchg_qimg_bytes(uint32_t dim) { return (size_t)(dim / 32u) * bg::STEP_BYTES; }
+
+// nq <= 64 queries against all rows: dense cosines [64][stride] (stride = n_rows rounded up to 4)
+int launch_batchg_scores(const float *rows, const float *norms, uint32_t n_rows, uint32_t dim, const float *d_queries, uint32_t nq,
+                         char *d_qimg, float *d_qq, float *d_dense, uint32_t stride, hipStream_t stream) {
+    using namespace bg;
+    if (!batchg_supported(dim, 1) || nq == 0 || nq > NQ) return set_err(CX_ERR_VALIDATION, "batchg: dim %u / %u queries not supported", dim, nq);
+    if (!n_rows) return CX_OK;
+    hipLaunchKernelGGL(batchg_split_queries_kernel, dim3(16), dim3(256), 0, stream, d_queries, nq, dim, d_qimg, d_qq);
+    static std::atomic<uint64_t> attr_devices{0};
+    if (first_use_on_device(attr_devices)) {
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchg_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchg_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchg_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    }
+    BatchGArgs a;
+    a.rows = rows; a.norms = norms; a.qimg = d_qimg; a.qq = d_qq; a.dense = d_dense;
+    a.n_rows = n_rows; a.dim = dim; a.nq = nq; a.stride = stride;
+    const uint32_t n_tiles = (n_rows + TILE_ROWS - 1) / TILE_ROWS;
+    const uint32_t grid = std::min<uint32_t>(n_tiles, 2u * device_cus());
+    static const int probe = getenv("CX_BATCHG_PROBE") ? atoi(getenv("CX_BATCHG_PROBE")) : 0;   // measurement arms, results invalid
+    if (probe == 1) hipLaunchKernelGGL(batchg_kernel<1>, dim3(grid), dim3(256), LDS_BYTES, stream, a);
+    else if (probe == 2) hipLaunchKernelGGL(batchg_kernel<2>, dim3(grid), dim3(256), LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL(batchg_kernel<0>, dim3(grid), dim3(256), LDS_BYTES, stream, a);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+
+}  // namespace cx

@@ -379,6 +379,45 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
         }
         return CX_OK;
     }
+    // the other row widths (1024-d: BGE-large): batchg.hip — dense cosines of <= 64 queries per pass over the f32 rows,
+    // then the top k of each
+    static const int bg_ok = getenv("CX_BATCHG") ? atoi(getenv("CX_BATCHG")) : 1;
+    if (bg_ok && topk_path && no_tails && nq >= (uint64_t)batch_min && k_eff >= 1 && batchg_supported(ix->dim, k_eff)) {
+        if (int rc = ensure_norms(ix, s)) return rc;
+        const uint32_t stride = (n + 3u) & ~3u, chunks = dense_topk_chunks(n);
+        const size_t qimg = batchg_qimg_bytes(ix->dim);
+        if (int rc = ensure_dev(c->d_dense, c->dn_cap, (size_t)64 * stride)) return rc;
+        if (int rc = ensure_dev(c->d_qimg, c->qi_cap, qimg + 64 * sizeof(float))) return rc;
+        if (int rc = ensure_dev(c->d_part_keys, c->pk_cap, (size_t)64 * chunks * k_eff)) return rc;
+        if (int rc = ensure_dev(c->d_part_sims, c->ps_cap, (size_t)64 * chunks * k_eff)) return rc;
+        for (uint64_t q0 = 0; q0 < nq; q0 += 64) {
+            const uint32_t m = (uint32_t)std::min<uint64_t>(64, nq - q0);
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (ix->profiling) {
+                CX_HIP(hipEventCreate(&e0));
+                CX_HIP(hipEventCreate(&e1));
+                std::lock_guard<std::mutex> g(ix->mu);
+                ix->prof_events.emplace_back(e0, e1);
+                CX_HIP(hipEventRecord(e0, s));
+            }
+            if (int rc = launch_batchg_scores(ix->d_rows, ix->d_norms, n, ix->dim, d_queries + q0 * ix->dim, m, c->d_qimg,
+                                              reinterpret_cast<float *>(c->d_qimg + qimg), c->d_dense, stride, s))
+                return rc;
+            if (e1) CX_HIP(hipEventRecord(e1, s));
+            if (int rc = launch_dense_topk(c->d_dense, stride, n, m, k_eff, flt, c->d_part_keys, c->d_part_sims, chunks, s)) return rc;
+            MergeArgs mg;
+            mg.part_keys = c->d_part_keys;
+            mg.part_sims = c->d_part_sims;
+            mg.n_lists = chunks;
+            mg.k = k_eff;
+            mg.out_rows = d_rows + q0 * k_eff;
+            mg.out_scores = d_scores + q0 * k_eff;
+            mg.out_dists = d_dists + q0 * k_eff;
+            mg.out_count = d_counts + q0;
+            if (int rc = launch_merge_batch(mg, m, s)) return rc;
+        }
+        return CX_OK;
+    }
     for (uint64_t i = 0; i < nq; i++) {
         ScanArgs a;
         memset(&a, 0, sizeof a);

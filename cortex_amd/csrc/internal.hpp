@@ -64,6 +64,8 @@ struct Ctx {
     uint64_t *d_part_keys = nullptr; size_t pk_cap = 0;
     float *d_part_sims = nullptr; size_t ps_cap = 0;
     uint32_t *d_gslots = nullptr; size_t gs_cap = 0;   // batched search: cross-block bound slots [64][32]
+    float *d_dense = nullptr; size_t dn_cap = 0;       // batchg: dense cosines [64][rows]
+    char *d_qimg = nullptr; size_t qi_cap = 0;         // batchg: split query images (+ 64 floats of |q|^2 behind them)
     uint32_t *d_out_rows = nullptr; size_t or_cap = 0;
     float *d_out_scores = nullptr; size_t os_cap = 0;
     float *d_out_dists = nullptr; size_t od_cap = 0;
@@ -85,6 +87,7 @@ struct Ctx {
 
     ~Ctx() {
         if (pass_scratch && pass_scratch_free) pass_scratch_free(pass_scratch);
+        (void)hipFree(d_dense); (void)hipFree(d_qimg);
         (void)hipFree(d_query); (void)hipFree(d_gslots); (void)hipFree(d_part_keys); (void)hipFree(d_part_sims); (void)hipFree(d_out_rows);
         (void)hipFree(d_out_scores); (void)hipFree(d_out_dists); (void)hipFree(d_out_counts); (void)hipFree(d_excl);
         (void)hipFree(d_kinds); (void)hipFree(d_keys); (void)hipFree(d_keys2); (void)hipFree(d_sims); (void)hipFree(d_sims2);

@@ -102,6 +102,15 @@ int launch_batch_scan(BatchArgs a, uint32_t grid, hipStream_t stream);
 // second stage for nq queries at once: query q's lists are part[q*n_lists*k ...], outputs at [q*k]
 int launch_merge_batch(const MergeArgs &m, uint32_t nq, hipStream_t stream);
 
+// ---- batched search for the other row widths (batchg.hip): dense cosines for <= 64 queries, then top-k ----
+bool batchg_supported(uint32_t dim, uint32_t k);       // dim % 128 == 0, dim <= 4096, k <= 256
+size_t batchg_qimg_bytes(uint32_t dim);                 // scratch for the split query images
+int launch_batchg_scores(const float *rows, const float *norms, uint32_t n_rows, uint32_t dim, const float *d_queries, uint32_t nq,
+                         char *d_qimg, float *d_qq, float *d_dense, uint32_t stride, hipStream_t stream);
+uint32_t dense_topk_chunks(uint32_t n_rows);
+int launch_dense_topk(const float *d_dense, uint32_t stride, uint32_t n_rows, uint32_t nq, uint32_t k, const DevFilter &flt,
+                      uint64_t *part_keys, float *part_sims, uint32_t chunks, hipStream_t stream);
+
 // ---- all-pairs auto-link pass (allpairs.hip) ----
 int launch_build_shadow(const float *rows, uint16_t *shadow, uint32_t row_lo, uint32_t row_hi, uint32_t dim,
                         hipStream_t stream);

@@ -458,6 +458,49 @@ int launch_merge_batch(const MergeArgs &m, uint32_t nq, hipStream_t stream) {
     return CX_OK;
 }
 
+// Top-k of nq dense cosine rows (batchg.hip's output, [nq][stride]): the second half of the single-query scan — keys
+// from (score, row), the row filter for the rows that beat the running bound, the wave's register list, the block's
+// partial list — on 4 B per row and query instead of the row itself.  grid = (chunks, nq).
+template <int KS>
+__global__ __launch_bounds__(256) void dense_topk_kernel(const float *dense, uint32_t stride, uint32_t n_rows, uint32_t k, const DevFilter flt,
+                                                         uint64_t *part_keys, float *part_sims) {
+    const uint32_t q = blockIdx.y, lane = (uint32_t)lane_id(), wave = threadIdx.x >> 6;
+    const float *d = dense + (size_t)q * stride;
+    WaveTopK<KS> top;
+    top.init(k);
+    const uint32_t per = (n_rows + gridDim.x - 1) / gridDim.x;
+    const uint32_t lo = blockIdx.x * per, hi = lo + per < n_rows ? lo + per : n_rows;
+    for (uint32_t r0 = lo + wave * 64u; r0 < hi; r0 += 256u) {
+        const uint32_t row = r0 + lane;
+        uint64_t key = 0ull;
+        float sim = 0.0f;
+        if (row < hi) {
+            sim = d[row];
+            key = make_key(score_of(distance_of(sim)), row);
+        }
+        top.offer_lanes(key, sim, [&flt](uint32_t rw) { return row_passes(flt, rw); });
+    }
+    const size_t base = (size_t)q * gridDim.x * k;
+    block_merge_store<KS>(top, k, part_keys + base, part_sims + base);
+}
+
+uint32_t dense_topk_chunks(uint32_t n_rows) {
+    const uint32_t c = (n_rows + 16383u) / 16384u;   // >= 16k rows per block: the running bound means something
+    return c < 1u ? 1u : (c > 256u ? 256u : c);
+}
+
+int launch_dense_topk(const float *d_dense, uint32_t stride, uint32_t n_rows, uint32_t nq, uint32_t k, const DevFilter &flt,
+                      uint64_t *part_keys, float *part_sims, uint32_t chunks, hipStream_t stream) {
+    if (!nq || !n_rows || !k) return CX_OK;
+    if (k > TOPK_MAX) return set_err(CX_ERR_VALIDATION, "dense top-k: k=%u exceeds %u", k, TOPK_MAX);
+    const dim3 grid(chunks, nq);
+    if (k <= 64) hipLaunchKernelGGL((dense_topk_kernel<1>), grid, dim3(256), 0, stream, d_dense, stride, n_rows, k, flt, part_keys, part_sims);
+    else if (k <= 128) hipLaunchKernelGGL((dense_topk_kernel<2>), grid, dim3(256), 0, stream, d_dense, stride, n_rows, k, flt, part_keys, part_sims);
+    else hipLaunchKernelGGL((dense_topk_kernel<4>), grid, dim3(256), 0, stream, d_dense, stride, n_rows, k, flt, part_keys, part_sims);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+
 int launch_scan_dense(const ScanArgs &a, bool nontemporal, hipStream_t stream) {
     const uint32_t grid = scan_grid_blocks(a.n_rows, a.dim);
     dispatch_scan<1>(a, grid, 1, nontemporal, stream);

@@ -309,6 +309,13 @@ def test_concurrent_filtered_readers(hip, oracle):
     (40, 384, 40, 70),       # wide lists for all 64 queries over fewer rows than one block's first tiles (k == n)
     (300, 768, 100, 64),     # the same at 768-d (single tile buffer), one full group
     (17, 768, 17, 33),       # a corpus of one ragged tile
+    (5000, 1024, 10, 64),    # 1024-d (BGE-large, config 5's width): batchg.hip — queries through LDS, rows split in registers
+    (3001, 1024, 100, 70),   # two passes (64 + 6), ragged last row tile, the linker's k
+    (777, 512, 32, 7),
+    (1300, 1536, 10, 3),     # three queries: the smallest batch that takes the batched path
+    (130, 128, 5, 40),       # one K-block per row; a little more than one row tile
+    (2000, 256, 256, 5),     # the largest in-register k
+    (40, 1024, 40, 70),      # k == n: fewer rows than one tile
 ])
 def test_search_batch_matches_oracle(hip, oracle, n, d, k, nq):
     rows = oracle.synth_rows(n, d)
