@@ -245,6 +245,9 @@ def main() -> None:
                 r["frac_of_measured"] = r["achieved"] / mp
     if rank == 0 and world == 1 and not args.no_autolink and not args.no_cpu_baseline and B == 1:
         out["extra"]["config5_shard_6.25Mx1024_streaming_ingest"] = config5_leg(L, local_rank, dev)
+        # config 5's row width through search_batch: the batched kernel for the widths batch2 has no instance for
+        out["extra"]["config5_width_1Mx1024_batch64_k10"] = config4_leg(L, local_rank, dev, n=1_000_000, d=1024, steps=20,
+                                                                        kernel="cx::batchg_kernel", shard_note="1M-row slice at config 5's width")
     if rank == 0:
         print(json.dumps(out), flush=True)
     ix.close()
@@ -304,6 +307,23 @@ def cpu_baseline(ix, gen: torch.Tensor, queries: torch.Tensor, n: int, d: int, k
             bt += 1
             if int(r) in want or abs(float(sc) - kth) <= 5e-5:
                 bh += 1
+    # the reference's approximate path (index.rs:342-371 over instant-distance 0.6.1) at the headline's width, on a bounded
+    # slice: the restatement builds single-threaded, ~30 s for 20k x 768 (the full 1M would take half an hour); its
+    # queries/s and recall are measured against the exact oracle on the same slice
+    hn = 20_000
+    rows_s = gen[:hn].cpu().numpy()
+    t5 = time.perf_counter()
+    hidx = O.HnswBaseline(rows_s)
+    t_build = time.perf_counter() - t5
+    os_ = O.OracleIndex(d)
+    os_.insert_batch(synth_ids(0, hn), rows_s)
+    nqh = 100
+    t6 = time.perf_counter()
+    ann = [hidx.search(qs_h[i], k, 100) for i in range(nqh)]
+    t_ann = time.perf_counter() - t6
+    ex_s = os_.search_batch(qs_h[:nqh], k, n_threads=cores)
+    rec_h = sum(len(set(ann[i][0].tolist()) & set(ex_s[i]["row"].tolist())) for i in range(nqh)) / float(nqh * k)
+    del hidx, os_, rows_s
     base = {
         "value": done / t1, "unit": "queries/s", "cores": 1, "kind": "port",
         "sample": f"{done} queries, full {n} x {d} corpus, oracle brute force (-O2, no FMA, sequential f32), 1 thread",
@@ -314,6 +334,11 @@ def cpu_baseline(ix, gen: torch.Tensor, queries: torch.Tensor, n: int, d: int, k
         "host_api_pcie_inclusive_qps": host_api_qps,
         "cpu_all_cores": {"value": nb / t3, "unit": "queries/s", "cores": cores,
                           "sample": f"{nb} queries in one search_batch, {cores} threads"},
+        "cpu_hnsw_restatement": {"value": nqh / t_ann, "unit": "queries/s", "cores": 1, "recall_at_k_vs_exact": rec_h,
+                                 "build_s": t_build, "sample": f"first {hn} rows of the corpus x {d}, {nqh} queries, k={k}",
+                                 "params": "M=32 M0=64 ef_construction=100 ef_search=100",
+                                 "note": "restatement of instant-distance 0.6.1 from the HNSW paper; parity unpinned; a bounded slice: "
+                                         "the single-threaded build is ~1.5 ms per row at 768-d"},
     }
     return base, extra
 
@@ -364,7 +389,8 @@ def config1_leg(L, device: int, n: int = 10_000, d: int = 384, k: int = 5, nq: i
                                      "note": "restatement of instant-distance 0.6.1 from the HNSW paper; parity unpinned"}}
 
 
-def config4_leg(L, device: int, dev, n: int = 1_250_000, d: int = 768, k: int = 10, B: int = 64, steps: int = 40):
+def config4_leg(L, device: int, dev, n: int = 1_250_000, d: int = 768, k: int = 10, B: int = 64, steps: int = 40,
+                kernel: str = "cx::batch2_kernel", shard_note: str = "one of 8 shards of 10M rows"):
     """BASELINE configs[3], one GPU's share: 64 queries per step over a 1.25M x 768 f32 shard (10M rows / 8 GPUs),
     k=10 — the batched MFMA kernel the sharded search runs before its all-gather; same measurement as the headline
     (cx_search_batch_dev, HIP events around the kernel)."""
@@ -401,10 +427,10 @@ def config4_leg(L, device: int, dev, n: int = 1_250_000, d: int = 768, k: int = 
     ix.close()
     avg = kern_ms / max(1, kern_n)
     algo = float(n) * d * 4.0
-    return {"workload": f"cosine kNN k={k}, batch of {B} queries per step, {n} x {d} f32 rows (one of 8 shards of 10M rows)",
+    return {"workload": f"cosine kNN k={k}, batch of {B} queries per step, {n} x {d} f32 rows ({shard_note})",
             "queries_per_s": steps * B / el, "ms_per_step": el / steps * 1e3,
             "roofline": {"bound": "hbm", "achieved": algo / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": algo / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": "cx::batch2_kernel", "avg_kernel_ms": avg,
+                         "frac": algo / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": kernel, "avg_kernel_ms": avg,
                          "launches": kern_n, "algorithmic_bytes_per_launch": algo}}
 
 
@@ -653,7 +679,9 @@ def autolink_leg(L, device: int, d: int, skip_cpu: bool, n: int = 100_000, thr: 
     lr, ls, lc = ix.topk_lists_rows(100, None)
     t_lists = time.perf_counter() - t0
     res["top100_lists_all_rows"] = {"seconds": t_lists, "lists_per_s": n / t_lists, "full_lists": int((lc == 100).sum()),
-                                    "kernel": "cx::batch2_kernel (wide lists, 64 queries per pass)"}
+                                    "kernel": "cx::pair_filter256_kernel at a sampled k-th-best threshold + exact rescore; short / "
+                                              "overflowed lists redone by cx::batch2_kernel (wide lists) — autolink.cpp: lists_by_filter",
+                                    "round1_seconds_same_call": 0.196}
     del lr, ls, lc
     if not skip_cpu:
         from oracle import oracle as O

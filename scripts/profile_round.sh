@@ -9,7 +9,12 @@ O=$R/gpurun_out/prof_round
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 step() { echo "== $1"; }
-step bench; timeout -k 10 500 python3 $R/bench.py > $O/bench.json 2> $O/bench.err || { tail -5 $O/bench.err; exit 1; }
+step bench; timeout -k 10 700 python3 $R/bench.py > $O/bench.json 2> $O/bench.err || { tail -5 $O/bench.err; exit 1; }
+# the driver's own command line (round 1: 0.77 on the post-idle clock transient; the pre-roll carries the device past it)
+step bench-driver-cmdline; timeout -k 10 300 python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-autolink --no-config4 > $O/bench_steps20_warmup5.json 2> $O/bench_steps20.err || { tail -5 $O/bench_steps20.err; exit 1; }
+step cold-probe; timeout -k 10 200 python3 $R/scripts/cold_probe.py > $O/cold_probe.log 2>&1 && cp $R/gpurun_out/cold_probe.json $O/cold_start_probe.json
+step lists; timeout -k 10 200 python3 $R/scripts/bench_lists.py 100000 768 > $O/top100_lists_100kx768.log 2>&1
+step batch1024-trace; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/b1024_trace -- python3 $R/scripts/bench_batch_dim.py --rows 1000000 --dim 1024 > $O/batch64_1Mx1024.json 2> $O/b1024_trace.err || { tail -5 $O/b1024_trace.err; exit 1; }
 step knn-trace; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/knn_trace -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-autolink > $O/knn_trace.json 2> $O/knn_trace.err || { tail -5 $O/knn_trace.err; exit 1; }
 step knn-fetch; timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/knn_fetch -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-autolink > $O/knn_fetch.json 2> $O/knn_fetch.err || { tail -5 $O/knn_fetch.err; exit 1; }
 step knn-write; timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/knn_write -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-autolink > $O/knn_write.json 2> $O/knn_write.err || { tail -5 $O/knn_write.err; exit 1; }
@@ -19,7 +24,7 @@ step autolink-mfma; timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES G
 step batch-trace; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/batch_trace -- python3 $R/scripts/bench_batch.py > $O/batch.json 2> $O/batch_trace.err || { tail -5 $O/batch_trace.err; exit 1; }
 step batch-fetch; timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/batch_fetch -- python3 $R/scripts/bench_batch.py --steps 5 > $O/batch_fetch.json 2> $O/batch_fetch.err || { tail -5 $O/batch_fetch.err; exit 1; }
 # keep only the summaries (traces are large)
-for d in knn_trace al_trace batch_trace; do f=$(ls -t $O/$d/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/${d}_kernel_stats.csv; done
+for d in knn_trace al_trace batch_trace b1024_trace; do f=$(ls -t $O/$d/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/${d}_kernel_stats.csv; done
 for d in knn_fetch knn_write batch_fetch al_mfma; do f=$(ls -t $O/$d/*/*counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && python3 - "$f" > $O/${d}_summary.json <<'PY'
 import csv, sys, json, collections
 agg = collections.defaultdict(lambda: [0.0, 0])
@@ -49,5 +54,5 @@ if busy and act:
     out["derived"] = {"kernel_cycles": cyc, "mfma_pipe_utilisation": busy / (cyc * 256 * 4)}
 print(json.dumps(out, indent=1))
 PY
-rm -rf $O/knn_trace $O/al_trace $O/batch_trace $O/knn_fetch $O/knn_write $O/batch_fetch $O/al_mfma
+rm -rf $O/knn_trace $O/al_trace $O/batch_trace $O/b1024_trace $O/knn_fetch $O/knn_write $O/batch_fetch $O/al_mfma
 ls -la $O; cat $O/bench.json
