@@ -308,9 +308,9 @@ def cpu_baseline(ix, gen: torch.Tensor, queries: torch.Tensor, n: int, d: int, k
             if int(r) in want or abs(float(sc) - kth) <= 5e-5:
                 bh += 1
     # the reference's approximate path (index.rs:342-371 over instant-distance 0.6.1) at the headline's width, on a bounded
-    # slice: the restatement builds single-threaded, ~30 s for 20k x 768 (the full 1M would take half an hour); its
+    # slice: the restatement builds single-threaded, ~25 s for 6k x 768 (20k rows took 290 s on the GPU box, the full 1M would take hours); its
     # queries/s and recall are measured against the exact oracle on the same slice
-    hn = 20_000
+    hn = 6_000
     rows_s = gen[:hn].cpu().numpy()
     t5 = time.perf_counter()
     hidx = O.HnswBaseline(rows_s)

@@ -10,9 +10,10 @@
 // as the MFMA A operand.  Any dim % 128 == 0 up to 4096; no split store, no shadow: the f32 rows are read once per
 // 64 queries.
 //
-//   block = 4 waves, row tile = 128 rows (wave w: rows 32 w .. 32 w + 31 = two 16-row A fragments m = 0, 1)
-//   K-block = 128 k = 4 MFMA steps of 32; per step and wave: 4 x global_load_dwordx4 (2 per fragment: whole 128-byte
-//     lines per row), 8 v_cvt_pk_bf16 pairs, 4 query groups x 2 fragments x 3 mfma_f32_16x16x32_bf16
+//   block = 8 waves, row tile = 256 rows (wave w: rows 32 w .. 32 w + 31 = two 16-row A fragments m = 0, 1)
+//   K-block = 128 k = 4 MFMA steps of 32 = two 64-k sub-blocks; per sub-block and wave: 8 x global_load_dwordx4 of one
+//     contiguous KiB each (4 rows x 256 B), handed through the wave's own 8 KiB LDS region into MFMA operand layout,
+//     split there (8 v_cvt_pk_bf16 pairs per step), 4 query groups x 2 fragments x 3 mfma_f32_16x16x32_bf16 per step
 //   queries: K-block kb+1 is fetched into registers while K-block kb is computed, written to the other LDS buffer at
 //     the top of the next iteration; ONE raw barrier per K-block
 //   epilogue: cosine with the scan kernel's arithmetic (cosine_from_sums), dense scores [query][row] to HBM
@@ -34,13 +35,14 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 namespace bg {
-constexpr int TILE_ROWS = 128;      // rows per block tile
+constexpr int TILE_ROWS = 256;      // rows per block tile: 8 waves x 32
 constexpr int KB = 128;             // k per K-block
 constexpr int STEPS = KB / 32;      // MFMA steps per K-block
 constexpr int NQ = 64;              // queries per pass
 constexpr int STEP_BYTES = 2 * NQ * 4 * 16;   // one step's query image: hi [64][4 kq][8 bf16] | lo = 8 KiB
 constexpr int KB_BYTES = STEPS * STEP_BYTES;  // 32 KiB
-constexpr int LDS_BYTES = 2 * KB_BYTES;       // double buffered: 64 KiB -> two blocks per CU
+constexpr int SUB_BYTES = 32 * 64 * 4;        // a wave's 32 rows x 64 k f32 = 8 KiB
+constexpr int LDS_BYTES = 2 * KB_BYTES + 8 * SUB_BYTES;   // query images double buffered + one row region per wave = 128 KiB
 
 __device__ inline void split4g(const f32x4 v, bf16x4_t &hi, bf16x4_t &lo) {   // as batch.hip's split4
     const uint32_t p01 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v.x, v.y}, bf16x2_t));
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(256) void batchg_split_queries_kernel(const float *
 }
 
 struct BatchGArgs {
-    const float *rows;     // [n_rows][dim]
+    const float *rows;     // [n_rows (+ 256 readable)][dim]
     const float *norms;    // |row|^2 (cx_index::d_norms)
     const char *qimg;      // split query images, dim / 32 steps of 8 KiB
     const float *qq;       // [64] |q|^2
@@ -98,8 +100,9 @@ struct BatchGArgs {
     uint32_t n_rows, dim, nq, stride;
 };
 
-template <int PROBE>   // 0 = the product; 1 = loads only (no split, no MFMA); 2 = no row loads (MFMAs on stale registers)
-__global__ __launch_bounds__(256, 2) void batchg_kernel(const BatchGArgs a) {
+// PROBE: 0 = the product; 1 = loads only (no LDS transpose, no split, no MFMA); 2 = no row loads (MFMAs on stale data)
+template <int PROBE>
+__global__ __launch_bounds__(512) void batchg_kernel(const BatchGArgs a) {
     using namespace bg;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -110,6 +113,8 @@ __global__ __launch_bounds__(256, 2) void batchg_kernel(const BatchGArgs a) {
     if (blockIdx.x >= n_tiles) return;
     const uint32_t my_tiles = (n_tiles - 1u - blockIdx.x) / gridDim.x + 1u;
     const uint32_t total_kb = my_tiles * n_kb;   // K-blocks this block walks: the query images cycle once per tile
+    char *Qs = smem;                                              // [2][KB_BYTES] query images, double buffered
+    char *Rw = smem + 2 * KB_BYTES + wave * SUB_BYTES;            // this wave's 32 rows x 64 k f32, pieces swizzled
 
     auto tile_barrier = [&]() {   // raw barrier: __syncthreads() would drain the rows in flight (vmcnt(0))
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -117,68 +122,66 @@ __global__ __launch_bounds__(256, 2) void batchg_kernel(const BatchGArgs a) {
         asm volatile("" ::: "memory");
     };
 
-    // query staging: a K-block image is 32 KiB = 8 x 16 B per thread
-    f32x4 qr[8];
+    // query staging: a K-block image is 32 KiB = 4 x 16 B per thread
+    f32x4 qr[4];
     auto q_fetch = [&](uint32_t kb) {
         const f32x4 *src = reinterpret_cast<const f32x4 *>(a.qimg + (size_t)(kb % n_kb) * KB_BYTES) + tid;
 #pragma unroll
-        for (int e = 0; e < 8; e++) qr[e] = src[e * 256];
+        for (int e = 0; e < 4; e++) qr[e] = src[e * 512];
     };
     auto q_store = [&](uint32_t buf) {
-        f32x4 *dst = reinterpret_cast<f32x4 *>(smem + buf * KB_BYTES) + tid;
+        f32x4 *dst = reinterpret_cast<f32x4 *>(Qs + buf * KB_BYTES) + tid;
 #pragma unroll
-        for (int e = 0; e < 8; e++) dst[e * 256] = qr[e];
+        for (int e = 0; e < 4; e++) dst[e * 512] = qr[e];
     };
 
-    // row side: lane (j, kq) of fragment m loads row 32 wave + 16 m + j, two float4 per step
+    // Row side.  A sub-block = 64 k of the wave's 32 rows = 8 load instructions of ONE KiB each: lane l reads piece
+    // l % 16 (16 B) of row 4 i + l / 16 — four rows x 256 contiguous bytes per instruction (the single-query scan's
+    // pattern, against 16 rows x 64 B when the loads follow the MFMA operand layout: 0.48 of the HBM peak, loads-only
+    // probe included).  The registers go to the wave's own LDS region and come back in MFMA layout — same wave, LDS
+    // executes a wave's instructions in order: no barrier.  Piece p of row r sits at p ^ (r & 15): the 16 lanes of a
+    // read group (one piece index, 16 rows) then hit 16 different 16-byte bank groups.
+    const uint32_t lrow = lane >> 4, lpiece = lane & 15u;
     f32x4 acc[2][4];
-    const f32x4 *rp[2], *rpn[2];
-    auto tile_ptrs = [&](uint32_t tile, const f32x4 *(&p)[2]) {
-#pragma unroll
-        for (int m = 0; m < 2; m++) {
-            uint32_t r = tile * TILE_ROWS + wave * 32u + (uint32_t)m * 16u + j;
-            r = r < a.n_rows ? r : a.n_rows - 1u;   // tail: re-read the last row, never stored
-            p[m] = reinterpret_cast<const f32x4 *>(a.rows + (size_t)r * a.dim) + kq;
-        }
-    };
     auto zero_acc = [&]() {
 #pragma unroll
         for (int m = 0; m < 2; m++)
 #pragma unroll
             for (int g = 0; g < 4; g++) acc[m][g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     };
-    // two register sets of HALF a K-block each (2 steps x 2 fragments x 2 float4 = 32 VGPRs): while one half is
-    // multiplied the other is in flight, and each set is re-requested for the next K-block the moment it has been used
-    constexpr int HS = STEPS / 2;
-    f32x4 ra[HS][2][2], rb[HS][2][2];
-    auto r_fetch = [&](f32x4 (&dst)[HS][2][2], const f32x4 *const (&p)[2], uint32_t step0) {   // step0: first MFMA step inside the row
+    // lane part of a row address (bytes): row lrow of a 4-row group, piece lpiece; the tile / group / sub-block part is scalar
+    const uint32_t lane_off = lrow * a.dim * 4u + lpiece * 16u;
+    f32x4 xa[8], xb[8];
+    auto r_fetch = [&](f32x4 (&dst)[8], uint32_t tile, uint32_t sub) {   // sub: 64-k sub-block inside the row
+        const char *base = reinterpret_cast<const char *>(a.rows) + ((size_t)tile * TILE_ROWS + wave * 32u) * a.dim * 4u + (size_t)sub * 256u;
 #pragma unroll
-        for (int s = 0; s < HS; s++)
-#pragma unroll
-            for (int m = 0; m < 2; m++) {
-                const f32x4 *q = p[m] + (size_t)(step0 + (uint32_t)s) * 8u;
-                if constexpr (PROBE == 2) { asm volatile("" : "+v"(dst[s][m][0]), "+v"(dst[s][m][1])); continue; }
-                dst[s][m][0] = __builtin_nontemporal_load(q);
-                dst[s][m][1] = __builtin_nontemporal_load(q + 4);
-            }
-    };
-    auto compute = [&](const f32x4 (&src)[HS][2][2], uint32_t buf, uint32_t half) {
-        const char *Q = smem + buf * KB_BYTES + half * (HS * STEP_BYTES) + (j * 4u + kq) * 16u;
-        if constexpr (PROBE == 1) {
-#pragma unroll
-            for (int s = 0; s < HS; s++)
-#pragma unroll
-                for (int m = 0; m < 2; m++) acc[m][0] += src[s][m][0] + src[s][m][1];
-            return;
+        for (int i = 0; i < 8; i++) {
+            if constexpr (PROBE == 2) { asm volatile("" : "+v"(dst[i])); continue; }
+            dst[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(base + (size_t)i * 4u * a.dim * 4u + lane_off));
         }
+    };
+    auto lds_put = [&](const f32x4 (&src)[8]) {
 #pragma unroll
-        for (int s = 0; s < HS; s++) {
+        for (int i = 0; i < 8; i++) {
+            const uint32_t r = 4u * (uint32_t)i + lrow;
+            *reinterpret_cast<f32x4 *>(Rw + r * 256u + ((lpiece ^ (r & 15u)) << 4)) = src[i];
+        }
+    };
+    // fragment m, step s (of the sub-block's two): lane (j, kq) needs k = 32 s + 4 kq .. + 3 and 32 s + 16 + 4 kq .. + 3 of
+    // row 16 m + j: pieces 8 s + kq and 8 s + 4 + kq
+    auto compute_sub = [&](uint32_t buf, uint32_t half) {
+        const char *Q = Qs + buf * KB_BYTES + half * (2 * STEP_BYTES) + (j * 4u + kq) * 16u;
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
             s16x8 ah[2], al[2];
 #pragma unroll
             for (int m = 0; m < 2; m++) {
+                const uint32_t r = 16u * (uint32_t)m + j;
+                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(Rw + r * 256u + (((8u * s + kq) ^ j) << 4));
+                const f32x4 v1 = *reinterpret_cast<const f32x4 *>(Rw + r * 256u + (((8u * s + 4u + kq) ^ j) << 4));
                 bf16x4_t h0, l0, h1, l1;
-                split4g(src[s][m][0], h0, l0);
-                split4g(src[s][m][1], h1, l1);
+                split4g(v0, h0, l0);
+                split4g(v1, h1, l1);
                 ah[m] = __builtin_bit_cast(s16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
                 al[m] = __builtin_bit_cast(s16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
             }
@@ -194,6 +197,15 @@ __global__ __launch_bounds__(256, 2) void batchg_kernel(const BatchGArgs a) {
                 }
             }
         }
+    };
+    auto consume = [&](const f32x4 (&src)[8], uint32_t buf, uint32_t half) {
+        if constexpr (PROBE == 1) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) acc[i & 1][(i >> 1) & 3] += src[i];
+            return;
+        }
+        lds_put(src);
+        compute_sub(buf, half);
     };
     // C layout: lane (j, kq) holds rows 4 kq + e (e = 0..3) of query j of group g: four consecutive rows -> one float4
     auto epilogue = [&](uint32_t tile) {
@@ -219,38 +231,34 @@ __global__ __launch_bounds__(256, 2) void batchg_kernel(const BatchGArgs a) {
         }
     };
 
-    // Pipeline over the block's K-blocks, tile by tile.  K-block `it` reads its query image from LDS buffer it & 1;
-    // the image of it + 1 (fetched during it - 1) is written to the other buffer at the top of the iteration and the
-    // image of it + 2 requested.  Rows: half a K-block per register set, each set re-requested (for the next K-block,
-    // which may open the next tile) right after it has been multiplied.  One barrier per K-block.
+    // Pipeline over the block's K-blocks, tile by tile.  K-block `it` (two sub-blocks: xa, xb) reads its query image from
+    // LDS buffer it & 1; the image of it + 1 (fetched during it - 1) is written to the other buffer at the top of the
+    // iteration and the image of it + 2 requested.  Each row register set is re-requested — for the next K-block, which
+    // may open the next tile — the moment it has been handed to LDS.  One barrier per K-block.
     uint32_t tile = blockIdx.x, it = 0;
-    tile_ptrs(tile, rp);
-    rpn[0] = rp[0]; rpn[1] = rp[1];
     zero_acc();
     q_fetch(0);
     q_store(0);
     if (total_kb > 1u) q_fetch(1);
-    r_fetch(ra, rp, 0);
-    r_fetch(rb, rp, HS);
+    r_fetch(xa, tile, 0);
+    r_fetch(xb, tile, 1);
     tile_barrier();
     for (uint32_t t = 0; t < my_tiles; t++) {
         const bool more_tiles = t + 1u < my_tiles;
-        if (more_tiles) tile_ptrs(tile + gridDim.x, rpn);
         for (uint32_t kbl = 0; kbl < n_kb; kbl++, it++) {
             const uint32_t buf = it & 1u;
             const bool last = kbl + 1u == n_kb;
             if (it + 1u < total_kb) q_store(buf ^ 1u);
             if (it + 2u < total_kb) q_fetch(it + 2u);
-            compute(ra, buf, 0);
-            if (!last) r_fetch(ra, rp, (kbl + 1u) * STEPS);
-            else if (more_tiles) r_fetch(ra, rpn, 0);
-            compute(rb, buf, 1);
-            if (!last) r_fetch(rb, rp, (kbl + 1u) * STEPS + HS);
-            else if (more_tiles) r_fetch(rb, rpn, HS);
+            consume(xa, buf, 0);
+            if (!last) r_fetch(xa, tile, 2u * (kbl + 1u));
+            else if (more_tiles) r_fetch(xa, tile + gridDim.x, 0);
+            consume(xb, buf, 1);
+            if (!last) r_fetch(xb, tile, 2u * (kbl + 1u) + 1u);
+            else if (more_tiles) r_fetch(xb, tile + gridDim.x, 1);
             if (last) {
                 epilogue(tile);
                 tile += gridDim.x;
-                rp[0] = rpn[0]; rp[1] = rpn[1];
                 zero_acc();
             }
             tile_barrier();
@@ -280,9 +288,9 @@ int launch_batchg_scores(const float *rows, const float *norms, uint32_t n_rows,
     const uint32_t n_tiles = (n_rows + TILE_ROWS - 1) / TILE_ROWS;
     const uint32_t grid = std::min<uint32_t>(n_tiles, 2u * device_cus());
     static const int probe = getenv("CX_BATCHG_PROBE") ? atoi(getenv("CX_BATCHG_PROBE")) : 0;   // measurement arms, results invalid
-    if (probe == 1) hipLaunchKernelGGL(batchg_kernel<1>, dim3(grid), dim3(256), LDS_BYTES, stream, a);
-    else if (probe == 2) hipLaunchKernelGGL(batchg_kernel<2>, dim3(grid), dim3(256), LDS_BYTES, stream, a);
-    else hipLaunchKernelGGL(batchg_kernel<0>, dim3(grid), dim3(256), LDS_BYTES, stream, a);
+    if (probe == 1) hipLaunchKernelGGL(batchg_kernel<1>, dim3(grid), dim3(512), LDS_BYTES, stream, a);
+    else if (probe == 2) hipLaunchKernelGGL(batchg_kernel<2>, dim3(grid), dim3(512), LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL(batchg_kernel<0>, dim3(grid), dim3(512), LDS_BYTES, stream, a);
     CX_HIP(hipGetLastError());
     return CX_OK;
 }

@@ -104,7 +104,7 @@ int grow_rows(cx_index *ix, uint64_t need) {
     uint64_t ncap = std::max<uint64_t>(need, std::max<uint64_t>(ix->cap * 2, 1024));
     float *nr = nullptr;
     uint32_t *nm = nullptr, *na = nullptr;
-    CX_HIP(hipMalloc((void **)&nr, (ncap + 16) * ix->dim * sizeof(float) + 64));  // + one batch tile of padding (batch.hip)
+    CX_HIP(hipMalloc((void **)&nr, (ncap + 256) * ix->dim * sizeof(float) + 64));  // + one row tile of readable padding (batch.hip: 16 rows, batchg.hip: 256)
     CX_HIP(hipMalloc((void **)&nm, ncap * sizeof(uint32_t)));
     CX_HIP(hipMalloc((void **)&na, ncap * sizeof(uint32_t)));
     CX_HIP(hipMemsetAsync(nm, 0, ncap * sizeof(uint32_t), ix->up_stream));
@@ -696,7 +696,7 @@ int cx_rebuild(cx_index *ix) try {
         uint32_t *meta = nullptr, *agent = nullptr, *keep = nullptr;
         ~NewStore() { (void)hipFree(rows); (void)hipFree(meta); (void)hipFree(agent); (void)hipFree(keep); }
     } ns;
-    CX_HIP(hipMalloc((void **)&ns.rows, (ncap + 16) * ix->dim * sizeof(float) + 64));  // + one batch tile of padding (batch.hip)
+    CX_HIP(hipMalloc((void **)&ns.rows, (ncap + 256) * ix->dim * sizeof(float) + 64));  // + one row tile of readable padding (batch.hip: 16 rows, batchg.hip: 256)
     CX_HIP(hipMalloc((void **)&ns.meta, ncap * sizeof(uint32_t)));
     CX_HIP(hipMalloc((void **)&ns.agent, ncap * sizeof(uint32_t)));
     CX_HIP(hipMemsetAsync(ns.meta, 0, ncap * sizeof(uint32_t), ix->up_stream));
