@@ -7,13 +7,13 @@
 // the operands swap: the queries (pre-split once per call into the MFMA B-operand layout, batchg_split_queries_kernel)
 // are staged K-block by K-block through LDS, and the ROWS go straight from HBM into registers, are split there
 // (hi = bf16(a), lo = bf16(a - hi): the same three-product scheme as batch.hip, |cos error| <= 1e-6) and multiplied
-// as the MFMA A operand.  Any dim % 128 == 0 up to 4096; no split store, no shadow: the f32 rows are read once per
+// as the MFMA A operand.  Any dim % 256 == 0 up to 4096; no split store, no shadow: the f32 rows are read once per
 // 64 queries.
 //
-//   block = 8 waves, row tile = 256 rows (wave w: rows 32 w .. 32 w + 31 = two 16-row A fragments m = 0, 1)
-//   K-block = 128 k = 4 MFMA steps of 32 = two 64-k sub-blocks; per sub-block and wave: 8 x global_load_dwordx4 of one
-//     contiguous KiB each (4 rows x 256 B), handed through the wave's own 8 KiB LDS region into MFMA operand layout,
-//     split there (8 v_cvt_pk_bf16 pairs per step), 4 query groups x 2 fragments x 3 mfma_f32_16x16x32_bf16 per step
+//   block = 8 waves, row tile = 128 rows (wave w: rows 16 w .. 16 w + 15 = one 16-row A fragment)
+//   K-block = 128 k = 4 MFMA steps of 32; per K-block and wave: 8 x global_load_dwordx4 of one contiguous KiB each
+//     (2 rows x 512 B), handed through the wave's own 8 KiB LDS region into MFMA operand layout, split there
+//     (4 v_cvt_pk_bf16 pairs per step), 4 query groups x 3 mfma_f32_16x16x32_bf16 per step
 //   queries: K-block kb+1 is fetched into registers while K-block kb is computed, written to the other LDS buffer at
 //     the top of the next iteration; ONE raw barrier per K-block
 //   epilogue: cosine with the scan kernel's arithmetic (cosine_from_sums), dense scores [query][row] to HBM
@@ -35,13 +35,13 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 namespace bg {
-constexpr int TILE_ROWS = 256;      // rows per block tile: 8 waves x 32
+constexpr int TILE_ROWS = 128;      // rows per block tile: 8 waves x 16
 constexpr int KB = 128;             // k per K-block
 constexpr int STEPS = KB / 32;      // MFMA steps per K-block
 constexpr int NQ = 64;              // queries per pass
 constexpr int STEP_BYTES = 2 * NQ * 4 * 16;   // one step's query image: hi [64][4 kq][8 bf16] | lo = 8 KiB
 constexpr int KB_BYTES = STEPS * STEP_BYTES;  // 32 KiB
-constexpr int SUB_BYTES = 32 * 64 * 4;        // a wave's 32 rows x 64 k f32 = 8 KiB
+constexpr int SUB_BYTES = 16 * KB * 4;        // a wave's 16 rows x one K-block f32 = 8 KiB
 constexpr int LDS_BYTES = 2 * KB_BYTES + 8 * SUB_BYTES;   // query images double buffered + one row region per wave = 128 KiB
 
 __device__ inline void split4g(const f32x4 v, bf16x4_t &hi, bf16x4_t &lo) {   // as batch.hip's split4
@@ -117,6 +117,7 @@ __global__ __launch_bounds__(512) void batchg_kernel(const BatchGArgs a) {
     char *Rw = smem + 2 * KB_BYTES + wave * SUB_BYTES;            // this wave's 32 rows x 64 k f32, pieces swizzled
 
     auto tile_barrier = [&]() {   // raw barrier: __syncthreads() would drain the rows in flight (vmcnt(0))
+        if constexpr (PROBE == 3 || PROBE == 4) return;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -124,139 +125,144 @@ __global__ __launch_bounds__(512) void batchg_kernel(const BatchGArgs a) {
 
     // query staging: a K-block image is 32 KiB = 4 x 16 B per thread
     f32x4 qr[4];
-    auto q_fetch = [&](uint32_t kb) {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(a.qimg + (size_t)(kb % n_kb) * KB_BYTES) + tid;
+    // (A rotated K-block order per tile — against all blocks walking the same 512-byte slice of every 4 KiB row in
+    // step — changed nothing: 0.896 ms either way; the memory system hashes addresses over its channels.)
+    auto phys_kb = [&](uint32_t, uint32_t kbl) { return kbl; };
+    auto q_fetch = [&](uint32_t it_) {   // it_: index in this block's K-block sequence
+        const uint32_t tile_ = blockIdx.x + (it_ / n_kb) * gridDim.x;
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(a.qimg + (size_t)phys_kb(tile_, it_ % n_kb) * KB_BYTES) + tid;
+        if constexpr (PROBE == 3) return;
 #pragma unroll
         for (int e = 0; e < 4; e++) qr[e] = src[e * 512];
     };
     auto q_store = [&](uint32_t buf) {
         f32x4 *dst = reinterpret_cast<f32x4 *>(Qs + buf * KB_BYTES) + tid;
+        if constexpr (PROBE == 3) return;
 #pragma unroll
         for (int e = 0; e < 4; e++) dst[e * 512] = qr[e];
     };
 
-    // Row side.  A sub-block = 64 k of the wave's 32 rows = 8 load instructions of ONE KiB each: lane l reads piece
-    // l % 16 (16 B) of row 4 i + l / 16 — four rows x 256 contiguous bytes per instruction (the single-query scan's
-    // pattern, against 16 rows x 64 B when the loads follow the MFMA operand layout: 0.48 of the HBM peak, loads-only
-    // probe included).  The registers go to the wave's own LDS region and come back in MFMA layout — same wave, LDS
-    // executes a wave's instructions in order: no barrier.  Piece p of row r sits at p ^ (r & 15): the 16 lanes of a
-    // read group (one piece index, 16 rows) then hit 16 different 16-byte bank groups.
-    const uint32_t lrow = lane >> 4, lpiece = lane & 15u;
-    f32x4 acc[2][4];
+    // Row side.  A wave owns 16 rows (one MFMA A fragment).  A K-block of them = 16 rows x 512 B = 8 load instructions of
+    // ONE KiB each: lane l reads piece l % 32 (16 B) of row 2 i + l / 32 — two rows x 512 contiguous bytes per
+    // instruction.  (Following the MFMA operand layout instead — 16 rows x 64 B per instruction — the kernel read at 0.48
+    // of the HBM peak, loads-only probe included; 4 rows x 256 B: 0.55 / 0.60.)  The registers go to the wave's own 8 KiB
+    // LDS region and come back in MFMA layout — same wave, LDS executes a wave's instructions in order: no barrier.
+    // Piece p of row r sits at p ^ (r & 15): the 16 lanes of a read group (one piece index, 16 rows) then hit 16
+    // different 16-byte bank groups; a write group is 16 consecutive pieces of one row, permuted inside 256 bytes.
+    const uint32_t lrow = lane >> 5, lpiece = lane & 31u;
+    f32x4 acc[4];
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int m = 0; m < 2; m++)
-#pragma unroll
-            for (int g = 0; g < 4; g++) acc[m][g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int g = 0; g < 4; g++) acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     };
-    // lane part of a row address (bytes): row lrow of a 4-row group, piece lpiece; the tile / group / sub-block part is scalar
+    // lane part of a row address (bytes): row lrow of a 2-row group, piece lpiece; the tile / group / K-block part is scalar
     const uint32_t lane_off = lrow * a.dim * 4u + lpiece * 16u;
-    f32x4 xa[8], xb[8];
-    auto r_fetch = [&](f32x4 (&dst)[8], uint32_t tile, uint32_t sub) {   // sub: 64-k sub-block inside the row
-        const char *base = reinterpret_cast<const char *>(a.rows) + ((size_t)tile * TILE_ROWS + wave * 32u) * a.dim * 4u + (size_t)sub * 256u;
+    f32x4 xa[8], xb[8];   // two K-blocks of this wave's rows in flight (16 KiB per wave, 128 KiB per CU)
+    auto r_fetch = [&](f32x4 (&dst)[8], uint32_t tile, uint32_t kb) {   // kb: K-block inside the row
+        const char *base = reinterpret_cast<const char *>(a.rows) + ((size_t)tile * TILE_ROWS + wave * 16u) * a.dim * 4u + (size_t)kb * 512u;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             if constexpr (PROBE == 2) { asm volatile("" : "+v"(dst[i])); continue; }
-            dst[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(base + (size_t)i * 4u * a.dim * 4u + lane_off));
+            dst[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(base + (size_t)i * 2u * a.dim * 4u + lane_off));
         }
     };
     auto lds_put = [&](const f32x4 (&src)[8]) {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const uint32_t r = 4u * (uint32_t)i + lrow;
-            *reinterpret_cast<f32x4 *>(Rw + r * 256u + ((lpiece ^ (r & 15u)) << 4)) = src[i];
+            const uint32_t r = 2u * (uint32_t)i + lrow;
+            *reinterpret_cast<f32x4 *>(Rw + r * 512u + ((lpiece ^ (r & 15u)) << 4)) = src[i];
         }
     };
-    // fragment m, step s (of the sub-block's two): lane (j, kq) needs k = 32 s + 4 kq .. + 3 and 32 s + 16 + 4 kq .. + 3 of
-    // row 16 m + j: pieces 8 s + kq and 8 s + 4 + kq
-    auto compute_sub = [&](uint32_t buf, uint32_t half) {
-        const char *Q = Qs + buf * KB_BYTES + half * (2 * STEP_BYTES) + (j * 4u + kq) * 16u;
+    // step s (of the K-block's four): lane (j, kq) needs k = 32 s + 4 kq .. + 3 and 32 s + 16 + 4 kq .. + 3 of row j:
+    // pieces 8 s + kq and 8 s + 4 + kq
+    auto compute_kb = [&](uint32_t buf) {
+        const char *Q = Qs + buf * KB_BYTES + (j * 4u + kq) * 16u;
 #pragma unroll
-        for (int s = 0; s < 2; s++) {
-            s16x8 ah[2], al[2];
-#pragma unroll
-            for (int m = 0; m < 2; m++) {
-                const uint32_t r = 16u * (uint32_t)m + j;
-                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(Rw + r * 256u + (((8u * s + kq) ^ j) << 4));
-                const f32x4 v1 = *reinterpret_cast<const f32x4 *>(Rw + r * 256u + (((8u * s + 4u + kq) ^ j) << 4));
-                bf16x4_t h0, l0, h1, l1;
-                split4g(v0, h0, l0);
-                split4g(v1, h1, l1);
-                ah[m] = __builtin_bit_cast(s16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
-                al[m] = __builtin_bit_cast(s16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
-            }
+        for (int s = 0; s < STEPS; s++) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(Rw + j * 512u + (((8u * s + kq) ^ j) << 4));
+            const f32x4 v1 = *reinterpret_cast<const f32x4 *>(Rw + j * 512u + (((8u * s + 4u + kq) ^ j) << 4));
+            bf16x4_t h0, l0, h1, l1;
+            split4g(v0, h0, l0);
+            split4g(v1, h1, l1);
+            const s16x8 ah = __builtin_bit_cast(s16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+            const s16x8 al = __builtin_bit_cast(s16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const s16x8 qh = *reinterpret_cast<const s16x8 *>(Q + s * STEP_BYTES + g * 1024);
                 const s16x8 ql = *reinterpret_cast<const s16x8 *>(Q + s * STEP_BYTES + STEP_BYTES / 2 + g * 1024);
-#pragma unroll
-                for (int m = 0; m < 2; m++) {
-                    acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], qh, acc[m][g], 0, 0, 0);   // small terms first
-                    acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], ql, acc[m][g], 0, 0, 0);
-                    acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], qh, acc[m][g], 0, 0, 0);
-                }
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, qh, acc[g], 0, 0, 0);   // small terms first
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ql, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, qh, acc[g], 0, 0, 0);
             }
         }
     };
-    auto consume = [&](const f32x4 (&src)[8], uint32_t buf, uint32_t half) {
-        if constexpr (PROBE == 1) {
+    auto consume = [&](const f32x4 (&src)[8], uint32_t buf) {
+        if constexpr (PROBE == 1 || PROBE == 3 || PROBE == 4) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) acc[i & 1][(i >> 1) & 3] += src[i];
+            for (int i = 0; i < 8; i++) acc[i & 3] += src[i];
             return;
         }
         lds_put(src);
-        compute_sub(buf, half);
+        compute_kb(buf);
     };
     // C layout: lane (j, kq) holds rows 4 kq + e (e = 0..3) of query j of group g: four consecutive rows -> one float4
     auto epilogue = [&](uint32_t tile) {
+        const uint32_t r0 = tile * TILE_ROWS + wave * 16u + 4u * kq;
+        if (r0 >= a.n_rows) return;
+        f32x4 rr = {1.0f, 1.0f, 1.0f, 1.0f};
+        if (r0 + 3u < a.n_rows) rr = *reinterpret_cast<const f32x4 *>(a.norms + r0);
+        else { for (uint32_t e = 0; e < 4u; e++) if (r0 + e < a.n_rows) rr[e] = a.norms[r0 + e]; }
 #pragma unroll
-        for (int m = 0; m < 2; m++) {
-            const uint32_t r0 = tile * TILE_ROWS + wave * 32u + (uint32_t)m * 16u + 4u * kq;
-            if (r0 >= a.n_rows) continue;
-            f32x4 rr = {1.0f, 1.0f, 1.0f, 1.0f};
-            if (r0 + 3u < a.n_rows) rr = *reinterpret_cast<const f32x4 *>(a.norms + r0);
-            else { for (uint32_t e = 0; e < 4u; e++) if (r0 + e < a.n_rows) rr[e] = a.norms[r0 + e]; }
+        for (int g = 0; g < 4; g++) {
+            const uint32_t q = (uint32_t)g * 16u + j;
+            if (q >= a.nq) continue;
+            const float qq = a.qq[q];
+            f32x4 c;
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const uint32_t q = (uint32_t)g * 16u + j;
-                if (q >= a.nq) continue;
-                const float qq = a.qq[q];
-                f32x4 c;
-#pragma unroll
-                for (int e = 0; e < 4; e++) c[e] = cosine_from_sums(acc[m][g][e], qq, rr[e]);
-                float *dst = a.dense + (size_t)q * a.stride + r0;
-                if (r0 + 3u < a.n_rows) *reinterpret_cast<f32x4 *>(dst) = c;
-                else { for (uint32_t e = 0; e < 4u; e++) if (r0 + e < a.n_rows) dst[e] = c[e]; }
-            }
+            for (int e = 0; e < 4; e++) c[e] = cosine_from_sums(acc[g][e], qq, rr[e]);
+            float *dst = a.dense + (size_t)q * a.stride + r0;
+            if (r0 + 3u < a.n_rows) *reinterpret_cast<f32x4 *>(dst) = c;
+            else { for (uint32_t e = 0; e < 4u; e++) if (r0 + e < a.n_rows) dst[e] = c[e]; }
         }
     };
 
-    // Pipeline over the block's K-blocks, tile by tile.  K-block `it` (two sub-blocks: xa, xb) reads its query image from
-    // LDS buffer it & 1; the image of it + 1 (fetched during it - 1) is written to the other buffer at the top of the
-    // iteration and the image of it + 2 requested.  Each row register set is re-requested — for the next K-block, which
-    // may open the next tile — the moment it has been handed to LDS.  One barrier per K-block.
+    // Pipeline over the block's K-blocks, tile by tile, two K-blocks per loop iteration (dim % 256 == 0).  K-block `it`
+    // reads its query image from LDS buffer it & 1; the image of it + 1 (fetched during it - 1) is written to the other
+    // buffer at the top of the K-block and the image of it + 2 requested.  Rows: two register sets = two K-blocks; a set
+    // is re-requested for the K-block TWO ahead (which may belong to the next tile) the moment it has been handed to LDS.
+    // One barrier per K-block, for the query hand-over only.
     uint32_t tile = blockIdx.x, it = 0;
     zero_acc();
     q_fetch(0);
     q_store(0);
     if (total_kb > 1u) q_fetch(1);
-    r_fetch(xa, tile, 0);
-    r_fetch(xb, tile, 1);
+    r_fetch(xa, tile, phys_kb(tile, 0));
+    r_fetch(xb, tile, phys_kb(tile, 1));
     tile_barrier();
+    // where K-block kbl + 2 of the current tile lives: (tile, kbl + 2) or the next tile's (kbl + 2 - n_kb); false = past the end
+    auto ahead = [&](uint32_t t, uint32_t kbl, uint32_t &tl, uint32_t &kb2) {
+        kb2 = kbl + 2u;
+        tl = tile;
+        if (kb2 >= n_kb) { kb2 -= n_kb; tl = tile + gridDim.x; return t + 1u < my_tiles; }
+        return true;
+    };
     for (uint32_t t = 0; t < my_tiles; t++) {
-        const bool more_tiles = t + 1u < my_tiles;
-        for (uint32_t kbl = 0; kbl < n_kb; kbl++, it++) {
-            const uint32_t buf = it & 1u;
-            const bool last = kbl + 1u == n_kb;
-            if (it + 1u < total_kb) q_store(buf ^ 1u);
+        for (uint32_t kbl = 0; kbl < n_kb; kbl += 2u, it += 2u) {
+            uint32_t tl, kb2;
+            // even K-block (buffer 0): xa
+            q_store(1);
             if (it + 2u < total_kb) q_fetch(it + 2u);
-            consume(xa, buf, 0);
-            if (!last) r_fetch(xa, tile, 2u * (kbl + 1u));
-            else if (more_tiles) r_fetch(xa, tile + gridDim.x, 0);
-            consume(xb, buf, 1);
-            if (!last) r_fetch(xb, tile, 2u * (kbl + 1u) + 1u);
-            else if (more_tiles) r_fetch(xb, tile + gridDim.x, 1);
-            if (last) {
+            const bool more0 = ahead(t, kbl, tl, kb2);
+            consume(xa, 0);
+            if (more0) r_fetch(xa, tl, phys_kb(tl, kb2));
+            tile_barrier();
+            // odd K-block (buffer 1): xb
+            if (it + 2u < total_kb) q_store(0);
+            if (it + 3u < total_kb) q_fetch(it + 3u);
+            const bool more1 = ahead(t, kbl + 1u, tl, kb2);
+            consume(xb, 1);
+            if (more1) r_fetch(xb, tl, phys_kb(tl, kb2));
+            if (kbl + 2u == n_kb) {
                 epilogue(tile);
                 tile += gridDim.x;
                 zero_acc();
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(512) void batchg_kernel(const BatchGArgs a) {
     }
 }
 
-bool batchg_supported(uint32_t dim, uint32_t k) { return dim % bg::KB == 0 && dim <= 4096 && k >= 1 && k <= TOPK_MAX; }
+bool batchg_supported(uint32_t dim, uint32_t k) { return dim % (2 * bg::KB) == 0 && dim <= 4096 && k >= 1 && k <= TOPK_MAX; }
 size_t batchg_qimg_bytes(uint32_t dim) { return (size_t)(dim / 32u) * bg::STEP_BYTES; }
 
 // nq <= 64 queries against all rows: dense cosines [64][stride] (stride = n_rows rounded up to 4)
@@ -281,6 +287,8 @@ int launch_batchg_scores(const float *rows, const float *norms, uint32_t n_rows,
         CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchg_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchg_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchg_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchg_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchg_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     }
     BatchGArgs a;
     a.rows = rows; a.norms = norms; a.qimg = d_qimg; a.qq = d_qq; a.dense = d_dense;
@@ -290,6 +298,8 @@ int launch_batchg_scores(const float *rows, const float *norms, uint32_t n_rows,
     static const int probe = getenv("CX_BATCHG_PROBE") ? atoi(getenv("CX_BATCHG_PROBE")) : 0;   // measurement arms, results invalid
     if (probe == 1) hipLaunchKernelGGL(batchg_kernel<1>, dim3(grid), dim3(512), LDS_BYTES, stream, a);
     else if (probe == 2) hipLaunchKernelGGL(batchg_kernel<2>, dim3(grid), dim3(512), LDS_BYTES, stream, a);
+    else if (probe == 3) hipLaunchKernelGGL(batchg_kernel<3>, dim3(grid), dim3(512), LDS_BYTES, stream, a);   // rows only: no barriers, no query staging
+    else if (probe == 4) hipLaunchKernelGGL(batchg_kernel<4>, dim3(grid), dim3(512), LDS_BYTES, stream, a);   // loads, query staging, no barriers
     else hipLaunchKernelGGL(batchg_kernel<0>, dim3(grid), dim3(512), LDS_BYTES, stream, a);
     CX_HIP(hipGetLastError());
     return CX_OK;

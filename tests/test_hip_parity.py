@@ -313,7 +313,7 @@ def test_concurrent_filtered_readers(hip, oracle):
     (3001, 1024, 100, 70),   # two passes (64 + 6), ragged last row tile, the linker's k
     (777, 512, 32, 7),
     (1300, 1536, 10, 3),     # three queries: the smallest batch that takes the batched path
-    (130, 128, 5, 40),       # one K-block per row; a little more than one row tile
+    (130, 256, 5, 40),       # one K-block pair per row; fewer rows than one row tile
     (2000, 256, 256, 5),     # the largest in-register k
     (40, 1024, 40, 70),      # k == n: fewer rows than one tile
 ])
