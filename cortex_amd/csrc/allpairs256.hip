@@ -23,7 +23,9 @@
 //    partner is in the same place.  Tried against that and rejected, all slower than the lockstep interleave: ping-pong
 //    between the SIMD partners with a second barrier per K-step (7.07 ms against 6.45), the same with the load half at
 //    s_setprio 1 (7.18) or no priorities (7.03), DMA issue slots staggered by wave & 3 (7.3) or between partners only
-//    (7.24), a 5-slot ring (6.78).  What is left is bytes per flop: a 256x256 tile moves 32 KiB per K-step through that
+//    (7.24), a 5-slot ring (6.78), and a persistent form (one block per CU, the ring running through the tile
+//    boundaries so that a tile's last three K-steps issue the next tile's first three DMAs: no prologue, no relaunch)
+//    6.96 ms at 100k rows and 749 against 647 ms at 1M.  What is left is bytes per flop: a 256x256 tile moves 32 KiB per K-step through that
 //    path whatever the schedule.
 //  - 16-byte pieces of a 64-byte row are stored at piece ^ (row >> 3 & 3): with rows at a 64-byte stride this
 //    makes every ds_read_b128 lane group (MI355X_MICROARCH.md §LDS) of the 32-row x 2-piece operand pattern hit
