@@ -41,10 +41,26 @@ while time.time() < t_end:
         scan = np.unique(rng.integers(0, n, int(rng.integers(1, 65)))).astype(np.uint32)       # stream / small kernels
     else:
         scan = np.unique(rng.integers(0, n, int(rng.integers(65, 600)))).astype(np.uint32)     # 128 / 256 tiles, asymmetric
-    what = f"case n={n} d={d} thr={thr} cap={cap_e} topk={topk} scan={'all' if scan is None else len(scan)} deleted={deleted is not None}"
+    scan_o = np.arange(n, dtype=np.uint32) if scan is None else scan
+    # existing edges of ~30 % of the scanned nodes (auto_linker.rs:226-231) and a per-cycle cap (:284-287), half of the cases
+    existing, cyc = None, None
+    if rng.random() < 0.5:
+        lists = [[int(x) for x in rng.integers(0, n, int(rng.integers(1, 12)))] if rng.random() < 0.3 else [] for _ in scan_o]
+        off = np.zeros(len(lists) + 1, np.uint64); off[1:] = np.cumsum([len(x) for x in lists])
+        existing = (off, np.array([t for x in lists for t in x], dtype=np.uint32))
+        cyc = int(rng.choice([2000, 37, 1 << 40]))
+    what = (f"case n={n} d={d} thr={thr} cap={cap_e} topk={topk} scan={'all' if scan is None else len(scan)} deleted={deleted is not None} "
+            f"existing={existing is not None} cycle_cap={cyc}")
     try:
-        fr, to, w = h.autolink_pass_rows(scan, topk, thr, cap_e, deleted)
-        want = o.autolink_pass(np.arange(n, dtype=np.uint32) if scan is None else scan, topk, np.float32(thr), cap_e, deleted, n_threads=8)
+        fr, to, w = h.autolink_pass_rows(scan, topk, thr, cap_e, deleted, existing=existing, max_edges_per_cycle=cyc)
+        want = o.autolink_pass(scan_o, topk, np.float32(thr), cap_e, deleted, n_threads=8, existing=existing, max_edges_per_cycle=cyc)
+        if cyc is not None and cyc < (1 << 40) and (len(fr) == cyc or len(want) == cyc):
+            # a truncated cycle: both sides must have cut at the same length; the common prefix is compared node by node below,
+            # except the node the cut fell in (near-ties may order its last edges differently)
+            assert len(fr) == len(want), f"{what}: {len(fr)} vs {len(want)} edges after the per-cycle cap"
+            last = int(want["from_row"][-1]) if len(want) else -1
+            keep_g = np.array([int(x) != last for x in fr], bool); keep_w = np.array([int(x) != last for x in want["from_row"]], bool)
+            fr, to, w, want = fr[keep_g], to[keep_g], w[keep_g], want[keep_w]
         compare_edges(per_node(fr, to, w), per_node(want["from_row"], want["to_row"], want["weight"]), thr, oracle_scores(o, rows), what)
         order = [int(x) for x in fr]
         scan_list = list(range(n)) if scan is None else [int(x) for x in scan]
