@@ -117,6 +117,11 @@ SIGNATURES = {
     "cx_sharded_search_threshold": (C.c_int, [_P, _P, _U64, C.c_float, _P, _U64, _P, _P, _P, _P, _P]),
     "cx_sharded_autolink_pass_rows": (C.c_int, [_P, _U64, _P, _U64, C.c_float, _U64, _U64, _P, _P, _P, _U64, _P, _P, _P, _P, _P]),
     "cx_sharded_dedup_scan_rows": (C.c_int, [_P, C.c_float, _P, _U64, _P, _P, _P, _P, _P]),
+    "cx_sharded_topk_lists_rows": (C.c_int, [_P, _U64, _P, _U64, _P, _P, _P]),
+    "cx_sharded_set_metadata_batch": (C.c_int, [_P, _U64, _P, _P, _P]),
+    "cx_sharded_bulk_load_nodes": (C.c_int, [_P, _U64, _P, _P, _U32, _P]),
+    "cx_sharded_set_node_stats_batch": (C.c_int, [_P, _U64, _P, _P, _P, _P, _P]),
+    "cx_sharded_search_decayed": (C.c_int, [_P, _P, _U64, _U64, _U64, _P, _P, C.c_float, C.c_int64, _U32, _P, _P, _P, _P]),
     "cx_profile_enable": (C.c_int, [_P, C.c_int]),
     "cx_profile_read": (C.c_int, [_P, _P, _P, C.c_int]),
     "cx_device_rows": (_P, [_P]),

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <algorithm>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -182,6 +183,17 @@ struct CtxLease {
 // read back from the device (rows of list i start at rows + i * stride)
 int check_result_block(const uint32_t *counts, const uint32_t *rows, uint64_t nq, uint64_t stride, uint64_t k_max,
                        uint64_t n_rows);
+// where the start-up bulk load (nodes.cpp) puts what it decoded: one index, or the shards of a cx_sharded
+struct BulkSink {
+    uint32_t dim = 0;
+    int device = 0;     // for the pinned staging buffer
+    std::function<int(uint64_t, const uint8_t *, const float *)> upsert;
+    std::function<uint32_t(const char *, uint64_t)> intern;
+    std::function<int(uint64_t, const uint8_t *, const uint32_t *, const int64_t *, const uint32_t *, const uint64_t *)> set_stats;
+    std::function<int(uint64_t, const uint8_t *, const uint32_t *, const uint32_t *)> set_meta;
+};
+int bulk_load_impl(const BulkSink &sink, uint64_t n, const uint8_t *blob, const uint64_t *offsets, uint32_t flags, ::cx_bulk_stats *stats);
+
 struct FilterUpload {
     DevFilter f;
     bool needs_sync = false;

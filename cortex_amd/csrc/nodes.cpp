@@ -228,11 +228,15 @@ int cx_node_decode(const uint8_t *record, uint64_t len, cx_node_view *out) try {
     return CX_OK;
 } catch (...) { return cx::on_exception(); }
 
-int cx_bulk_load_nodes(cx_index *ix, uint64_t n, const uint8_t *blob, const uint64_t *offsets, uint32_t flags,
-                       cx_bulk_stats *stats) try {
+}  // extern "C"
+
+namespace cx {
+// The loader behind cx_bulk_load_nodes and cx_sharded_bulk_load_nodes: decode, filter and order like list_nodes, then hand
+// the embeddings (pinned staging, 256 MB chunks) and the per-node side data to the sink.
+int bulk_load_impl(const BulkSink &ix, uint64_t n, const uint8_t *blob, const uint64_t *offsets, uint32_t flags,
+                   cx_bulk_stats *stats) {
     cx_bulk_stats st{};
     if (stats) *stats = st;
-    if (!ix) return set_err(CX_ERR_VALIDATION, "null index");
     if (n && (!blob || !offsets)) return set_err(CX_ERR_VALIDATION, "null records");
     for (uint64_t i = 0; i < n; i++)
         if (offsets[i + 1] < offsets[i]) return set_err(CX_ERR_VALIDATION, "record offsets must not decrease (record %llu)", (unsigned long long)i);
@@ -257,7 +261,7 @@ int cx_bulk_load_nodes(cx_index *ix, uint64_t n, const uint8_t *blob, const uint
             uint8_t state = 1;
             if (v.deleted && !(flags & CX_BULK_INCLUDE_DELETED)) state = 2;
             else if (!v.has_embedding) state = 3;
-            else if (v.embedding_len != ix->dim) state = 4;
+            else if (v.embedding_len != ix.dim) state = 4;
             s = {v.created_at_s, v.created_at_ns, state};
         }
     };
@@ -298,18 +302,18 @@ int cx_bulk_load_nodes(cx_index *ix, uint64_t n, const uint8_t *blob, const uint
             st.dim_mismatch++;
             if (flags & CX_BULK_STRICT) {
                 if (stats) *stats = st;
-                return set_err(CX_ERR_VALIDATION, "Embedding dimension mismatch: expected %u, got %llu", ix->dim,
+                return set_err(CX_ERR_VALIDATION, "Embedding dimension mismatch: expected %u, got %llu", ix.dim,
                                (unsigned long long)views[(size_t)i].embedding_len);
             }
             continue;
         }
         take.push_back(i);
     }
-    const uint64_t dim = ix->dim;
+    const uint64_t dim = ix.dim;
     const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(take.size(), (256ull << 20) / std::max<uint64_t>(1, dim * 4)));
     // staging in pinned host memory (the H2D copy runs at link rate), filled by the same host threads
     if (take.empty()) { if (stats) *stats = st; return CX_OK; }
-    if (int rc = use_device(ix)) return rc;
+    CX_HIP(hipSetDevice(ix.device));
     float *stage = nullptr;
     CX_HIP(hipHostMalloc((void **)&stage, (size_t)(chunk * dim * 4 + 16), hipHostMallocDefault));
     struct Unpin { float *p; ~Unpin() { (void)hipHostFree(p); } } unpin{stage};
@@ -333,7 +337,7 @@ int cx_bulk_load_nodes(cx_index *ix, uint64_t n, const uint8_t *blob, const uint
             for (uint64_t t = 0; t < f_thr; t++) pool.emplace_back(fill, std::min(m, t * per), std::min(m, (t + 1) * per));
             for (auto &t : pool) t.join();
         }
-        if (int rc = cx_upsert_batch(ix, m, ids.data(), stage, dim)) { if (stats) *stats = st; return rc; }
+        if (int rc = ix.upsert(m, ids.data(), stage)) { if (stats) *stats = st; return rc; }
         st.indexed += m;
         if (flags & CX_BULK_SET_STATS) {
             std::vector<uint32_t> kc((size_t)m), lns((size_t)m);
@@ -341,25 +345,44 @@ int cx_bulk_load_nodes(cx_index *ix, uint64_t n, const uint8_t *blob, const uint
             std::vector<uint64_t> ac((size_t)m);
             for (uint64_t j = 0; j < m; j++) {
                 const cx_node_view &v = views[(size_t)take[(size_t)(lo + j)]];
-                kc[(size_t)j] = cx_intern(ix, v.kind, v.kind_len);
+                kc[(size_t)j] = ix.intern(v.kind, v.kind_len);
                 ls[(size_t)j] = v.last_accessed_at_s; lns[(size_t)j] = v.last_accessed_at_ns; ac[(size_t)j] = v.access_count;
             }
-            if (int rc = cx_set_node_stats_batch(ix, m, ids.data(), kc.data(), ls.data(), lns.data(), ac.data())) { if (stats) *stats = st; return rc; }
+            if (int rc = ix.set_stats(m, ids.data(), kc.data(), ls.data(), lns.data(), ac.data())) { if (stats) *stats = st; return rc; }
         }
         if (flags & CX_BULK_SET_METADATA) {
             kinds.resize((size_t)m);
             agents.resize((size_t)m);
             for (uint64_t j = 0; j < m; j++) {
                 const cx_node_view &v = views[(size_t)take[(size_t)(lo + j)]];
-                kinds[(size_t)j] = cx_intern(ix, v.kind, v.kind_len);
-                agents[(size_t)j] = cx_intern(ix, v.agent, v.agent_len);
+                kinds[(size_t)j] = ix.intern(v.kind, v.kind_len);
+                agents[(size_t)j] = ix.intern(v.agent, v.agent_len);
             }
-            if (int rc = cx_set_metadata_batch(ix, m, ids.data(), kinds.data(), agents.data())) { if (stats) *stats = st; return rc; }
+            if (int rc = ix.set_meta(m, ids.data(), kinds.data(), agents.data())) { if (stats) *stats = st; return rc; }
         }
     }
     if (diag) fprintf(stderr, "[bulk] decode %.1f ms, order %.1f ms, stage+insert %.1f ms\n", ms(t_0, t_1), ms(t_1, t_2), ms(t_2, now()));
     if (stats) *stats = st;
     return CX_OK;
+}
+}  // namespace cx
+
+extern "C" {
+
+int cx_bulk_load_nodes(cx_index *ix, uint64_t n, const uint8_t *blob, const uint64_t *offsets, uint32_t flags,
+                       cx_bulk_stats *stats) try {
+    if (stats) *stats = cx_bulk_stats{};
+    if (!ix) return set_err(CX_ERR_VALIDATION, "null index");
+    cx::BulkSink sink;
+    sink.dim = ix->dim;
+    sink.device = ix->device;
+    sink.upsert = [ix](uint64_t m, const uint8_t *ids, const float *embs) { return cx_upsert_batch(ix, m, ids, embs, ix->dim); };
+    sink.intern = [ix](const char *p, uint64_t len) { return cx_intern(ix, p, len); };
+    sink.set_stats = [ix](uint64_t m, const uint8_t *ids, const uint32_t *kc, const int64_t *ls, const uint32_t *lns, const uint64_t *ac) {
+        return cx_set_node_stats_batch(ix, m, ids, kc, ls, lns, ac);
+    };
+    sink.set_meta = [ix](uint64_t m, const uint8_t *ids, const uint32_t *k, const uint32_t *a) { return cx_set_metadata_batch(ix, m, ids, k, a); };
+    return cx::bulk_load_impl(sink, n, blob, offsets, flags, stats);
 } catch (...) { return cx::on_exception(); }
 
 }  // extern "C"

@@ -89,6 +89,7 @@ struct cx_sharded {
     uint64_t n_alive = 0, n_fresh = 0;
     std::unordered_map<IdKey, uint32_t, IdHash> map;                          // id -> global row (live ids)
     std::unordered_map<IdKey, std::pair<uint32_t, uint32_t>, IdHash> pending_meta;   // as cx_index::pending_meta
+    std::vector<NodeStats> h_stats;              // per global row: what apply_score_decay reads (decay.cpp); empty until set
     std::vector<std::vector<uint32_t>> h_gseq;   // [shard][local row] -> global row
     std::vector<uint32_t *> d_gseq;              // the same on the shard's device
     std::vector<size_t> c_gseq, n_gseq_up;       // capacity / rows uploaded
@@ -461,6 +462,13 @@ int cx_sharded_rebuild(cx_sharded *h) try {
         gseq[s].push_back(nq);
         h->map.emplace(id_key(&h->seq_ids[16 * q]), nq);
     }
+    if (!h->h_stats.empty()) {   // the stats move with their rows
+        std::vector<NodeStats> st;
+        st.reserve(h->n_alive);
+        for (size_t q = 0; q < n_old; q++)
+            if (h->seq_alive[q]) st.push_back(q < h->h_stats.size() ? h->h_stats[q] : NodeStats{});
+        h->h_stats.swap(st);
+    }
     h->seq_ids.swap(ids);
     h->seq_shard.swap(shard);
     h->seq_row.swap(row);
@@ -586,10 +594,14 @@ namespace {
 
 // AutoLinker::run_cycle's kNN loop (auto_linker.rs:215-264) / DedupScanner::scan (dedup.rs:65-127) over the shards,
 // in global rows.  scan: the scanned global rows in scan order (live rows only).
+// lists_out != null: no rule walk — the merged ordered top-k lists of the scanned rows themselves (cx_sharded_topk_lists_rows:
+// `search(&emb, topk, None)` per scanned node, auto_linker.rs:221) go to lists_out->{rows, scores, counts} at the scan positions
+// in lists_out->pos; every shard then runs its batched search over the block instead of the thresholded filter pass.
+struct ListsOut { uint32_t *rows; float *scores; uint32_t *counts; const uint32_t *pos; };
 int link_pass_sharded(const cx_sharded *h, const std::vector<uint32_t> &scan, const std::vector<uint64_t> &ex_off,
                       const uint32_t *ex_to, uint32_t topk, float threshold, uint32_t max_edges, uint64_t max_cycle,
                       const uint8_t *deleted, bool dedup, std::vector<uint32_t> &o_from, std::vector<uint32_t> &o_to,
-                      std::vector<float> &o_w) {
+                      std::vector<float> &o_w, const ListsOut *lists_out = nullptr) {
     const size_t P = h->shards.size();
     const uint32_t dim = h->dim;
     const uint64_t n_seq = h->seq_shard.size();
@@ -677,9 +689,15 @@ int link_pass_sharded(const cx_sharded *h, const std::vector<uint32_t> &scan, co
                         if (ix->n_rows == 0) {
                             if (hipMemsetAsync(part + 3 * (size_t)m * topk, 0, (size_t)m * 4, l.stream) != hipSuccess) rc = set_err(CX_ERR_DEVICE, "memset failed");
                         } else {
-                            rc = cx_autolink_lists_dev(ix, m, l.d_q, topk, threshold, l.d_rows, l.d_scores, l.d_dists, l.d_cnt, l.stream);
+                            uint32_t k_src = topk;
+                            if (lists_out) {   // this shard's own top-k of the block's vectors (lists k_src wide)
+                                k_src = (uint32_t)std::min<uint64_t>(topk, ix->n_rows);
+                                rc = cx_search_batch_dev(ix, m, l.d_q, k_src, nullptr, l.d_rows, l.d_scores, l.d_dists, l.d_cnt, l.stream);
+                            } else {
+                                rc = cx_autolink_lists_dev(ix, m, l.d_q, topk, threshold, l.d_rows, l.d_scores, l.d_dists, l.d_cnt, l.stream);
+                            }
                             if (rc == CX_OK)
-                                rc = launch_publish_part(l.d_rows, l.d_scores, l.d_dists, l.d_cnt, h->d_gseq[t], m, topk, topk,
+                                rc = launch_publish_part(l.d_rows, l.d_scores, l.d_dists, l.d_cnt, h->d_gseq[t], m, k_src, topk,
                                                          (uint32_t)ix->n_rows, part, l.stream);
                         }
                     }
@@ -702,6 +720,22 @@ int link_pass_sharded(const cx_sharded *h, const std::vector<uint32_t> &scan, co
                                             reinterpret_cast<const float *>(g + 2 * n), g + 3 * n, L, reinterpret_cast<float *>(L + n),
                                             reinterpret_cast<float *>(L + 2 * n), L + 3 * n, root->stream))
             return rc;
+        if (lists_out) {
+            std::vector<uint32_t> hr(n), hc(m);
+            std::vector<float> hs(n);
+            CX_HIP(hipMemcpyAsync(hr.data(), L, n * 4, hipMemcpyDeviceToHost, root->stream));
+            CX_HIP(hipMemcpyAsync(hs.data(), L + n, n * 4, hipMemcpyDeviceToHost, root->stream));
+            CX_HIP(hipMemcpyAsync(hc.data(), L + 3 * n, (size_t)m * 4, hipMemcpyDeviceToHost, root->stream));
+            CX_HIP(hipStreamSynchronize(root->stream));
+            if (int rc = check_result_block(hc.data(), hr.data(), m, topk, topk, n_seq)) return rc;
+            for (uint32_t i = 0; i < m; i++) {
+                const size_t p = lists_out->pos[lo + i];
+                lists_out->counts[p] = hc[i];
+                memcpy(lists_out->rows + p * topk, hr.data() + (size_t)i * topk, (size_t)hc[i] * 4);
+                memcpy(lists_out->scores + p * topk, hs.data() + (size_t)i * topk, (size_t)hc[i] * 4);
+            }
+            continue;
+        }
         CX_HIP(hipMemcpyAsync(root->d_scan, scan.data() + lo, (size_t)m * 4, hipMemcpyHostToDevice, root->stream));
         LinkArgs a;
         memset(&a, 0, sizeof a);
@@ -851,6 +885,116 @@ int cx_sharded_dedup_scan_rows(const cx_sharded *h, float dedup_threshold, const
     std::vector<float> w;
     if (int rc = link_pass_sharded(h, scan, {}, nullptr, TOPK_MAX, dedup_threshold, 0, ~0ull, deleted, true, f, t, w)) return rc;
     return hand_over(f, t, w, cap, out_a, out_b, out_similarity, n_out, n_needed);
+} catch (...) { return cx::on_exception(); }
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------ the rest of the single-index surface, sharded
+
+extern "C" {
+
+int cx_sharded_topk_lists_rows(const cx_sharded *h, uint64_t n_scan, const uint32_t *scan_rows, uint64_t topk64,
+                               uint32_t *out_rows, float *out_scores, uint32_t *out_counts) try {
+    if (!h || !out_rows || !out_scores || !out_counts) return set_err(CX_ERR_VALIDATION, "null argument");
+    if (topk64 == 0 || topk64 > TOPK_MAX) return set_err(CX_ERR_VALIDATION, "topk lists: topk must be in 1..%u", TOPK_MAX);
+    const uint64_t n_seq = h->seq_shard.size();
+    if (!scan_rows) n_scan = n_seq;
+    std::vector<uint32_t> scan, pos;
+    for (uint64_t i = 0; i < n_scan; i++) {
+        const uint64_t q = scan_rows ? scan_rows[i] : i;
+        if (q >= n_seq) return set_err(CX_ERR_VALIDATION, "scan row %llu out of range", (unsigned long long)q);
+        out_counts[i] = 0;                    // a removed row has no embedding: no list (auto_linker.rs:217-218)
+        if (!h->seq_alive[q]) continue;
+        scan.push_back((uint32_t)q);
+        pos.push_back((uint32_t)i);
+    }
+    ListsOut lo{out_rows, out_scores, out_counts, pos.data()};
+    std::vector<uint32_t> f, t;
+    std::vector<float> w;
+    return link_pass_sharded(h, scan, {}, nullptr, (uint32_t)topk64, 0.0f, 0, ~0ull, nullptr, false, f, t, w, &lo);
+} catch (...) { return cx::on_exception(); }
+
+int cx_sharded_set_metadata_batch(cx_sharded *h, uint64_t n, const uint8_t *ids, const uint32_t *kind_codes,
+                                  const uint32_t *agent_codes) try {
+    if (!h) return set_err(CX_ERR_VALIDATION, "null index");
+    if (n && (!ids || !kind_codes || !agent_codes)) return set_err(CX_ERR_VALIDATION, "null argument");
+    for (uint64_t i = 0; i < n; i++)
+        if (int rc = cx_sharded_set_metadata(h, ids + 16 * i, kind_codes[i], agent_codes[i])) return rc;
+    return CX_OK;
+} catch (...) { return cx::on_exception(); }
+
+int cx_sharded_set_node_stats_batch(cx_sharded *h, uint64_t n, const uint8_t *ids, const uint32_t *kind_codes,
+                                    const int64_t *last_accessed_s, const uint32_t *last_accessed_ns,
+                                    const uint64_t *access_counts) try {
+    if (!h) return set_err(CX_ERR_VALIDATION, "null index");
+    if (!n) return CX_OK;
+    if (!ids || !kind_codes || !last_accessed_s || !access_counts) return set_err(CX_ERR_VALIDATION, "null argument");
+    if (h->h_stats.size() < h->seq_shard.size()) h->h_stats.resize(h->seq_shard.size());
+    for (uint64_t i = 0; i < n; i++) {
+        auto it = h->map.find(id_key(ids + 16 * i));
+        if (it == h->map.end()) continue;   // a node without a vector never shows up in a search
+        NodeStats &s = h->h_stats[it->second];
+        s.last_s = last_accessed_s[i];
+        s.last_ns = last_accessed_ns ? last_accessed_ns[i] : 0u;
+        s.kind = kind_codes[i];
+        s.access = access_counts[i];
+    }
+    return CX_OK;
+} catch (...) { return cx::on_exception(); }
+
+int cx_sharded_bulk_load_nodes(cx_sharded *h, uint64_t n, const uint8_t *blob, const uint64_t *offsets, uint32_t flags,
+                               cx_bulk_stats *stats) try {
+    if (stats) *stats = cx_bulk_stats{};
+    if (!h) return set_err(CX_ERR_VALIDATION, "null index");
+    cx::BulkSink sink;
+    sink.dim = h->dim;
+    sink.device = h->root;
+    sink.upsert = [h](uint64_t m, const uint8_t *ids, const float *embs) { return cx_sharded_upsert_batch(h, m, ids, embs, h->dim); };
+    sink.intern = [h](const char *p, uint64_t len) { return cx_sharded_intern(h, p, len); };
+    sink.set_stats = [h](uint64_t m, const uint8_t *ids, const uint32_t *kc, const int64_t *ls, const uint32_t *lns, const uint64_t *ac) {
+        return cx_sharded_set_node_stats_batch(h, m, ids, kc, ls, lns, ac);
+    };
+    sink.set_meta = [h](uint64_t m, const uint8_t *ids, const uint32_t *k, const uint32_t *a) { return cx_sharded_set_metadata_batch(h, m, ids, k, a); };
+    return cx::bulk_load_impl(sink, n, blob, offsets, flags, stats);
+} catch (...) { return cx::on_exception(); }
+
+/* cx_search_decayed over the shards: the handler's candidates -> apply_score_decay -> stable re-rank -> truncate
+ * (routes.rs:889-947), with the candidates from cx_sharded_search and the node stats kept per global row. */
+int cx_sharded_search_decayed(const cx_sharded *h, const float *query, uint64_t len, uint64_t limit, uint64_t candidate_limit,
+                              const cx_filter *filter, const cx_decay_config *cfg, float recency_bias, int64_t now_s,
+                              uint32_t now_ns, uint8_t *out_ids, float *out_scores, float *out_raw_scores, uint64_t *n_out) try {
+    if (!h || !query || !cfg || !n_out) return set_err(CX_ERR_VALIDATION, "null argument");
+    *n_out = 0;
+    if (cfg->n_by_kind && (!cfg->kind_codes || !cfg->kind_rates)) return set_err(CX_ERR_VALIDATION, "null by_kind table");
+    if (candidate_limit < limit) candidate_limit = limit;
+    const uint64_t cap = std::max<uint64_t>(1, std::min<uint64_t>(candidate_limit, h->seq_shard.size()));
+    std::vector<uint8_t> ids(16 * (size_t)cap);
+    std::vector<float> raw((size_t)cap), dist((size_t)cap);
+    uint64_t n = 0;
+    if (int rc = cx_sharded_search(h, query, len, candidate_limit, filter, ids.data(), raw.data(), dist.data(), &n)) return rc;
+    if (n && limit && (!out_ids || !out_scores || !out_raw_scores)) return set_err(CX_ERR_VALIDATION, "null output buffer");
+    std::vector<float> fin((size_t)n);
+    std::vector<uint32_t> order((size_t)n);
+    for (uint64_t i = 0; i < n; i++) {
+        auto it = h->map.find(id_key(&ids[16 * (size_t)i]));
+        int64_t ls = 0; uint32_t lns = 0, kind = 0; uint64_t ac = 0;   // nodes nobody described: the epoch, never accessed (types.rs:56)
+        if (it != h->map.end() && it->second < h->h_stats.size()) {
+            const NodeStats &s = h->h_stats[it->second];
+            ls = s.last_s; lns = s.last_ns; kind = s.kind; ac = s.access;
+        }
+        fin[i] = cx_apply_score_decay(cfg, raw[i], recency_bias, now_s, now_ns, kind, ls, lns, ac);
+        order[i] = (uint32_t)i;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return fin[a] > fin[b]; });
+    const uint64_t take = std::min<uint64_t>(n, limit);
+    for (uint64_t j = 0; j < take; j++) {
+        const uint32_t i = order[j];
+        memcpy(out_ids + 16 * j, &ids[16 * (size_t)i], 16);
+        out_scores[j] = fin[i];
+        out_raw_scores[j] = raw[i];
+    }
+    *n_out = take;
+    return CX_OK;
 } catch (...) { return cx::on_exception(); }
 
 }  // extern "C"

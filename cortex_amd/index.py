@@ -485,9 +485,10 @@ class _ShardedAbi:
     """Presents the cx_sharded_* entry points under the names of their single-index counterparts, so that
     ShardedHipIndex IS HipIndex with a different handle: every method that has a sharded form runs unchanged; one
     that has none fails loudly instead of reaching a shard behind the index's back."""
-    _HAVE = {"upsert", "upsert_batch", "upsert_batch_dev", "remove", "set_metadata", "intern", "lookup", "len", "dimension",
-             "row_count", "row_id", "rows_of", "rebuild", "search", "search_batch", "search_threshold",
-             "autolink_pass_rows", "dedup_scan_rows"}
+    _HAVE = {"upsert", "upsert_batch", "upsert_batch_dev", "remove", "set_metadata", "set_metadata_batch", "intern", "lookup",
+             "len", "dimension", "row_count", "row_id", "rows_of", "rebuild", "search", "search_batch", "search_threshold",
+             "autolink_pass_rows", "dedup_scan_rows", "topk_lists_rows", "bulk_load_nodes", "set_node_stats_batch",
+             "search_decayed"}
 
     def __init__(self, L):
         self._L = L

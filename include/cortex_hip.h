@@ -412,6 +412,25 @@ int cx_sharded_autolink_pass_rows(const cx_sharded *h, uint64_t n_scan, const ui
 int cx_sharded_dedup_scan_rows(const cx_sharded *h, float dedup_threshold, const uint8_t *deleted, uint64_t cap,
                                uint32_t *out_a, uint32_t *out_b, float *out_similarity, uint64_t *n_out,
                                uint64_t *n_needed);
+/* cx_topk_lists_rows over all shards (the linker's `search(&emb, topk, None)` per scanned node when the reference's
+ * structural rules are on, SURVEY a14'): global rows in, global rows out; every shard runs its batched search over
+ * each block of scanned vectors, the lists are merged on the root. */
+int cx_sharded_topk_lists_rows(const cx_sharded *h, uint64_t n_scan, const uint32_t *scan_rows, uint64_t topk,
+                               uint32_t *out_rows, float *out_scores, uint32_t *out_counts);
+/* cx_set_metadata_batch / cx_bulk_load_nodes / cx_set_node_stats_batch / cx_search_decayed, sharded: the start-up
+ * load from the nodes table (serve.rs:105-123) and the HTTP handler's decayed search (routes.rs:889-947) work on the
+ * multi-GPU index unchanged; node stats are kept per global row. */
+int cx_sharded_set_metadata_batch(cx_sharded *h, uint64_t n, const uint8_t *ids, const uint32_t *kind_codes,
+                                  const uint32_t *agent_codes);
+int cx_sharded_bulk_load_nodes(cx_sharded *h, uint64_t n, const uint8_t *blob, const uint64_t *offsets, uint32_t flags,
+                               cx_bulk_stats *stats);
+int cx_sharded_set_node_stats_batch(cx_sharded *h, uint64_t n, const uint8_t *ids, const uint32_t *kind_codes,
+                                    const int64_t *last_accessed_s, const uint32_t *last_accessed_ns,
+                                    const uint64_t *access_counts);
+int cx_sharded_search_decayed(const cx_sharded *h, const float *query, uint64_t len, uint64_t limit,
+                              uint64_t candidate_limit, const cx_filter *filter, const cx_decay_config *cfg,
+                              float recency_bias, int64_t now_s, uint32_t now_ns, uint8_t *out_ids,
+                              float *out_scores, float *out_raw_scores, uint64_t *n_out);
 
 /* ---- measurement and diagnostics -------------------------------------- */
 

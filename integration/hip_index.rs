@@ -91,6 +91,15 @@ extern "C" {
                                      out_to: *mut u32, out_weight: *mut f32, n_out: *mut u64, n_needed: *mut u64) -> c_int;
     fn cx_sharded_dedup_scan_rows(h: *const c_void, dedup_threshold: f32, deleted: *const u8, cap: u64, out_a: *mut u32,
                                   out_b: *mut u32, out_similarity: *mut f32, n_out: *mut u64, n_needed: *mut u64) -> c_int;
+    fn cx_sharded_topk_lists_rows(h: *const c_void, n_scan: u64, scan_rows: *const u32, topk: u64, out_rows: *mut u32,
+                                  out_scores: *mut f32, out_counts: *mut u32) -> c_int;
+    fn cx_sharded_bulk_load_nodes(h: *mut c_void, n: u64, blob: *const u8, offsets: *const u64, flags: u32,
+                                  stats: *mut CxBulkStats) -> c_int;
+    fn cx_sharded_set_node_stats_batch(h: *mut c_void, n: u64, ids: *const u8, kind_codes: *const u32, last_accessed_s: *const i64,
+                                       last_accessed_ns: *const u32, access_counts: *const u64) -> c_int;
+    fn cx_sharded_search_decayed(h: *const c_void, q: *const f32, len: u64, limit: u64, candidate_limit: u64, f: *const CxFilter,
+                                 cfg: *const CxDecayConfig, recency_bias: f32, now_s: i64, now_ns: u32, ids: *mut u8,
+                                 scores: *mut f32, raw_scores: *mut f32, n_out: *mut u64) -> c_int;
     // start-up bulk load from the nodes table
     fn cx_bulk_load_nodes(ix: *mut c_void, n: u64, blob: *const u8, offsets: *const u64, flags: u32,
                           stats: *mut CxBulkStats) -> c_int;
@@ -361,6 +370,16 @@ impl ShardedHipIndex {
         check(unsafe { cx_sharded_upsert_batch(self.h, ids.len() as u64, flat.as_ptr(), embeddings.as_ptr(), len as u64) })
     }
     fn lookup(&self, s: &str) -> u32 { unsafe { cx_sharded_lookup(self.h, s.as_ptr() as *const c_char, s.len() as u64) } }
+    /// serve.rs:105-123 in one call, as HipIndex::bulk_load_nodes: the records are decoded once on the host and the
+    /// embeddings dealt to the shards block by block.
+    pub fn bulk_load_nodes<'a>(&mut self, values: impl Iterator<Item = &'a [u8]>, strict: bool) -> Result<CxBulkStats> {
+        let (mut blob, mut offsets): (Vec<u8>, Vec<u64>) = (Vec::new(), vec![0]);
+        for v in values { blob.extend_from_slice(v); offsets.push(blob.len() as u64); }
+        let mut st = CxBulkStats::default();
+        check(unsafe { cx_sharded_bulk_load_nodes(self.h, (offsets.len() - 1) as u64, blob.as_ptr(), offsets.as_ptr(),
+                                                  if strict { CX_BULK_STRICT } else { 0 }, &mut st) })?;
+        Ok(st)
+    }
     fn filter(&self, f: Option<&VectorFilter>) -> Option<Box<FilterBuf>> {
         let f = f?;
         let mut b = Box::new(FilterBuf { ex: Vec::new(), kinds: Vec::new(), c: unsafe { std::mem::zeroed() } });

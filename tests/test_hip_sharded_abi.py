@@ -212,3 +212,47 @@ def test_sharded_concurrent_readers_and_empty_shards(hip, oracle):
     assert not errs, errs[0]
     with pytest.raises(hip.ValidationError):
         sh.save("/tmp/x")                                                 # no sharded form: fails loudly
+
+
+def test_sharded_lists_bulk_load_and_decayed_search(hip, oracle, monkeypatch):
+    """The rest of the single-index surface on the multi-GPU index: the linker's ordered top-k lists, the start-up load from
+    stored `Node` records (serve.rs:105-123) and the HTTP handler's decayed search (routes.rs:889-947) — each equal to
+    the single index over the same input."""
+    import test_hip_bulk_load as BL
+    from cortex_amd import scoring as S
+    monkeypatch.setenv("CX_SHARD_PLACEMENT_BLOCK", "512")        # several placement blocks per shard at this size
+    n, d = 4000, 384
+    recs, nodes = BL._records(oracle, n, d, seed=5)
+    one = hip.HipIndex(d)
+    sh = hip.ShardedHipIndex(d, [0, 0, 0])
+    st1 = one.bulk_load_nodes(recs, set_metadata=True, set_stats=True)
+    st2 = sh.bulk_load_nodes(recs, set_metadata=True, set_stats=True)
+    assert st1 == st2 and st2["indexed"] > 2500
+    assert len(sh) == len(one) and all(sh.shard_len(i) > 0 for i in range(3))
+    qs = oracle.synth_queries(n, d, 8)
+    for q in qs[:4]:
+        same_lists(sh.search_arrays(q, 20), one.search_arrays(q, 20), "after bulk load")
+        same_lists(sh.search_arrays(q, 20, hip.VectorFilter(kinds=["decision"], source_agent="agent-1")),
+                   one.search_arrays(q, 20, hip.VectorFilter(kinds=["decision"], source_agent="agent-1")), "metadata from the records")
+    # decayed search: the node stats came with the records
+    cfg = S.ScoreDecayConfig()
+    now = (1_704_067_200 + 90 * 86400, 0)
+    for q in qs:
+        for limit, rb in ((10, None), (5, 0.5), (3, 1.0)):
+            assert sh.search_decayed(q, limit, cfg, recency_bias=rb, now=now) == one.search_decayed(q, limit, cfg, recency_bias=rb, now=now)
+    # ordered top-k lists of scanned rows (global rows), removed rows included in the scan
+    for ix in (one, sh):
+        ix.remove(ix.row_id(17).bytes)
+    scan = np.array([0, 5, 17, 999, 2000, one.row_count() - 1] + list(range(100, 400, 7)), dtype=np.uint32)
+    a = sh.topk_lists_rows(50, scan)
+    b = one.topk_lists_rows(50, scan)
+    assert np.array_equal(a[2], b[2]) and a[2][2] == 0
+    for p in range(len(scan)):
+        c = int(b[2][p])
+        assert_topk_parity(a[0][p, :c].astype(np.int64), a[1][p, :c], b[0][p, :c].astype(np.int64), b[1][p, :c], tol=1e-5, what=f"lists row {scan[p]}")
+    a = sh.topk_lists_rows(100, None)
+    b = one.topk_lists_rows(100, None)        # >= 256 rows: the single index takes its filter path, the shards their batched search
+    assert np.array_equal(a[2], b[2])
+    for p in range(0, one.row_count(), 97):
+        c = int(b[2][p])
+        assert_topk_parity(a[0][p, :c].astype(np.int64), a[1][p, :c], b[0][p, :c].astype(np.int64), b[1][p, :c], tol=1e-5, what=f"all-rows lists row {p}")
