@@ -42,7 +42,7 @@ constexpr int NQ = 64;              // queries per pass
 constexpr int STEP_BYTES = 2 * NQ * 4 * 16;   // one step's query image: hi [64][4 kq][8 bf16] | lo = 8 KiB
 constexpr int KB_BYTES = STEPS * STEP_BYTES;  // 32 KiB
 constexpr int SUB_BYTES = 16 * KB * 4;        // a wave's 16 rows x one K-block f32 = 8 KiB
-constexpr int LDS_BYTES = 2 * KB_BYTES + 8 * SUB_BYTES;   // query images double buffered + one row region per wave = 128 KiB
+constexpr int LDS_BYTES = 2 * KB_BYTES + 8 * SUB_BYTES + 256;   // query images double buffered + one row region per wave (+ 64 counters) = 128 KiB
 
 __device__ inline void split4g(const f32x4 v, bf16x4_t &hi, bf16x4_t &lo) {   // as batch.hip's split4
     const uint32_t p01 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v.x, v.y}, bf16x2_t));
@@ -96,28 +96,41 @@ struct BatchGArgs {
     const float *norms;    // |row|^2 (cx_index::d_norms)
     const char *qimg;      // split query images, dim / 32 steps of 8 KiB
     const float *qq;       // [64] |q|^2
-    float *dense;          // [64][stride] cosines out
+    float *dense;          // dense mode: [64][stride] cosines out
     uint32_t n_rows, dim, nq, stride;
+    uint32_t tile_step;    // dense mode over a sample: block tile t reads row tile t * tile_step, writes dense column tile t
+    uint32_t n_tiles;      // tiles this launch walks
+    // filter mode (tau_ord != null): instead of 4 bytes per row and query, only the (key, cosine) of the rows whose score
+    // reaches the query's bound, into this block's list of the query
+    const uint32_t *tau_ord;   // [64] score_ord of the bound (0: everything passes)
+    uint64_t *cand_keys;       // [64][gridDim.x][cb], zeroed by the caller
+    float *cand_sims;
+    uint32_t *overflow;        // [1] set when a block's list of some query was too short
+    uint32_t cb;
+    const uint32_t *run_if;    // non-null: the launch does nothing unless *run_if != 0 (the exact fallback)
 };
 
 // PROBE: 0 = the product; 1 = loads only (no LDS transpose, no split, no MFMA); 2 = no row loads (MFMAs on stale data)
-template <int PROBE>
+template <int PROBE, bool FILTER>
 __global__ __launch_bounds__(512) void batchg_kernel(const BatchGArgs a) {
     using namespace bg;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (a.run_if && *a.run_if == 0u) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const uint32_t j = lane & 15u, kq = lane >> 4;
-    const uint32_t n_tiles = (a.n_rows + TILE_ROWS - 1) / TILE_ROWS;
+    const uint32_t n_tiles = a.n_tiles;
     const uint32_t n_kb = a.dim / KB;
     if (blockIdx.x >= n_tiles) return;
     const uint32_t my_tiles = (n_tiles - 1u - blockIdx.x) / gridDim.x + 1u;
     const uint32_t total_kb = my_tiles * n_kb;   // K-blocks this block walks: the query images cycle once per tile
     char *Qs = smem;                                              // [2][KB_BYTES] query images, double buffered
-    char *Rw = smem + 2 * KB_BYTES + wave * SUB_BYTES;            // this wave's 32 rows x 64 k f32, pieces swizzled
+    char *Rw = smem + 2 * KB_BYTES + wave * SUB_BYTES;            // this wave's 16 rows x 128 k f32, pieces swizzled
+    uint32_t *Cnt = reinterpret_cast<uint32_t *>(smem + 2 * KB_BYTES + 8 * SUB_BYTES);   // filter mode: entries in this block's list of each query
+    if (FILTER && tid < 64u) Cnt[tid] = 0u;
 
     auto tile_barrier = [&]() {   // raw barrier: __syncthreads() would drain the rows in flight (vmcnt(0))
-        if constexpr (PROBE == 3 || PROBE == 4) return;
+        if constexpr (PROBE == 3) return;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -159,7 +172,7 @@ __global__ __launch_bounds__(512) void batchg_kernel(const BatchGArgs a) {
     const uint32_t lane_off = lrow * a.dim * 4u + lpiece * 16u;
     f32x4 xa[8], xb[8];   // two K-blocks of this wave's rows in flight (16 KiB per wave, 128 KiB per CU)
     auto r_fetch = [&](f32x4 (&dst)[8], uint32_t tile, uint32_t kb) {   // kb: K-block inside the row
-        const char *base = reinterpret_cast<const char *>(a.rows) + ((size_t)tile * TILE_ROWS + wave * 16u) * a.dim * 4u + (size_t)kb * 512u;
+        const char *base = reinterpret_cast<const char *>(a.rows) + ((size_t)tile * a.tile_step * TILE_ROWS + wave * 16u) * a.dim * 4u + (size_t)kb * 512u;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             if constexpr (PROBE == 2) { asm volatile("" : "+v"(dst[i])); continue; }
@@ -197,7 +210,7 @@ __global__ __launch_bounds__(512) void batchg_kernel(const BatchGArgs a) {
         }
     };
     auto consume = [&](const f32x4 (&src)[8], uint32_t buf) {
-        if constexpr (PROBE == 1 || PROBE == 3 || PROBE == 4) {
+        if constexpr (PROBE == 1 || PROBE == 3) {
 #pragma unroll
             for (int i = 0; i < 8; i++) acc[i & 3] += src[i];
             return;
@@ -205,63 +218,94 @@ __global__ __launch_bounds__(512) void batchg_kernel(const BatchGArgs a) {
         lds_put(src);
         compute_kb(buf);
     };
-    // C layout: lane (j, kq) holds rows 4 kq + e (e = 0..3) of query j of group g: four consecutive rows -> one float4
+    // C layout: lane (j, kq) holds rows 4 kq + e (e = 0..3) of query j of group g: four consecutive rows -> one float4.
+    // Nothing here may be a vector load: vmcnt is in order, so waiting for one would first drain the row loads of the next
+    // two K-blocks — the whole prefetch, once per tile (the round-2 v3 kernel did exactly that: 0.60 of the peak where
+    // its own row stream alone reaches 0.86).  |q|^2 sits in registers from the start, |row|^2 comes by scalar loads
+    // (the 16 rows of a wave are a uniform address; d_norms has 64 floats of readable padding).
+    float qqv[4];
+    uint32_t tauv[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const uint32_t q = (uint32_t)g * 16u + j;
+        qqv[g] = q < a.nq ? a.qq[q] : 1.0f;
+        tauv[g] = (FILTER && q < a.nq) ? a.tau_ord[q] : 0u;
+    }
+    const __attribute__((address_space(4))) float *norms_c = (const __attribute__((address_space(4))) float *)a.norms;
     auto epilogue = [&](uint32_t tile) {
-        const uint32_t r0 = tile * TILE_ROWS + wave * 16u + 4u * kq;
+        const uint32_t w0 = tile * a.tile_step * TILE_ROWS + wave * 16u, r0 = w0 + 4u * kq;   // rows in the store
+        float tn[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++) tn[e] = norms_c[(size_t)w0 + e];
+        f32x4 rr = {tn[0], tn[1], tn[2], tn[3]};
+#pragma unroll
+        for (int c = 1; c < 4; c++)
+            if (kq == (uint32_t)c) rr = f32x4{tn[4 * c], tn[4 * c + 1], tn[4 * c + 2], tn[4 * c + 3]};
         if (r0 >= a.n_rows) return;
-        f32x4 rr = {1.0f, 1.0f, 1.0f, 1.0f};
-        if (r0 + 3u < a.n_rows) rr = *reinterpret_cast<const f32x4 *>(a.norms + r0);
-        else { for (uint32_t e = 0; e < 4u; e++) if (r0 + e < a.n_rows) rr[e] = a.norms[r0 + e]; }
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             const uint32_t q = (uint32_t)g * 16u + j;
             if (q >= a.nq) continue;
-            const float qq = a.qq[q];
             f32x4 c;
 #pragma unroll
-            for (int e = 0; e < 4; e++) c[e] = cosine_from_sums(acc[g][e], qq, rr[e]);
-            float *dst = a.dense + (size_t)q * a.stride + r0;
-            if (r0 + 3u < a.n_rows) *reinterpret_cast<f32x4 *>(dst) = c;
-            else { for (uint32_t e = 0; e < 4u; e++) if (r0 + e < a.n_rows) dst[e] = c[e]; }
+            for (int e = 0; e < 4; e++) c[e] = cosine_from_sums(acc[g][e], qqv[g], rr[e]);
+            if constexpr (FILTER) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float score = score_of(distance_of(c[e]));
+                    if (score_ord(score) >= tauv[g] && r0 + (uint32_t)e < a.n_rows) {
+                        const uint32_t slot = atomicAdd(&Cnt[q], 1u);   // LDS: a returning GLOBAL atomic would drain the row prefetch
+                        if (slot < a.cb) {
+                            const size_t at = ((size_t)q * gridDim.x + blockIdx.x) * a.cb + slot;
+                            a.cand_keys[at] = make_key(score, r0 + (uint32_t)e);
+                            a.cand_sims[at] = c[e];
+                        }
+                    }
+                }
+            } else {
+                float *dst = a.dense + (size_t)q * a.stride + (r0 - (w0 - wave * 16u) + tile * TILE_ROWS);   // dense column: the tile as this launch counts it
+                if (r0 + 3u < a.n_rows) *reinterpret_cast<f32x4 *>(dst) = c;
+                else { for (uint32_t e = 0; e < 4u; e++) if (r0 + e < a.n_rows) dst[e] = c[e]; }
+            }
         }
     };
 
-    // Pipeline over the block's K-blocks, tile by tile, two K-blocks per loop iteration (dim % 256 == 0).  K-block `it`
-    // reads its query image from LDS buffer it & 1; the image of it + 1 (fetched during it - 1) is written to the other
-    // buffer at the top of the K-block and the image of it + 2 requested.  Rows: two register sets = two K-blocks; a set
-    // is re-requested for the K-block TWO ahead (which may belong to the next tile) the moment it has been handed to LDS.
-    // One barrier per K-block, for the query hand-over only.
+    // Every fetch below is UNCONDITIONAL (past the end the address is clamped to data already read): with a load that may
+    // or may not have been issued the compiler cannot count vmcnt and falls back to vmcnt(0) — a drain of the prefetch.
     uint32_t tile = blockIdx.x, it = 0;
     zero_acc();
     q_fetch(0);
     q_store(0);
-    if (total_kb > 1u) q_fetch(1);
+    q_fetch(total_kb > 1u ? 1u : 0u);
     r_fetch(xa, tile, phys_kb(tile, 0));
     r_fetch(xb, tile, phys_kb(tile, 1));
     tile_barrier();
-    // where K-block kbl + 2 of the current tile lives: (tile, kbl + 2) or the next tile's (kbl + 2 - n_kb); false = past the end
+    // where K-block kbl + 2 of the current tile lives: (tile, kbl + 2) or the next tile's (kbl + 2 - n_kb); past the end: (tile, kbl)
     auto ahead = [&](uint32_t t, uint32_t kbl, uint32_t &tl, uint32_t &kb2) {
         kb2 = kbl + 2u;
         tl = tile;
-        if (kb2 >= n_kb) { kb2 -= n_kb; tl = tile + gridDim.x; return t + 1u < my_tiles; }
-        return true;
+        if (kb2 >= n_kb) {
+            if (t + 1u < my_tiles) { kb2 -= n_kb; tl = tile + gridDim.x; }
+            else kb2 = kbl;
+        }
     };
+    const uint32_t last_kb = total_kb - 1u;
     for (uint32_t t = 0; t < my_tiles; t++) {
         for (uint32_t kbl = 0; kbl < n_kb; kbl += 2u, it += 2u) {
             uint32_t tl, kb2;
             // even K-block (buffer 0): xa
             q_store(1);
-            if (it + 2u < total_kb) q_fetch(it + 2u);
-            const bool more0 = ahead(t, kbl, tl, kb2);
+            q_fetch(std::min(it + 2u, last_kb));
+            ahead(t, kbl, tl, kb2);
             consume(xa, 0);
-            if (more0) r_fetch(xa, tl, phys_kb(tl, kb2));
+            r_fetch(xa, tl, phys_kb(tl, kb2));
             tile_barrier();
             // odd K-block (buffer 1): xb
-            if (it + 2u < total_kb) q_store(0);
-            if (it + 3u < total_kb) q_fetch(it + 3u);
-            const bool more1 = ahead(t, kbl + 1u, tl, kb2);
+            q_store(0);
+            q_fetch(std::min(it + 3u, last_kb));
+            ahead(t, kbl + 1u, tl, kb2);
             consume(xb, 1);
-            if (more1) r_fetch(xb, tl, phys_kb(tl, kb2));
+            r_fetch(xb, tl, phys_kb(tl, kb2));
             if (kbl + 2u == n_kb) {
                 epilogue(tile);
                 tile += gridDim.x;
@@ -270,39 +314,79 @@ __global__ __launch_bounds__(512) void batchg_kernel(const BatchGArgs a) {
             tile_barrier();
         }
     }
+    if constexpr (FILTER) {
+        if (tid < 64u && Cnt[tid] > a.cb) *a.overflow = 1u;   // the last tile_barrier() ordered the counters
+    }
 }
 
 bool batchg_supported(uint32_t dim, uint32_t k) { return dim % (2 * bg::KB) == 0 && dim <= 4096 && k >= 1 && k <= TOPK_MAX; }
 size_t batchg_qimg_bytes(uint32_t dim) { return (size_t)(dim / 32u) * bg::STEP_BYTES; }
 
-// nq <= 64 queries against all rows: dense cosines [64][stride] (stride = n_rows rounded up to 4)
-int launch_batchg_scores(const float *rows, const float *norms, uint32_t n_rows, uint32_t dim, const float *d_queries, uint32_t nq,
-                         char *d_qimg, float *d_qq, float *d_dense, uint32_t stride, hipStream_t stream) {
-    using namespace bg;
-    if (!batchg_supported(dim, 1) || nq == 0 || nq > NQ) return set_err(CX_ERR_VALIDATION, "batchg: dim %u / %u queries not supported", dim, nq);
-    if (!n_rows) return CX_OK;
+uint32_t batchg_grid(uint32_t n_rows) {
+    const uint32_t n_tiles = (n_rows + bg::TILE_ROWS - 1) / bg::TILE_ROWS;
+    return std::min<uint32_t>(n_tiles, 2u * device_cus());
+}
+uint32_t batchg_sample_rows(uint32_t n_rows, uint32_t tile_step, uint32_t *n_tiles_out) {
+    if (n_tiles_out) *n_tiles_out = 0;
+    if (!n_rows || !tile_step) return 0;
+    const uint32_t n_tiles = (n_rows + bg::TILE_ROWS - 1) / bg::TILE_ROWS, ns = (n_tiles + tile_step - 1) / tile_step;
+    const uint32_t last_phys = (ns - 1u) * tile_step * bg::TILE_ROWS;
+    if (n_tiles_out) *n_tiles_out = ns;
+    return (ns - 1u) * bg::TILE_ROWS + std::min<uint32_t>(bg::TILE_ROWS, n_rows - last_phys);
+}
+
+int launch_batchg_split(const float *d_queries, uint32_t nq, uint32_t dim, char *d_qimg, float *d_qq, hipStream_t stream) {
+    if (!batchg_supported(dim, 1) || nq == 0 || nq > bg::NQ) return set_err(CX_ERR_VALIDATION, "batchg: dim %u / %u queries not supported", dim, nq);
     hipLaunchKernelGGL(batchg_split_queries_kernel, dim3(16), dim3(256), 0, stream, d_queries, nq, dim, d_qimg, d_qq);
-    static std::atomic<uint64_t> attr_devices{0};
-    if (first_use_on_device(attr_devices)) {
-        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchg_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchg_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchg_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchg_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchg_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    }
-    BatchGArgs a;
-    a.rows = rows; a.norms = norms; a.qimg = d_qimg; a.qq = d_qq; a.dense = d_dense;
-    a.n_rows = n_rows; a.dim = dim; a.nq = nq; a.stride = stride;
-    const uint32_t n_tiles = (n_rows + TILE_ROWS - 1) / TILE_ROWS;
-    const uint32_t grid = std::min<uint32_t>(n_tiles, 2u * device_cus());
-    static const int probe = getenv("CX_BATCHG_PROBE") ? atoi(getenv("CX_BATCHG_PROBE")) : 0;   // measurement arms, results invalid
-    if (probe == 1) hipLaunchKernelGGL(batchg_kernel<1>, dim3(grid), dim3(512), LDS_BYTES, stream, a);
-    else if (probe == 2) hipLaunchKernelGGL(batchg_kernel<2>, dim3(grid), dim3(512), LDS_BYTES, stream, a);
-    else if (probe == 3) hipLaunchKernelGGL(batchg_kernel<3>, dim3(grid), dim3(512), LDS_BYTES, stream, a);   // rows only: no barriers, no query staging
-    else if (probe == 4) hipLaunchKernelGGL(batchg_kernel<4>, dim3(grid), dim3(512), LDS_BYTES, stream, a);   // loads, query staging, no barriers
-    else hipLaunchKernelGGL(batchg_kernel<0>, dim3(grid), dim3(512), LDS_BYTES, stream, a);
     CX_HIP(hipGetLastError());
     return CX_OK;
+}
+
+// nq <= 64 queries (already split: launch_batchg_split) against the rows.
+//   dense mode (f == null): cosines [64][stride]; tile_step > 1 walks every tile_step-th row tile only and packs the
+//     columns (the bound-finding sample of the filter mode); run_if: see BatchGArgs
+//   filter mode: candidates of each query into cand_keys / cand_sims [64][batchg_grid(n_rows)][cb]
+int launch_batchg_pass(const float *rows, const float *norms, uint32_t n_rows, uint32_t dim, uint32_t nq, const char *d_qimg, const float *d_qq,
+                       float *d_dense, uint32_t stride, uint32_t tile_step, const BatchGFilter *f, const uint32_t *run_if, hipStream_t stream) {
+    using namespace bg;
+    if (!batchg_supported(dim, 1) || nq == 0 || nq > NQ || tile_step == 0) return set_err(CX_ERR_VALIDATION, "batchg: dim %u / %u queries not supported", dim, nq);
+    if (!n_rows) return CX_OK;
+    static std::atomic<uint64_t> attr_devices{0};
+    if (first_use_on_device(attr_devices)) {
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchg_kernel<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchg_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchg_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchg_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchg_kernel<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    }
+    BatchGArgs a;
+    memset(&a, 0, sizeof a);
+    a.rows = rows; a.norms = norms; a.qimg = d_qimg; a.qq = d_qq; a.dense = d_dense;
+    a.n_rows = n_rows; a.dim = dim; a.nq = nq; a.stride = stride; a.tile_step = tile_step; a.run_if = run_if;
+    const uint32_t n_tiles = (n_rows + TILE_ROWS - 1) / TILE_ROWS;
+    a.n_tiles = (n_tiles + tile_step - 1) / tile_step;
+    uint32_t grid = std::min<uint32_t>(a.n_tiles, 2u * device_cus());
+    if (f) {
+        a.tau_ord = f->tau_ord; a.cand_keys = f->cand_keys; a.cand_sims = f->cand_sims; a.overflow = f->overflow; a.cb = f->cb;
+        grid = batchg_grid(n_rows);   // the candidate lists are laid out for exactly this grid
+        hipLaunchKernelGGL((batchg_kernel<0, true>), dim3(grid), dim3(512), LDS_BYTES, stream, a);
+        CX_HIP(hipGetLastError());
+        return CX_OK;
+    }
+    static const int probe = getenv("CX_BATCHG_PROBE") ? atoi(getenv("CX_BATCHG_PROBE")) : 0;   // measurement arms, results invalid
+    if (probe == 1) hipLaunchKernelGGL((batchg_kernel<1, false>), dim3(grid), dim3(512), LDS_BYTES, stream, a);        // loads only
+    else if (probe == 2) hipLaunchKernelGGL((batchg_kernel<2, false>), dim3(grid), dim3(512), LDS_BYTES, stream, a);   // no row loads
+    else if (probe == 3) hipLaunchKernelGGL((batchg_kernel<3, false>), dim3(grid), dim3(512), LDS_BYTES, stream, a);   // rows only: no barriers, no query staging
+    else hipLaunchKernelGGL((batchg_kernel<0, false>), dim3(grid), dim3(512), LDS_BYTES, stream, a);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+
+// the round-2 entry: split + one dense pass over every row
+int launch_batchg_scores(const float *rows, const float *norms, uint32_t n_rows, uint32_t dim, const float *d_queries, uint32_t nq,
+                         char *d_qimg, float *d_qq, float *d_dense, uint32_t stride, hipStream_t stream) {
+    if (int rc = launch_batchg_split(d_queries, nq, dim, d_qimg, d_qq, stream)) return rc;
+    return launch_batchg_pass(rows, norms, n_rows, dim, nq, d_qimg, d_qq, d_dense, stride, 1, nullptr, nullptr, stream);
 }
 
 }  // namespace cx

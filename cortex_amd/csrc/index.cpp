@@ -328,7 +328,8 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
     bool no_tails = true;
     for (uint64_t i = 0; tails && i < nq; i++) no_tails = no_tails && tails[i] == 0.0f;
     static const int batch_min = getenv("CX_BATCH_MIN") ? atoi(getenv("CX_BATCH_MIN")) : 3;
-    if (topk_path && no_tails && nq >= (uint64_t)batch_min && k_eff >= 1 && batch_supported(ix->dim, k_eff)) {
+    static const int b2_ok = getenv("CX_BATCH2") ? atoi(getenv("CX_BATCH2")) : 1;   // 0: 768-d through batchg.hip (tests)
+    if (b2_ok && topk_path && no_tails && nq >= (uint64_t)batch_min && k_eff >= 1 && batch_supported(ix->dim, k_eff)) {
         if (int rc = ensure_norms(ix, s)) return rc;
         const uint32_t qpp = batch_queries_per_pass(ix->dim, k_eff, nq);
         uint32_t bgrid = 1, groups = 1;
@@ -390,30 +391,77 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
         if (int rc = ensure_dev(c->d_qimg, c->qi_cap, qimg + 64 * sizeof(float))) return rc;
         if (int rc = ensure_dev(c->d_part_keys, c->pk_cap, (size_t)64 * chunks * k_eff)) return rc;
         if (int rc = ensure_dev(c->d_part_sims, c->ps_cap, (size_t)64 * chunks * k_eff)) return rc;
+        // Large stores with no row filter: bound each query from a 1-in-32 sample of the row tiles, then write only the
+        // rows that reach the bound (kernels.hpp: BatchGFilter) — the 4 bytes per row and query of the dense pass cost
+        // the row stream a fifth of its rate, and launch_dense_topk reads them all back.
+        static const int filter_ok = getenv("CX_BATCHG_FILTER") ? atoi(getenv("CX_BATCHG_FILTER")) : 1;
+        static const uint32_t filter_min = getenv("CX_BATCHG_FILTER_MIN") ? (uint32_t)atoi(getenv("CX_BATCHG_FILTER_MIN")) : 262144u;
+        static const uint32_t tile_step = getenv("CX_BATCHG_SAMPLE_STEP") ? (uint32_t)std::max(1, atoi(getenv("CX_BATCHG_SAMPLE_STEP"))) : 32u;
+        uint32_t s_tiles = 0;
+        const uint32_t s_rows = batchg_sample_rows(n, tile_step, &s_tiles), s_stride = (s_rows + 3u) & ~3u;
+        const bool filtered = filter_ok && flt.trivial && n >= filter_min && s_rows >= k_eff;
+        const uint32_t bgrid = batchg_grid(n);
+        uint32_t cb = std::max<uint32_t>(k_eff, 32u);
+        if (getenv("CX_BATCHG_CAND_CAP")) cb = std::max<uint32_t>(k_eff, (uint32_t)atoi(getenv("CX_BATCHG_CAND_CAP")));   // tests: force the fallback
+        cb = (cb + k_eff - 1u) / k_eff * k_eff;
+        const uint32_t s_chunks = dense_topk_chunks(s_rows);
+        if (filtered) {
+            if (int rc = ensure_dev(c->d_cand_keys, c->ck_cap, (size_t)64 * bgrid * cb)) return rc;
+            if (int rc = ensure_dev(c->d_cand_sims, c->cs_cap, (size_t)64 * bgrid * cb)) return rc;
+            if (int rc = ensure_dev(c->d_bg_ctl, c->bc_cap, (size_t)80)) return rc;
+        }
         for (uint64_t q0 = 0; q0 < nq; q0 += 64) {
             const uint32_t m = (uint32_t)std::min<uint64_t>(64, nq - q0);
+            float *d_qq = reinterpret_cast<float *>(c->d_qimg + qimg);
             hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (ix->profiling) {
+            auto prof_begin = [&]() -> int {
+                if (!ix->profiling) return CX_OK;
                 CX_HIP(hipEventCreate(&e0));
                 CX_HIP(hipEventCreate(&e1));
                 std::lock_guard<std::mutex> g(ix->mu);
                 ix->prof_events.emplace_back(e0, e1);
                 CX_HIP(hipEventRecord(e0, s));
-            }
-            if (int rc = launch_batchg_scores(ix->d_rows, ix->d_norms, n, ix->dim, d_queries + q0 * ix->dim, m, c->d_qimg,
-                                              reinterpret_cast<float *>(c->d_qimg + qimg), c->d_dense, stride, s))
-                return rc;
-            if (e1) CX_HIP(hipEventRecord(e1, s));
-            if (int rc = launch_dense_topk(c->d_dense, stride, n, m, k_eff, flt, c->d_part_keys, c->d_part_sims, chunks, s)) return rc;
+                return CX_OK;
+            };
             MergeArgs mg;
             mg.part_keys = c->d_part_keys;
             mg.part_sims = c->d_part_sims;
-            mg.n_lists = chunks;
             mg.k = k_eff;
             mg.out_rows = d_rows + q0 * k_eff;
             mg.out_scores = d_scores + q0 * k_eff;
             mg.out_dists = d_dists + q0 * k_eff;
             mg.out_count = d_counts + q0;
+            if (int rc = launch_batchg_split(d_queries + q0 * ix->dim, m, ix->dim, c->d_qimg, d_qq, s)) return rc;
+            const uint32_t *run_if = nullptr;
+            if (filtered) {
+                uint32_t *tau = c->d_bg_ctl, *overflow = c->d_bg_ctl + 64;
+                // 1. the bound: top k of the sampled tiles (the output arrays hold it until the real merge overwrites them)
+                if (int rc = launch_batchg_pass(ix->d_rows, ix->d_norms, n, ix->dim, m, c->d_qimg, d_qq, c->d_dense, s_stride, tile_step, nullptr, nullptr, s)) return rc;
+                if (int rc = launch_dense_topk(c->d_dense, s_stride, s_rows, m, k_eff, flt, c->d_part_keys, c->d_part_sims, s_chunks, s)) return rc;
+                mg.n_lists = s_chunks;
+                if (int rc = launch_merge_batch(mg, m, s)) return rc;
+                if (int rc = launch_bound_from_topk(mg.out_scores, mg.out_count, m, k_eff, tau, s)) return rc;
+                // 2. every row, candidates only
+                CX_HIP(hipMemsetAsync(c->d_cand_keys, 0, (size_t)m * bgrid * cb * sizeof(uint64_t), s));
+                CX_HIP(hipMemsetAsync(overflow, 0, sizeof(uint32_t), s));
+                BatchGFilter f{tau, c->d_cand_keys, c->d_cand_sims, overflow, cb};
+                if (int rc = prof_begin()) return rc;
+                if (int rc = launch_batchg_pass(ix->d_rows, ix->d_norms, n, ix->dim, m, c->d_qimg, d_qq, nullptr, 0, 1, &f, nullptr, s)) return rc;
+                if (e1) CX_HIP(hipEventRecord(e1, s));
+                MergeArgs mc = mg;
+                mc.part_keys = c->d_cand_keys;
+                mc.part_sims = c->d_cand_sims;
+                mc.n_lists = bgrid * (cb / k_eff);
+                if (int rc = launch_merge_batch(mc, m, s, false)) return rc;
+                // 3. the exact fallback below runs only if some list overflowed
+                run_if = overflow;
+                e0 = e1 = nullptr;
+            } else if (int rc = prof_begin()) return rc;
+            if (int rc = launch_batchg_pass(ix->d_rows, ix->d_norms, n, ix->dim, m, c->d_qimg, d_qq, c->d_dense, stride, 1, nullptr, run_if, s)) return rc;
+            if (e1) CX_HIP(hipEventRecord(e1, s));
+            if (int rc = launch_dense_topk(c->d_dense, stride, n, m, k_eff, flt, c->d_part_keys, c->d_part_sims, chunks, s, run_if)) return rc;
+            mg.n_lists = chunks;
+            mg.run_if = run_if;
             if (int rc = launch_merge_batch(mg, m, s)) return rc;
         }
         return CX_OK;

@@ -18,6 +18,7 @@ struct MergeArgs {
     float *out_scores;    // [k]
     float *out_dists;     // [k]
     uint32_t *out_count;  // [1]
+    const uint32_t *run_if = nullptr;   // non-null: the launch does nothing unless *run_if != 0
 };
 
 // One single-query scan over the row store.
@@ -99,17 +100,37 @@ uint32_t batch_queries_per_pass(uint32_t dim, uint32_t k, uint64_t nq);
 void batch_launch_shape(uint32_t n_rows, uint32_t dim, uint64_t nq, uint32_t k, uint32_t *chunks, uint32_t *groups);
 // one pass of <= 64 queries; per-block lists, to be folded by launch_merge_batch
 int launch_batch_scan(BatchArgs a, uint32_t grid, hipStream_t stream);
-// second stage for nq queries at once: query q's lists are part[q*n_lists*k ...], outputs at [q*k]
-int launch_merge_batch(const MergeArgs &m, uint32_t nq, hipStream_t stream);
+// second stage for nq queries at once: query q's lists are part[q*n_lists*k ...], outputs at [q*k]; sorted_lists = false:
+// the lists are unordered sets with empty (0) slots anywhere (batchg's candidate lists)
+int launch_merge_batch(const MergeArgs &m, uint32_t nq, hipStream_t stream, bool sorted_lists = true);
 
 // ---- batched search for the other row widths (batchg.hip): dense cosines for <= 64 queries, then top-k ----
 bool batchg_supported(uint32_t dim, uint32_t k);       // dim % 256 == 0, dim <= 4096, k <= 256
 size_t batchg_qimg_bytes(uint32_t dim);                 // scratch for the split query images
 int launch_batchg_scores(const float *rows, const float *norms, uint32_t n_rows, uint32_t dim, const float *d_queries, uint32_t nq,
-                         char *d_qimg, float *d_qq, float *d_dense, uint32_t stride, hipStream_t stream);
+                         char *d_qimg, float *d_qq, float *d_dense, uint32_t stride, hipStream_t stream);   // split + one dense pass
+// The pass in pieces.  Filter mode: a dense pass over every tile_step-th row tile gives each query a bound (the k-th best
+// score of the sample: the k-th best of all rows can only be higher), the pass over all rows then writes only the rows that
+// reach it — (key, cosine) into per-block lists that launch_merge_batch folds like any other partial lists — instead of
+// 4 bytes per row and query.  A block whose list of some query runs over sets *overflow; the caller then runs the dense
+// pass with run_if = overflow (kernels that return at once when the flag is 0), which is exact whatever the data.
+struct BatchGFilter {
+    const uint32_t *tau_ord;   // [64] score_ord of each query's bound
+    uint64_t *cand_keys;       // [64][batchg_grid(n_rows)][cb], zeroed
+    float *cand_sims;
+    uint32_t *overflow;        // [1], zeroed
+    uint32_t cb;               // entries per block and query: a multiple of k
+};
+uint32_t batchg_grid(uint32_t n_rows);
+uint32_t batchg_sample_rows(uint32_t n_rows, uint32_t tile_step, uint32_t *n_tiles_out);   // dense columns a sampled pass fills
+int launch_batchg_split(const float *d_queries, uint32_t nq, uint32_t dim, char *d_qimg, float *d_qq, hipStream_t stream);
+int launch_batchg_pass(const float *rows, const float *norms, uint32_t n_rows, uint32_t dim, uint32_t nq, const char *d_qimg, const float *d_qq,
+                       float *d_dense, uint32_t stride, uint32_t tile_step, const BatchGFilter *f, const uint32_t *run_if, hipStream_t stream);
+// tau_ord[q] = score_ord(scores[q][k-1]) if counts[q] >= k else 0
+int launch_bound_from_topk(const float *scores, const uint32_t *counts, uint32_t nq, uint32_t k, uint32_t *tau_ord, hipStream_t stream);
 uint32_t dense_topk_chunks(uint32_t n_rows);
 int launch_dense_topk(const float *d_dense, uint32_t stride, uint32_t n_rows, uint32_t nq, uint32_t k, const DevFilter &flt,
-                      uint64_t *part_keys, float *part_sims, uint32_t chunks, hipStream_t stream);
+                      uint64_t *part_keys, float *part_sims, uint32_t chunks, hipStream_t stream, const uint32_t *run_if = nullptr);
 
 // ---- all-pairs auto-link pass (allpairs.hip) ----
 int launch_build_shadow(const float *rows, uint16_t *shadow, uint32_t row_lo, uint32_t row_hi, uint32_t dim,

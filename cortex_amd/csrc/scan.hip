@@ -193,6 +193,7 @@ __global__ __launch_bounds__(256) void scan_generic_kernel(const ScanArgs a) {
 // then wave 0 folds the 15 other lists and ranks the k survivors.
 template <int KS>
 __global__ __launch_bounds__(1024) void merge_kernel(const MergeArgs m0) {
+    if (m0.run_if && *m0.run_if == 0u) return;
     MergeArgs m = m0;  // one block per query
     m.part_keys += (size_t)blockIdx.x * m0.n_lists * m0.k;
     m.part_sims += (size_t)blockIdx.x * m0.n_lists * m0.k;
@@ -263,6 +264,7 @@ constexpr uint32_t MERGE_SMALL_MAX_LISTS = 2048;
 template <int NT>
 __device__ inline void merge_small_body(const MergeArgs &m0) {
     // one block per query: query q's lists start at q*n_lists*k, its outputs at q*k
+    if (m0.run_if && *m0.run_if == 0u) return;
     MergeArgs m = m0;
     m.part_keys += (size_t)blockIdx.x * m0.n_lists * m0.k;
     m.part_sims += (size_t)blockIdx.x * m0.n_lists * m0.k;
@@ -446,9 +448,10 @@ int launch_scan_topk(const ScanArgs &a, const MergeArgs &m, bool nontemporal, hi
     return CX_OK;
 }
 
-int launch_merge_batch(const MergeArgs &m, uint32_t nq, hipStream_t stream) {
+int launch_merge_batch(const MergeArgs &m, uint32_t nq, hipStream_t stream, bool sorted_lists) {
     if (!nq || !m.k) return CX_OK;
-    if (m.k <= 32 && m.n_lists <= MERGE_SMALL_MAX_LISTS) hipLaunchKernelGGL(merge_small_kernel, dim3(nq), dim3(1024), 0, stream, m);
+    if (!sorted_lists) hipLaunchKernelGGL(merge_radix_kernel, dim3(nq), dim3(1024), 0, stream, m);   // a selection over all entries
+    else if (m.k <= 32 && m.n_lists <= MERGE_SMALL_MAX_LISTS) hipLaunchKernelGGL(merge_small_kernel, dim3(nq), dim3(1024), 0, stream, m);
     else if (use_old_merge()) {
         if (m.k <= 64) hipLaunchKernelGGL((merge_kernel<1>), dim3(nq), dim3(1024), 0, stream, m);
         else if (m.k <= 128) hipLaunchKernelGGL((merge_kernel<2>), dim3(nq), dim3(1024), 0, stream, m);
@@ -463,7 +466,8 @@ int launch_merge_batch(const MergeArgs &m, uint32_t nq, hipStream_t stream) {
 // partial list — on 4 B per row and query instead of the row itself.  grid = (chunks, nq).
 template <int KS>
 __global__ __launch_bounds__(256) void dense_topk_kernel(const float *dense, uint32_t stride, uint32_t n_rows, uint32_t k, const DevFilter flt,
-                                                         uint64_t *part_keys, float *part_sims) {
+                                                         uint64_t *part_keys, float *part_sims, const uint32_t *run_if) {
+    if (run_if && *run_if == 0u) return;
     const uint32_t q = blockIdx.y, lane = (uint32_t)lane_id(), wave = threadIdx.x >> 6;
     const float *d = dense + (size_t)q * stride;
     WaveTopK<KS> top;
@@ -484,19 +488,30 @@ __global__ __launch_bounds__(256) void dense_topk_kernel(const float *dense, uin
     block_merge_store<KS>(top, k, part_keys + base, part_sims + base);
 }
 
+__global__ void bound_from_topk_kernel(const float *scores, const uint32_t *counts, uint32_t nq, uint32_t k, uint32_t *tau_ord) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nq) tau_ord[q] = counts[q] >= k ? score_ord(scores[(size_t)q * k + k - 1u]) : 0u;
+}
+int launch_bound_from_topk(const float *scores, const uint32_t *counts, uint32_t nq, uint32_t k, uint32_t *tau_ord, hipStream_t stream) {
+    if (!nq || !k) return CX_OK;
+    hipLaunchKernelGGL(bound_from_topk_kernel, dim3((nq + 63u) / 64u), dim3(64), 0, stream, scores, counts, nq, k, tau_ord);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+
 uint32_t dense_topk_chunks(uint32_t n_rows) {
     const uint32_t c = (n_rows + 16383u) / 16384u;   // >= 16k rows per block: the running bound means something
     return c < 1u ? 1u : (c > 256u ? 256u : c);
 }
 
 int launch_dense_topk(const float *d_dense, uint32_t stride, uint32_t n_rows, uint32_t nq, uint32_t k, const DevFilter &flt,
-                      uint64_t *part_keys, float *part_sims, uint32_t chunks, hipStream_t stream) {
+                      uint64_t *part_keys, float *part_sims, uint32_t chunks, hipStream_t stream, const uint32_t *run_if) {
     if (!nq || !n_rows || !k) return CX_OK;
     if (k > TOPK_MAX) return set_err(CX_ERR_VALIDATION, "dense top-k: k=%u exceeds %u", k, TOPK_MAX);
     const dim3 grid(chunks, nq);
-    if (k <= 64) hipLaunchKernelGGL((dense_topk_kernel<1>), grid, dim3(256), 0, stream, d_dense, stride, n_rows, k, flt, part_keys, part_sims);
-    else if (k <= 128) hipLaunchKernelGGL((dense_topk_kernel<2>), grid, dim3(256), 0, stream, d_dense, stride, n_rows, k, flt, part_keys, part_sims);
-    else hipLaunchKernelGGL((dense_topk_kernel<4>), grid, dim3(256), 0, stream, d_dense, stride, n_rows, k, flt, part_keys, part_sims);
+    if (k <= 64) hipLaunchKernelGGL((dense_topk_kernel<1>), grid, dim3(256), 0, stream, d_dense, stride, n_rows, k, flt, part_keys, part_sims, run_if);
+    else if (k <= 128) hipLaunchKernelGGL((dense_topk_kernel<2>), grid, dim3(256), 0, stream, d_dense, stride, n_rows, k, flt, part_keys, part_sims, run_if);
+    else hipLaunchKernelGGL((dense_topk_kernel<4>), grid, dim3(256), 0, stream, d_dense, stride, n_rows, k, flt, part_keys, part_sims, run_if);
     CX_HIP(hipGetLastError());
     return CX_OK;
 }
@@ -521,6 +536,7 @@ int launch_scan_dense(const ScanArgs &a, bool nontemporal, hipStream_t stream) {
 // 0.9 ms at k = 256 for 512 lists — as long as the scan itself).
 constexpr uint32_t MERGE_RADIX_CAP = 2048;
 __global__ __launch_bounds__(1024) void merge_radix_kernel(const MergeArgs m0) {
+    if (m0.run_if && *m0.run_if == 0u) return;
     MergeArgs m = m0;  // one block per query
     m.part_keys += (size_t)blockIdx.x * m0.n_lists * m0.k;
     m.part_sims += (size_t)blockIdx.x * m0.n_lists * m0.k;

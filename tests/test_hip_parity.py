@@ -665,3 +665,68 @@ def test_scores_against_f64_ground_truth(hip, oracle, d):
     outside = set(np.nonzero(truth[0] < 0.6 - SCORE_TOL)[0].tolist())
     assert inside <= set(r.tolist()) and not (outside & set(r.tolist()))
     assert worst <= 1e-5, f"scores drifted from the f64 truth: {worst}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [
+    {"CX_BATCH2": "0"},                                                   # 768-d through batchg.hip (batch2_kernel normally serves it)
+    {"CX_BATCHG_FILTER_MIN": "1000"},                                     # the bound + candidates path at test sizes
+    {"CX_BATCHG_FILTER_MIN": "1000", "CX_BATCHG_SAMPLE_STEP": "100000"},  # a one-tile sample: weak bounds, lists overflow, exact fallback
+    {"CX_BATCHG_FILTER": "0"},                                            # the dense pass only
+])
+def test_search_batch_other_kernel_instances(env):
+    """batchg.hip's paths the default dispatch does not reach at test sizes — each against the oracle in its own
+    process (the switches are read once)."""
+    import subprocess, sys, os
+    code = r"""
+import numpy as np, sys, os
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import cortex_amd
+from oracle import oracle
+from conftest import assert_topk_parity, ids_for
+oracle.build()
+for n, d, k, nq in [(3001, 768, 10, 70), (1520, 768, 100, 9), (9100, 1024, 10, 64), (30000, 512, 32, 7), (130, 256, 5, 40), (5000, 1536, 256, 3)]:
+    rows = oracle.synth_rows(n, d); qs = oracle.synth_queries(n, d, nq); ids = ids_for(n)
+    lut = {ids[i].tobytes(): i for i in range(n)}
+    h = cortex_amd.HipIndex(d); h.insert_batch(ids, rows)
+    o = oracle.OracleIndex(d); o.insert_batch(ids, rows)
+    bi, bs, bd, bc = h.search_batch_arrays(qs, k)
+    for i in range(nq):
+        e = o.search(qs[i], k); m = int(bc[i])
+        assert m == len(e["row"]), (m, len(e["row"]))
+        got = np.array([lut[g.tobytes()] for g in bi[i, :m]], dtype=np.int64)
+        assert_topk_parity(got, bs[i, :m], e["row"], e["score"], what="n=%%d d=%%d k=%%d q%%d" %% (n, d, k, i))
+print("ok")
+""" % ((os.path.dirname(os.path.dirname(os.path.abspath(__file__))),) * 2)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.gpu
+def test_batched_search_bound_and_candidates_at_scale(hip):
+    """400k x 1024 (1.6 GB), 70 queries, k = 10 and 100: batchg.hip's default path at this size — a bound per query from a
+    1-in-32 sample of the row tiles, then only the rows that reach it — must return what 70 single-query scans return
+    (ids, order, scores: both paths compute f32-exact cosines, the scan is pinned to the oracle above)."""
+    import torch
+    from cortex_amd import _lib
+    L = _lib.load()
+    n, d, nq = 400_000, 1024, 70
+    gen = torch.empty((n, d), dtype=torch.float32, device="cuda:0")
+    assert L.cx_synth_fill_dev(0, gen.data_ptr(), 20260313, 20260313, 20260315, n // 50, 0, n, d, 1) == 0
+    ids = np.zeros((n, 16), np.uint8)
+    ids[:, 8:] = np.arange(n, dtype=np.uint64).astype(">u8").view(np.uint8).reshape(n, 8)
+    h = hip.HipIndex(d)
+    h.insert_batch_dev(ids, gen.data_ptr(), n, d)
+    qs_t = torch.empty((nq, d), dtype=torch.float32, device="cuda:0")
+    assert L.cx_synth_fill_dev(0, qs_t.data_ptr(), 20260313, 20260314, 20260315, n // 50, 0, nq, d, 0) == 0
+    qs = qs_t.cpu().numpy()
+    del gen
+    for k in (10, 100):
+        bi, bs, bd, bc = h.search_batch_arrays(qs, k)
+        for i in range(nq):
+            gi, gs, gd = h.search_arrays(qs[i], k)
+            m = int(bc[i])
+            assert m == len(gs) == k
+            got = np.array([int.from_bytes(bytes(x[8:]), "big") for x in bi[i, :m]])
+            exp = np.array([int.from_bytes(bytes(x[8:]), "big") for x in gi])
+            assert_topk_parity(got, bs[i, :m], exp, gs, what=f"k={k} q{i}")
