@@ -246,8 +246,8 @@ def main() -> None:
     if rank == 0 and world == 1 and not args.no_autolink and not args.no_cpu_baseline and B == 1:
         out["extra"]["config5_shard_6.25Mx1024_streaming_ingest"] = config5_leg(L, local_rank, dev)
         # config 5's row width through search_batch: the batched kernel for the widths batch2 has no instance for
-        out["extra"]["config5_width_1Mx1024_batch64_k10"] = config4_leg(L, local_rank, dev, n=1_000_000, d=1024, steps=20,
-                                                                        kernel="cx::batchg_kernel", shard_note="1M-row slice at config 5's width")
+        out["extra"]["config5_shard_6.25Mx1024_batch64_k10"] = config4_leg(L, local_rank, dev, n=6_250_000, d=1024, steps=10,
+                                                                           kernel="cx::batchg_kernel<0, true>", shard_note="one of 8 shards of config 5's 50M rows")
     if rank == 0:
         print(json.dumps(out), flush=True)
     ix.close()

@@ -7,18 +7,30 @@
 // the operands swap: the queries (pre-split once per call into the MFMA B-operand layout, batchg_split_queries_kernel)
 // are staged K-block by K-block through LDS, and the ROWS go straight from HBM into registers, are split there
 // (hi = bf16(a), lo = bf16(a - hi): the same three-product scheme as batch.hip, |cos error| <= 1e-6) and multiplied
-// as the MFMA A operand.  Any dim % 256 == 0 up to 4096; no split store, no shadow: the f32 rows are read once per
+// as the MFMA A operand.  Any dim % 128 == 0 up to 4096; no split store, no shadow: the f32 rows are read once per
 // 64 queries.
 //
-//   block = 8 waves, row tile = 128 rows (wave w: rows 16 w .. 16 w + 15 = one 16-row A fragment)
-//   K-block = 128 k = 4 MFMA steps of 32; per K-block and wave: 8 x global_load_dwordx4 of one contiguous KiB each
-//     (2 rows x 512 B), handed through the wave's own 8 KiB LDS region into MFMA operand layout, split there
-//     (4 v_cvt_pk_bf16 pairs per step), 4 query groups x 3 mfma_f32_16x16x32_bf16 per step
+//   block = 4 waves, TWO blocks per CU (each runs into its own barriers), row tile = 128 rows (wave w: rows 32 w .. + 31 =
+//     two 16-row A fragments: a query fragment read from LDS feeds six MFMAs — LDS bandwidth, 48 KiB per 8 KiB of rows in
+//     the first version of this kernel, was what its arithmetic side was bound by)
+//   K-block = 64 k = 2 MFMA steps of 32; per K-block and wave: 8 x global_load_dwordx4 of one KiB each (4 rows x 256 B),
+//     handed through the wave's own 8 KiB LDS region into MFMA operand layout, split there, 4 query groups x 2 fragments
+//     x 3 mfma_f32_16x16x32_bf16 per step
 //   queries: K-block kb+1 is fetched into registers while K-block kb is computed, written to the other LDS buffer at
 //     the top of the next iteration; ONE raw barrier per K-block
-//   epilogue: cosine with the scan kernel's arithmetic (cosine_from_sums), dense scores [query][row] to HBM
-//     (256 B per row against the row's dim * 4: + 6 % traffic at 1024-d); launch_dense_topk (scan.hip) then takes
-//     the top k per query with the register lists of the single-query scan and the usual merge.
+//   the main loop holds no vector memory operation but the row / query fetches, and every one of them is unconditional:
+//     vmcnt is one in-order queue, so a load the epilogue waits for (a norm, |q|^2) or a fetch the compiler cannot count
+//     (inside an `if`) turns its waits into vmcnt(0) — a drain of the two K-blocks of rows in flight
+//   epilogue, dense mode: cosines [query][row] to HBM, launch_dense_topk (scan.hip) then takes the top k per query.  Those
+//     4 bytes per row and query are 6 % of the traffic at 1024-d and cost the row stream a FIFTH of its rate (64-byte
+//     pieces into 64 distant streams; profiles/r02/tuning.md section 4), and they are read back once more
+//   epilogue, filter mode (the default from 262,144 rows when no row filter is set): a first dense pass over 1 row tile in
+//     64 (32 for k > 32) gives every query a bound — the k-th best score of the sample; the k-th best of all rows can only
+//     be higher — and the pass over all rows writes only the (key, cosine) of the rows that reach it, ~64 k per query, into
+//     per-block lists (slots from LDS counters: a returning global atomic would be one more load in the vmcnt queue) that
+//     the radix merge folds.  A pair is divided out only if dot >= (bound - 1e-4) |q| |row|.  A block list that runs over
+//     sets a flag; the dense pass, its top-k and merge are launched behind it with run_if = that flag and return at
+//     once when it is 0 — exact whatever the data, no host round trip
 // Bound: HBM.  Algorithmic bytes per launch = n_rows * dim * 4.
 #include <algorithm>
 
@@ -35,14 +47,15 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 namespace bg {
-constexpr int TILE_ROWS = 128;      // rows per block tile: 8 waves x 16
-constexpr int KB = 128;             // k per K-block
+constexpr int WAVES = 4;            // per block; two blocks per CU
+constexpr int TILE_ROWS = 128;      // rows per block tile: 4 waves x 32
+constexpr int KB = 64;              // k per K-block
 constexpr int STEPS = KB / 32;      // MFMA steps per K-block
 constexpr int NQ = 64;              // queries per pass
 constexpr int STEP_BYTES = 2 * NQ * 4 * 16;   // one step's query image: hi [64][4 kq][8 bf16] | lo = 8 KiB
-constexpr int KB_BYTES = STEPS * STEP_BYTES;  // 32 KiB
-constexpr int SUB_BYTES = 16 * KB * 4;        // a wave's 16 rows x one K-block f32 = 8 KiB
-constexpr int LDS_BYTES = 2 * KB_BYTES + 8 * SUB_BYTES + 256;   // query images double buffered + one row region per wave (+ 64 counters) = 128 KiB
+constexpr int KB_BYTES = STEPS * STEP_BYTES;  // 16 KiB
+constexpr int SUB_BYTES = 32 * KB * 4;        // a wave's 32 rows x one K-block f32 = 8 KiB
+constexpr int LDS_BYTES = 2 * KB_BYTES + WAVES * SUB_BYTES + 256;   // query images double buffered + one row region per wave + 64 counters = 64.25 KiB
 
 __device__ inline void split4g(const f32x4 v, bf16x4_t &hi, bf16x4_t &lo) {   // as batch.hip's split4
     const uint32_t p01 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v.x, v.y}, bf16x2_t));
@@ -110,9 +123,10 @@ struct BatchGArgs {
     const uint32_t *run_if;    // non-null: the launch does nothing unless *run_if != 0 (the exact fallback)
 };
 
-// PROBE: 0 = the product; 1 = loads only (no LDS transpose, no split, no MFMA); 2 = no row loads (MFMAs on stale data)
+// PROBE: 0 = the product; 1 = loads only (no LDS transpose, no split, no MFMA); 2 = no row loads (MFMAs on stale data);
+// 3 = rows only (no barriers, no query staging)
 template <int PROBE, bool FILTER>
-__global__ __launch_bounds__(512) void batchg_kernel(const BatchGArgs a) {
+__global__ __launch_bounds__(256, 2) void batchg_kernel(const BatchGArgs a) {
     using namespace bg;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (a.run_if && *a.run_if == 0u) return;
@@ -125,8 +139,8 @@ __global__ __launch_bounds__(512) void batchg_kernel(const BatchGArgs a) {
     const uint32_t my_tiles = (n_tiles - 1u - blockIdx.x) / gridDim.x + 1u;
     const uint32_t total_kb = my_tiles * n_kb;   // K-blocks this block walks: the query images cycle once per tile
     char *Qs = smem;                                              // [2][KB_BYTES] query images, double buffered
-    char *Rw = smem + 2 * KB_BYTES + wave * SUB_BYTES;            // this wave's 16 rows x 128 k f32, pieces swizzled
-    uint32_t *Cnt = reinterpret_cast<uint32_t *>(smem + 2 * KB_BYTES + 8 * SUB_BYTES);   // filter mode: entries in this block's list of each query
+    char *Rw = smem + 2 * KB_BYTES + wave * SUB_BYTES;            // this wave's 32 rows x 64 k f32, pieces swizzled
+    uint32_t *Cnt = reinterpret_cast<uint32_t *>(smem + 2 * KB_BYTES + WAVES * SUB_BYTES);   // filter mode: entries in this block's list of each query
     if (FILTER && tid < 64u) Cnt[tid] = 0u;
 
     auto tile_barrier = [&]() {   // raw barrier: __syncthreads() would drain the rows in flight (vmcnt(0))
@@ -136,140 +150,162 @@ __global__ __launch_bounds__(512) void batchg_kernel(const BatchGArgs a) {
         asm volatile("" ::: "memory");
     };
 
-    // query staging: a K-block image is 32 KiB = 4 x 16 B per thread
+    // query staging: a K-block image is 16 KiB = 4 x 16 B per thread
     f32x4 qr[4];
-    // (A rotated K-block order per tile — against all blocks walking the same 512-byte slice of every 4 KiB row in
-    // step — changed nothing: 0.896 ms either way; the memory system hashes addresses over its channels.)
-    auto phys_kb = [&](uint32_t, uint32_t kbl) { return kbl; };
     auto q_fetch = [&](uint32_t it_) {   // it_: index in this block's K-block sequence
-        const uint32_t tile_ = blockIdx.x + (it_ / n_kb) * gridDim.x;
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(a.qimg + (size_t)phys_kb(tile_, it_ % n_kb) * KB_BYTES) + tid;
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(a.qimg + (size_t)(it_ % n_kb) * KB_BYTES) + tid;
         if constexpr (PROBE == 3) return;
 #pragma unroll
-        for (int e = 0; e < 4; e++) qr[e] = src[e * 512];
+        for (int e = 0; e < 4; e++) qr[e] = src[e * 256];
     };
     auto q_store = [&](uint32_t buf) {
         f32x4 *dst = reinterpret_cast<f32x4 *>(Qs + buf * KB_BYTES) + tid;
         if constexpr (PROBE == 3) return;
 #pragma unroll
-        for (int e = 0; e < 4; e++) dst[e * 512] = qr[e];
+        for (int e = 0; e < 4; e++) dst[e * 256] = qr[e];
     };
 
-    // Row side.  A wave owns 16 rows (one MFMA A fragment).  A K-block of them = 16 rows x 512 B = 8 load instructions of
-    // ONE KiB each: lane l reads piece l % 32 (16 B) of row 2 i + l / 32 — two rows x 512 contiguous bytes per
-    // instruction.  (Following the MFMA operand layout instead — 16 rows x 64 B per instruction — the kernel read at 0.48
-    // of the HBM peak, loads-only probe included; 4 rows x 256 B: 0.55 / 0.60.)  The registers go to the wave's own 8 KiB
-    // LDS region and come back in MFMA layout — same wave, LDS executes a wave's instructions in order: no barrier.
-    // Piece p of row r sits at p ^ (r & 15): the 16 lanes of a read group (one piece index, 16 rows) then hit 16
-    // different 16-byte bank groups; a write group is 16 consecutive pieces of one row, permuted inside 256 bytes.
-    const uint32_t lrow = lane >> 5, lpiece = lane & 31u;
-    f32x4 acc[4];
+    // Row side.  A wave owns 32 rows (two MFMA A fragments: every query fragment read from LDS feeds six MFMAs).  A K-block
+    // of them = 32 rows x 256 B = 8 load instructions of ONE KiB each: lane l reads piece l % 16 (16 B) of row
+    // 4 i + l / 16.  The registers go to the wave's own 8 KiB LDS region and come back in MFMA layout — same wave, LDS
+    // executes a wave's instructions in order: no barrier.  Piece p of row r sits at p ^ (r & 15): the 16 lanes of a
+    // read group (one piece index, 16 rows) then hit 16 different 16-byte bank groups; a write group is the 16 pieces
+    // of one row, permuted inside its 256 bytes.
+    const uint32_t lrow = lane >> 4, lpiece = lane & 15u;
+    f32x4 acc[2][4];
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int g = 0; g < 4; g++) acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int f = 0; f < 2; f++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) acc[f][g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     };
-    // lane part of a row address (bytes): row lrow of a 2-row group, piece lpiece; the tile / group / K-block part is scalar
     const uint32_t lane_off = lrow * a.dim * 4u + lpiece * 16u;
     f32x4 xa[8], xb[8];   // two K-blocks of this wave's rows in flight (16 KiB per wave, 128 KiB per CU)
     auto r_fetch = [&](f32x4 (&dst)[8], uint32_t tile, uint32_t kb) {   // kb: K-block inside the row
-        const char *base = reinterpret_cast<const char *>(a.rows) + ((size_t)tile * a.tile_step * TILE_ROWS + wave * 16u) * a.dim * 4u + (size_t)kb * 512u;
+        const char *base = reinterpret_cast<const char *>(a.rows) + ((size_t)tile * a.tile_step * TILE_ROWS + wave * 32u) * a.dim * 4u + (size_t)kb * (KB * 4u);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             if constexpr (PROBE == 2) { asm volatile("" : "+v"(dst[i])); continue; }
-            dst[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(base + (size_t)i * 2u * a.dim * 4u + lane_off));
+            dst[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(base + (size_t)i * 4u * a.dim * 4u + lane_off));
         }
     };
     auto lds_put = [&](const f32x4 (&src)[8]) {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const uint32_t r = 2u * (uint32_t)i + lrow;
-            *reinterpret_cast<f32x4 *>(Rw + r * 512u + ((lpiece ^ (r & 15u)) << 4)) = src[i];
+            const uint32_t r = 4u * (uint32_t)i + lrow;
+            *reinterpret_cast<f32x4 *>(Rw + r * 256u + ((lpiece ^ (r & 15u)) << 4)) = src[i];
         }
     };
-    // step s (of the K-block's four): lane (j, kq) needs k = 32 s + 4 kq .. + 3 and 32 s + 16 + 4 kq .. + 3 of row j:
-    // pieces 8 s + kq and 8 s + 4 + kq
+    // step s (of the K-block's two): lane (j, kq) needs k = 32 s + 4 kq .. + 3 and 32 s + 16 + 4 kq .. + 3 of rows j
+    // and 16 + j: pieces 8 s + kq and 8 s + 4 + kq
     auto compute_kb = [&](uint32_t buf) {
         const char *Q = Qs + buf * KB_BYTES + (j * 4u + kq) * 16u;
 #pragma unroll
         for (int s = 0; s < STEPS; s++) {
-            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(Rw + j * 512u + (((8u * s + kq) ^ j) << 4));
-            const f32x4 v1 = *reinterpret_cast<const f32x4 *>(Rw + j * 512u + (((8u * s + 4u + kq) ^ j) << 4));
-            bf16x4_t h0, l0, h1, l1;
-            split4g(v0, h0, l0);
-            split4g(v1, h1, l1);
-            const s16x8 ah = __builtin_bit_cast(s16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
-            const s16x8 al = __builtin_bit_cast(s16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+            s16x8 ah[2], al[2];
+#pragma unroll
+            for (int f = 0; f < 2; f++) {
+                const char *R = Rw + (16u * f + j) * 256u;
+                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(R + (((8u * s + kq) ^ j) << 4));
+                const f32x4 v1 = *reinterpret_cast<const f32x4 *>(R + (((8u * s + 4u + kq) ^ j) << 4));
+                bf16x4_t h0, l0, h1, l1;
+                split4g(v0, h0, l0);
+                split4g(v1, h1, l1);
+                ah[f] = __builtin_bit_cast(s16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+                al[f] = __builtin_bit_cast(s16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const s16x8 qh = *reinterpret_cast<const s16x8 *>(Q + s * STEP_BYTES + g * 1024);
                 const s16x8 ql = *reinterpret_cast<const s16x8 *>(Q + s * STEP_BYTES + STEP_BYTES / 2 + g * 1024);
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, qh, acc[g], 0, 0, 0);   // small terms first
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ql, acc[g], 0, 0, 0);
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, qh, acc[g], 0, 0, 0);
+#pragma unroll
+                for (int f = 0; f < 2; f++) {
+                    acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[f], qh, acc[f][g], 0, 0, 0);   // small terms first
+                    acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], ql, acc[f][g], 0, 0, 0);
+                    acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], qh, acc[f][g], 0, 0, 0);
+                }
             }
         }
     };
     auto consume = [&](const f32x4 (&src)[8], uint32_t buf) {
         if constexpr (PROBE == 1 || PROBE == 3) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) acc[i & 3] += src[i];
+            for (int i = 0; i < 8; i++) acc[0][i & 3] += src[i];
             return;
         }
         lds_put(src);
         compute_kb(buf);
     };
-    // C layout: lane (j, kq) holds rows 4 kq + e (e = 0..3) of query j of group g: four consecutive rows -> one float4.
+    // C layout: lane (j, kq) holds rows 4 kq + e (e = 0..3) of fragment f for query j of group g: four consecutive rows.
     // Nothing here may be a vector load: vmcnt is in order, so waiting for one would first drain the row loads of the next
-    // two K-blocks — the whole prefetch, once per tile (the round-2 v3 kernel did exactly that: 0.60 of the peak where
-    // its own row stream alone reaches 0.86).  |q|^2 sits in registers from the start, |row|^2 comes by scalar loads
-    // (the 16 rows of a wave are a uniform address; d_norms has 64 floats of readable padding).
-    float qqv[4];
+    // two K-blocks — the whole prefetch, once per tile.  |q|^2 and the bounds sit in registers from the start, |row|^2
+    // comes by scalar loads (a fragment's 16 rows are a uniform address; d_norms has 64 floats of readable padding).
+    // The square roots are hoisted (|q| once per kernel, |row| once per row instead of once per pair): the same IEEE values
+    // as cosine_from_sums.  Filter mode divides only where the pair can reach the bound: score ~ dot / (|q| |row|) within
+    // a few ulp, so dot < (bound - 1e-4) |q| |row| rules a pair out with two multiplies (a NaN or zero norm fails the
+    // comparison and takes the exact path) — 99.9 % of the pairs at k = 10.
+    float nqv[4], thrv[4];
     uint32_t tauv[4];
 #pragma unroll
     for (int g = 0; g < 4; g++) {
         const uint32_t q = (uint32_t)g * 16u + j;
-        qqv[g] = q < a.nq ? a.qq[q] : 1.0f;
+        nqv[g] = sqrtf(q < a.nq ? a.qq[q] : 1.0f);
         tauv[g] = (FILTER && q < a.nq) ? a.tau_ord[q] : 0u;
+        thrv[g] = tauv[g] > 1u ? __uint_as_float(tauv[g] - 2u) - 1e-4f : -__builtin_inff();   // bound 0 / NaN: every pair is a candidate
     }
     const __attribute__((address_space(4))) float *norms_c = (const __attribute__((address_space(4))) float *)a.norms;
     auto epilogue = [&](uint32_t tile) {
-        const uint32_t w0 = tile * a.tile_step * TILE_ROWS + wave * 16u, r0 = w0 + 4u * kq;   // rows in the store
-        float tn[16];
 #pragma unroll
-        for (int e = 0; e < 16; e++) tn[e] = norms_c[(size_t)w0 + e];
-        f32x4 rr = {tn[0], tn[1], tn[2], tn[3]};
+        for (int f = 0; f < 2; f++) {
+            const uint32_t in_tile = wave * 32u + 16u * f + 4u * kq;                 // first of this lane's four rows, inside the tile
+            const uint32_t w0 = tile * a.tile_step * TILE_ROWS + wave * 32u + 16u * f, r0 = w0 + 4u * kq;   // ... in the store
+            float tn[16];
 #pragma unroll
-        for (int c = 1; c < 4; c++)
-            if (kq == (uint32_t)c) rr = f32x4{tn[4 * c], tn[4 * c + 1], tn[4 * c + 2], tn[4 * c + 3]};
-        if (r0 >= a.n_rows) return;
+            for (int e = 0; e < 16; e++) tn[e] = norms_c[(size_t)w0 + e];
+            f32x4 rr = {tn[0], tn[1], tn[2], tn[3]};
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const uint32_t q = (uint32_t)g * 16u + j;
-            if (q >= a.nq) continue;
-            f32x4 c;
+            for (int c = 1; c < 4; c++)
+                if (kq == (uint32_t)c) rr = f32x4{tn[4 * c], tn[4 * c + 1], tn[4 * c + 2], tn[4 * c + 3]};
+            if (r0 >= a.n_rows) continue;
+            f32x4 nr;
 #pragma unroll
-            for (int e = 0; e < 4; e++) c[e] = cosine_from_sums(acc[g][e], qqv[g], rr[e]);
-            if constexpr (FILTER) {
+            for (int e = 0; e < 4; e++) nr[e] = sqrtf(rr[e]);
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const float score = score_of(distance_of(c[e]));
-                    if (score_ord(score) >= tauv[g] && r0 + (uint32_t)e < a.n_rows) {
-                        const uint32_t slot = atomicAdd(&Cnt[q], 1u);   // LDS: a returning GLOBAL atomic would drain the row prefetch
-                        if (slot < a.cb) {
-                            const size_t at = ((size_t)q * gridDim.x + blockIdx.x) * a.cb + slot;
-                            a.cand_keys[at] = make_key(score, r0 + (uint32_t)e);
-                            a.cand_sims[at] = c[e];
+            for (int g = 0; g < 4; g++) {
+                const uint32_t q = (uint32_t)g * 16u + j;
+                if (q >= a.nq) continue;
+                if constexpr (FILTER) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        if (acc[f][g][e] < thrv[g] * (nqv[g] * nr[e])) continue;
+                        const float sim = cosine_from_norms(acc[f][g][e], nqv[g], nr[e]);
+                        const float score = score_of(distance_of(sim));
+                        if (score_ord(score) >= tauv[g] && r0 + (uint32_t)e < a.n_rows) {
+                            const uint32_t slot = atomicAdd(&Cnt[q], 1u);   // LDS: a returning GLOBAL atomic would drain the row prefetch
+                            if (slot < a.cb) {
+                                const size_t at = ((size_t)q * gridDim.x + blockIdx.x) * a.cb + slot;
+                                a.cand_keys[at] = make_key(score, r0 + (uint32_t)e);
+                                a.cand_sims[at] = sim;
+                            }
                         }
                     }
+                } else {
+                    f32x4 c;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) c[e] = cosine_from_norms(acc[f][g][e], nqv[g], nr[e]);
+                    float *dst = a.dense + (size_t)q * a.stride + ((size_t)tile * TILE_ROWS + in_tile);   // dense column: the tile as this launch counts it
+                    if (r0 + 3u < a.n_rows) *reinterpret_cast<f32x4 *>(dst) = c;
+                    else { for (uint32_t e = 0; e < 4u; e++) if (r0 + e < a.n_rows) dst[e] = c[e]; }
                 }
-            } else {
-                float *dst = a.dense + (size_t)q * a.stride + (r0 - (w0 - wave * 16u) + tile * TILE_ROWS);   // dense column: the tile as this launch counts it
-                if (r0 + 3u < a.n_rows) *reinterpret_cast<f32x4 *>(dst) = c;
-                else { for (uint32_t e = 0; e < 4u; e++) if (r0 + e < a.n_rows) dst[e] = c[e]; }
             }
         }
     };
 
+    // Pipeline over the block's K-blocks, tile by tile, two K-blocks per loop iteration (dim % 256 == 0).  K-block `it`
+    // reads its query image from LDS buffer it & 1; the image of it + 1 (fetched during it - 1) is written to the other
+    // buffer at the top of the K-block and the image of it + 2 requested.  Rows: two register sets = two K-blocks; a set
+    // is re-requested for the K-block TWO ahead (which may belong to the next tile) the moment it has been handed to LDS.
+    // One barrier per K-block, for the query hand-over only.
     // Every fetch below is UNCONDITIONAL (past the end the address is clamped to data already read): with a load that may
     // or may not have been issued the compiler cannot count vmcnt and falls back to vmcnt(0) — a drain of the prefetch.
     uint32_t tile = blockIdx.x, it = 0;
@@ -277,8 +313,8 @@ __global__ __launch_bounds__(512) void batchg_kernel(const BatchGArgs a) {
     q_fetch(0);
     q_store(0);
     q_fetch(total_kb > 1u ? 1u : 0u);
-    r_fetch(xa, tile, phys_kb(tile, 0));
-    r_fetch(xb, tile, phys_kb(tile, 1));
+    r_fetch(xa, tile, 0);
+    r_fetch(xb, tile, 1);
     tile_barrier();
     // where K-block kbl + 2 of the current tile lives: (tile, kbl + 2) or the next tile's (kbl + 2 - n_kb); past the end: (tile, kbl)
     auto ahead = [&](uint32_t t, uint32_t kbl, uint32_t &tl, uint32_t &kb2) {
@@ -298,14 +334,14 @@ __global__ __launch_bounds__(512) void batchg_kernel(const BatchGArgs a) {
             q_fetch(std::min(it + 2u, last_kb));
             ahead(t, kbl, tl, kb2);
             consume(xa, 0);
-            r_fetch(xa, tl, phys_kb(tl, kb2));
+            r_fetch(xa, tl, kb2);
             tile_barrier();
             // odd K-block (buffer 1): xb
             q_store(0);
             q_fetch(std::min(it + 3u, last_kb));
             ahead(t, kbl + 1u, tl, kb2);
             consume(xb, 1);
-            r_fetch(xb, tl, phys_kb(tl, kb2));
+            r_fetch(xb, tl, kb2);
             if (kbl + 2u == n_kb) {
                 epilogue(tile);
                 tile += gridDim.x;
@@ -369,15 +405,15 @@ int launch_batchg_pass(const float *rows, const float *norms, uint32_t n_rows, u
     if (f) {
         a.tau_ord = f->tau_ord; a.cand_keys = f->cand_keys; a.cand_sims = f->cand_sims; a.overflow = f->overflow; a.cb = f->cb;
         grid = batchg_grid(n_rows);   // the candidate lists are laid out for exactly this grid
-        hipLaunchKernelGGL((batchg_kernel<0, true>), dim3(grid), dim3(512), LDS_BYTES, stream, a);
+        hipLaunchKernelGGL((batchg_kernel<0, true>), dim3(grid), dim3(256), LDS_BYTES, stream, a);
         CX_HIP(hipGetLastError());
         return CX_OK;
     }
     static const int probe = getenv("CX_BATCHG_PROBE") ? atoi(getenv("CX_BATCHG_PROBE")) : 0;   // measurement arms, results invalid
-    if (probe == 1) hipLaunchKernelGGL((batchg_kernel<1, false>), dim3(grid), dim3(512), LDS_BYTES, stream, a);        // loads only
-    else if (probe == 2) hipLaunchKernelGGL((batchg_kernel<2, false>), dim3(grid), dim3(512), LDS_BYTES, stream, a);   // no row loads
-    else if (probe == 3) hipLaunchKernelGGL((batchg_kernel<3, false>), dim3(grid), dim3(512), LDS_BYTES, stream, a);   // rows only: no barriers, no query staging
-    else hipLaunchKernelGGL((batchg_kernel<0, false>), dim3(grid), dim3(512), LDS_BYTES, stream, a);
+    if (probe == 1) hipLaunchKernelGGL((batchg_kernel<1, false>), dim3(grid), dim3(256), LDS_BYTES, stream, a);        // loads only
+    else if (probe == 2) hipLaunchKernelGGL((batchg_kernel<2, false>), dim3(grid), dim3(256), LDS_BYTES, stream, a);   // no row loads
+    else if (probe == 3) hipLaunchKernelGGL((batchg_kernel<3, false>), dim3(grid), dim3(256), LDS_BYTES, stream, a);   // rows only: no barriers, no query staging
+    else hipLaunchKernelGGL((batchg_kernel<0, false>), dim3(grid), dim3(256), LDS_BYTES, stream, a);
     CX_HIP(hipGetLastError());
     return CX_OK;
 }

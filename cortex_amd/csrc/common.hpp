@@ -117,6 +117,12 @@ __device__ inline float cosine_from_sums(float dot, float qq, float rr) {
     const float den = norm_a * norm_b;
     return dot / den;
 }
+// the same value from the two square roots (callers that reuse a norm over many pairs)
+__device__ inline float cosine_from_norms(float dot, float norm_a, float norm_b) {
+#pragma clang fp contract(off)
+    const float den = norm_a * norm_b;
+    return dot / den;
+}
 __host__ __device__ inline float distance_of(float sim) { return 1.0f - sim; }
 __host__ __device__ inline float score_of(float distance) {
     float s = 1.0f - distance;

@@ -389,14 +389,16 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
         const size_t qimg = batchg_qimg_bytes(ix->dim);
         if (int rc = ensure_dev(c->d_dense, c->dn_cap, (size_t)64 * stride)) return rc;
         if (int rc = ensure_dev(c->d_qimg, c->qi_cap, qimg + 64 * sizeof(float))) return rc;
-        if (int rc = ensure_dev(c->d_part_keys, c->pk_cap, (size_t)64 * chunks * k_eff)) return rc;
-        if (int rc = ensure_dev(c->d_part_sims, c->ps_cap, (size_t)64 * chunks * k_eff)) return rc;
-        // Large stores with no row filter: bound each query from a 1-in-32 sample of the row tiles, then write only the
+        if (int rc = ensure_dev(c->d_part_keys, c->pk_cap, (size_t)64 * std::max(chunks, 64u) * k_eff)) return rc;   // 64: the sample's chunks at most
+        if (int rc = ensure_dev(c->d_part_sims, c->ps_cap, (size_t)64 * std::max(chunks, 64u) * k_eff)) return rc;
+        // Large stores with no row filter: bound each query from a 1-in-64 (k <= 32) or 1-in-32 sample of the row tiles, then write only the
         // rows that reach the bound (kernels.hpp: BatchGFilter) — the 4 bytes per row and query of the dense pass cost
         // the row stream a fifth of its rate, and launch_dense_topk reads them all back.
         static const int filter_ok = getenv("CX_BATCHG_FILTER") ? atoi(getenv("CX_BATCHG_FILTER")) : 1;
         static const uint32_t filter_min = getenv("CX_BATCHG_FILTER_MIN") ? (uint32_t)atoi(getenv("CX_BATCHG_FILTER_MIN")) : 262144u;
-        static const uint32_t tile_step = getenv("CX_BATCHG_SAMPLE_STEP") ? (uint32_t)std::max(1, atoi(getenv("CX_BATCHG_SAMPLE_STEP"))) : 32u;
+        // expected candidates per query = k * step (the sample's k-th best against step times as many rows)
+        static const uint32_t step_env = getenv("CX_BATCHG_SAMPLE_STEP") ? (uint32_t)std::max(1, atoi(getenv("CX_BATCHG_SAMPLE_STEP"))) : 0u;
+        const uint32_t tile_step = step_env ? step_env : (k_eff <= 32u ? 64u : 32u);
         uint32_t s_tiles = 0;
         const uint32_t s_rows = batchg_sample_rows(n, tile_step, &s_tiles), s_stride = (s_rows + 3u) & ~3u;
         const bool filtered = filter_ok && flt.trivial && n >= filter_min && s_rows >= k_eff;
@@ -404,7 +406,7 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
         uint32_t cb = std::max<uint32_t>(k_eff, 32u);
         if (getenv("CX_BATCHG_CAND_CAP")) cb = std::max<uint32_t>(k_eff, (uint32_t)atoi(getenv("CX_BATCHG_CAND_CAP")));   // tests: force the fallback
         cb = (cb + k_eff - 1u) / k_eff * k_eff;
-        const uint32_t s_chunks = dense_topk_chunks(s_rows);
+        const uint32_t s_chunks = std::max<uint32_t>(1u, std::min<uint32_t>(64u, s_rows / 2048u));   // a small array: spread it, the bound is not the point here
         if (filtered) {
             if (int rc = ensure_dev(c->d_cand_keys, c->ck_cap, (size_t)64 * bgrid * cb)) return rc;
             if (int rc = ensure_dev(c->d_cand_sims, c->cs_cap, (size_t)64 * bgrid * cb)) return rc;

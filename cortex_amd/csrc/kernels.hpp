@@ -105,7 +105,7 @@ int launch_batch_scan(BatchArgs a, uint32_t grid, hipStream_t stream);
 int launch_merge_batch(const MergeArgs &m, uint32_t nq, hipStream_t stream, bool sorted_lists = true);
 
 // ---- batched search for the other row widths (batchg.hip): dense cosines for <= 64 queries, then top-k ----
-bool batchg_supported(uint32_t dim, uint32_t k);       // dim % 256 == 0, dim <= 4096, k <= 256
+bool batchg_supported(uint32_t dim, uint32_t k);       // dim % 128 == 0, dim <= 4096, k <= 256
 size_t batchg_qimg_bytes(uint32_t dim);                 // scratch for the split query images
 int launch_batchg_scores(const float *rows, const float *norms, uint32_t n_rows, uint32_t dim, const float *d_queries, uint32_t nq,
                          char *d_qimg, float *d_qq, float *d_dense, uint32_t stride, hipStream_t stream);   // split + one dense pass

@@ -316,6 +316,8 @@ def test_concurrent_filtered_readers(hip, oracle):
     (130, 256, 5, 40),       # one K-block pair per row; fewer rows than one row tile
     (2000, 256, 256, 5),     # the largest in-register k
     (40, 1024, 40, 70),      # k == n: fewer rows than one tile
+    (1300, 640, 10, 9),      # dim % 128 == 0 is all batchg.hip asks for
+    (700, 128, 64, 33),
 ])
 def test_search_batch_matches_oracle(hip, oracle, n, d, k, nq):
     rows = oracle.synth_rows(n, d)
