@@ -116,8 +116,9 @@ struct BatchGArgs {
     // filter mode (tau_ord != null): instead of 4 bytes per row and query, only the (key, cosine) of the rows whose score
     // reaches the query's bound, into this block's list of the query
     const uint32_t *tau_ord;   // [64] score_ord of the bound (0: everything passes)
-    uint64_t *cand_keys;       // [64][gridDim.x][cb], zeroed by the caller
+    uint64_t *cand_keys;       // [64][gridDim.x][cb]
     float *cand_sims;
+    uint32_t *cand_counts;     // [64][gridDim.x] out: entries written to each list
     uint32_t *overflow;        // [1] set when a block's list of some query was too short
     uint32_t cb;
     const uint32_t *run_if;    // non-null: the launch does nothing unless *run_if != 0 (the exact fallback)
@@ -351,7 +352,11 @@ __global__ __launch_bounds__(256, 2) void batchg_kernel(const BatchGArgs a) {
         }
     }
     if constexpr (FILTER) {
-        if (tid < 64u && Cnt[tid] > a.cb) *a.overflow = 1u;   // the last tile_barrier() ordered the counters
+        if (tid < 64u) {   // the last tile_barrier() ordered the counters
+            const uint32_t c = Cnt[tid];
+            a.cand_counts[(size_t)tid * gridDim.x + blockIdx.x] = c < a.cb ? c : a.cb;
+            if (c > a.cb) *a.overflow = 1u;
+        }
     }
 }
 
@@ -403,7 +408,7 @@ int launch_batchg_pass(const float *rows, const float *norms, uint32_t n_rows, u
     a.n_tiles = (n_tiles + tile_step - 1) / tile_step;
     uint32_t grid = std::min<uint32_t>(a.n_tiles, 2u * device_cus());
     if (f) {
-        a.tau_ord = f->tau_ord; a.cand_keys = f->cand_keys; a.cand_sims = f->cand_sims; a.overflow = f->overflow; a.cb = f->cb;
+        a.tau_ord = f->tau_ord; a.cand_keys = f->cand_keys; a.cand_sims = f->cand_sims; a.cand_counts = f->cand_counts; a.overflow = f->overflow; a.cb = f->cb;
         grid = batchg_grid(n_rows);   // the candidate lists are laid out for exactly this grid
         hipLaunchKernelGGL((batchg_kernel<0, true>), dim3(grid), dim3(256), LDS_BYTES, stream, a);
         CX_HIP(hipGetLastError());

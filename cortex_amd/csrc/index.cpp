@@ -329,7 +329,13 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
     for (uint64_t i = 0; tails && i < nq; i++) no_tails = no_tails && tails[i] == 0.0f;
     static const int batch_min = getenv("CX_BATCH_MIN") ? atoi(getenv("CX_BATCH_MIN")) : 3;
     static const int b2_ok = getenv("CX_BATCH2") ? atoi(getenv("CX_BATCH2")) : 1;   // 0: 768-d through batchg.hip (tests)
-    if (b2_ok && topk_path && no_tails && nq >= (uint64_t)batch_min && k_eff >= 1 && batch_supported(ix->dim, k_eff)) {
+    static const int bg_ok = getenv("CX_BATCHG") ? atoi(getenv("CX_BATCHG")) : 1;
+    static const int filter_ok = getenv("CX_BATCHG_FILTER") ? atoi(getenv("CX_BATCHG_FILTER")) : 1;
+    static const uint32_t filter_min = getenv("CX_BATCHG_FILTER_MIN") ? (uint32_t)atoi(getenv("CX_BATCHG_FILTER_MIN")) : 262144u;
+    // wide lists (k > 32) on a large unfiltered store: batchg.hip's bound + candidates pass runs at 0.71-0.75 of the HBM
+    // peak whatever k is, batch2_kernel's in-kernel wide lists at 0.40-0.49 (1.25M x 384 / 768, k = 100)
+    const bool wide_to_bg = k_eff > 32 && bg_ok && filter_ok && flt.trivial && n >= filter_min && batchg_supported(ix->dim, k_eff);
+    if (b2_ok && !wide_to_bg && topk_path && no_tails && nq >= (uint64_t)batch_min && k_eff >= 1 && batch_supported(ix->dim, k_eff)) {
         if (int rc = ensure_norms(ix, s)) return rc;
         const uint32_t qpp = batch_queries_per_pass(ix->dim, k_eff, nq);
         uint32_t bgrid = 1, groups = 1;
@@ -382,20 +388,17 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
     }
     // the other row widths (1024-d: BGE-large): batchg.hip — dense cosines of <= 64 queries per pass over the f32 rows,
     // then the top k of each
-    static const int bg_ok = getenv("CX_BATCHG") ? atoi(getenv("CX_BATCHG")) : 1;
     if (bg_ok && topk_path && no_tails && nq >= (uint64_t)batch_min && k_eff >= 1 && batchg_supported(ix->dim, k_eff)) {
         if (int rc = ensure_norms(ix, s)) return rc;
         const uint32_t stride = (n + 3u) & ~3u, chunks = dense_topk_chunks(n);
         const size_t qimg = batchg_qimg_bytes(ix->dim);
         if (int rc = ensure_dev(c->d_dense, c->dn_cap, (size_t)64 * stride)) return rc;
         if (int rc = ensure_dev(c->d_qimg, c->qi_cap, qimg + 64 * sizeof(float))) return rc;
-        if (int rc = ensure_dev(c->d_part_keys, c->pk_cap, (size_t)64 * std::max(chunks, 64u) * k_eff)) return rc;   // 64: the sample's chunks at most
-        if (int rc = ensure_dev(c->d_part_sims, c->ps_cap, (size_t)64 * std::max(chunks, 64u) * k_eff)) return rc;
+        if (int rc = ensure_dev(c->d_part_keys, c->pk_cap, (size_t)64 * chunks * k_eff)) return rc;
+        if (int rc = ensure_dev(c->d_part_sims, c->ps_cap, (size_t)64 * chunks * k_eff)) return rc;
         // Large stores with no row filter: bound each query from a 1-in-64 (k <= 32) or 1-in-32 sample of the row tiles, then write only the
         // rows that reach the bound (kernels.hpp: BatchGFilter) — the 4 bytes per row and query of the dense pass cost
         // the row stream a fifth of its rate, and launch_dense_topk reads them all back.
-        static const int filter_ok = getenv("CX_BATCHG_FILTER") ? atoi(getenv("CX_BATCHG_FILTER")) : 1;
-        static const uint32_t filter_min = getenv("CX_BATCHG_FILTER_MIN") ? (uint32_t)atoi(getenv("CX_BATCHG_FILTER_MIN")) : 262144u;
         // expected candidates per query = k * step (the sample's k-th best against step times as many rows)
         static const uint32_t step_env = getenv("CX_BATCHG_SAMPLE_STEP") ? (uint32_t)std::max(1, atoi(getenv("CX_BATCHG_SAMPLE_STEP"))) : 0u;
         const uint32_t tile_step = step_env ? step_env : (k_eff <= 32u ? 64u : 32u);
@@ -406,11 +409,10 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
         uint32_t cb = std::max<uint32_t>(k_eff, 32u);
         if (getenv("CX_BATCHG_CAND_CAP")) cb = std::max<uint32_t>(k_eff, (uint32_t)atoi(getenv("CX_BATCHG_CAND_CAP")));   // tests: force the fallback
         cb = (cb + k_eff - 1u) / k_eff * k_eff;
-        const uint32_t s_chunks = std::max<uint32_t>(1u, std::min<uint32_t>(64u, s_rows / 2048u));   // a small array: spread it, the bound is not the point here
         if (filtered) {
             if (int rc = ensure_dev(c->d_cand_keys, c->ck_cap, (size_t)64 * bgrid * cb)) return rc;
             if (int rc = ensure_dev(c->d_cand_sims, c->cs_cap, (size_t)64 * bgrid * cb)) return rc;
-            if (int rc = ensure_dev(c->d_bg_ctl, c->bc_cap, (size_t)80)) return rc;
+            if (int rc = ensure_dev(c->d_bg_ctl, c->bc_cap, (size_t)80 + (size_t)64 * bgrid)) return rc;   // bounds, flag, list counts
         }
         for (uint64_t q0 = 0; q0 < nq; q0 += 64) {
             const uint32_t m = (uint32_t)std::min<uint64_t>(64, nq - q0);
@@ -437,16 +439,13 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
             const uint32_t *run_if = nullptr;
             if (filtered) {
                 uint32_t *tau = c->d_bg_ctl, *overflow = c->d_bg_ctl + 64;
-                // 1. the bound: top k of the sampled tiles (the output arrays hold it until the real merge overwrites them)
+                // 1. the bound: the k-th best score of the sampled tiles
+                uint32_t *counts = c->d_bg_ctl + 80;
                 if (int rc = launch_batchg_pass(ix->d_rows, ix->d_norms, n, ix->dim, m, c->d_qimg, d_qq, c->d_dense, s_stride, tile_step, nullptr, nullptr, s)) return rc;
-                if (int rc = launch_dense_topk(c->d_dense, s_stride, s_rows, m, k_eff, flt, c->d_part_keys, c->d_part_sims, s_chunks, s)) return rc;
-                mg.n_lists = s_chunks;
-                if (int rc = launch_merge_batch(mg, m, s)) return rc;
-                if (int rc = launch_bound_from_topk(mg.out_scores, mg.out_count, m, k_eff, tau, s)) return rc;
+                if (int rc = launch_bound_select(c->d_dense, s_stride, s_rows, m, k_eff, tau, s)) return rc;
                 // 2. every row, candidates only
-                CX_HIP(hipMemsetAsync(c->d_cand_keys, 0, (size_t)m * bgrid * cb * sizeof(uint64_t), s));
                 CX_HIP(hipMemsetAsync(overflow, 0, sizeof(uint32_t), s));
-                BatchGFilter f{tau, c->d_cand_keys, c->d_cand_sims, overflow, cb};
+                BatchGFilter f{tau, c->d_cand_keys, c->d_cand_sims, counts, overflow, cb};
                 if (int rc = prof_begin()) return rc;
                 if (int rc = launch_batchg_pass(ix->d_rows, ix->d_norms, n, ix->dim, m, c->d_qimg, d_qq, nullptr, 0, 1, &f, nullptr, s)) return rc;
                 if (e1) CX_HIP(hipEventRecord(e1, s));
@@ -454,6 +453,8 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
                 mc.part_keys = c->d_cand_keys;
                 mc.part_sims = c->d_cand_sims;
                 mc.n_lists = bgrid * (cb / k_eff);
+                mc.seg_counts = counts;
+                mc.seg_len = cb;
                 if (int rc = launch_merge_batch(mc, m, s, false)) return rc;
                 // 3. the exact fallback below runs only if some list overflowed
                 run_if = overflow;

@@ -19,6 +19,8 @@ struct MergeArgs {
     float *out_dists;     // [k]
     uint32_t *out_count;  // [1]
     const uint32_t *run_if = nullptr;   // non-null: the launch does nothing unless *run_if != 0
+    const uint32_t *seg_counts = nullptr;   // radix merge of unsorted lists only: [nq][n_lists * k / seg_len] valid entries per segment
+    uint32_t seg_len = 0;
 };
 
 // One single-query scan over the row store.
@@ -116,8 +118,9 @@ int launch_batchg_scores(const float *rows, const float *norms, uint32_t n_rows,
 // pass with run_if = overflow (kernels that return at once when the flag is 0), which is exact whatever the data.
 struct BatchGFilter {
     const uint32_t *tau_ord;   // [64] score_ord of each query's bound
-    uint64_t *cand_keys;       // [64][batchg_grid(n_rows)][cb], zeroed
+    uint64_t *cand_keys;       // [64][batchg_grid(n_rows)][cb]
     float *cand_sims;
+    uint32_t *cand_counts;     // [64][batchg_grid(n_rows)] entries each block wrote (<= cb)
     uint32_t *overflow;        // [1], zeroed
     uint32_t cb;               // entries per block and query: a multiple of k
 };
@@ -126,8 +129,8 @@ uint32_t batchg_sample_rows(uint32_t n_rows, uint32_t tile_step, uint32_t *n_til
 int launch_batchg_split(const float *d_queries, uint32_t nq, uint32_t dim, char *d_qimg, float *d_qq, hipStream_t stream);
 int launch_batchg_pass(const float *rows, const float *norms, uint32_t n_rows, uint32_t dim, uint32_t nq, const char *d_qimg, const float *d_qq,
                        float *d_dense, uint32_t stride, uint32_t tile_step, const BatchGFilter *f, const uint32_t *run_if, hipStream_t stream);
-// tau_ord[q] = score_ord(scores[q][k-1]) if counts[q] >= k else 0
-int launch_bound_from_topk(const float *scores, const uint32_t *counts, uint32_t nq, uint32_t k, uint32_t *tau_ord, hipStream_t stream);
+// tau_ord[q] = score_ord of the k-th best score among dense[q][0 .. n) (0 when n < k)
+int launch_bound_select(const float *d_dense, uint32_t stride, uint32_t n, uint32_t nq, uint32_t k, uint32_t *tau_ord, hipStream_t stream);
 uint32_t dense_topk_chunks(uint32_t n_rows);
 int launch_dense_topk(const float *d_dense, uint32_t stride, uint32_t n_rows, uint32_t nq, uint32_t k, const DevFilter &flt,
                       uint64_t *part_keys, float *part_sims, uint32_t chunks, hipStream_t stream, const uint32_t *run_if = nullptr);
