@@ -15,6 +15,14 @@ step bench-driver-cmdline; timeout -k 10 300 python3 $R/bench.py --steps 20 --wa
 step cold-probe; timeout -k 10 200 python3 $R/scripts/cold_probe.py > $O/cold_probe.log 2>&1 && cp $R/gpurun_out/cold_probe.json $O/cold_start_probe.json
 step lists; timeout -k 10 200 python3 $R/scripts/bench_lists.py 100000 768 > $O/top100_lists_100kx768.log 2>&1
 step batch1024-trace; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/b1024_trace -- python3 $R/scripts/bench_batch_dim.py --rows 1000000 --dim 1024 > $O/batch64_1Mx1024.json 2> $O/b1024_trace.err || { tail -5 $O/b1024_trace.err; exit 1; }
+step batch1024-fetch; timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/b1024_fetch -- python3 $R/scripts/bench_batch_dim.py --rows 1000000 --dim 1024 --steps 5 > $O/b1024_fetch.json 2> $O/b1024_fetch.err || { tail -5 $O/b1024_fetch.err; exit 1; }
+step batch1024-write; timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/b1024_write -- python3 $R/scripts/bench_batch_dim.py --rows 1000000 --dim 1024 --steps 5 > $O/b1024_write.json 2> $O/b1024_write.err || { tail -5 $O/b1024_write.err; exit 1; }
+step batch-shapes; for a in "4000000 1024 10" "1250000 768 100" "2000000 512 10" "1000000 1536 10"; do set -- $a; timeout -k 10 200 python3 $R/scripts/bench_batch_dim.py --rows $1 --dim $2 --k $3 --steps 10 2>/dev/null; done > $O/batch64_other_shapes.jsonl
+# the stand-alone probes behind profiles/rNN/tuning.md section 4 (built here if the snapshot has no binaries)
+step probes; P=$R/scripts/probes
+[ -x $P/_shape_probe ] || (cd $P && hipcc --offload-arch=gfx950 -O3 -std=c++17 -o _shape_probe shape_probe.hip 2>/dev/null)
+[ -x $P/_mfma_shape_probe ] || (cd $P && hipcc --offload-arch=gfx950 -O3 -std=c++17 -o _mfma_shape_probe mfma_shape_probe.hip 2>/dev/null)
+timeout -k 10 120 $P/_shape_probe 1 40 > $O/read_shape_probe.log 2>&1; timeout -k 10 120 $P/_mfma_shape_probe > $O/mfma_shape_probe.log 2>&1
 step knn-trace; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/knn_trace -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-autolink > $O/knn_trace.json 2> $O/knn_trace.err || { tail -5 $O/knn_trace.err; exit 1; }
 step knn-fetch; timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/knn_fetch -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-autolink > $O/knn_fetch.json 2> $O/knn_fetch.err || { tail -5 $O/knn_fetch.err; exit 1; }
 step knn-write; timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/knn_write -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-autolink > $O/knn_write.json 2> $O/knn_write.err || { tail -5 $O/knn_write.err; exit 1; }
@@ -25,7 +33,7 @@ step batch-trace; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-fo
 step batch-fetch; timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/batch_fetch -- python3 $R/scripts/bench_batch.py --steps 5 > $O/batch_fetch.json 2> $O/batch_fetch.err || { tail -5 $O/batch_fetch.err; exit 1; }
 # keep only the summaries (traces are large)
 for d in knn_trace al_trace batch_trace b1024_trace; do f=$(ls -t $O/$d/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/${d}_kernel_stats.csv; done
-for d in knn_fetch knn_write batch_fetch al_mfma; do f=$(ls -t $O/$d/*/*counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && python3 - "$f" > $O/${d}_summary.json <<'PY'
+for d in knn_fetch knn_write batch_fetch al_mfma b1024_fetch b1024_write; do f=$(ls -t $O/$d/*/*counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && python3 - "$f" > $O/${d}_summary.json <<'PY'
 import csv, sys, json, collections
 agg = collections.defaultdict(lambda: [0.0, 0])
 for r in csv.DictReader(open(sys.argv[1])):
@@ -54,5 +62,5 @@ if busy and act:
     out["derived"] = {"kernel_cycles": cyc, "mfma_pipe_utilisation": busy / (cyc * 256 * 4)}
 print(json.dumps(out, indent=1))
 PY
-rm -rf $O/knn_trace $O/al_trace $O/batch_trace $O/b1024_trace $O/knn_fetch $O/knn_write $O/batch_fetch $O/al_mfma
+rm -rf $O/knn_trace $O/al_trace $O/batch_trace $O/b1024_trace $O/knn_fetch $O/knn_write $O/batch_fetch $O/al_mfma $O/b1024_fetch $O/b1024_write
 ls -la $O; cat $O/bench.json
