@@ -24,7 +24,7 @@
 //   epilogue, dense mode: cosines [query][row] to HBM, launch_dense_topk (scan.hip) then takes the top k per query.  Those
 //     4 bytes per row and query are 6 % of the traffic at 1024-d and cost the row stream a FIFTH of its rate (64-byte
 //     pieces into 64 distant streams; profiles/r02/tuning.md section 4), and they are read back once more
-//   epilogue, filter mode (the default from 262,144 rows when no row filter is set): a first dense pass over 1 row tile in
+//   epilogue, filter mode (the default from 262,144 rows; a row filter is applied to the sample and to the candidates): a first dense pass over 1 row tile in
 //     64 (32 for k > 32) gives every query a bound — the k-th best score of the sample; the k-th best of all rows can only
 //     be higher — and the pass over all rows writes only the (key, cosine) of the rows that reach it, ~64 k per query, into
 //     per-block lists (slots from LDS counters: a returning global atomic would be one more load in the vmcnt queue) that
@@ -121,6 +121,7 @@ struct BatchGArgs {
     uint32_t *cand_counts;     // [64][gridDim.x] out: entries written to each list
     uint32_t *overflow;        // [1] set when a block's list of some query was too short
     uint32_t cb;
+    DevFilter flt;             // filter mode: checked for the rows that reach the bound only
     const uint32_t *run_if;    // non-null: the launch does nothing unless *run_if != 0 (the exact fallback)
 };
 
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void batchg_kernel(const BatchGArgs a) {
                         if (acc[f][g][e] < thrv[g] * (nqv[g] * nr[e])) continue;
                         const float sim = cosine_from_norms(acc[f][g][e], nqv[g], nr[e]);
                         const float score = score_of(distance_of(sim));
-                        if (score_ord(score) >= tauv[g] && r0 + (uint32_t)e < a.n_rows) {
+                        if (score_ord(score) >= tauv[g] && r0 + (uint32_t)e < a.n_rows && row_passes(a.flt, r0 + (uint32_t)e)) {
                             const uint32_t slot = atomicAdd(&Cnt[q], 1u);   // LDS: a returning GLOBAL atomic would drain the row prefetch
                             if (slot < a.cb) {
                                 const size_t at = ((size_t)q * gridDim.x + blockIdx.x) * a.cb + slot;
@@ -363,6 +364,7 @@ __global__ __launch_bounds__(256, 2) void batchg_kernel(const BatchGArgs a) {
 bool batchg_supported(uint32_t dim, uint32_t k) { return dim % (2 * bg::KB) == 0 && dim <= 4096 && k >= 1 && k <= TOPK_MAX; }
 size_t batchg_qimg_bytes(uint32_t dim) { return (size_t)(dim / 32u) * bg::STEP_BYTES; }
 
+uint32_t batchg_tile_rows() { return bg::TILE_ROWS; }
 uint32_t batchg_grid(uint32_t n_rows) {
     const uint32_t n_tiles = (n_rows + bg::TILE_ROWS - 1) / bg::TILE_ROWS;
     return std::min<uint32_t>(n_tiles, 2u * device_cus());
@@ -402,13 +404,14 @@ int launch_batchg_pass(const float *rows, const float *norms, uint32_t n_rows, u
     }
     BatchGArgs a;
     memset(&a, 0, sizeof a);
+    a.flt.trivial = 1;
     a.rows = rows; a.norms = norms; a.qimg = d_qimg; a.qq = d_qq; a.dense = d_dense;
     a.n_rows = n_rows; a.dim = dim; a.nq = nq; a.stride = stride; a.tile_step = tile_step; a.run_if = run_if;
     const uint32_t n_tiles = (n_rows + TILE_ROWS - 1) / TILE_ROWS;
     a.n_tiles = (n_tiles + tile_step - 1) / tile_step;
     uint32_t grid = std::min<uint32_t>(a.n_tiles, 2u * device_cus());
     if (f) {
-        a.tau_ord = f->tau_ord; a.cand_keys = f->cand_keys; a.cand_sims = f->cand_sims; a.cand_counts = f->cand_counts; a.overflow = f->overflow; a.cb = f->cb;
+        a.tau_ord = f->tau_ord; a.cand_keys = f->cand_keys; a.cand_sims = f->cand_sims; a.cand_counts = f->cand_counts; a.overflow = f->overflow; a.cb = f->cb; a.flt = f->flt;
         grid = batchg_grid(n_rows);   // the candidate lists are laid out for exactly this grid
         hipLaunchKernelGGL((batchg_kernel<0, true>), dim3(grid), dim3(256), LDS_BYTES, stream, a);
         CX_HIP(hipGetLastError());

@@ -334,7 +334,7 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
     static const uint32_t filter_min = getenv("CX_BATCHG_FILTER_MIN") ? (uint32_t)atoi(getenv("CX_BATCHG_FILTER_MIN")) : 262144u;
     // wide lists (k > 32) on a large unfiltered store: batchg.hip's bound + candidates pass runs at 0.71-0.75 of the HBM
     // peak whatever k is, batch2_kernel's in-kernel wide lists at 0.40-0.49 (1.25M x 384 / 768, k = 100)
-    const bool wide_to_bg = k_eff > 32 && bg_ok && filter_ok && flt.trivial && n >= filter_min && batchg_supported(ix->dim, k_eff);
+    const bool wide_to_bg = k_eff > 32 && bg_ok && filter_ok && n >= filter_min && batchg_supported(ix->dim, k_eff);
     if (b2_ok && !wide_to_bg && topk_path && no_tails && nq >= (uint64_t)batch_min && k_eff >= 1 && batch_supported(ix->dim, k_eff)) {
         if (int rc = ensure_norms(ix, s)) return rc;
         const uint32_t qpp = batch_queries_per_pass(ix->dim, k_eff, nq);
@@ -396,7 +396,7 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
         if (int rc = ensure_dev(c->d_qimg, c->qi_cap, qimg + 64 * sizeof(float))) return rc;
         if (int rc = ensure_dev(c->d_part_keys, c->pk_cap, (size_t)64 * chunks * k_eff)) return rc;
         if (int rc = ensure_dev(c->d_part_sims, c->ps_cap, (size_t)64 * chunks * k_eff)) return rc;
-        // Large stores with no row filter: bound each query from a 1-in-64 (k <= 32) or 1-in-32 sample of the row tiles, then write only the
+        // Large stores: bound each query from a 1-in-64 (k <= 32) or 1-in-32 sample of the row tiles, then write only the
         // rows that reach the bound (kernels.hpp: BatchGFilter) — the 4 bytes per row and query of the dense pass cost
         // the row stream a fifth of its rate, and launch_dense_topk reads them all back.
         // expected candidates per query = k * step (the sample's k-th best against step times as many rows)
@@ -404,7 +404,7 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
         const uint32_t tile_step = step_env ? step_env : (k_eff <= 32u ? 64u : 32u);
         uint32_t s_tiles = 0;
         const uint32_t s_rows = batchg_sample_rows(n, tile_step, &s_tiles), s_stride = (s_rows + 3u) & ~3u;
-        const bool filtered = filter_ok && flt.trivial && n >= filter_min && s_rows >= k_eff;
+        const bool filtered = filter_ok && n >= filter_min && s_rows >= k_eff;
         const uint32_t bgrid = batchg_grid(n);
         uint32_t cb = std::max<uint32_t>(k_eff, 32u);
         if (getenv("CX_BATCHG_CAND_CAP")) cb = std::max<uint32_t>(k_eff, (uint32_t)atoi(getenv("CX_BATCHG_CAND_CAP")));   // tests: force the fallback
@@ -442,10 +442,10 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
                 // 1. the bound: the k-th best score of the sampled tiles
                 uint32_t *counts = c->d_bg_ctl + 80;
                 if (int rc = launch_batchg_pass(ix->d_rows, ix->d_norms, n, ix->dim, m, c->d_qimg, d_qq, c->d_dense, s_stride, tile_step, nullptr, nullptr, s)) return rc;
-                if (int rc = launch_bound_select(c->d_dense, s_stride, s_rows, m, k_eff, tau, s)) return rc;
+                if (int rc = launch_bound_select(c->d_dense, s_stride, s_rows, m, k_eff, tau, flt, batchg_tile_rows(), tile_step, s)) return rc;
                 // 2. every row, candidates only
                 CX_HIP(hipMemsetAsync(overflow, 0, sizeof(uint32_t), s));
-                BatchGFilter f{tau, c->d_cand_keys, c->d_cand_sims, counts, overflow, cb};
+                BatchGFilter f{tau, c->d_cand_keys, c->d_cand_sims, counts, overflow, cb, flt};
                 if (int rc = prof_begin()) return rc;
                 if (int rc = launch_batchg_pass(ix->d_rows, ix->d_norms, n, ix->dim, m, c->d_qimg, d_qq, nullptr, 0, 1, &f, nullptr, s)) return rc;
                 if (e1) CX_HIP(hipEventRecord(e1, s));

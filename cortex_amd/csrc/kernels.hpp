@@ -123,14 +123,18 @@ struct BatchGFilter {
     uint32_t *cand_counts;     // [64][batchg_grid(n_rows)] entries each block wrote (<= cb)
     uint32_t *overflow;        // [1], zeroed
     uint32_t cb;               // entries per block and query: a multiple of k
+    DevFilter flt;             // rows that fail it are no candidates
 };
+uint32_t batchg_tile_rows();
 uint32_t batchg_grid(uint32_t n_rows);
 uint32_t batchg_sample_rows(uint32_t n_rows, uint32_t tile_step, uint32_t *n_tiles_out);   // dense columns a sampled pass fills
 int launch_batchg_split(const float *d_queries, uint32_t nq, uint32_t dim, char *d_qimg, float *d_qq, hipStream_t stream);
 int launch_batchg_pass(const float *rows, const float *norms, uint32_t n_rows, uint32_t dim, uint32_t nq, const char *d_qimg, const float *d_qq,
                        float *d_dense, uint32_t stride, uint32_t tile_step, const BatchGFilter *f, const uint32_t *run_if, hipStream_t stream);
-// tau_ord[q] = score_ord of the k-th best score among dense[q][0 .. n) (0 when n < k)
-int launch_bound_select(const float *d_dense, uint32_t stride, uint32_t n, uint32_t nq, uint32_t k, uint32_t *tau_ord, hipStream_t stream);
+// tau_ord[q] = score_ord of the k-th best score among dense[q][0 .. n) over the columns whose row passes flt (0 when fewer
+// than k do); column e stands for row (e / tile_rows) * tile_step * tile_rows + e % tile_rows
+int launch_bound_select(const float *d_dense, uint32_t stride, uint32_t n, uint32_t nq, uint32_t k, uint32_t *tau_ord, const DevFilter &flt,
+                        uint32_t tile_rows, uint32_t tile_step, hipStream_t stream);
 uint32_t dense_topk_chunks(uint32_t n_rows);
 int launch_dense_topk(const float *d_dense, uint32_t stride, uint32_t n_rows, uint32_t nq, uint32_t k, const DevFilter &flt,
                       uint64_t *part_keys, float *part_sims, uint32_t chunks, hipStream_t stream, const uint32_t *run_if = nullptr);

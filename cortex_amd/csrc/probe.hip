@@ -33,10 +33,18 @@ __global__ __launch_bounds__(256) void probe_read_kernel(const f32x4 *src, size_
     if (v == 123456.789f) *sink = v;   // keeps the loads alive; never true for the probe's data
 }
 
-__global__ __launch_bounds__(256) void probe_mfma_kernel(uint32_t iters, float *sink) {
-    bf16x8 a, b;
+// Operands are RANDOM (hashed mantissas and signs): the clock the chip holds under an MFMA-dense loop depends on the data —
+// the same loop on near-constant operands ran at 2.24 PFLOP/s, on random ones at 1.78-1.81 (scripts/probes/
+// mfma_shape_probe.hip; MI355X_MICROARCH.md, DVFS give-back) — and the kernels this is a ceiling for see random data.
+__device__ inline uint32_t probe_hash(uint32_t x) { x *= 2654435761u; x ^= x >> 15; x *= 2246822519u; x ^= x >> 13; return x; }
+__device__ inline bf16x8 probe_rand_frag(uint32_t seed) {
+    bf16x8 v;
 #pragma unroll
-    for (int e = 0; e < 8; e++) { a[e] = (short)(0x3C00 + (threadIdx.x & 63) + e); b[e] = (short)(0x3B80 + (threadIdx.x & 31) * 3 + e); }
+    for (int e = 0; e < 8; e++) v[e] = (short)(0x3C00 | (probe_hash(seed * 8u + (uint32_t)e) & 0x83FF));   // +-[0.0078, 0.0156)
+    return v;
+}
+__global__ __launch_bounds__(256) void probe_mfma_kernel(uint32_t iters, float *sink) {
+    const bf16x8 a = probe_rand_frag(2u * (blockIdx.x * 256u + threadIdx.x)), b = probe_rand_frag(2u * (blockIdx.x * 256u + threadIdx.x) + 1u);
     f32x16 c0, c1, c2, c3;
 #pragma unroll
     for (int e = 0; e < 16; e++) { c0[e] = 0.0f; c1[e] = 0.0f; c2[e] = 0.0f; c3[e] = 0.0f; }
@@ -60,7 +68,8 @@ template <int DMA>   // 0 none, 1 LDS-DMA, 2 register-staged (global_load_dwordx
 __global__ __launch_bounds__(512) void probe_mfma_lds_kernel(uint32_t iters, float *sink, const char *src) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 32 KiB read slot (A 16 KiB + B 16 KiB) [+ 96 KiB of DMA targets]
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    for (uint32_t i = tid; i < 32768u / 16u; i += 512u) *reinterpret_cast<f32x4 *>(smem + i * 16u) = f32x4{1.0f, 0.5f, 0.25f, 0.125f};
+    for (uint32_t i = tid; i < 32768u / 16u; i += 512u)   // random bf16 operands (see probe_rand_frag)
+        *reinterpret_cast<bf16x8 *>(smem + i * 16u) = probe_rand_frag(blockIdx.x * 2048u + i);
     __syncthreads();
     const uint32_t wm = wave >> 2, wn = wave & 3u, fr = lane & 31u, fq = lane >> 5;
     uint32_t offA[4][2], offB[2][2];

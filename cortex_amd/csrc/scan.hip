@@ -488,17 +488,19 @@ __global__ __launch_bounds__(256) void dense_topk_kernel(const float *dense, uin
     block_merge_store<KS>(top, k, part_keys + base, part_sims + base);
 }
 
-// tau_ord[q] = score_ord of the k-th largest score among the cosines dense[q][0 .. n) (0 when n < k): a block-wide radix
+// tau_ord[q] = score_ord of the k-th largest score among the cosines dense[q][0 .. n) of rows that pass the filter (0 when
+// fewer than k do): a block-wide radix
 // select over the 32-bit ordinals, one block per query, most significant byte first — a bound needs no list.  (The
 // wave-list top-k + merge this replaces took 0.15 + 0.04 ms on a 39k-row sample at k = 100: more than a fifth of the
 // pass it prepares.)
-__global__ __launch_bounds__(1024) void bound_select_kernel(const float *dense, uint32_t stride, uint32_t n, uint32_t k, uint32_t *tau_ord) {
+__global__ __launch_bounds__(1024) void bound_select_kernel(const float *dense, uint32_t stride, uint32_t n, uint32_t k, uint32_t *tau_ord,
+                                                           const DevFilter flt, uint32_t tile_rows, uint32_t tile_step) {
     __shared__ uint32_t hist[256];
-    __shared__ uint32_t s_prefix, s_mask, s_need;
+    __shared__ uint32_t s_prefix, s_mask, s_need, s_found_all, s_found;
     const uint32_t tid = threadIdx.x, NT = 1024;
     if (n < k) { if (tid == 0) tau_ord[blockIdx.x] = 0u; return; }
     const float *d = dense + (size_t)blockIdx.x * stride;
-    if (tid == 0) { s_prefix = 0u; s_mask = 0u; s_need = k; }
+    if (tid == 0) { s_prefix = 0u; s_mask = 0u; s_need = k; s_found_all = 1u; s_found = 0u; }
     for (int shift = 24; shift >= 0; shift -= 8) {
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
@@ -510,7 +512,9 @@ __global__ __launch_bounds__(1024) void bound_select_kernel(const float *dense, 
 #pragma unroll
             for (uint32_t u = 0; u < 8; u++) {
                 const uint32_t o = score_ord(score_of(distance_of(v[u])));
-                const bool act = e0 + u * NT < n && (o & mask) == prefix;
+                const uint32_t e = e0 + u * NT;   // column e of the sample = row (e / tile_rows) * tile_step * tile_rows + e % tile_rows
+                bool act = e < n && (o & mask) == prefix;
+                if (act && !flt.trivial) act = row_passes(flt, (e / tile_rows) * tile_step * tile_rows + e % tile_rows);
                 const uint32_t bin = (o >> shift) & 255u;
                 const uint64_t am = __ballot(act);
                 if (am == 0ull) continue;
@@ -526,7 +530,7 @@ __global__ __launch_bounds__(1024) void bound_select_kernel(const float *dense, 
             }
         }
         __syncthreads();
-        if (tid < 256) {   // the bin that holds the need-th largest of the values still in play (n >= k: there is one)
+        if (tid < 256) {   // the bin that holds the need-th largest of the values still in play
             const uint32_t need = s_need;
             uint32_t above = 0;
             for (uint32_t b = tid + 1; b < 256; b++) above += hist[b];
@@ -535,15 +539,19 @@ __global__ __launch_bounds__(1024) void bound_select_kernel(const float *dense, 
                 s_prefix = prefix | (tid << shift);
                 s_mask = mask | (0xFFu << shift);
                 s_need = need - above;
+                s_found = 1u;
             }
         }
         __syncthreads();
+        if (tid == 0) { if (!s_found) s_found_all = 0u; s_found = 0u; }   // fewer than k rows pass the filter: no bound
+        __syncthreads();
     }
-    if (tid == 0) tau_ord[blockIdx.x] = s_prefix;
+    if (tid == 0) tau_ord[blockIdx.x] = s_found_all ? s_prefix : 0u;
 }
-int launch_bound_select(const float *d_dense, uint32_t stride, uint32_t n, uint32_t nq, uint32_t k, uint32_t *tau_ord, hipStream_t stream) {
+int launch_bound_select(const float *d_dense, uint32_t stride, uint32_t n, uint32_t nq, uint32_t k, uint32_t *tau_ord, const DevFilter &flt,
+                        uint32_t tile_rows, uint32_t tile_step, hipStream_t stream) {
     if (!nq || !k) return CX_OK;
-    hipLaunchKernelGGL(bound_select_kernel, dim3(nq), dim3(1024), 0, stream, d_dense, stride, n, k, tau_ord);
+    hipLaunchKernelGGL(bound_select_kernel, dim3(nq), dim3(1024), 0, stream, d_dense, stride, n, k, tau_ord, flt, tile_rows, tile_step);
     CX_HIP(hipGetLastError());
     return CX_OK;
 }

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Copy the judged summaries of gpurun_out/prof_round (scripts/profile_round.sh) into profiles/<round>/ and derive the
+per-launch HBM traffic figures from the PMC passes (MI355X_MICROARCH.md §HBM: counters in KB; gfx950 FETCH_SIZE reports
+half of a wide coalesced streaming read -> read bytes = FETCH_SIZE * 1024 * 2; WRITE_SIZE * 1024 exact)."""
+import json, os, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+S, D = os.path.join(ROOT, "gpurun_out", "prof_round"), os.path.join(ROOT, "profiles", rnd)
+os.makedirs(D, exist_ok=True)
+CORR = ("MI355X_MICROARCH.md §HBM: counters in KB; gfx950 FETCH_SIZE reports 1/2 of a wide coalesced streaming read -> "
+        "read bytes = FETCH_SIZE*1024*2; WRITE_SIZE*1024 exact")
+
+
+def cp(src, dst):
+    if os.path.exists(os.path.join(S, src)):
+        shutil.copy(os.path.join(S, src), os.path.join(D, dst))
+
+
+def per_dispatch(summary, kernel, counter):
+    p = os.path.join(S, summary)
+    if not os.path.exists(p):
+        return None, 0
+    for r in json.load(open(p)):
+        if kernel in r["kernel"] and r["counter"] == counter:
+            return r["per_dispatch"], r["dispatches"]
+    return None, 0
+
+
+def traffic(name, cmd, kernel, fetch_sum, write_sum, algo, key):
+    f, nf = per_dispatch(fetch_sum, kernel, "FETCH_SIZE")
+    w, _ = per_dispatch(write_sum, kernel, "WRITE_SIZE") if write_sum else (None, 0)
+    if f is None:
+        return
+    total = f * 1024 * 2 + (w or 0.0) * 1024
+    json.dump({"command": cmd, "correction": CORR, "kernel": kernel, "FETCH_SIZE_mean_KB": f, "WRITE_SIZE_mean_KB": w, "launches": nf,
+               key: total, "algorithmic_bytes_per_launch": algo, "ratio": total / algo}, open(os.path.join(D, name), "w"), indent=1)
+
+
+for src, dst in (("bench.json", f"bench_{rnd}.json"), ("bench_steps20_warmup5.json", "bench_steps20_warmup5.json"),
+                 ("cold_start_probe.json", "cold_start_probe.json"), ("cold_probe.log", "cold_start_probe.log"),
+                 ("knn_trace_kernel_stats.csv", "knn_1Mx768_kernel_stats.csv"), ("al_trace_kernel_stats.csv", "autolink_100kx768_kernel_stats.csv"),
+                 ("autolink.json", "autolink_100kx768_bench.json"), ("al_mfma_summary.json", "autolink_100kx768_pmc_summary.json"),
+                 ("autolink_mfma_utilisation.json", "autolink_100kx768_mfma_utilisation.json"),
+                 ("batch_trace_kernel_stats.csv", "batch64_1.25Mx768_kernel_stats.csv"), ("batch.json", "batch64_1.25Mx768_bench.json"),
+                 ("b1024_trace_kernel_stats.csv", "batch64_1Mx1024_kernel_stats.csv"), ("batch64_1Mx1024.json", "batch64_1Mx1024_bench.json"),
+                 ("batch64_other_shapes.jsonl", "batch64_other_shapes.jsonl"), ("top100_lists_100kx768.log", "top100_lists_100kx768.log"),
+                 ("read_shape_probe.log", "read_shape_probe.log"), ("mfma_shape_probe.log", "mfma_shape_probe.log")):
+    cp(src, dst)
+if not os.path.exists(os.path.join(S, "cold_start_probe.json")) and os.path.exists(os.path.join(ROOT, "gpurun_out", "cold_probe.json")):
+    shutil.copy(os.path.join(ROOT, "gpurun_out", "cold_probe.json"), os.path.join(D, "cold_start_probe.json"))
+traffic("knn_1Mx768_pmc_final.json", "scripts/profile_round.sh: rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- "
+        "python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-autolink", "scan_kernel<768", "knn_fetch_summary.json", "knn_write_summary.json",
+        3_072_000_000, "scan_kernel_hbm_bytes_per_launch")
+traffic("batch64_1.25Mx768_pmc_final.json", "scripts/profile_round.sh: rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 scripts/bench_batch.py --steps 5",
+        "batch2_kernel", "batch_fetch_summary.json", None, 1_250_000 * 768 * 4, "batch_kernel_hbm_read_bytes_per_launch")
+traffic("batch64_1Mx1024_pmc_final.json", "scripts/profile_round.sh: rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- "
+        "python3 scripts/bench_batch_dim.py --rows 1000000 --dim 1024 --steps 5", "batchg_kernel<0, true>", "b1024_fetch_summary.json", "b1024_write_summary.json",
+        1_000_000 * 1024 * 4, "batchg_kernel_hbm_bytes_per_launch")
+print(sorted(os.listdir(D)))

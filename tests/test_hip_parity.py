@@ -698,6 +698,20 @@ for n, d, k, nq in [(3001, 768, 10, 70), (1520, 768, 100, 9), (9100, 1024, 10, 6
         assert m == len(e["row"]), (m, len(e["row"]))
         got = np.array([lut[g.tobytes()] for g in bi[i, :m]], dtype=np.int64)
         assert_topk_parity(got, bs[i, :m], e["row"], e["score"], what="n=%%d d=%%d k=%%d q%%d" %% (n, d, k, i))
+    if n == 9100:   # the same store with removed rows, metadata and a filter: the bound counts passing rows only
+        for r in range(0, n, 3):
+            kind = "fact" if r %% 2 else "event"
+            h.set_metadata(ids[r].tobytes(), kind, "kai"); o.set_metadata(ids[r].tobytes(), kind, "kai")
+        for r in (10, 11, 500, 4097):
+            h.remove(ids[r].tobytes()); o.remove(ids[r].tobytes())
+        excl = [ids[i].tobytes() for i in (1, 2, 3, 130)]
+        for hf, of in ((None, None), (cortex_amd.VectorFilter(kinds=["fact"], exclude=excl), oracle.Filter(kinds=["fact"], exclude=excl))):
+            bi, bs, bd, bc = h.search_batch_arrays(qs, k, hf)
+            for i in range(nq):
+                e = o.search(qs[i], k, of); m = int(bc[i])
+                assert m == len(e["row"]), (m, len(e["row"]))
+                got = np.array([lut[g.tobytes()] for g in bi[i, :m]], dtype=np.int64)
+                assert_topk_parity(got, bs[i, :m], e["row"], e["score"], what="filtered n=%%d d=%%d k=%%d q%%d" %% (n, d, k, i))
 print("ok")
 """ % ((os.path.dirname(os.path.dirname(os.path.abspath(__file__))),) * 2)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
