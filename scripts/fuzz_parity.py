@@ -20,7 +20,7 @@ rng = np.random.default_rng(a.seed)
 t_end = time.time() + a.seconds
 cases = 0
 while time.time() < t_end:
-    d = int(rng.choice([384, 768, 384, 768, 128, 100, 1024, 64]))
+    d = int(rng.choice([384, 768, 384, 768, 128, 100, 1024, 64, 512, 640]))
     n = int(rng.choice([rng.integers(1, 200), rng.integers(200, 5000), rng.integers(5000, 40000)]))
     k = int(rng.choice([1, 5, 10, 16, 32, 33, 64, 100, 104, 105, 300]))
     nq = int(rng.choice([1, 2, 3, 17, 32, 33, 64, 65, 130]))

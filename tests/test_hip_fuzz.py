@@ -15,6 +15,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ("fuzz_parity.py", ["--seconds", "10", "--seed", "101"], {}),
     ("fuzz_parity.py", ["--big", "--seconds", "12", "--seed", "102"], {}),
     ("fuzz_parity.py", ["--seconds", "8", "--seed", "105"], {"CX_BATCH_WIDE_MIN_K": "8"}),     # wide lists from k = 8
+    # batchg.hip's bound + candidates path at fuzz sizes, 384/768-d included, with the fuzzer's filters and tombstones
+    ("fuzz_parity.py", ["--seconds", "12", "--seed", "107"], {"CX_BATCHG_FILTER_MIN": "300", "CX_BATCH2": "0"}),
+    ("fuzz_parity.py", ["--seconds", "8", "--seed", "108"], {"CX_BATCHG_FILTER_MIN": "300", "CX_BATCHG_SAMPLE_STEP": "7", "CX_BATCHG_CAND_CAP": "1"}),  # short lists: overflow -> dense fallback
+    ("fuzz_stateful.py", ["--seconds", "8", "--seed", "109"], {"CX_BATCHG_FILTER_MIN": "300", "CX_BATCH2": "0"}),
     ("fuzz_autolink.py", ["--seconds", "12", "--seed", "103"], {}),
     ("fuzz_autolink.py", ["--seconds", "10", "--seed", "106"], {"CX_PAIR_CAND_CAP": "24"}),     # most rows on the exact path
     ("fuzz_stateful.py", ["--seconds", "10", "--seed", "104"], {}),
