@@ -56,6 +56,8 @@ SIGNATURES = {
     "cx_last_error": (C.c_char_p, []),
     "cx_device_count": (C.c_int, []),
     "cx_create": (_P, [_U32, C.c_int]),
+    "cx_create_ex": (_P, [_U32, C.c_int, C.c_int]),
+    "cx_dtype": (C.c_int, [_P]),
     "cx_destroy": (None, [_P]),
     "cx_reserve": (C.c_int, [_P, _U64]),
     "cx_upsert": (C.c_int, [_P, _P, _P, _U64]),
@@ -75,6 +77,7 @@ SIGNATURES = {
     "cx_rebuild": (C.c_int, [_P]),
     "cx_save": (C.c_int, [_P, C.c_char_p]),
     "cx_load": (_P, [C.c_char_p, C.c_int]),
+    "cx_load_ex": (_P, [C.c_char_p, C.c_int, C.c_int]),
     "cx_len": (_U64, [_P]),
     "cx_dimension": (_U32, [_P]),
     "cx_row_count": (_U64, [_P]),
@@ -95,6 +98,7 @@ SIGNATURES = {
     "cx_merge_topk_dev": (C.c_int, [C.c_int, _U64, _U64, _U64, _U64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     # one index over several GPUs (sharded.cpp)
     "cx_sharded_create": (_P, [_U32, _U32, _P]),
+    "cx_sharded_create_ex": (_P, [_U32, _U32, _P, C.c_int]),
     "cx_sharded_destroy": (None, [_P]),
     "cx_sharded_n_shards": (_U32, [_P]),
     "cx_sharded_shard": (_P, [_P, _U32]),

@@ -53,20 +53,21 @@ __device__ inline float wave_sum(float v) {
 
 // ---------------------------------------------------------------- 1. shadow
 
-__global__ __launch_bounds__(256) void build_shadow_kernel(const float *rows, uint16_t *shadow, uint32_t row_lo,
+template <typename S>
+__global__ __launch_bounds__(256) void build_shadow_kernel(const S *rows, uint16_t *shadow, uint32_t row_lo,
                                                            uint32_t row_hi, uint32_t dim) {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t r = row_lo + wave; r < row_hi; r += n_waves) {
-        const float *p = rows + (size_t)r * dim;
+        const S *p = rows + (size_t)r * dim;
         float ss = 0.0f;
-        for (uint32_t j = lane; j < dim; j += 64u) ss += p[j] * p[j];
+        for (uint32_t j = lane; j < dim; j += 64u) { const float x = ldf(p + j); ss += x * x; }
         ss = wave_sum(ss);
         const float inv = ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f;  // zero rows -> zero shadow (never a candidate)
         uint16_t *o = shadow + (size_t)r * dim;
         for (uint32_t j = lane; j < dim; j += 64u) {
-            const float v = p[j] * inv;
+            const float v = ldf(p + j) * inv;
             o[j] = (v == v && fabsf(v) <= 3.0e38f) ? f32_to_bf16_rne(v) : (uint16_t)0;
         }
     }
@@ -77,7 +78,16 @@ int launch_build_shadow(const float *rows, uint16_t *shadow, uint32_t row_lo, ui
     if (row_hi <= row_lo) return CX_OK;
     uint32_t grid = (row_hi - row_lo + 3u) / 4u;
     if (grid > 8192u) grid = 8192u;
-    hipLaunchKernelGGL(build_shadow_kernel, dim3(grid), dim3(256), 0, stream, rows, shadow, row_lo, row_hi, dim);
+    hipLaunchKernelGGL(build_shadow_kernel<float>, dim3(grid), dim3(256), 0, stream, rows, shadow, row_lo, row_hi, dim);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+int launch_build_shadow(const uint16_t *rows16, uint16_t *shadow, uint32_t row_lo, uint32_t row_hi, uint32_t dim,
+                        hipStream_t stream) {
+    if (row_hi <= row_lo) return CX_OK;
+    uint32_t grid = (row_hi - row_lo + 3u) / 4u;
+    if (grid > 8192u) grid = 8192u;
+    hipLaunchKernelGGL(build_shadow_kernel<uint16_t>, dim3(grid), dim3(256), 0, stream, rows16, shadow, row_lo, row_hi, dim);
     CX_HIP(hipGetLastError());
     return CX_OK;
 }
@@ -296,8 +306,13 @@ int launch_pair_filter(const PairFilterArgs &a, hipStream_t stream) {
 // strided f32 partials + butterfly, reference epilogue) of every candidate,
 // exact threshold, ordered top-k.  Rows whose candidate list overflowed are
 // flagged and redone by the caller on the exact scan path.
-template <int KS>
+template <typename S> struct StoreOf;
+template <> struct StoreOf<float> { static __device__ const float *get(const RescoreArgs &a) { return a.rows; } };
+template <> struct StoreOf<uint16_t> { static __device__ const uint16_t *get(const RescoreArgs &a) { return a.rows16; } };
+
+template <int KS, typename S>
 __global__ __launch_bounds__(256) void rescore_kernel(const RescoreArgs a) {
+    const S *rows = StoreOf<S>::get(a);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -305,19 +320,20 @@ __global__ __launch_bounds__(256) void rescore_kernel(const RescoreArgs a) {
     const bool vec4 = (dim & 3u) == 0;
     for (uint32_t i = wave; i < a.n_scan; i += n_waves) {
         const uint32_t qrow = a.scan_rows ? a.scan_rows[i] : i;
-        const float *q = (a.q_rows ? a.q_rows : a.rows) + (size_t)qrow * dim;
+        // the scanned vector: an external f32 vector, or a row of the store (either element type)
+        auto q4 = [&](uint32_t j) -> f32x4 { return a.q_rows ? reinterpret_cast<const f32x4 *>(a.q_rows + (size_t)qrow * dim)[j] : row4(rows, qrow, dim, j); };
+        auto q1 = [&](uint32_t j) -> float { return a.q_rows ? a.q_rows[(size_t)qrow * dim + j] : ldf(rows + (size_t)qrow * dim + j); };
         const uint32_t total = a.cand_cnt[i];
         const uint32_t cnt = total < a.cap ? total : a.cap;
         if (lane == 0) a.overflow[i] = total > a.cap ? 1u : 0u;
         float qq = 0.0f;
         if (vec4) {
-            const f32x4 *q4 = reinterpret_cast<const f32x4 *>(q);
             for (uint32_t j = lane; j < dim / 4u; j += 64u) {
-                const f32x4 x = q4[j];
+                const f32x4 x = q4(j);
                 qq = fmaf(x.w, x.w, fmaf(x.z, x.z, fmaf(x.y, x.y, fmaf(x.x, x.x, qq))));
             }
         } else {
-            for (uint32_t j = lane; j < dim; j += 64u) qq = fmaf(q[j], q[j], qq);
+            for (uint32_t j = lane; j < dim; j += 64u) { const float x = q1(j); qq = fmaf(x, x, qq); }
         }
         qq = wave_sum(qq);
         WaveTopK<KS> top;
@@ -331,12 +347,11 @@ __global__ __launch_bounds__(256) void rescore_kernel(const RescoreArgs a) {
 #pragma unroll
             for (int u = 0; u < 4; u++) jrow[u] = a.cand[(size_t)i * a.cap + (c0 + u < cnt ? c0 + u : cnt - 1u)];
             if (vec4) {
-                const f32x4 *q4 = reinterpret_cast<const f32x4 *>(q);
                 for (uint32_t j = lane; j < dim / 4u; j += 64u) {
-                    const f32x4 y = q4[j];
+                    const f32x4 y = q4(j);
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
-                        const f32x4 x = reinterpret_cast<const f32x4 *>(a.rows + (size_t)jrow[u] * dim)[j];
+                        const f32x4 x = row4(rows, jrow[u], dim, j);
                         // explicit fixed-order FMA chains: a pair's score must not depend on which of the four
                         // slots it landed in (left to the compiler, slots get different packed/scalar FMA trees)
                         d0[u] = fmaf(x.w, y.w, fmaf(x.z, y.z, fmaf(x.y, y.y, fmaf(x.x, y.x, d0[u]))));
@@ -345,10 +360,10 @@ __global__ __launch_bounds__(256) void rescore_kernel(const RescoreArgs a) {
                 }
             } else {
                 for (uint32_t j = lane; j < dim; j += 64u) {
-                    const float y = q[j];
+                    const float y = q1(j);
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
-                        const float x = a.rows[(size_t)jrow[u] * dim + j];
+                        const float x = ldf(rows + (size_t)jrow[u] * dim + j);
                         d0[u] = fmaf(x, y, d0[u]);
                         n0[u] = fmaf(x, x, n0[u]);
                     }
@@ -402,7 +417,9 @@ __global__ __launch_bounds__(256) void pair_sims_clear_kernel(const RescoreArgs 
     }
 }
 
+template <typename S>
 __global__ __launch_bounds__(256) void pair_score_kernel(const RescoreArgs a) {
+    const S *rows = StoreOf<S>::get(a);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t dim = a.dim;
@@ -411,16 +428,14 @@ __global__ __launch_bounds__(256) void pair_score_kernel(const RescoreArgs a) {
         const uint32_t total = a.cand_cnt[i];
         if (total > a.cap) continue;                       // overflowed: redone on the exact path, nobody waits for it
         const uint32_t cnt = total;
-        const float *q = a.rows + (size_t)i * dim;
         float qq = 0.0f;
         if (vec4) {
-            const f32x4 *q4 = reinterpret_cast<const f32x4 *>(q);
             for (uint32_t j = lane; j < dim / 4u; j += 64u) {
-                const f32x4 x = q4[j];
+                const f32x4 x = row4(rows, i, dim, j);
                 qq = fmaf(x.w, x.w, fmaf(x.z, x.z, fmaf(x.y, x.y, fmaf(x.x, x.x, qq))));
             }
         } else {
-            for (uint32_t j = lane; j < dim; j += 64u) qq = fmaf(q[j], q[j], qq);
+            for (uint32_t j = lane; j < dim; j += 64u) { const float x = ldf(rows + (size_t)i * dim + j); qq = fmaf(x, x, qq); }
         }
         qq = wave_sum(qq);
         // 64 list entries at a time, one per lane; the ones this row has to sum are then taken four at a time (their
@@ -446,24 +461,23 @@ __global__ __launch_bounds__(256) void pair_score_kernel(const RescoreArgs a) {
                 }
                 // the same fixed-order chains as rescore_kernel: a pair scores the same through either kernel
                 if (vec4) {
-                    const f32x4 *q4 = reinterpret_cast<const f32x4 *>(q);
                     for (uint32_t j = lane; j < dim / 4u; j += 64u) {
-                        const f32x4 y = q4[j];
+                        const f32x4 y = row4(rows, i, dim, j);
 #pragma unroll
                         for (int u = 0; u < 4; u++) {
                             if (!need[u]) continue;
-                            const f32x4 x = reinterpret_cast<const f32x4 *>(a.rows + (size_t)jrow[u] * dim)[j];
+                            const f32x4 x = row4(rows, jrow[u], dim, j);
                             d0[u] = fmaf(x.w, y.w, fmaf(x.z, y.z, fmaf(x.y, y.y, fmaf(x.x, y.x, d0[u]))));
                             n0[u] = fmaf(x.w, x.w, fmaf(x.z, x.z, fmaf(x.y, x.y, fmaf(x.x, x.x, n0[u]))));
                         }
                     }
                 } else {
                     for (uint32_t j = lane; j < dim; j += 64u) {
-                        const float y = q[j];
+                        const float y = ldf(rows + (size_t)i * dim + j);
 #pragma unroll
                         for (int u = 0; u < 4; u++) {
                             if (!need[u]) continue;
-                            const float x = a.rows[(size_t)jrow[u] * dim + j];
+                            const float x = ldf(rows + (size_t)jrow[u] * dim + j);
                             d0[u] = fmaf(x, y, d0[u]);
                             n0[u] = fmaf(x, x, n0[u]);
                         }
@@ -566,7 +580,8 @@ int launch_rescore(const RescoreArgs &a, hipStream_t stream) {
         uint32_t g = (a.n_scan + 3u) / 4u;
         if (g > 16384u) g = 16384u;
         hipLaunchKernelGGL(pair_sims_clear_kernel, dim3(g), dim3(256), 0, stream, a);
-        hipLaunchKernelGGL(pair_score_kernel, dim3(g), dim3(256), 0, stream, a);
+        if (a.rows16) hipLaunchKernelGGL(pair_score_kernel<uint16_t>, dim3(g), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(pair_score_kernel<float>, dim3(g), dim3(256), 0, stream, a);
         if (a.topk <= 64) hipLaunchKernelGGL((select_lists_kernel<1>), dim3(g), dim3(256), 0, stream, a);
         else if (a.topk <= 128) hipLaunchKernelGGL((select_lists_kernel<2>), dim3(g), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((select_lists_kernel<4>), dim3(g), dim3(256), 0, stream, a);
@@ -575,9 +590,13 @@ int launch_rescore(const RescoreArgs &a, hipStream_t stream) {
     }
     uint32_t grid = (a.n_scan + 3u) / 4u;
     if (grid > 16384u) grid = 16384u;
-    if (a.topk <= 64) hipLaunchKernelGGL((rescore_kernel<1>), dim3(grid), dim3(256), 0, stream, a);
-    else if (a.topk <= 128) hipLaunchKernelGGL((rescore_kernel<2>), dim3(grid), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((rescore_kernel<4>), dim3(grid), dim3(256), 0, stream, a);
+    if (a.rows16) {
+        if (a.topk <= 64) hipLaunchKernelGGL((rescore_kernel<1, uint16_t>), dim3(grid), dim3(256), 0, stream, a);
+        else if (a.topk <= 128) hipLaunchKernelGGL((rescore_kernel<2, uint16_t>), dim3(grid), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((rescore_kernel<4, uint16_t>), dim3(grid), dim3(256), 0, stream, a);
+    } else if (a.topk <= 64) hipLaunchKernelGGL((rescore_kernel<1, float>), dim3(grid), dim3(256), 0, stream, a);
+    else if (a.topk <= 128) hipLaunchKernelGGL((rescore_kernel<2, float>), dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((rescore_kernel<4, float>), dim3(grid), dim3(256), 0, stream, a);
     CX_HIP(hipGetLastError());
     return CX_OK;
 }

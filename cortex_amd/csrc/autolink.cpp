@@ -41,13 +41,13 @@ int ensure_shadow(const cx_index *ix, hipStream_t s) {
     }
     for (uint32_t r : ix->shadow_stale)
         if (r < ix->shadow_rows) {
-            if (int rc = launch_build_shadow(ix->d_rows, ix->d_shadow, r, r + 1, ix->dim, s)) return rc;
+            if (int rc = (ix->dtype == 1 ? launch_build_shadow(ix->rows16(), ix->d_shadow, r, r + 1, ix->dim, s) : launch_build_shadow(ix->d_rows, ix->d_shadow, r, r + 1, ix->dim, s))) return rc;
             if (tiled)
                 if (int rc = launch_tile_shadow(ix->d_shadow, ix->d_shadow_t, r, r + 1, ix->dim, s)) return rc;
         }
     ix->shadow_stale.clear();
     if (ix->shadow_rows < n) {
-        if (int rc = launch_build_shadow(ix->d_rows, ix->d_shadow, (uint32_t)ix->shadow_rows, (uint32_t)n, ix->dim, s)) return rc;
+        if (int rc = (ix->dtype == 1 ? launch_build_shadow(ix->rows16(), ix->d_shadow, (uint32_t)ix->shadow_rows, (uint32_t)n, ix->dim, s) : launch_build_shadow(ix->d_rows, ix->d_shadow, (uint32_t)ix->shadow_rows, (uint32_t)n, ix->dim, s))) return rc;
         if (tiled)
             if (int rc = launch_tile_shadow(ix->d_shadow, ix->d_shadow_t, (uint32_t)ix->shadow_rows, (uint32_t)n, ix->dim, s)) return rc;
         ix->shadow_rows = n;
@@ -134,7 +134,7 @@ static int redo_lists(const cx_index *ix, Ctx *c, PassScratch &ps, hipStream_t s
         for (uint32_t i = 0; i < m; i++) src[i] = (scan_rows && !d_ext_queries) ? scan_rows[redo[lo + i]] : redo[lo + i];
         CX_HIP(hipMemcpyAsync(rs.d_src, src.data(), (size_t)m * 4, hipMemcpyHostToDevice, s));
         CX_HIP(hipMemcpyAsync(rs.d_pos, redo.data() + lo, (size_t)m * 4, hipMemcpyHostToDevice, s));
-        if (int rc = launch_gather_rows(d_ext_queries ? d_ext_queries : ix->d_rows, rs.d_vec, rs.d_src, m, ix->dim, s)) return rc;
+        if (int rc = ((!d_ext_queries && ix->dtype == 1) ? launch_gather_rows(ix->rows16(), rs.d_vec, rs.d_src, m, ix->dim, s) : launch_gather_rows(d_ext_queries ? d_ext_queries : ix->d_rows, rs.d_vec, rs.d_src, m, ix->dim, s))) return rc;
         const uint32_t *l_rows = rs.d_rows, *l_cnt = rs.d_cnt;
         if (k_eff == 0) {
             CX_HIP(hipMemsetAsync(rs.d_cnt, 0, (size_t)m * 4, s));
@@ -144,7 +144,8 @@ static int redo_lists(const cx_index *ix, Ctx *c, PassScratch &ps, hipStream_t s
                 return rc;
             RescoreArgs r;
             memset(&r, 0, sizeof r);
-            r.rows = ix->d_rows;
+            r.rows = ix->rows32();
+            r.rows16 = ix->rows16();
             r.q_rows = rs.d_vec;          // the gathered vectors, in redo order
             r.out_dists = rs.d_dists;
             r.meta = ix->d_meta;
@@ -301,7 +302,8 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
             if (phase_ms && lo == 0) CX_HIP(hipEventRecord(ev[2], s));
             RescoreArgs r;
             memset(&r, 0, sizeof r);
-            r.rows = ix->d_rows;
+            r.rows = ix->rows32();
+            r.rows16 = ix->rows16();
             r.meta = ix->d_meta;
             r.scan_rows = f.scan_rows;
             r.cand_cnt = ps.d_cand_cnt;
@@ -564,7 +566,8 @@ int cx_autolink_lists_dev(const cx_index *ix, uint64_t nq64, const float *d_quer
         } else if (int rc = ((int64_t)nq >= big_min) ? launch_pair_filter256(f, s) : launch_pair_filter(f, s)) return rc;
         RescoreArgs r;
         memset(&r, 0, sizeof r);
-        r.rows = ix->d_rows;
+        r.rows = ix->rows32();
+            r.rows16 = ix->rows16();
         r.q_rows = d_queries;
         r.meta = ix->d_meta;
         r.cand_cnt = ps.d_cand_cnt;
@@ -630,7 +633,7 @@ bool lists_by_filter(const cx_index *ix, Ctx *c, PassScratch &ps, uint32_t n_sca
     if (int e = ensure_dev(ps.d_list_dists, ps.c_list_dists, (size_t)S * topk)) return fail(e);
     if (int e = ensure_dev(ps.d_list_cnt, ps.c_list_cnt, (size_t)S)) return fail(e);
     if (hipMemcpyAsync(ps.d_scan, samp.data(), (size_t)S * 4, hipMemcpyHostToDevice, s) != hipSuccess) return fail(set_err(CX_ERR_DEVICE, "copy failed"));
-    if (int e = launch_gather_rows(ix->d_rows, ps.d_w, ps.d_scan, S, ix->dim, s)) return fail(e);
+    if (int e = (ix->dtype == 1 ? launch_gather_rows(ix->rows16(), ps.d_w, ps.d_scan, S, ix->dim, s) : launch_gather_rows(ix->d_rows, ps.d_w, ps.d_scan, S, ix->dim, s))) return fail(e);
     DevFilter flt;
     memset(&flt, 0, sizeof flt);
     flt.meta = ix->d_meta;
@@ -735,7 +738,10 @@ int cx_topk_lists_rows(const cx_index *ix, uint64_t n_scan64, const uint32_t *sc
         const float *d_q;
         if (scan_rows) {
             CX_HIP(hipMemcpyAsync(ps.d_scan, scan_rows + lo, (size_t)m * 4, hipMemcpyHostToDevice, s));
-            if (int rc = launch_gather_rows(ix->d_rows, ps.d_w, ps.d_scan, m, ix->dim, s)) return rc;
+            if (int rc = (ix->dtype == 1 ? launch_gather_rows(ix->rows16(), ps.d_w, ps.d_scan, m, ix->dim, s) : launch_gather_rows(ix->d_rows, ps.d_w, ps.d_scan, m, ix->dim, s))) return rc;
+            d_q = ps.d_w;
+        } else if (ix->dtype == 1) {   // bf16 store: the block of rows, expanded
+            if (int rc = launch_gather_rows(ix->rows16() + (size_t)lo * ix->dim, ps.d_w, nullptr, m, ix->dim, s)) return rc;
             d_q = ps.d_w;
         } else {
             d_q = ix->d_rows + (size_t)lo * ix->dim;   // every row in order: the store itself is the query block
@@ -771,6 +777,7 @@ int cx_copy_rows_dev(const cx_index *ix, uint64_t row_lo, uint64_t n, float *d_d
     if (!ix || !d_dst) return set_err(CX_ERR_VALIDATION, "null argument");
     if (row_lo + n > ix->n_rows) return set_err(CX_ERR_VALIDATION, "rows [%llu, %llu) out of range", (unsigned long long)row_lo, (unsigned long long)(row_lo + n));
     if (int rc = use_device(ix)) return rc;
+    if (n && ix->dtype == 1) return launch_gather_rows(ix->rows16() + (size_t)row_lo * ix->dim, d_dst, nullptr, (uint32_t)n, ix->dim, (hipStream_t)stream);
     if (n) CX_HIP(hipMemcpyAsync(d_dst, ix->d_rows + (size_t)row_lo * ix->dim, (size_t)n * ix->dim * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return CX_OK;
 } catch (...) { return cx::on_exception(); }

@@ -75,15 +75,16 @@ __device__ inline void split4g(const f32x4 v, bf16x4_t &hi, bf16x4_t &lo) {   //
 // Lane kq of the MFMA holds the k values {32 s + 4 kq .. + 3} and {32 s + 16 + 4 kq .. + 3} (the row side loads the
 // same two float4 per lane: 64 contiguous bytes per row per load instruction); queries beyond nq are zero.
 // Also |q|^2 per query.
-__global__ __launch_bounds__(256) void batchg_split_queries_kernel(const float *queries, uint32_t nq, uint32_t dim, char *qimg, float *qq) {
+// perm16 (bf16 row stores): lane kq of the MFMA holds the 8 CONSECUTIVE k values 32 s + 8 kq .. + 7 — one 16-byte piece of a bf16 row.
+__global__ __launch_bounds__(256) void batchg_split_queries_kernel(const float *queries, uint32_t nq, uint32_t dim, char *qimg, float *qq, int perm16) {
     const uint32_t n_steps = dim / 32u;
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_steps * bg::NQ * 4u; t += gridDim.x * blockDim.x) {
         const uint32_t s = t / (bg::NQ * 4u), j = (t / 4u) % bg::NQ, kq = t % 4u;
         f32x4 v0 = {0.0f, 0.0f, 0.0f, 0.0f}, v1 = v0;
         if (j < nq) {
             const f32x4 *q4 = reinterpret_cast<const f32x4 *>(queries + (size_t)j * dim + 32u * s);
-            v0 = q4[kq];
-            v1 = q4[4u + kq];
+            v0 = perm16 ? q4[2u * kq] : q4[kq];
+            v1 = perm16 ? q4[2u * kq + 1u] : q4[4u + kq];
         }
         bf16x4_t h0, l0, h1, l1;
         bg::split4g(v0, h0, l0);
@@ -105,7 +106,8 @@ __global__ __launch_bounds__(256) void batchg_split_queries_kernel(const float *
 }
 
 struct BatchGArgs {
-    const float *rows;     // [n_rows (+ 256 readable)][dim]
+    const float *rows;     // [n_rows (+ 256 readable)][dim]; null for a bf16 store
+    const uint16_t *rows16;   // bf16 store: the rows ARE the A operand (no split, two products per pair)
     const float *norms;    // |row|^2 (cx_index::d_norms)
     const char *qimg;      // split query images, dim / 32 steps of 8 KiB
     const float *qq;       // [64] |q|^2
@@ -127,7 +129,7 @@ struct BatchGArgs {
 
 // PROBE: 0 = the product; 1 = loads only (no LDS transpose, no split, no MFMA); 2 = no row loads (MFMAs on stale data);
 // 3 = rows only (no barriers, no query staging)
-template <int PROBE, bool FILTER>
+template <int PROBE, bool FILTER, bool R16>
 __global__ __launch_bounds__(256, 2) void batchg_kernel(const BatchGArgs a) {
     using namespace bg;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -183,7 +185,18 @@ __global__ __launch_bounds__(256, 2) void batchg_kernel(const BatchGArgs a) {
     };
     const uint32_t lane_off = lrow * a.dim * 4u + lpiece * 16u;
     f32x4 xa[8], xb[8];   // two K-blocks of this wave's rows in flight (16 KiB per wave, 128 KiB per CU)
+    // bf16 store: a K-block of a row is 128 B = 8 pieces of 8 elements; lane l reads piece l % 8 of row 8 i + l / 8, four
+    // load instructions per K-block; piece p of row r sits at p ^ ((r >> 1) & 7) (rows are 128 B apart: two rows per 256 B
+    // of banks)
+    const uint32_t lrow16 = lane >> 3, lpiece16 = lane & 7u;
+    const uint32_t lane_off16 = lrow16 * a.dim * 2u + lpiece16 * 16u;
     auto r_fetch = [&](f32x4 (&dst)[8], uint32_t tile, uint32_t kb) {   // kb: K-block inside the row
+        if constexpr (R16) {
+            const char *base = reinterpret_cast<const char *>(a.rows16) + ((size_t)tile * a.tile_step * TILE_ROWS + wave * 32u) * a.dim * 2u + (size_t)kb * (KB * 2u);
+#pragma unroll
+            for (int i = 0; i < 4; i++) dst[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(base + (size_t)i * 8u * a.dim * 2u + lane_off16));
+            return;
+        }
         const char *base = reinterpret_cast<const char *>(a.rows) + ((size_t)tile * a.tile_step * TILE_ROWS + wave * 32u) * a.dim * 4u + (size_t)kb * (KB * 4u);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -192,6 +205,14 @@ __global__ __launch_bounds__(256, 2) void batchg_kernel(const BatchGArgs a) {
         }
     };
     auto lds_put = [&](const f32x4 (&src)[8]) {
+        if constexpr (R16) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t r = 8u * (uint32_t)i + lrow16;
+                *reinterpret_cast<f32x4 *>(Rw + r * 128u + ((lpiece16 ^ ((r >> 1) & 7u)) << 4)) = src[i];
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const uint32_t r = 4u * (uint32_t)i + lrow;
@@ -205,6 +226,24 @@ __global__ __launch_bounds__(256, 2) void batchg_kernel(const BatchGArgs a) {
 #pragma unroll
         for (int s = 0; s < STEPS; s++) {
             s16x8 ah[2], al[2];
+            if constexpr (R16) {
+#pragma unroll
+                for (int f = 0; f < 2; f++) {
+                    const uint32_t row = 16u * f + j;
+                    ah[f] = *reinterpret_cast<const s16x8 *>(Rw + row * 128u + (((4u * s + kq) ^ ((row >> 1) & 7u)) << 4));
+                }
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const s16x8 qh = *reinterpret_cast<const s16x8 *>(Q + s * STEP_BYTES + g * 1024);
+                    const s16x8 ql = *reinterpret_cast<const s16x8 *>(Q + s * STEP_BYTES + STEP_BYTES / 2 + g * 1024);
+#pragma unroll
+                    for (int f = 0; f < 2; f++) {
+                        acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], ql, acc[f][g], 0, 0, 0);   // small term first
+                        acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], qh, acc[f][g], 0, 0, 0);
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int f = 0; f < 2; f++) {
                 const char *R = Rw + (16u * f + j) * 256u;
@@ -378,9 +417,9 @@ uint32_t batchg_sample_rows(uint32_t n_rows, uint32_t tile_step, uint32_t *n_til
     return (ns - 1u) * bg::TILE_ROWS + std::min<uint32_t>(bg::TILE_ROWS, n_rows - last_phys);
 }
 
-int launch_batchg_split(const float *d_queries, uint32_t nq, uint32_t dim, char *d_qimg, float *d_qq, hipStream_t stream) {
+int launch_batchg_split(const float *d_queries, uint32_t nq, uint32_t dim, char *d_qimg, float *d_qq, hipStream_t stream, bool rows16) {
     if (!batchg_supported(dim, 1) || nq == 0 || nq > bg::NQ) return set_err(CX_ERR_VALIDATION, "batchg: dim %u / %u queries not supported", dim, nq);
-    hipLaunchKernelGGL(batchg_split_queries_kernel, dim3(16), dim3(256), 0, stream, d_queries, nq, dim, d_qimg, d_qq);
+    hipLaunchKernelGGL(batchg_split_queries_kernel, dim3(16), dim3(256), 0, stream, d_queries, nq, dim, d_qimg, d_qq, rows16 ? 1 : 0);
     CX_HIP(hipGetLastError());
     return CX_OK;
 }
@@ -390,22 +429,25 @@ int launch_batchg_split(const float *d_queries, uint32_t nq, uint32_t dim, char 
 //     columns (the bound-finding sample of the filter mode); run_if: see BatchGArgs
 //   filter mode: candidates of each query into cand_keys / cand_sims [64][batchg_grid(n_rows)][cb]
 int launch_batchg_pass(const float *rows, const float *norms, uint32_t n_rows, uint32_t dim, uint32_t nq, const char *d_qimg, const float *d_qq,
-                       float *d_dense, uint32_t stride, uint32_t tile_step, const BatchGFilter *f, const uint32_t *run_if, hipStream_t stream) {
+                       float *d_dense, uint32_t stride, uint32_t tile_step, const BatchGFilter *f, const uint32_t *run_if, hipStream_t stream,
+                       const uint16_t *rows16) {
     using namespace bg;
     if (!batchg_supported(dim, 1) || nq == 0 || nq > NQ || tile_step == 0) return set_err(CX_ERR_VALIDATION, "batchg: dim %u / %u queries not supported", dim, nq);
     if (!n_rows) return CX_OK;
     static std::atomic<uint64_t> attr_devices{0};
     if (first_use_on_device(attr_devices)) {
-        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchg_kernel<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchg_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchg_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchg_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchg_kernel<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchg_kernel<0, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchg_kernel<0, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchg_kernel<1, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchg_kernel<2, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchg_kernel<3, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchg_kernel<0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchg_kernel<0, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     }
     BatchGArgs a;
     memset(&a, 0, sizeof a);
     a.flt.trivial = 1;
-    a.rows = rows; a.norms = norms; a.qimg = d_qimg; a.qq = d_qq; a.dense = d_dense;
+    a.rows = rows; a.rows16 = rows16; a.norms = norms; a.qimg = d_qimg; a.qq = d_qq; a.dense = d_dense;
     a.n_rows = n_rows; a.dim = dim; a.nq = nq; a.stride = stride; a.tile_step = tile_step; a.run_if = run_if;
     const uint32_t n_tiles = (n_rows + TILE_ROWS - 1) / TILE_ROWS;
     a.n_tiles = (n_tiles + tile_step - 1) / tile_step;
@@ -413,15 +455,21 @@ int launch_batchg_pass(const float *rows, const float *norms, uint32_t n_rows, u
     if (f) {
         a.tau_ord = f->tau_ord; a.cand_keys = f->cand_keys; a.cand_sims = f->cand_sims; a.cand_counts = f->cand_counts; a.overflow = f->overflow; a.cb = f->cb; a.flt = f->flt;
         grid = batchg_grid(n_rows);   // the candidate lists are laid out for exactly this grid
-        hipLaunchKernelGGL((batchg_kernel<0, true>), dim3(grid), dim3(256), LDS_BYTES, stream, a);
+        if (rows16) hipLaunchKernelGGL((batchg_kernel<0, true, true>), dim3(grid), dim3(256), LDS_BYTES, stream, a);
+        else hipLaunchKernelGGL((batchg_kernel<0, true, false>), dim3(grid), dim3(256), LDS_BYTES, stream, a);
+        CX_HIP(hipGetLastError());
+        return CX_OK;
+    }
+    if (rows16) {
+        hipLaunchKernelGGL((batchg_kernel<0, false, true>), dim3(grid), dim3(256), LDS_BYTES, stream, a);
         CX_HIP(hipGetLastError());
         return CX_OK;
     }
     static const int probe = getenv("CX_BATCHG_PROBE") ? atoi(getenv("CX_BATCHG_PROBE")) : 0;   // measurement arms, results invalid
-    if (probe == 1) hipLaunchKernelGGL((batchg_kernel<1, false>), dim3(grid), dim3(256), LDS_BYTES, stream, a);        // loads only
-    else if (probe == 2) hipLaunchKernelGGL((batchg_kernel<2, false>), dim3(grid), dim3(256), LDS_BYTES, stream, a);   // no row loads
-    else if (probe == 3) hipLaunchKernelGGL((batchg_kernel<3, false>), dim3(grid), dim3(256), LDS_BYTES, stream, a);   // rows only: no barriers, no query staging
-    else hipLaunchKernelGGL((batchg_kernel<0, false>), dim3(grid), dim3(256), LDS_BYTES, stream, a);
+    if (probe == 1) hipLaunchKernelGGL((batchg_kernel<1, false, false>), dim3(grid), dim3(256), LDS_BYTES, stream, a);        // loads only
+    else if (probe == 2) hipLaunchKernelGGL((batchg_kernel<2, false, false>), dim3(grid), dim3(256), LDS_BYTES, stream, a);   // no row loads
+    else if (probe == 3) hipLaunchKernelGGL((batchg_kernel<3, false, false>), dim3(grid), dim3(256), LDS_BYTES, stream, a);   // rows only: no barriers, no query staging
+    else hipLaunchKernelGGL((batchg_kernel<0, false, false>), dim3(grid), dim3(256), LDS_BYTES, stream, a);
     CX_HIP(hipGetLastError());
     return CX_OK;
 }
@@ -429,8 +477,8 @@ int launch_batchg_pass(const float *rows, const float *norms, uint32_t n_rows, u
 // the round-2 entry: split + one dense pass over every row
 int launch_batchg_scores(const float *rows, const float *norms, uint32_t n_rows, uint32_t dim, const float *d_queries, uint32_t nq,
                          char *d_qimg, float *d_qq, float *d_dense, uint32_t stride, hipStream_t stream) {
-    if (int rc = launch_batchg_split(d_queries, nq, dim, d_qimg, d_qq, stream)) return rc;
-    return launch_batchg_pass(rows, norms, n_rows, dim, nq, d_qimg, d_qq, d_dense, stride, 1, nullptr, nullptr, stream);
+    if (int rc = launch_batchg_split(d_queries, nq, dim, d_qimg, d_qq, stream, false)) return rc;
+    return launch_batchg_pass(rows, norms, n_rows, dim, nq, d_qimg, d_qq, d_dense, stride, 1, nullptr, nullptr, stream, nullptr);
 }
 
 }  // namespace cx

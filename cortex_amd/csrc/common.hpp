@@ -124,6 +124,38 @@ __device__ inline float cosine_from_norms(float dot, float norm_a, float norm_b)
     return dot / den;
 }
 __host__ __device__ inline float distance_of(float sim) { return 1.0f - sim; }
+// bf16 row stores (cx_create_ex, CX_DTYPE_BF16): an element is the upper half of an f32
+__host__ __device__ inline float bf16_bits_to_f32(uint16_t b) {
+    const uint32_t u = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+// round to nearest even (what v_cvt_pk_bf16_f32 does); NaN stays NaN, overflow goes to infinity
+__host__ __device__ inline uint16_t f32_to_bf16_bits(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x0040u);   // quiet NaN
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+#ifdef __HIPCC__
+// row elements of either store type
+__device__ inline float ldf(const float *p) { return *p; }
+__device__ inline float ldf(const uint16_t *p) { return bf16_bits_to_f32(*p); }
+__device__ inline void stf(float *p, float v) { *p = v; }
+__device__ inline void stf(uint16_t *p, float v) { *p = f32_to_bf16_bits(v); }
+typedef float cx_f32x4 __attribute__((ext_vector_type(4)));
+// elements 4 j .. 4 j + 3 of row `row` (dim % 4 == 0)
+__device__ inline cx_f32x4 row4(const float *rows, size_t row, uint32_t dim, uint32_t j) {
+    return reinterpret_cast<const cx_f32x4 *>(rows + row * dim)[j];
+}
+__device__ inline cx_f32x4 row4(const uint16_t *rows, size_t row, uint32_t dim, uint32_t j) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 w = reinterpret_cast<const u32x2 *>(rows + row * dim)[j];
+    return cx_f32x4{__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xFFFF0000u), __uint_as_float(w.y << 16), __uint_as_float(w.y & 0xFFFF0000u)};
+}
+#endif
 __host__ __device__ inline float score_of(float distance) {
     float s = 1.0f - distance;
     if (s < 0.0f) s = 0.0f;

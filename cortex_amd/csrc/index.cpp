@@ -104,13 +104,13 @@ int grow_rows(cx_index *ix, uint64_t need) {
     uint64_t ncap = std::max<uint64_t>(need, std::max<uint64_t>(ix->cap * 2, 1024));
     float *nr = nullptr;
     uint32_t *nm = nullptr, *na = nullptr;
-    CX_HIP(hipMalloc((void **)&nr, (ncap + 256) * ix->dim * sizeof(float) + 64));  // + one row tile of readable padding (batch.hip: 16 rows, batchg.hip: 256)
+    CX_HIP(hipMalloc((void **)&nr, (ncap + 256) * ix->dim * ix->elem + 64));  // + one row tile of readable padding (batch.hip: 16 rows, batchg.hip: 256)
     CX_HIP(hipMalloc((void **)&nm, ncap * sizeof(uint32_t)));
     CX_HIP(hipMalloc((void **)&na, ncap * sizeof(uint32_t)));
     CX_HIP(hipMemsetAsync(nm, 0, ncap * sizeof(uint32_t), ix->up_stream));
     CX_HIP(hipMemsetAsync(na, 0, ncap * sizeof(uint32_t), ix->up_stream));
     if (ix->n_rows) {
-        CX_HIP(hipMemcpyAsync(nr, ix->d_rows, ix->n_rows * ix->dim * sizeof(float), hipMemcpyDeviceToDevice, ix->up_stream));
+        CX_HIP(hipMemcpyAsync(nr, ix->d_rows, ix->n_rows * ix->dim * ix->elem, hipMemcpyDeviceToDevice, ix->up_stream));
         CX_HIP(hipMemcpyAsync(nm, ix->d_meta, ix->n_rows * sizeof(uint32_t), hipMemcpyDeviceToDevice, ix->up_stream));
         CX_HIP(hipMemcpyAsync(na, ix->d_agent, ix->n_rows * sizeof(uint32_t), hipMemcpyDeviceToDevice, ix->up_stream));
     }
@@ -145,6 +145,29 @@ int upsert_impl(cx_index *ix, uint64_t n, const uint8_t *ids, const float *embs,
     if (int rc = grow_rows(ix, ix->n_rows + n)) return rc;
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     const size_t row_bytes = (size_t)ix->dim * sizeof(float);
+    // bf16 store: the f32 rows (staged on the device if they came from the host) are rounded into place, run by run
+    const float *d_src = embs;
+    if (ix->dtype == 1 && row_bytes) {
+        if (!on_device) {
+            const size_t need = (size_t)n * ix->dim;
+            if (ix->stage_cap < need) {
+                if (ix->d_stage) CX_HIP(hipFree(ix->d_stage));
+                ix->d_stage = nullptr;
+                ix->stage_cap = 0;
+                CX_HIP(hipMalloc((void **)&ix->d_stage, need * sizeof(float)));
+                ix->stage_cap = need;
+            }
+            CX_HIP(hipMemcpyAsync(ix->d_stage, embs, need * sizeof(float), hipMemcpyHostToDevice, ix->up_stream));
+            d_src = ix->d_stage;
+        }
+    }
+    auto put_rows = [&](uint64_t first_row, uint64_t src_row, uint64_t count) -> int {   // count rows of the batch -> rows of the store
+        if (!row_bytes || !count) return CX_OK;
+        if (ix->dtype == 1)
+            return launch_gather_rows(d_src + src_row * len, ix->rows16_mut() + (size_t)first_row * ix->dim, nullptr, (uint32_t)count, ix->dim, ix->up_stream);
+        CX_HIP(hipMemcpyAsync(ix->d_rows + (size_t)first_row * ix->dim, embs + src_row * len, count * row_bytes, kind, ix->up_stream));
+        return CX_OK;
+    };
     uint64_t i = 0;
     uint64_t meta_lo = UINT64_MAX, meta_hi = 0;   // new rows that took pending metadata: [meta_lo, meta_hi)
     while (i < n) {
@@ -153,8 +176,7 @@ int upsert_impl(cx_index *ix, uint64_t n, const uint8_t *ids, const float *embs,
         if (it != ix->map.end()) {  // replace in place, row position kept
             if (it->second < ix->shadow_rows) ix->shadow_stale.push_back(it->second);
             if (it->second < ix->norms_rows) ix->norms_stale.push_back(it->second);
-            if (row_bytes)
-                CX_HIP(hipMemcpyAsync(ix->d_rows + (size_t)it->second * ix->dim, embs + i * len, row_bytes, kind, ix->up_stream));
+            if (int rc = put_rows(it->second, i, 1)) return rc;
             i++;
             continue;
         }
@@ -183,15 +205,18 @@ int upsert_impl(cx_index *ix, uint64_t n, const uint8_t *ids, const float *embs,
             ix->n_alive++;
             i++;
         }
-        if (row_bytes)
-            CX_HIP(hipMemcpyAsync(ix->d_rows + (size_t)first_row * ix->dim, embs + run_start * len,
-                                  (i - run_start) * row_bytes, kind, ix->up_stream));
+        if (int rc = put_rows(first_row, run_start, i - run_start)) return rc;
     }
     if (meta_lo < meta_hi) {
         CX_HIP(hipMemcpyAsync(ix->d_meta + meta_lo, &ix->h_meta[meta_lo], (size_t)(meta_hi - meta_lo) * 4, hipMemcpyHostToDevice, ix->up_stream));
         CX_HIP(hipMemcpyAsync(ix->d_agent + meta_lo, &ix->h_agent[meta_lo], (size_t)(meta_hi - meta_lo) * 4, hipMemcpyHostToDevice, ix->up_stream));
     }
     CX_HIP(hipStreamSynchronize(ix->up_stream));
+    if (ix->stage_cap * sizeof(float) > ((size_t)256 << 20)) {   // a bulk load's staging area is not kept
+        (void)hipFree(ix->d_stage);
+        ix->d_stage = nullptr;
+        ix->stage_cap = 0;
+    }
     return CX_OK;
 }
 
@@ -264,7 +289,7 @@ namespace cx {
 int ensure_norms(const cx_index *ix, hipStream_t s) {
     std::lock_guard<std::mutex> g(ix->norms_mu);
     const uint64_t n = ix->n_rows;
-    const bool want_split = batch_supported(ix->dim, 1);
+    const bool want_split = ix->dtype == 0 && batch_supported(ix->dim, 1);   // a bf16 store is its own MFMA operand
     bool work = false;
     if (ix->norms_cap < n) {
         if (ix->d_norms) CX_HIP(hipFree(ix->d_norms));
@@ -286,6 +311,7 @@ int ensure_norms(const cx_index *ix, hipStream_t s) {
         work = true;
     }
     auto refresh = [&](uint32_t lo, uint32_t hi) -> int {
+        if (ix->dtype == 1) return launch_row_norms(ix->rows16(), ix->d_norms, lo, hi, ix->dim, s);
         if (int rc = launch_row_norms(ix->d_rows, ix->d_norms, lo, hi, ix->dim, s)) return rc;
         if (want_split)
             if (int rc = launch_build_split(ix->d_rows, ix->d_split, lo, hi, ix->dim, s)) return rc;
@@ -335,7 +361,7 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
     // wide lists (k > 32) on a large unfiltered store: batchg.hip's bound + candidates pass runs at 0.71-0.75 of the HBM
     // peak whatever k is, batch2_kernel's in-kernel wide lists at 0.40-0.49 (1.25M x 384 / 768, k = 100)
     const bool wide_to_bg = k_eff > 32 && bg_ok && filter_ok && n >= filter_min && batchg_supported(ix->dim, k_eff);
-    if (b2_ok && !wide_to_bg && topk_path && no_tails && nq >= (uint64_t)batch_min && k_eff >= 1 && batch_supported(ix->dim, k_eff)) {
+    if (b2_ok && ix->dtype == 0 && !wide_to_bg && topk_path && no_tails && nq >= (uint64_t)batch_min && k_eff >= 1 && batch_supported(ix->dim, k_eff)) {
         if (int rc = ensure_norms(ix, s)) return rc;
         const uint32_t qpp = batch_queries_per_pass(ix->dim, k_eff, nq);
         uint32_t bgrid = 1, groups = 1;
@@ -435,19 +461,19 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
             mg.out_scores = d_scores + q0 * k_eff;
             mg.out_dists = d_dists + q0 * k_eff;
             mg.out_count = d_counts + q0;
-            if (int rc = launch_batchg_split(d_queries + q0 * ix->dim, m, ix->dim, c->d_qimg, d_qq, s)) return rc;
+            if (int rc = launch_batchg_split(d_queries + q0 * ix->dim, m, ix->dim, c->d_qimg, d_qq, s, ix->dtype == 1)) return rc;
             const uint32_t *run_if = nullptr;
             if (filtered) {
                 uint32_t *tau = c->d_bg_ctl, *overflow = c->d_bg_ctl + 64;
                 // 1. the bound: the k-th best score of the sampled tiles
                 uint32_t *counts = c->d_bg_ctl + 80;
-                if (int rc = launch_batchg_pass(ix->d_rows, ix->d_norms, n, ix->dim, m, c->d_qimg, d_qq, c->d_dense, s_stride, tile_step, nullptr, nullptr, s)) return rc;
+                if (int rc = launch_batchg_pass(ix->rows32(), ix->d_norms, n, ix->dim, m, c->d_qimg, d_qq, c->d_dense, s_stride, tile_step, nullptr, nullptr, s, ix->rows16())) return rc;
                 if (int rc = launch_bound_select(c->d_dense, s_stride, s_rows, m, k_eff, tau, flt, batchg_tile_rows(), tile_step, s)) return rc;
                 // 2. every row, candidates only
                 CX_HIP(hipMemsetAsync(overflow, 0, sizeof(uint32_t), s));
                 BatchGFilter f{tau, c->d_cand_keys, c->d_cand_sims, counts, overflow, cb, flt};
                 if (int rc = prof_begin()) return rc;
-                if (int rc = launch_batchg_pass(ix->d_rows, ix->d_norms, n, ix->dim, m, c->d_qimg, d_qq, nullptr, 0, 1, &f, nullptr, s)) return rc;
+                if (int rc = launch_batchg_pass(ix->rows32(), ix->d_norms, n, ix->dim, m, c->d_qimg, d_qq, nullptr, 0, 1, &f, nullptr, s, ix->rows16())) return rc;
                 if (e1) CX_HIP(hipEventRecord(e1, s));
                 MergeArgs mc = mg;
                 mc.part_keys = c->d_cand_keys;
@@ -460,7 +486,7 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
                 run_if = overflow;
                 e0 = e1 = nullptr;
             } else if (int rc = prof_begin()) return rc;
-            if (int rc = launch_batchg_pass(ix->d_rows, ix->d_norms, n, ix->dim, m, c->d_qimg, d_qq, c->d_dense, stride, 1, nullptr, run_if, s)) return rc;
+            if (int rc = launch_batchg_pass(ix->rows32(), ix->d_norms, n, ix->dim, m, c->d_qimg, d_qq, c->d_dense, stride, 1, nullptr, run_if, s, ix->rows16())) return rc;
             if (e1) CX_HIP(hipEventRecord(e1, s));
             if (int rc = launch_dense_topk(c->d_dense, stride, n, m, k_eff, flt, c->d_part_keys, c->d_part_sims, chunks, s, run_if)) return rc;
             mg.n_lists = chunks;
@@ -472,7 +498,8 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
     for (uint64_t i = 0; i < nq; i++) {
         ScanArgs a;
         memset(&a, 0, sizeof a);
-        a.rows = ix->d_rows;
+        a.rows = ix->rows32();
+        a.rows16 = ix->rows16();
         a.query = d_queries + i * ix->dim;
         a.q_tail_sumsq = tails ? tails[i] : 0.0f;
         a.n_rows = n;
@@ -590,7 +617,15 @@ int cx_device_count(void) try {
     return n;
 } catch (...) { return cx::on_exception(); }
 
-cx_index *cx_create(uint32_t dimension, int device) try {
+cx_index *cx_create(uint32_t dimension, int device) { return cx_create_ex(dimension, device, CX_DTYPE_F32); }
+
+int cx_dtype(const cx_index *ix) { return ix ? ix->dtype : -1; }
+
+cx_index *cx_create_ex(uint32_t dimension, int device, int dtype) try {
+    if (dtype != CX_DTYPE_F32 && dtype != CX_DTYPE_BF16) {
+        set_err(CX_ERR_VALIDATION, "unknown storage dtype %d", dtype);
+        return nullptr;
+    }
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
@@ -609,6 +644,8 @@ cx_index *cx_create(uint32_t dimension, int device) try {
     cx_index *ix = new cx_index();
     ix->dim = dimension;
     ix->device = device;
+    ix->dtype = dtype;
+    ix->elem = dtype == CX_DTYPE_BF16 ? 2u : 4u;
     if (hipStreamCreateWithFlags(&ix->up_stream, hipStreamNonBlocking) != hipSuccess) {
         set_err(CX_ERR_DEVICE, "hipStreamCreate failed");
         delete ix;
@@ -624,6 +661,7 @@ void cx_destroy(cx_index *ix) {
     for (Ctx *c : ix->pool) delete c;
     for (auto &kv : ix->by_stream) delete kv.second;
     (void)hipFree(ix->d_rows);
+    (void)hipFree(ix->d_stage);
     (void)hipFree(ix->d_meta);
     (void)hipFree(ix->d_agent);
     (void)hipFree(ix->d_shadow);
@@ -747,7 +785,7 @@ int cx_rebuild(cx_index *ix) try {
         uint32_t *meta = nullptr, *agent = nullptr, *keep = nullptr;
         ~NewStore() { (void)hipFree(rows); (void)hipFree(meta); (void)hipFree(agent); (void)hipFree(keep); }
     } ns;
-    CX_HIP(hipMalloc((void **)&ns.rows, (ncap + 256) * ix->dim * sizeof(float) + 64));  // + one row tile of readable padding (batch.hip: 16 rows, batchg.hip: 256)
+    CX_HIP(hipMalloc((void **)&ns.rows, (ncap + 256) * ix->dim * ix->elem + 64));  // + one row tile of readable padding (batch.hip: 16 rows, batchg.hip: 256)
     CX_HIP(hipMalloc((void **)&ns.meta, ncap * sizeof(uint32_t)));
     CX_HIP(hipMalloc((void **)&ns.agent, ncap * sizeof(uint32_t)));
     CX_HIP(hipMemsetAsync(ns.meta, 0, ncap * sizeof(uint32_t), ix->up_stream));
@@ -768,8 +806,11 @@ int cx_rebuild(cx_index *ix) try {
     if (n_new) {
         CX_HIP(hipMalloc((void **)&ns.keep, n_new * 4));
         CX_HIP(hipMemcpyAsync(ns.keep, keep.data(), n_new * 4, hipMemcpyHostToDevice, ix->up_stream));
-        if (ix->dim)
-            if (int rc = launch_gather_rows(ix->d_rows, ns.rows, ns.keep, (uint32_t)n_new, ix->dim, ix->up_stream)) return rc;
+        if (ix->dim) {
+            const int rc = ix->dtype == 1 ? launch_gather_rows(ix->rows16(), reinterpret_cast<uint16_t *>(ns.rows), ns.keep, (uint32_t)n_new, ix->dim, ix->up_stream)
+                                          : launch_gather_rows(ix->d_rows, ns.rows, ns.keep, (uint32_t)n_new, ix->dim, ix->up_stream);
+            if (rc) return rc;
+        }
         CX_HIP(hipMemcpyAsync(ns.meta, nmeta.data(), n_new * 4, hipMemcpyHostToDevice, ix->up_stream));
         CX_HIP(hipMemcpyAsync(ns.agent, nagent.data(), n_new * 4, hipMemcpyHostToDevice, ix->up_stream));
     }
@@ -835,7 +876,7 @@ int cx_profile_read(cx_index *ix, double *kernel_ms_sum, uint64_t *launches, int
 uint64_t cx_len(const cx_index *ix) { return ix ? ix->n_alive : 0; }
 uint32_t cx_dimension(const cx_index *ix) { return ix ? ix->dim : 0; }
 uint64_t cx_row_count(const cx_index *ix) { return ix ? ix->n_rows : 0; }
-const float *cx_device_rows(const cx_index *ix) { return ix ? ix->d_rows : nullptr; }
+const float *cx_device_rows(const cx_index *ix) { return ix ? ix->rows32() : nullptr; }   // null for a bf16 store
 
 int cx_row_id(const cx_index *ix, uint64_t row, uint8_t out_id[16]) try {
     if (!ix || !out_id) return set_err(CX_ERR_VALIDATION, "null argument");

@@ -117,7 +117,17 @@ struct NodeStats {
 struct cx_index {
     uint32_t dim = 0;
     int device = 0;
+    // Row store.  dtype CX_DTYPE_F32: f32 [cap][dim].  CX_DTYPE_BF16 (cx_create_ex): the SAME pointer holds bf16 [cap][dim]
+    // — every inserted row rounded to nearest even once, at insert — and every consumer goes through rows32() / rows16()
+    // below (exactly one of them is non-null), sizes through elem.
+    int dtype = 0;
+    uint32_t elem = 4;
     float *d_rows = nullptr;
+    const float *rows32() const { return dtype == 0 ? d_rows : nullptr; }
+    const uint16_t *rows16() const { return dtype == 1 ? reinterpret_cast<const uint16_t *>(d_rows) : nullptr; }
+    uint16_t *rows16_mut() { return dtype == 1 ? reinterpret_cast<uint16_t *>(d_rows) : nullptr; }
+    char *row_bytes_ptr(uint64_t row) { return reinterpret_cast<char *>(d_rows) + (size_t)row * dim * elem; }
+    float *d_stage = nullptr; size_t stage_cap = 0;   // bf16 stores: host rows land here as f32 before they are rounded
     uint32_t *d_meta = nullptr;
     uint32_t *d_agent = nullptr;
     uint64_t cap = 0;

@@ -25,7 +25,8 @@ struct MergeArgs {
 
 // One single-query scan over the row store.
 struct ScanArgs {
-    const float *rows;     // [n_rows][dim] f32 row-major, 16-byte aligned when dim % 4 == 0
+    const float *rows;     // [n_rows][dim] f32 row-major, 16-byte aligned when dim % 4 == 0; null for a bf16 store
+    const uint16_t *rows16 = nullptr;   // bf16 store (cx_create_ex): [n_rows][dim] bf16 row-major
     const float *query;    // [dim] f32 in HBM
     float q_tail_sumsq;    // sum of squares of query elements beyond dim (host queries longer than dim)
     uint32_t n_rows;
@@ -77,6 +78,8 @@ int launch_publish_part(const uint32_t *rows, const float *scores, const float *
 // rows of this shard -> given vectors of a query block (possibly on a peer device)
 int launch_scatter_rows(const float *src, float *dst, const uint32_t *d_src_rows, const uint32_t *d_dst_pos, uint32_t n,
                         uint32_t dim, hipStream_t stream);
+int launch_scatter_rows(const uint16_t *src, float *dst, const uint32_t *d_src_rows, const uint32_t *d_dst_pos, uint32_t n,
+                        uint32_t dim, hipStream_t stream);   // bf16 store
 
 // ---- batched search (batch.hip) ----
 struct BatchArgs {
@@ -128,9 +131,10 @@ struct BatchGFilter {
 uint32_t batchg_tile_rows();
 uint32_t batchg_grid(uint32_t n_rows);
 uint32_t batchg_sample_rows(uint32_t n_rows, uint32_t tile_step, uint32_t *n_tiles_out);   // dense columns a sampled pass fills
-int launch_batchg_split(const float *d_queries, uint32_t nq, uint32_t dim, char *d_qimg, float *d_qq, hipStream_t stream);
+int launch_batchg_split(const float *d_queries, uint32_t nq, uint32_t dim, char *d_qimg, float *d_qq, hipStream_t stream, bool rows16 = false);
 int launch_batchg_pass(const float *rows, const float *norms, uint32_t n_rows, uint32_t dim, uint32_t nq, const char *d_qimg, const float *d_qq,
-                       float *d_dense, uint32_t stride, uint32_t tile_step, const BatchGFilter *f, const uint32_t *run_if, hipStream_t stream);
+                       float *d_dense, uint32_t stride, uint32_t tile_step, const BatchGFilter *f, const uint32_t *run_if, hipStream_t stream,
+                       const uint16_t *rows16 = nullptr);   // rows16: a bf16 store (rows == null; the split must have been made with rows16 = true)
 // tau_ord[q] = score_ord of the k-th best score among dense[q][0 .. n) over the columns whose row passes flt (0 when fewer
 // than k do); column e stands for row (e / tile_rows) * tile_step * tile_rows + e % tile_rows
 int launch_bound_select(const float *d_dense, uint32_t stride, uint32_t n, uint32_t nq, uint32_t k, uint32_t *tau_ord, const DevFilter &flt,
@@ -142,6 +146,8 @@ int launch_dense_topk(const float *d_dense, uint32_t stride, uint32_t n_rows, ui
 // ---- all-pairs auto-link pass (allpairs.hip) ----
 int launch_build_shadow(const float *rows, uint16_t *shadow, uint32_t row_lo, uint32_t row_hi, uint32_t dim,
                         hipStream_t stream);
+int launch_build_shadow(const uint16_t *rows16, uint16_t *shadow, uint32_t row_lo, uint32_t row_hi, uint32_t dim,
+                        hipStream_t stream);   // bf16 store
 
 // rows [row_lo, row_hi) of a row-major bf16 shadow -> the piece-tiled copy the 256-tile kernel's LDS-DMA reads:
 // element (r, k) -> tile (r / 16, k / 32) of 512 elements, inside at (r % 16) * 32 + (((k % 32) / 8) ^ ((r >> 3) & 3)) * 8 + k % 8
@@ -173,7 +179,8 @@ bool pair_filter_stream_supported(const PairFilterArgs &a);
 int launch_pair_filter_stream(const PairFilterArgs &a, hipStream_t stream);
 
 struct RescoreArgs {
-    const float *rows;
+    const float *rows;     // f32 store; null for a bf16 store
+    const uint16_t *rows16 = nullptr;   // bf16 store
     const float *q_rows;   // scanned vectors when they are not rows of this shard ([n_scan][dim]); null = rows
     float *out_dists;      // optional [n_scan][topk]
     const uint32_t *meta;
@@ -227,9 +234,14 @@ int launch_scatter_lists(const uint32_t *src_rows, const float *src_scores, cons
 
 // |row|^2 of rows [row_lo, row_hi) -> norms[row] (one wave per row)
 int launch_row_norms(const float *rows, float *norms, uint32_t row_lo, uint32_t row_hi, uint32_t dim, hipStream_t stream);
+int launch_row_norms(const uint16_t *rows, float *norms, uint32_t row_lo, uint32_t row_hi, uint32_t dim, hipStream_t stream);
 
 // row maintenance
 int launch_gather_rows(const float *src, float *dst, const uint32_t *d_src_rows, uint32_t n_dst, uint32_t dim,
                        hipStream_t stream);
+// bf16 stores (d_src_rows == null: rows 0 .. n_dst in order): rows out as f32, rows moved inside the store, f32 rows in (RNE)
+int launch_gather_rows(const uint16_t *src, float *dst, const uint32_t *d_src_rows, uint32_t n_dst, uint32_t dim, hipStream_t stream);
+int launch_gather_rows(const uint16_t *src, uint16_t *dst, const uint32_t *d_src_rows, uint32_t n_dst, uint32_t dim, hipStream_t stream);
+int launch_gather_rows(const float *src, uint16_t *dst, const uint32_t *d_src_rows, uint32_t n_dst, uint32_t dim, hipStream_t stream);
 
 }  // namespace cx

@@ -67,10 +67,16 @@ int cx_save(const cx_index *ix, const char *path) try {
     // vectors: stream the row store back in 32 MiB slabs
     const uint64_t slab_rows = std::max<uint64_t>(1, (32ull << 20) / std::max<uint64_t>(1, (uint64_t)dim * 4));
     std::vector<float> host((size_t)slab_rows * std::max(dim, 1u));
+    std::vector<uint16_t> host16(ix->dtype == 1 ? host.size() : 0);   // a bf16 store is written as the f32 values it holds
     for (uint64_t r0 = 0; r0 < ix->n_rows; r0 += slab_rows) {
         const uint64_t m = std::min(slab_rows, ix->n_rows - r0);
         if (dim) {
-            hipError_t e = hipMemcpy(host.data(), ix->d_rows + (size_t)r0 * dim, (size_t)m * dim * 4, hipMemcpyDeviceToHost);
+            hipError_t e;
+            if (ix->dtype == 1) {
+                e = hipMemcpy(host16.data(), ix->rows16() + (size_t)r0 * dim, (size_t)m * dim * 2, hipMemcpyDeviceToHost);
+                for (size_t t = 0; t < (size_t)m * dim; t++) host[t] = bf16_bits_to_f32(host16[t]);
+            } else
+                e = hipMemcpy(host.data(), ix->d_rows + (size_t)r0 * dim, (size_t)m * dim * 4, hipMemcpyDeviceToHost);
             if (e != hipSuccess) {
                 fclose(f);
                 return set_err(CX_ERR_DEVICE, "Failed to write index file: device read failed: %s", hipGetErrorString(e));
@@ -116,7 +122,9 @@ int cx_save(const cx_index *ix, const char *path) try {
     return CX_OK;
 } catch (...) { return cx::on_exception(); }
 
-cx_index *cx_load(const char *path, int device) try {
+cx_index *cx_load(const char *path, int device) { return cx_load_ex(path, device, CX_DTYPE_F32); }
+
+cx_index *cx_load_ex(const char *path, int device, int dtype) try {
     if (!path) {
         set_err(CX_ERR_VALIDATION, "null path");
         return nullptr;
@@ -157,7 +165,7 @@ cx_index *cx_load(const char *path, int device) try {
         if (!ix) {
             if (len > 0xFFFFFFFFull) return fail(nullptr, "vector too long");
             dim = len;
-            ix = cx_create((uint32_t)dim, device);
+            ix = cx_create_ex((uint32_t)dim, device, dtype);
             if (!ix) { fclose(f); return nullptr; }
             if (cx_reserve(ix, n_vec) != CX_OK) { fclose(f); cx_destroy(ix); return nullptr; }
         } else if (len != dim) {
@@ -186,7 +194,7 @@ cx_index *cx_load(const char *path, int device) try {
     fclose(f);
     if (!ix) {  // no vectors: the trailer is the only source of the dimension
         if (dimension > 0xFFFFFFFFull) { set_err(CX_ERR_VALIDATION, "Failed to deserialize index: dimension out of range"); return nullptr; }
-        ix = cx_create((uint32_t)dimension, device);
+        ix = cx_create_ex((uint32_t)dimension, device, dtype);
         if (!ix) return nullptr;
     } else if (dimension != dim) {
         cx_destroy(ix);

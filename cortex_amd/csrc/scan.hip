@@ -148,6 +148,94 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a) {
     if constexpr (MODE == 0) block_merge_store<KS>(top, a.k, a.part_keys, a.part_sims);
 }
 
+// The same scan over a bf16 row store (cx_create_ex, CX_DTYPE_BF16): a 16-byte load is 8 elements, G lanes x 16 B cover a
+// row piece, the products of bf16 values are exact in f32 and everything from there on is the f32 kernel's arithmetic —
+// the reference's distance on the bf16-rounded rows.  Half the bytes per row: the roofline is n_rows * dim * 2.
+template <int D, int G, int R, int KS, bool NT, int MODE>
+__global__ __launch_bounds__(256) void scan16_kernel(const ScanArgs a) {
+    constexpr int GPW = 64 / G;        // rows per wave-level load instruction
+    constexpr int NJ = D / (8 * G);    // 16-byte loads per lane per row
+    constexpr int RPW = R * GPW;
+    static_assert(D % (8 * G) == 0, "dim must be a multiple of 8*G");
+    const int lane = lane_id();
+    const int wave = (int)(threadIdx.x >> 6);
+    const int lig = lane % G;
+    const int grp = lane / G;
+    f32x4 q[NJ][2];
+    const f32x4 *q4 = reinterpret_cast<const f32x4 *>(a.query);
+    float qq = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            q[j][h] = q4[(j * G + lig) * 2 + h];
+            qq += q[j][h].x * q[j][h].x + q[j][h].y * q[j][h].y + q[j][h].z * q[j][h].z + q[j][h].w * q[j][h].w;
+        }
+    qq = group_sum<G>(qq) + a.q_tail_sumsq;
+
+    WaveTopK<KS> top;
+    if constexpr (MODE == 0) top.init(a.k);
+    const uint32_t n_rows = a.n_rows;
+    const uint32_t n_tiles = (n_rows + RPW - 1) / RPW;
+    const uint32_t stride = gridDim.x * 4u;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    for (uint32_t t = blockIdx.x * 4u + (uint32_t)wave; t < n_tiles; t += stride) {
+        const uint32_t base = t * RPW;
+        f32x4 v[R][NJ];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            uint32_t row = base + (uint32_t)(r * GPW + grp);
+            row = row < n_rows ? row : n_rows - 1;
+            const f32x4 *p = reinterpret_cast<const f32x4 *>(a.rows16 + (size_t)row * D) + lig;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) v[r][j] = ld4<NT>(p + j * G);
+        }
+        float dot[R], rr[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            float d0 = 0.0f, n0 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                const u32x4 u = __builtin_bit_cast(u32x4, v[r][j]);
+                // element 2 i is the low half of word i, element 2 i + 1 the high half
+                const f32x4 lo = {__uint_as_float(u.x << 16), __uint_as_float(u.y << 16), __uint_as_float(u.z << 16), __uint_as_float(u.w << 16)};
+                const f32x4 hi = {__uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y & 0xFFFF0000u), __uint_as_float(u.z & 0xFFFF0000u), __uint_as_float(u.w & 0xFFFF0000u)};
+                // elements 0..7 = lo.x hi.x lo.y hi.y lo.z hi.z lo.w hi.w against q[j][0] = elements 0..3, q[j][1] = 4..7
+                d0 += lo.x * q[j][0].x + hi.x * q[j][0].y + lo.y * q[j][0].z + hi.y * q[j][0].w;
+                d0 += lo.z * q[j][1].x + hi.z * q[j][1].y + lo.w * q[j][1].z + hi.w * q[j][1].w;
+                n0 += lo.x * lo.x + hi.x * hi.x + lo.y * lo.y + hi.y * hi.y;
+                n0 += lo.z * lo.z + hi.z * hi.z + lo.w * lo.w + hi.w * hi.w;
+            }
+            dot[r] = d0;
+            rr[r] = n0;
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            dot[r] = group_sum<G>(dot[r]);
+            rr[r] = group_sum<G>(rr[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t row = base + (uint32_t)(r * GPW + grp);
+            const float sim = cosine_from_sums(dot[r], qq, rr[r]);
+            const float score = score_of(distance_of(sim));
+            if constexpr (MODE == 0) {
+                const uint64_t key = (row < n_rows && lig == 0) ? make_key(score, row) : 0ull;
+                const DevFilter &f = a.flt;
+                top.offer_lanes(key, sim, [&f](uint32_t rw) { return row_passes(f, rw); });
+            } else {
+                if (row < n_rows && lig == 0) {
+                    bool ok = row_passes(a.flt, row);
+                    if (a.has_threshold) ok = ok && (score >= a.threshold);
+                    a.dense_keys[row] = ok ? make_key(score, row) : 0ull;
+                    a.dense_sims[row] = sim;
+                }
+            }
+        }
+    }
+    if constexpr (MODE == 0) block_merge_store<KS>(top, a.k, a.part_keys, a.part_sims);
+}
+
 // Any dimension (the reference's own tests use dim = 3): one wave per row,
 // lane l takes elements l, l+64, ...; scalar loads.  Correctness path only.
 template <int KS, int MODE>
@@ -164,9 +252,10 @@ __global__ __launch_bounds__(256) void scan_generic_kernel(const ScanArgs a) {
     const uint32_t stride = gridDim.x * 4u;
     for (uint32_t row = blockIdx.x * 4u + (uint32_t)wave; row < a.n_rows; row += stride) {
         const float *p = a.rows + (size_t)row * dim;
+        const uint16_t *p16 = a.rows16 + (size_t)row * dim;
         float d0 = 0.0f, n0 = 0.0f;
         for (uint32_t j = (uint32_t)lane; j < dim; j += 64u) {
-            const float x = p[j];
+            const float x = a.rows16 ? bf16_bits_to_f32(p16[j]) : p[j];
             d0 += x * a.query[j];
             n0 += x * x;
         }
@@ -394,8 +483,40 @@ static void launch_generic(const ScanArgs &a, uint32_t grid, int ks, hipStream_t
     }
 }
 
+template <int D, int G, int R, int MODE>
+static void launch_fixed16(const ScanArgs &a, uint32_t grid, int ks, bool nt, hipStream_t s) {
+#define CX_LAUNCH(KS_)                                                                        \
+    do {                                                                                       \
+        if (nt) hipLaunchKernelGGL((scan16_kernel<D, G, R, KS_, true, MODE>), dim3(grid), dim3(256), 0, s, a);  \
+        else hipLaunchKernelGGL((scan16_kernel<D, G, R, KS_, false, MODE>), dim3(grid), dim3(256), 0, s, a);    \
+    } while (0)
+    if constexpr (MODE == 1) { CX_LAUNCH(1); }
+    else {
+        if (ks == 1) CX_LAUNCH(1);
+        else if (ks == 2) CX_LAUNCH(2);
+        else CX_LAUNCH(4);
+    }
+#undef CX_LAUNCH
+}
+
 template <int MODE>
 static void dispatch_scan(const ScanArgs &a, uint32_t grid, int ks, bool nt, hipStream_t s) {
+    if (a.rows16) {   // bf16 store: G lanes x 16 B = G x 8 elements per row piece
+        const bool aligned16 = ((reinterpret_cast<uintptr_t>(a.rows16) | reinterpret_cast<uintptr_t>(a.query)) & 15u) == 0;
+        if (aligned16) {
+            switch (a.dim) {
+                case 128: return launch_fixed16<128, 16, 8, MODE>(a, grid, ks, nt, s);
+                case 256: return launch_fixed16<256, 32, 8, MODE>(a, grid, ks, nt, s);
+                case 384: return launch_fixed16<384, 16, 4, MODE>(a, grid, ks, nt, s);
+                case 512: return launch_fixed16<512, 64, 8, MODE>(a, grid, ks, nt, s);
+                case 768: return launch_fixed16<768, 32, 4, MODE>(a, grid, ks, nt, s);
+                case 1024: return launch_fixed16<1024, 64, 4, MODE>(a, grid, ks, nt, s);
+                case 1536: return launch_fixed16<1536, 64, 2, MODE>(a, grid, ks, nt, s);
+                default: break;
+            }
+        }
+        return launch_generic<MODE>(a, grid, ks, s);
+    }
     const bool aligned = ((reinterpret_cast<uintptr_t>(a.rows) | reinterpret_cast<uintptr_t>(a.query)) & 15u) == 0;
     if (aligned) {
         switch (a.dim) {
@@ -847,15 +968,16 @@ int launch_publish_part(const uint32_t *rows, const float *scores, const float *
 }
 
 // rows src_rows[i] of this shard -> vector dst_pos[i] of a query block that may live on another device
-__global__ __launch_bounds__(256) void scatter_rows_kernel(const float *src, float *dst, const uint32_t *src_rows,
+template <typename S>
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const S *src, float *dst, const uint32_t *src_rows,
                                                            const uint32_t *dst_pos, uint32_t n, uint32_t dim) {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t r = wave; r < n; r += n_waves) {
-        const float *s = src + (size_t)src_rows[r] * dim;
+        const S *s = src + (size_t)src_rows[r] * dim;
         float *d = dst + (size_t)dst_pos[r] * dim;
-        for (uint32_t j = lane; j < dim; j += 64u) d[j] = s[j];
+        for (uint32_t j = lane; j < dim; j += 64u) d[j] = ldf(s + j);
     }
 }
 
@@ -863,32 +985,43 @@ int launch_scatter_rows(const float *src, float *dst, const uint32_t *d_src_rows
                         uint32_t dim, hipStream_t stream) {
     if (!n || !dim) return CX_OK;
     const uint32_t blocks = std::min<uint32_t>((n + 3u) / 4u, 2048u);
-    hipLaunchKernelGGL(scatter_rows_kernel, dim3(blocks), dim3(256), 0, stream, src, dst, d_src_rows, d_dst_pos, n, dim);
+    hipLaunchKernelGGL(scatter_rows_kernel<float>, dim3(blocks), dim3(256), 0, stream, src, dst, d_src_rows, d_dst_pos, n, dim);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+int launch_scatter_rows(const uint16_t *src, float *dst, const uint32_t *d_src_rows, const uint32_t *d_dst_pos, uint32_t n,
+                        uint32_t dim, hipStream_t stream) {
+    if (!n || !dim) return CX_OK;
+    const uint32_t blocks = std::min<uint32_t>((n + 3u) / 4u, 2048u);
+    hipLaunchKernelGGL(scatter_rows_kernel<uint16_t>, dim3(blocks), dim3(256), 0, stream, src, dst, d_src_rows, d_dst_pos, n, dim);
     CX_HIP(hipGetLastError());
     return CX_OK;
 }
 
 // ------------------------------------------------------- row maintenance
 
-__global__ __launch_bounds__(256) void gather_rows_kernel(const float *src, float *dst, const uint32_t *src_rows,
+// src_rows == null: rows 0 .. n_dst in order (a conversion of a contiguous block)
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const S *src, D *dst, const uint32_t *src_rows,
                                                           uint32_t n_dst, uint32_t dim) {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t r = wave; r < n_dst; r += n_waves) {
-        const float *s = src + (size_t)src_rows[r] * dim;
-        float *d = dst + (size_t)r * dim;
-        for (uint32_t j = lane; j < dim; j += 64u) d[j] = s[j];
+        const S *s = src + (size_t)(src_rows ? src_rows[r] : r) * dim;
+        D *d = dst + (size_t)r * dim;
+        for (uint32_t j = lane; j < dim; j += 64u) stf(d + j, ldf(s + j));
     }
 }
 
-__global__ __launch_bounds__(256) void row_norms_kernel(const float *rows, float *norms, uint32_t row_lo, uint32_t row_hi, uint32_t dim) {
+template <typename S>
+__global__ __launch_bounds__(256) void row_norms_kernel(const S *rows, float *norms, uint32_t row_lo, uint32_t row_hi, uint32_t dim) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t r = row_lo + wave; r < row_hi; r += n_waves) {
-        const float *p = rows + (size_t)r * dim;
+        const S *p = rows + (size_t)r * dim;
         float s = 0.0f;
-        for (uint32_t c = lane; c < dim; c += 64u) s = fmaf(p[c], p[c], s);
+        for (uint32_t c = lane; c < dim; c += 64u) { const float x = ldf(p + c); s = fmaf(x, x, s); }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
         if (lane == 0) norms[r] = s;
@@ -899,7 +1032,15 @@ int launch_row_norms(const float *rows, float *norms, uint32_t row_lo, uint32_t 
     if (row_hi <= row_lo) return CX_OK;
     const uint32_t n = row_hi - row_lo;
     const uint32_t blocks = n / 4u + 1u < 4096u ? n / 4u + 1u : 4096u;
-    hipLaunchKernelGGL(row_norms_kernel, dim3(blocks), dim3(256), 0, stream, rows, norms, row_lo, row_hi, dim);
+    hipLaunchKernelGGL(row_norms_kernel<float>, dim3(blocks), dim3(256), 0, stream, rows, norms, row_lo, row_hi, dim);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+int launch_row_norms(const uint16_t *rows, float *norms, uint32_t row_lo, uint32_t row_hi, uint32_t dim, hipStream_t stream) {
+    if (row_hi <= row_lo) return CX_OK;
+    const uint32_t n = row_hi - row_lo;
+    const uint32_t blocks = n / 4u + 1u < 4096u ? n / 4u + 1u : 4096u;
+    hipLaunchKernelGGL(row_norms_kernel<uint16_t>, dim3(blocks), dim3(256), 0, stream, rows, norms, row_lo, row_hi, dim);
     CX_HIP(hipGetLastError());
     return CX_OK;
 }
@@ -927,14 +1068,27 @@ int launch_scatter_lists(const uint32_t *src_rows, const float *src_scores, cons
     return CX_OK;
 }
 
-int launch_gather_rows(const float *src, float *dst, const uint32_t *d_src_rows, uint32_t n_dst, uint32_t dim,
-                       hipStream_t stream) {
+template <typename S, typename D>
+static int gather_rows_t(const S *src, D *dst, const uint32_t *d_src_rows, uint32_t n_dst, uint32_t dim, hipStream_t stream) {
     if (!n_dst) return CX_OK;
     uint32_t grid = (n_dst + 3u) / 4u;
     if (grid > 4096u) grid = 4096u;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, stream, src, dst, d_src_rows, n_dst, dim);
+    hipLaunchKernelGGL((gather_rows_kernel<S, D>), dim3(grid), dim3(256), 0, stream, src, dst, d_src_rows, n_dst, dim);
     CX_HIP(hipGetLastError());
     return CX_OK;
+}
+int launch_gather_rows(const float *src, float *dst, const uint32_t *d_src_rows, uint32_t n_dst, uint32_t dim, hipStream_t stream) {
+    return gather_rows_t(src, dst, d_src_rows, n_dst, dim, stream);
+}
+// bf16 stores: rows out as f32 (query blocks, save, copies to the caller), rows moved inside the store, f32 rows in
+int launch_gather_rows(const uint16_t *src, float *dst, const uint32_t *d_src_rows, uint32_t n_dst, uint32_t dim, hipStream_t stream) {
+    return gather_rows_t(src, dst, d_src_rows, n_dst, dim, stream);
+}
+int launch_gather_rows(const uint16_t *src, uint16_t *dst, const uint32_t *d_src_rows, uint32_t n_dst, uint32_t dim, hipStream_t stream) {
+    return gather_rows_t(src, dst, d_src_rows, n_dst, dim, stream);
+}
+int launch_gather_rows(const float *src, uint16_t *dst, const uint32_t *d_src_rows, uint32_t n_dst, uint32_t dim, hipStream_t stream) {
+    return gather_rows_t(src, dst, d_src_rows, n_dst, dim, stream);
 }
 
 }  // namespace cx

@@ -326,14 +326,18 @@ int hits_of(const cx_sharded *h, size_t s, const uint8_t *ids, const float *sc, 
 
 extern "C" {
 
-cx_sharded *cx_sharded_create(uint32_t dimension, uint32_t n_shards, const int *device_ids) try {
+cx_sharded *cx_sharded_create(uint32_t dimension, uint32_t n_shards, const int *device_ids) {
+    return cx_sharded_create_ex(dimension, n_shards, device_ids, CX_DTYPE_F32);
+}
+
+cx_sharded *cx_sharded_create_ex(uint32_t dimension, uint32_t n_shards, const int *device_ids, int dtype) try {
     if (!n_shards || !device_ids) { set_err(CX_ERR_VALIDATION, "sharded: no devices"); return nullptr; }
     if (n_shards > MAX_PARTS) { set_err(CX_ERR_VALIDATION, "sharded: at most %u shards", MAX_PARTS); return nullptr; }
     std::unique_ptr<cx_sharded> h(new cx_sharded());
     h->dim = dimension;
     if (const char *e = getenv("CX_SHARD_PLACEMENT_BLOCK")) h->block = std::max<long long>(1, atoll(e));
     for (uint32_t s = 0; s < n_shards; s++) {
-        cx_index *ix = cx_create(dimension, device_ids[s]);
+        cx_index *ix = cx_create_ex(dimension, device_ids[s], dtype);
         if (!ix) { for (cx_index *p : h->shards) cx_destroy(p); return nullptr; }
         h->shards.push_back(ix);
         h->devices.push_back(device_ids[s]);
@@ -666,7 +670,7 @@ int link_pass_sharded(const cx_sharded *h, const std::vector<uint32_t> &scan, co
                 CX_HIP(hipMemcpyAsync(l.d_pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice, l.stream));
                 CX_HIP(hipStreamSynchronize(l.stream));   // src / pos are reused for the next owner
                 for (size_t t = 0; t < P; t++)
-                    if (int rc = launch_scatter_rows(h->shards[o]->d_rows, ls[t]->d_q, l.d_src, l.d_pos, (uint32_t)src.size(), dim, l.stream))
+                    if (int rc = (h->shards[o]->dtype == 1 ? launch_scatter_rows(h->shards[o]->rows16(), ls[t]->d_q, l.d_src, l.d_pos, (uint32_t)src.size(), dim, l.stream) : launch_scatter_rows(h->shards[o]->d_rows, ls[t]->d_q, l.d_src, l.d_pos, (uint32_t)src.size(), dim, l.stream)))
                         return rc;
             }
             CX_HIP(hipEventRecord(l.scattered, l.stream));

@@ -72,19 +72,29 @@ class VectorFilter:
         return self
 
 
+def _dtype_code(dtype: str) -> int:
+    try:
+        return {"f32": 0, "bf16": 1}[dtype]
+    except KeyError:
+        raise ValidationError(f"unknown storage dtype {dtype!r} (f32 | bf16)") from None
+
+
 class HipIndex:
     """Drop-in for HnswIndex (vector/index.rs:182-473) on one MI355X.
 
     Exact search: inserts are visible to the next search and `rebuild()` is
     never needed for correctness."""
 
-    def __init__(self, dimension: int, device: int = 0):
+    def __init__(self, dimension: int, device: int = 0, dtype: str = "f32"):
+        """dtype "bf16" (cx_create_ex): every inserted vector is rounded to bf16 once and kept as 2 bytes per element;
+        results are the reference's for the rounded vectors."""
         self._L = _lib.load()
-        self._h = self._L.cx_create(dimension, device)
+        self._h = self._L.cx_create_ex(dimension, device, _dtype_code(dtype))
         if not self._h:
             raise CortexError(self._err())
         self.dimension = dimension
         self.device = device
+        self.dtype = dtype
 
     @classmethod
     def new(cls, dimension: int, device: int = 0) -> "HipIndex":
@@ -246,15 +256,15 @@ class HipIndex:
         self._check(self._L.cx_save(self._h, str(path).encode()))
 
     @classmethod
-    def load(cls, path, device: int = 0) -> "HipIndex":
+    def load(cls, path, device: int = 0, dtype: str = "f32") -> "HipIndex":
         """vector/index.rs:447-473."""
         L = _lib.load()
-        h = L.cx_load(str(path).encode(), device)
+        h = L.cx_load_ex(str(path).encode(), device, _dtype_code(dtype))
         if not h:
             msg = (L.cx_last_error() or b"").decode(errors="replace")
             raise ValidationError(msg)
         self = cls.__new__(cls)
-        self._L, self._h, self.device = L, h, device
+        self._L, self._h, self.device, self.dtype = L, h, device, dtype
         self.dimension = int(L.cx_dimension(h))
         return self
 
@@ -507,11 +517,12 @@ class ShardedHipIndex(HipIndex):
     dedup_scan_rows, rows_of, row_id, row_count) are GLOBAL rows = insertion sequence numbers, i.e. exactly the rows of
     a single HipIndex that saw the same calls."""
 
-    def __init__(self, dimension: int, devices: Sequence[int]):
+    def __init__(self, dimension: int, devices: Sequence[int], dtype: str = "f32"):
         L = _lib.load()
         self._L = _ShardedAbi(L)
         devs = (C.c_int * len(devices))(*[int(d) for d in devices])
-        self._h = L.cx_sharded_create(dimension, len(devices), devs)
+        self._h = L.cx_sharded_create_ex(dimension, len(devices), devs, _dtype_code(dtype))
+        self.dtype = dtype
         if not self._h:
             raise CortexError(self._err())
         self.dimension = dimension

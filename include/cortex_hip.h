@@ -69,6 +69,16 @@ int cx_device_count(void);
 /* HnswIndex::new(dimension) / with_metadata — vector/index.rs:204-216.
  * device: HIP device ordinal this shard lives on.  NULL on failure. */
 cx_index *cx_create(uint32_t dimension, int device);
+/* The same with a storage dtype for the HBM row store (cx_create(dim, dtype, ...); BASELINE config 5 is a
+ * bf16 store).  CX_DTYPE_F32: cx_create.  CX_DTYPE_BF16: every vector is rounded to bf16 (nearest even) ONCE, when it is
+ * inserted, and kept as 2 bytes per element — half the HBM footprint and half the bytes of every scan; all arithmetic
+ * stays f32 (products of bf16 values are exact in f32), so every result is what the reference's distance path
+ * (vector/index.rs:169-179, :254-294) returns for the rounded vectors, and that is what cx_save writes.  Every entry point
+ * of this header works on either kind of handle; cx_device_rows is NULL for a bf16 store. */
+#define CX_DTYPE_F32 0
+#define CX_DTYPE_BF16 1
+cx_index *cx_create_ex(uint32_t dimension, int device, int dtype);
+int cx_dtype(const cx_index *ix);   /* CX_DTYPE_*; -1 for NULL */
 void cx_destroy(cx_index *ix);
 /* pre-size the HBM row store (rows, not bytes); optional */
 int cx_reserve(cx_index *ix, uint64_t rows);
@@ -111,6 +121,7 @@ int cx_rebuild(cx_index *ix);
  * "Failed to deserialize index: ...").  cx_load returns NULL on failure. */
 int cx_save(const cx_index *ix, const char *path);
 cx_index *cx_load(const char *path, int device);
+cx_index *cx_load_ex(const char *path, int device, int dtype);   /* the file's f32 vectors into a store of that dtype (cx_create_ex) */
 
 /* ---- bulk load from stored nodes ----------------------- */
 
@@ -362,6 +373,7 @@ int cx_merge_topk_dev(int device, uint64_t n_parts, uint64_t nq, uint64_t k, uin
 typedef struct cx_sharded cx_sharded;
 
 cx_sharded *cx_sharded_create(uint32_t dimension, uint32_t n_shards, const int *device_ids);   /* NULL on failure */
+cx_sharded *cx_sharded_create_ex(uint32_t dimension, uint32_t n_shards, const int *device_ids, int dtype);   /* dtype: cx_create_ex */
 void cx_sharded_destroy(cx_sharded *h);
 uint32_t cx_sharded_n_shards(const cx_sharded *h);
 /* shard i as a plain index (read-only uses: cx_len, cx_row_count, cx_device_rows ...) */

@@ -112,7 +112,8 @@ class HipIndex final : public VectorIndex {
     }
 
 public:
-    explicit HipIndex(size_t dimension, int device = 0) : h_(cx_create((uint32_t)dimension, device)) {  // index.rs:204
+    // dtype CX_DTYPE_BF16: vectors rounded to bf16 once at insert, 2 bytes per element in HBM (cortex_hip.h: cx_create_ex)
+    explicit HipIndex(size_t dimension, int device = 0, int dtype = CX_DTYPE_F32) : h_(cx_create_ex((uint32_t)dimension, device, dtype)) {  // index.rs:204
         if (!h_) throw CortexError(CX_ERR_DEVICE, cx_last_error());
     }
     static HipIndex with_metadata(size_t dimension, int device = 0) { return HipIndex(dimension, device); }  // :214
@@ -171,8 +172,8 @@ public:
     size_t len() const override { return (size_t)cx_len(h_); }
     void rebuild() override { check(cx_rebuild(h_)); }
     void save(const std::string &path) const override { check(cx_save(h_, path.c_str())); }
-    static HipIndex load(const std::string &path, int device = 0) {  // :447-473
-        cx_index *h = cx_load(path.c_str(), device);
+    static HipIndex load(const std::string &path, int device = 0, int dtype = CX_DTYPE_F32) {  // :447-473
+        cx_index *h = cx_load_ex(path.c_str(), device, dtype);
         if (!h) throw CortexError(CX_ERR_VALIDATION, cx_last_error());
         return HipIndex(h);
     }
@@ -257,7 +258,8 @@ class ShardedHipIndex final : public VectorIndex {
     }
 
 public:
-    ShardedHipIndex(size_t dimension, const std::vector<int> &devices) : h_(cx_sharded_create((uint32_t)dimension, (uint32_t)devices.size(), devices.data())) {
+    ShardedHipIndex(size_t dimension, const std::vector<int> &devices, int dtype = CX_DTYPE_F32)
+        : h_(cx_sharded_create_ex((uint32_t)dimension, (uint32_t)devices.size(), devices.data(), dtype)) {
         if (!h_) throw CortexError(CX_ERR_DEVICE, cx_last_error());
     }
     ShardedHipIndex(const ShardedHipIndex &) = delete;

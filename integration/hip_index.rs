@@ -28,6 +28,8 @@ struct CxFilter {
 extern "C" {
     fn cx_last_error() -> *const c_char;
     fn cx_create(dimension: u32, device: c_int) -> *mut c_void;
+    fn cx_create_ex(dimension: u32, device: c_int, dtype: c_int) -> *mut c_void;
+    fn cx_dtype(h: *const c_void) -> c_int;
     fn cx_destroy(ix: *mut c_void);
     fn cx_upsert(ix: *mut c_void, id: *const u8, emb: *const f32, len: u64) -> c_int;
     fn cx_remove(ix: *mut c_void, id: *const u8) -> c_int;
@@ -58,6 +60,7 @@ extern "C" {
     fn cx_rows_alive(ix: *const c_void, row_lo: u64, n: u64, out_alive: *mut u8) -> c_int;
     fn cx_save(ix: *const c_void, path: *const c_char) -> c_int;
     fn cx_load(path: *const c_char, device: c_int) -> *mut c_void;
+    fn cx_load_ex(path: *const c_char, device: c_int, dtype: c_int) -> *mut c_void;
     // query-time score decay + re-rank
     fn cx_set_node_stats_batch(ix: *mut c_void, n: u64, ids: *const u8, kind_codes: *const u32, last_accessed_s: *const i64,
                                last_accessed_ns: *const u32, access_counts: *const u64) -> c_int;
@@ -66,6 +69,7 @@ extern "C" {
                          scores: *mut f32, raw_scores: *mut f32, n_out: *mut u64) -> c_int;
     // one index over several GPUs of the node: same contracts, `cx_sharded` handle
     fn cx_sharded_create(dimension: u32, n_shards: u32, device_ids: *const c_int) -> *mut c_void;
+    fn cx_sharded_create_ex(dimension: u32, n_shards: u32, device_ids: *const c_int, dtype: c_int) -> *mut c_void;
     fn cx_sharded_destroy(h: *mut c_void);
     fn cx_sharded_upsert(h: *mut c_void, id: *const u8, emb: *const f32, len: u64) -> c_int;
     fn cx_sharded_upsert_batch(h: *mut c_void, n: u64, ids: *const u8, embs: *const f32, len: u64) -> c_int;
@@ -158,6 +162,13 @@ impl HipIndex {
         let h = unsafe { cx_create(dimension as u32, device) };
         if h.is_null() { Err(last_error()) } else { Ok(Self { h, dimension }) }
     }
+    /// A bf16 row store (BASELINE config 5): vectors rounded to bf16 once at insert, 2 bytes per element in HBM; results
+    /// are the reference's for the rounded vectors.  dtype: 0 = f32, 1 = bf16.
+    pub fn with_dtype(dimension: usize, device: i32, dtype: i32) -> Result<Self> {
+        let h = unsafe { cx_create_ex(dimension as u32, device, dtype) };
+        if h.is_null() { Err(last_error()) } else { Ok(Self { h, dimension }) }
+    }
+    pub fn is_bf16(&self) -> bool { unsafe { cx_dtype(self.h) == 1 } }
     // adds the string if new: only from &mut self (set_metadata, bulk load)
     fn intern(&mut self, s: &str) -> u32 { unsafe { cx_intern(self.h, s.as_ptr() as *const c_char, s.len() as u64) } }
     // read-only: filters on the concurrent &self path; 0 = never interned = matches no row that has metadata
@@ -338,7 +349,9 @@ impl VectorIndex for HipIndex {
     }
     fn load(path: &Path) -> Result<Self> {
         let p = std::ffi::CString::new(path.to_string_lossy().as_bytes()).map_err(|e| CortexError::Validation(e.to_string()))?;
-        let h = unsafe { cx_load(p.as_ptr(), 0) };
+        // CORTEX_HIP_DTYPE=bf16 loads the file's f32 vectors into a bf16 store (cx_load_ex)
+        let bf16 = std::env::var("CORTEX_HIP_DTYPE").map(|v| v == "bf16").unwrap_or(false);
+        let h = unsafe { if bf16 { cx_load_ex(p.as_ptr(), 0, 1) } else { cx_load(p.as_ptr(), 0) } };
         if h.is_null() { return Err(last_error()); }
         Ok(Self { h, dimension: 0 })
     }
@@ -356,6 +369,10 @@ impl Drop for ShardedHipIndex { fn drop(&mut self) { unsafe { cx_sharded_destroy
 impl ShardedHipIndex {
     pub fn new(dimension: usize, devices: &[i32]) -> Result<Self> {
         let h = unsafe { cx_sharded_create(dimension as u32, devices.len() as u32, devices.as_ptr()) };
+        if h.is_null() { Err(last_error()) } else { Ok(Self { h }) }
+    }
+    pub fn with_dtype(dimension: usize, devices: &[i32], dtype: i32) -> Result<Self> {
+        let h = unsafe { cx_sharded_create_ex(dimension as u32, devices.len() as u32, devices.as_ptr(), dtype) };
         if h.is_null() { Err(last_error()) } else { Ok(Self { h }) }
     }
     pub fn set_metadata(&mut self, id: NodeId, kind: NodeKind, source_agent: String) {
