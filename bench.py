@@ -247,7 +247,9 @@ def main() -> None:
         out["extra"]["config5_shard_6.25Mx1024_streaming_ingest"] = config5_leg(L, local_rank, dev)
         # config 5's row width through search_batch: the batched kernel for the widths batch2 has no instance for
         out["extra"]["config5_shard_6.25Mx1024_batch64_k10"] = config4_leg(L, local_rank, dev, n=6_250_000, d=1024, steps=10,
-                                                                           kernel="cx::batchg_kernel<0, true>", shard_note="one of 8 shards of config 5's 50M rows")
+                                                                           kernel="cx::batchg_kernel<0, true, false>", shard_note="one of 8 shards of config 5's 50M rows, f32 store")
+        out["extra"]["config5_shard_6.25Mx1024_bf16_batch64_k10"] = config4_leg(L, local_rank, dev, n=6_250_000, d=1024, steps=10, dtype="bf16",
+                                                                                kernel="cx::batchg_kernel<0, true, true>", shard_note="one of 8 shards of config 5's 50M rows, bf16 store")
     if rank == 0:
         print(json.dumps(out), flush=True)
     ix.close()
@@ -390,14 +392,14 @@ def config1_leg(L, device: int, n: int = 10_000, d: int = 384, k: int = 5, nq: i
 
 
 def config4_leg(L, device: int, dev, n: int = 1_250_000, d: int = 768, k: int = 10, B: int = 64, steps: int = 40,
-                kernel: str = "cx::batch2_kernel", shard_note: str = "one of 8 shards of 10M rows"):
+                kernel: str = "cx::batch2_kernel", shard_note: str = "one of 8 shards of 10M rows", dtype: str = "f32"):
     """BASELINE configs[3], one GPU's share: 64 queries per step over a 1.25M x 768 f32 shard (10M rows / 8 GPUs),
     k=10 — the batched MFMA kernel the sharded search runs before its all-gather; same measurement as the headline
     (cx_search_batch_dev, HIP events around the kernel)."""
     import cortex_amd
     gen = torch.empty((n, d), dtype=torch.float32, device=dev)
     assert L.cx_synth_fill_dev(device, gen.data_ptr(), SEED_CORPUS, SEED_CORPUS, SEED_DUP, n // 50, 0, n, d, 1) == 0
-    ix = cortex_amd.HipIndex(d, device=device)
+    ix = cortex_amd.HipIndex(d, device=device, dtype=dtype)
     ix.reserve(n)
     ix.insert_batch_dev(synth_ids(0, n), gen.data_ptr(), n, d)
     del gen
@@ -426,8 +428,8 @@ def config4_leg(L, device: int, dev, n: int = 1_250_000, d: int = 768, k: int = 
     kern_ms, kern_n = ix.profile_read(reset=True)
     ix.close()
     avg = kern_ms / max(1, kern_n)
-    algo = float(n) * d * 4.0
-    return {"workload": f"cosine kNN k={k}, batch of {B} queries per step, {n} x {d} f32 rows ({shard_note})",
+    algo = float(n) * d * (2.0 if dtype == "bf16" else 4.0)
+    return {"workload": f"cosine kNN k={k}, batch of {B} queries per step, {n} x {d} {dtype} rows ({shard_note})",
             "queries_per_s": steps * B / el, "ms_per_step": el / steps * 1e3,
             "roofline": {"bound": "hbm", "achieved": algo / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": algo / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": kernel, "avg_kernel_ms": avg,
@@ -500,9 +502,11 @@ def config4_sharded_leg(L, device: int, dev, rank: int, world: int, total: int =
 def config5_leg(L, device: int, dev, n: int = 6_250_000, d: int = 1024, thr: float = 0.85):
     """BASELINE configs[4], one GPU's share: a 6.25M x 1024 shard (50M rows / 8 GPUs; 25.6 GB f32 + 12.8 GB bf16
     shadow), streaming auto-link ingest — batches of 64 and 500 new rows linked against the whole shard
-    (cx_autolink_pass_timed).  The filter streams the bf16 shadow once per batch: HBM-bound at 64, MFMA-bound at 500."""
+    (cx_autolink_pass_timed).  The filter streams the bf16 shadow once per batch: HBM-bound at 64, MFMA-bound at 500.
+    The store itself is bf16 (cx_create_ex: config 5's storage dtype — 12.8 GB of rows instead of 25.6), so the exact
+    rescore reads bf16 rows and the edges are the reference's for the rounded vectors."""
     import cortex_amd
-    ix = cortex_amd.HipIndex(d, device=device)
+    ix = cortex_amd.HipIndex(d, device=device, dtype="bf16")
     ix.reserve(n)
     chunk = 1_000_000
     for lo in range(0, n, chunk):
@@ -513,7 +517,8 @@ def config5_leg(L, device: int, dev, n: int = 6_250_000, d: int = 1024, thr: flo
         del gen
     t = float(np.float32(thr))
     ix.autolink_pass_timed(100, t, 50, np.arange(n - 64, n, dtype=np.uint32))   # builds the shadow
-    out = {"workload": f"streaming auto-link ingest against a {n} x {d} shard (bf16 shadow {n * d * 2 / 1e9:.1f} GB), threshold {thr}, top-100, 50 edges/node"}
+    out = {"workload": f"streaming auto-link ingest against a {n} x {d} bf16 shard ({n * d * 2 / 1e9:.1f} GB of rows + the normalised bf16 shadow the filter streams), threshold {thr}, top-100, 50 edges/node",
+           "storage_dtype": "bf16"}
     for b in (64, 500):
         scan = np.arange(n - b, n, dtype=np.uint32)
         best = None

@@ -13,11 +13,13 @@ ap.add_argument("--dim", type=int, default=1024)
 ap.add_argument("--k", type=int, default=10)
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--dtype", default="f32", help="storage dtype of the index: f32 | bf16 (cx_create_ex)")
+ap.add_argument("--single", action="store_true", help="time single-query scans instead of batches")
 a = ap.parse_args()
 L = _lib.load()
 n, d, k, B = a.rows, a.dim, a.k, a.batch
 dev = torch.device("cuda", 0)
-ix = cortex_amd.HipIndex(d); ix.reserve(n)
+ix = cortex_amd.HipIndex(d, dtype=a.dtype); ix.reserve(n)
 for lo in range(0, n, 1_000_000):
     m = min(1_000_000, n - lo)
     gen = torch.empty((m, d), dtype=torch.float32, device=dev)
@@ -29,6 +31,8 @@ assert L.cx_synth_fill_dev(0, qs.data_ptr(), 20260313, 20260314, 20260315, n // 
 o_rows = torch.empty((B, k), dtype=torch.int32, device=dev); o_sc = torch.empty((B, k), dtype=torch.float32, device=dev)
 o_di = torch.empty((B, k), dtype=torch.float32, device=dev); o_cnt = torch.empty(B, dtype=torch.int32, device=dev)
 stream = torch.cuda.current_stream().cuda_stream
+if a.single:
+    B = 1
 one = lambda i: ix.search_batch_dev(qs.data_ptr() + ((i * B) % (256 - B + 1)) * d * 4, B, k, o_rows.data_ptr(), o_sc.data_ptr(), o_di.data_ptr(), o_cnt.data_ptr(), stream)
 for i in range(8): one(i)
 torch.cuda.synchronize()
@@ -39,7 +43,7 @@ torch.cuda.synchronize()
 el = time.perf_counter() - t0
 ix.profile_enable(False)
 ms, cnt = ix.profile_read(reset=True)
-avg = ms / max(1, cnt); algo = float(n) * d * 4
-print(json.dumps({"rows": n, "dim": d, "k": k, "batch": B, "queries_per_s": a.steps * B / el, "ms_per_step": el / a.steps * 1e3,
+avg = ms / max(1, cnt); algo = float(n) * d * (2 if a.dtype == "bf16" else 4)
+print(json.dumps({"rows": n, "dim": d, "dtype": a.dtype, "k": k, "batch": B, "queries_per_s": a.steps * B / el, "ms_per_step": el / a.steps * 1e3,
                   "kernel_ms": avg, "launches": cnt, "hbm_GBs": algo / (avg * 1e-3) / 1e9 if avg else None,
                   "frac_of_8TBs": algo / (avg * 1e-3) / 8e12 if avg else None}))

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <string>
 
@@ -318,6 +319,52 @@ TEST(test_sharded_single_process) {
     CHECK(threw);
 }
 
+TEST(test_bf16_store_runs_the_reference_tests) {   // the reference's own cases (:484-535, :538-566, :667-684) on a bf16 row store
+    HipIndex index(3, 0, CX_DTYPE_BF16);
+    auto id1 = now_v7(), id2 = now_v7(), id3 = now_v7();
+    index.insert(id1, {1.0f, 0.0f, 0.0f});
+    index.insert(id2, {0.9f, 0.1f, 0.0f});
+    index.insert(id3, {0.0f, 1.0f, 0.0f});
+    index.rebuild();
+    auto results = index.search({1.0f, 0.0f, 0.0f}, 2);
+    CHECK(results.size() == 2 && results[0].node_id == id1 && results[1].node_id == id2);
+    CHECK(std::fabs(results[0].score - 1.0f) < 1e-6f);
+    auto thr = index.search_threshold({1.0f, 0.0f, 0.0f}, 0.95f);
+    CHECK(thr.size() == 2);   // 0.9/0.1 rounds to bf16 and still scores 0.9939 >= 0.95
+    const std::string path = std::string(std::getenv("TMPDIR") ? std::getenv("TMPDIR") : "/tmp") + "/cx_cpp_test_bf16.hnsw";
+    index.save(path);
+    HipIndex loaded = HipIndex::load(path, 0, CX_DTYPE_BF16);
+    CHECK(loaded.len() == 3);
+    auto again = loaded.search({1.0f, 0.0f, 0.0f}, 2);
+    CHECK(again.size() == 2 && again[0].node_id == id1 && again[0].score == results[0].score && again[1].score == results[1].score);
+    std::remove(path.c_str());
+    // a wider store through the batched path: bf16 index against an f32 index fed the rounded vectors gives the same ids
+    const size_t dim = 256, n = 600;
+    std::mt19937 rng(11);
+    std::normal_distribution<float> g(0.0f, 1.0f);
+    auto round_bf16 = [](float x) { uint32_t u; std::memcpy(&u, &x, 4); u += 0x7FFFu + ((u >> 16) & 1u); u &= 0xFFFF0000u; float y; std::memcpy(&y, &u, 4); return y; };
+    HipIndex b(dim, 0, CX_DTYPE_BF16), f(dim);
+    std::vector<NodeId> ids(n);
+    std::vector<Embedding> rows(n, Embedding(dim));
+    for (size_t i = 0; i < n; i++) {
+        ids[i] = now_v7();
+        for (auto &x : rows[i]) x = g(rng);
+        b.insert(ids[i], rows[i]);
+        Embedding r = rows[i];
+        for (auto &x : r) x = round_bf16(x);
+        f.insert(ids[i], r);
+    }
+    std::vector<std::pair<NodeId, Embedding>> qs;
+    for (size_t i = 0; i < 40; i++) qs.emplace_back(ids[i], rows[i]);
+    auto rb = b.search_batch(qs, 5), rf = f.search_batch(qs, 5);
+    CHECK(rb.size() == rf.size());
+    for (auto &kv : rb) {
+        auto &x = kv.second; auto &y = rf[kv.first];
+        CHECK(x.size() == y.size());
+        for (size_t i = 0; i < x.size() && i < y.size(); i++) CHECK(x[i].node_id == y[i].node_id && std::fabs(x[i].score - y[i].score) < 5e-5f);
+    }
+}
+
 int main() {
     if (cx_device_count() <= 0) { std::fprintf(stderr, "no HIP device: %s\n", "this test needs a GPU"); return 2; }
     run_test_index_insert_and_search(); run_test_threshold_search(); run_test_index_persistence();
@@ -325,6 +372,7 @@ int main() {
     run_test_filter_by_kind(); run_test_filter_exclude(); run_test_remove_doesnt_crash_search(); run_test_search_batch();
     run_test_similarity_score_range(); run_test_threshold_returns_only_above(); run_test_config();
     run_test_linker_similarity_edges_and_dedup(); run_test_bulk_load_nodes(); run_test_search_decayed_reranks(); run_test_sharded_single_process();
+    run_test_bf16_store_runs_the_reference_tests();
     std::printf("%d tests run, %d checks failed\n", g_run, g_failed);
     return g_failed ? 1 : 0;
 }

@@ -24,4 +24,4 @@ def test_reference_tests_pass_through_the_cpp_mirror(tmp_path):
     env = dict(os.environ, TMPDIR=str(tmp_path))
     p = subprocess.run([BIN], capture_output=True, text=True, timeout=120, env=env)
     assert p.returncode == 0, p.stdout + p.stderr
-    assert "17 tests run, 0 checks failed" in p.stdout
+    assert "18 tests run, 0 checks failed" in p.stdout
