@@ -48,7 +48,7 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 namespace bg {
 constexpr int WAVES = 4;            // per block; two blocks per CU
-constexpr int TILE_ROWS = 128;      // rows per block tile: 4 waves x 32
+constexpr int TILE_ROWS = 128;      // rows per block tile of the f32 instance: 4 waves x 32 (the bf16 instance: 4 x 64)
 constexpr int KB = 64;              // k per K-block
 constexpr int STEPS = KB / 32;      // MFMA steps per K-block
 constexpr int NQ = 64;              // queries per pass
@@ -132,6 +132,11 @@ struct BatchGArgs {
 template <int PROBE, bool FILTER, bool R16>
 __global__ __launch_bounds__(256, 2) void batchg_kernel(const BatchGArgs a) {
     using namespace bg;
+    // rows per wave: an f32 K-block of a row is 256 B, a bf16 one 128 B — the bf16 instance gives every wave twice the rows
+    // (four A fragments), so that a K-block is the same 8 KiB of rows per wave and a query fragment feeds eight MFMAs
+    constexpr int NF = R16 ? 4 : 2;                 // 16-row A fragments per wave
+    constexpr uint32_t RPW = 16u * NF;              // rows per wave
+    constexpr uint32_t TR = WAVES * RPW;            // rows per block tile: 128 (f32) / 256 (bf16)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (a.run_if && *a.run_if == 0u) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -176,28 +181,28 @@ __global__ __launch_bounds__(256, 2) void batchg_kernel(const BatchGArgs a) {
     // read group (one piece index, 16 rows) then hit 16 different 16-byte bank groups; a write group is the 16 pieces
     // of one row, permuted inside its 256 bytes.
     const uint32_t lrow = lane >> 4, lpiece = lane & 15u;
-    f32x4 acc[2][4];
+    f32x4 acc[NF][4];
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int f = 0; f < 2; f++)
+        for (int f = 0; f < NF; f++)
 #pragma unroll
             for (int g = 0; g < 4; g++) acc[f][g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     };
     const uint32_t lane_off = lrow * a.dim * 4u + lpiece * 16u;
     f32x4 xa[8], xb[8];   // two K-blocks of this wave's rows in flight (16 KiB per wave, 128 KiB per CU)
-    // bf16 store: a K-block of a row is 128 B = 8 pieces of 8 elements; lane l reads piece l % 8 of row 8 i + l / 8, four
-    // load instructions per K-block; piece p of row r sits at p ^ ((r >> 1) & 7) (rows are 128 B apart: two rows per 256 B
+    // bf16 store: a K-block of a row is 128 B = 8 pieces of 8 elements; lane l reads piece l % 8 of row 8 i + l / 8, eight
+    // load instructions (64 rows) per K-block; piece p of row r sits at p ^ ((r >> 1) & 7) (rows are 128 B apart: two rows per 256 B
     // of banks)
     const uint32_t lrow16 = lane >> 3, lpiece16 = lane & 7u;
     const uint32_t lane_off16 = lrow16 * a.dim * 2u + lpiece16 * 16u;
     auto r_fetch = [&](f32x4 (&dst)[8], uint32_t tile, uint32_t kb) {   // kb: K-block inside the row
         if constexpr (R16) {
-            const char *base = reinterpret_cast<const char *>(a.rows16) + ((size_t)tile * a.tile_step * TILE_ROWS + wave * 32u) * a.dim * 2u + (size_t)kb * (KB * 2u);
+            const char *base = reinterpret_cast<const char *>(a.rows16) + ((size_t)tile * a.tile_step * TR + wave * RPW) * a.dim * 2u + (size_t)kb * (KB * 2u);
 #pragma unroll
-            for (int i = 0; i < 4; i++) dst[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(base + (size_t)i * 8u * a.dim * 2u + lane_off16));
+            for (int i = 0; i < 8; i++) dst[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(base + (size_t)i * 8u * a.dim * 2u + lane_off16));
             return;
         }
-        const char *base = reinterpret_cast<const char *>(a.rows) + ((size_t)tile * a.tile_step * TILE_ROWS + wave * 32u) * a.dim * 4u + (size_t)kb * (KB * 4u);
+        const char *base = reinterpret_cast<const char *>(a.rows) + ((size_t)tile * a.tile_step * TR + wave * RPW) * a.dim * 4u + (size_t)kb * (KB * 4u);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             if constexpr (PROBE == 2) { asm volatile("" : "+v"(dst[i])); continue; }
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void batchg_kernel(const BatchGArgs a) {
     auto lds_put = [&](const f32x4 (&src)[8]) {
         if constexpr (R16) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < 8; i++) {
                 const uint32_t r = 8u * (uint32_t)i + lrow16;
                 *reinterpret_cast<f32x4 *>(Rw + r * 128u + ((lpiece16 ^ ((r >> 1) & 7u)) << 4)) = src[i];
             }
@@ -225,10 +230,10 @@ __global__ __launch_bounds__(256, 2) void batchg_kernel(const BatchGArgs a) {
         const char *Q = Qs + buf * KB_BYTES + (j * 4u + kq) * 16u;
 #pragma unroll
         for (int s = 0; s < STEPS; s++) {
-            s16x8 ah[2], al[2];
+            s16x8 ah[NF], al[2];
             if constexpr (R16) {
 #pragma unroll
-                for (int f = 0; f < 2; f++) {
+                for (int f = 0; f < NF; f++) {
                     const uint32_t row = 16u * f + j;
                     ah[f] = *reinterpret_cast<const s16x8 *>(Rw + row * 128u + (((4u * s + kq) ^ ((row >> 1) & 7u)) << 4));
                 }
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void batchg_kernel(const BatchGArgs a) {
                     const s16x8 qh = *reinterpret_cast<const s16x8 *>(Q + s * STEP_BYTES + g * 1024);
                     const s16x8 ql = *reinterpret_cast<const s16x8 *>(Q + s * STEP_BYTES + STEP_BYTES / 2 + g * 1024);
 #pragma unroll
-                    for (int f = 0; f < 2; f++) {
+                    for (int f = 0; f < NF; f++) {
                         acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], ql, acc[f][g], 0, 0, 0);   // small term first
                         acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], qh, acc[f][g], 0, 0, 0);
                     }
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void batchg_kernel(const BatchGArgs a) {
     // C layout: lane (j, kq) holds rows 4 kq + e (e = 0..3) of fragment f for query j of group g: four consecutive rows.
     // Nothing here may be a vector load: vmcnt is in order, so waiting for one would first drain the row loads of the next
     // two K-blocks — the whole prefetch, once per tile.  |q|^2 and the bounds sit in registers from the start, |row|^2
-    // comes by scalar loads (a fragment's 16 rows are a uniform address; d_norms has 64 floats of readable padding).
+    // comes by scalar loads (a fragment's 16 rows are a uniform address; d_norms has a row tile (256 floats) of readable padding).
     // The square roots are hoisted (|q| once per kernel, |row| once per row instead of once per pair): the same IEEE values
     // as cosine_from_sums.  Filter mode divides only where the pair can reach the bound: score ~ dot / (|q| |row|) within
     // a few ulp, so dot < (bound - 1e-4) |q| |row| rules a pair out with two multiplies (a NaN or zero norm fails the
@@ -297,9 +302,9 @@ __global__ __launch_bounds__(256, 2) void batchg_kernel(const BatchGArgs a) {
     const __attribute__((address_space(4))) float *norms_c = (const __attribute__((address_space(4))) float *)a.norms;
     auto epilogue = [&](uint32_t tile) {
 #pragma unroll
-        for (int f = 0; f < 2; f++) {
-            const uint32_t in_tile = wave * 32u + 16u * f + 4u * kq;                 // first of this lane's four rows, inside the tile
-            const uint32_t w0 = tile * a.tile_step * TILE_ROWS + wave * 32u + 16u * f, r0 = w0 + 4u * kq;   // ... in the store
+        for (int f = 0; f < NF; f++) {
+            const uint32_t in_tile = wave * RPW + 16u * f + 4u * kq;                 // first of this lane's four rows, inside the tile
+            const uint32_t w0 = tile * a.tile_step * TR + wave * RPW + 16u * f, r0 = w0 + 4u * kq;   // ... in the store
             float tn[16];
 #pragma unroll
             for (int e = 0; e < 16; e++) tn[e] = norms_c[(size_t)w0 + e];
@@ -334,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void batchg_kernel(const BatchGArgs a) {
                     f32x4 c;
 #pragma unroll
                     for (int e = 0; e < 4; e++) c[e] = cosine_from_norms(acc[f][g][e], nqv[g], nr[e]);
-                    float *dst = a.dense + (size_t)q * a.stride + ((size_t)tile * TILE_ROWS + in_tile);   // dense column: the tile as this launch counts it
+                    float *dst = a.dense + (size_t)q * a.stride + ((size_t)tile * TR + in_tile);   // dense column: the tile as this launch counts it
                     if (r0 + 3u < a.n_rows) *reinterpret_cast<f32x4 *>(dst) = c;
                     else { for (uint32_t e = 0; e < 4u; e++) if (r0 + e < a.n_rows) dst[e] = c[e]; }
                 }
@@ -403,18 +408,19 @@ __global__ __launch_bounds__(256, 2) void batchg_kernel(const BatchGArgs a) {
 bool batchg_supported(uint32_t dim, uint32_t k) { return dim % (2 * bg::KB) == 0 && dim <= 4096 && k >= 1 && k <= TOPK_MAX; }
 size_t batchg_qimg_bytes(uint32_t dim) { return (size_t)(dim / 32u) * bg::STEP_BYTES; }
 
-uint32_t batchg_tile_rows() { return bg::TILE_ROWS; }
-uint32_t batchg_grid(uint32_t n_rows) {
-    const uint32_t n_tiles = (n_rows + bg::TILE_ROWS - 1) / bg::TILE_ROWS;
+uint32_t batchg_tile_rows(bool rows16) { return rows16 ? 2u * bg::TILE_ROWS : (uint32_t)bg::TILE_ROWS; }
+uint32_t batchg_grid(uint32_t n_rows, bool rows16) {
+    const uint32_t tr = batchg_tile_rows(rows16), n_tiles = (n_rows + tr - 1) / tr;
     return std::min<uint32_t>(n_tiles, 2u * device_cus());
 }
-uint32_t batchg_sample_rows(uint32_t n_rows, uint32_t tile_step, uint32_t *n_tiles_out) {
+uint32_t batchg_sample_rows(uint32_t n_rows, uint32_t tile_step, uint32_t *n_tiles_out, bool rows16) {
     if (n_tiles_out) *n_tiles_out = 0;
     if (!n_rows || !tile_step) return 0;
-    const uint32_t n_tiles = (n_rows + bg::TILE_ROWS - 1) / bg::TILE_ROWS, ns = (n_tiles + tile_step - 1) / tile_step;
-    const uint32_t last_phys = (ns - 1u) * tile_step * bg::TILE_ROWS;
+    const uint32_t tr = batchg_tile_rows(rows16);
+    const uint32_t n_tiles = (n_rows + tr - 1) / tr, ns = (n_tiles + tile_step - 1) / tile_step;
+    const uint32_t last_phys = (ns - 1u) * tile_step * tr;
     if (n_tiles_out) *n_tiles_out = ns;
-    return (ns - 1u) * bg::TILE_ROWS + std::min<uint32_t>(bg::TILE_ROWS, n_rows - last_phys);
+    return (ns - 1u) * tr + std::min<uint32_t>(tr, n_rows - last_phys);
 }
 
 int launch_batchg_split(const float *d_queries, uint32_t nq, uint32_t dim, char *d_qimg, float *d_qq, hipStream_t stream, bool rows16) {
@@ -449,12 +455,12 @@ int launch_batchg_pass(const float *rows, const float *norms, uint32_t n_rows, u
     a.flt.trivial = 1;
     a.rows = rows; a.rows16 = rows16; a.norms = norms; a.qimg = d_qimg; a.qq = d_qq; a.dense = d_dense;
     a.n_rows = n_rows; a.dim = dim; a.nq = nq; a.stride = stride; a.tile_step = tile_step; a.run_if = run_if;
-    const uint32_t n_tiles = (n_rows + TILE_ROWS - 1) / TILE_ROWS;
+    const uint32_t tr = batchg_tile_rows(rows16 != nullptr), n_tiles = (n_rows + tr - 1) / tr;
     a.n_tiles = (n_tiles + tile_step - 1) / tile_step;
     uint32_t grid = std::min<uint32_t>(a.n_tiles, 2u * device_cus());
     if (f) {
         a.tau_ord = f->tau_ord; a.cand_keys = f->cand_keys; a.cand_sims = f->cand_sims; a.cand_counts = f->cand_counts; a.overflow = f->overflow; a.cb = f->cb; a.flt = f->flt;
-        grid = batchg_grid(n_rows);   // the candidate lists are laid out for exactly this grid
+        grid = batchg_grid(n_rows, rows16 != nullptr);   // the candidate lists are laid out for exactly this grid
         if (rows16) hipLaunchKernelGGL((batchg_kernel<0, true, true>), dim3(grid), dim3(256), LDS_BYTES, stream, a);
         else hipLaunchKernelGGL((batchg_kernel<0, true, false>), dim3(grid), dim3(256), LDS_BYTES, stream, a);
         CX_HIP(hipGetLastError());

@@ -298,8 +298,8 @@ int ensure_norms(const cx_index *ix, hipStream_t s) {
         ix->d_split = nullptr;
         ix->norms_cap = 0;
         const uint64_t cap = std::max<uint64_t>(n, ix->cap);
-        CX_HIP(hipMalloc((void **)&ix->d_norms, (cap + 64) * sizeof(float)));   // + a tile of readable padding
-        CX_HIP(hipMemsetAsync(ix->d_norms, 0, (cap + 64) * sizeof(float), s));
+        CX_HIP(hipMalloc((void **)&ix->d_norms, (cap + 256) * sizeof(float)));   // + a row tile of readable padding (batchg.hip reads the norms of a whole 128- / 256-row tile)
+        CX_HIP(hipMemsetAsync(ix->d_norms, 0, (cap + 256) * sizeof(float), s));
         if (want_split) {
             const size_t bytes = (size_t)((cap + 31) / 16) * 16 * ix->dim * sizeof(float);   // whole tiles
             CX_HIP(hipMalloc((void **)&ix->d_split, bytes));
@@ -340,7 +340,7 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
     const bool topk_path = !has_thr && k_eff <= TOPK_MAX;
     uint32_t grid = 0;
     if (topk_path) {
-        grid = scan_grid_blocks(n, ix->dim);
+        grid = scan_grid_blocks(n, ix->dim, ix->dtype == 1);
         if (int rc = ensure_dev(c->d_part_keys, c->pk_cap, (size_t)grid * std::max(k_eff, 1u))) return rc;
         if (int rc = ensure_dev(c->d_part_sims, c->ps_cap, (size_t)grid * std::max(k_eff, 1u))) return rc;
     } else {
@@ -429,9 +429,9 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
         static const uint32_t step_env = getenv("CX_BATCHG_SAMPLE_STEP") ? (uint32_t)std::max(1, atoi(getenv("CX_BATCHG_SAMPLE_STEP"))) : 0u;
         const uint32_t tile_step = step_env ? step_env : (k_eff <= 32u ? 64u : 32u);
         uint32_t s_tiles = 0;
-        const uint32_t s_rows = batchg_sample_rows(n, tile_step, &s_tiles), s_stride = (s_rows + 3u) & ~3u;
+        const uint32_t s_rows = batchg_sample_rows(n, tile_step, &s_tiles, ix->dtype == 1), s_stride = (s_rows + 3u) & ~3u;
         const bool filtered = filter_ok && n >= filter_min && s_rows >= k_eff;
-        const uint32_t bgrid = batchg_grid(n);
+        const uint32_t bgrid = batchg_grid(n, ix->dtype == 1);
         uint32_t cb = std::max<uint32_t>(k_eff, 32u);
         if (getenv("CX_BATCHG_CAND_CAP")) cb = std::max<uint32_t>(k_eff, (uint32_t)atoi(getenv("CX_BATCHG_CAND_CAP")));   // tests: force the fallback
         cb = (cb + k_eff - 1u) / k_eff * k_eff;
@@ -468,7 +468,7 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
                 // 1. the bound: the k-th best score of the sampled tiles
                 uint32_t *counts = c->d_bg_ctl + 80;
                 if (int rc = launch_batchg_pass(ix->rows32(), ix->d_norms, n, ix->dim, m, c->d_qimg, d_qq, c->d_dense, s_stride, tile_step, nullptr, nullptr, s, ix->rows16())) return rc;
-                if (int rc = launch_bound_select(c->d_dense, s_stride, s_rows, m, k_eff, tau, flt, batchg_tile_rows(), tile_step, s)) return rc;
+                if (int rc = launch_bound_select(c->d_dense, s_stride, s_rows, m, k_eff, tau, flt, batchg_tile_rows(ix->dtype == 1), tile_step, s)) return rc;
                 // 2. every row, candidates only
                 CX_HIP(hipMemsetAsync(overflow, 0, sizeof(uint32_t), s));
                 BatchGFilter f{tau, c->d_cand_keys, c->d_cand_sims, counts, overflow, cb, flt};

@@ -44,7 +44,7 @@ struct ScanArgs {
 };
 
 // number of blocks launch_scan_topk will use for this shape (scratch sizing)
-uint32_t scan_grid_blocks(uint32_t n_rows, uint32_t dim);
+uint32_t scan_grid_blocks(uint32_t n_rows, uint32_t dim, bool rows16 = false);
 // k <= TOPK_MAX.  scan + merge, results sorted best-first.
 // ev0/ev1 (optional) are recorded on the stream right before / after the scan kernel.
 int launch_scan_topk(const ScanArgs &a, const MergeArgs &m, bool nontemporal, hipStream_t stream,
@@ -128,9 +128,9 @@ struct BatchGFilter {
     uint32_t cb;               // entries per block and query: a multiple of k
     DevFilter flt;             // rows that fail it are no candidates
 };
-uint32_t batchg_tile_rows();
-uint32_t batchg_grid(uint32_t n_rows);
-uint32_t batchg_sample_rows(uint32_t n_rows, uint32_t tile_step, uint32_t *n_tiles_out);   // dense columns a sampled pass fills
+uint32_t batchg_tile_rows(bool rows16 = false);
+uint32_t batchg_grid(uint32_t n_rows, bool rows16 = false);
+uint32_t batchg_sample_rows(uint32_t n_rows, uint32_t tile_step, uint32_t *n_tiles_out, bool rows16 = false);   // dense columns a sampled pass fills
 int launch_batchg_split(const float *d_queries, uint32_t nq, uint32_t dim, char *d_qimg, float *d_qq, hipStream_t stream, bool rows16 = false);
 int launch_batchg_pass(const float *rows, const float *norms, uint32_t n_rows, uint32_t dim, uint32_t nq, const char *d_qimg, const float *d_qq,
                        float *d_dense, uint32_t stride, uint32_t tile_step, const BatchGFilter *f, const uint32_t *run_if, hipStream_t stream,

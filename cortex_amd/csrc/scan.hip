@@ -431,7 +431,7 @@ static int num_cus() { return (int)device_cus(); }
 
 // Blocks per CU of the scan grid: enough row bytes in flight per CU to cover HBM latency.  Measured optimum per
 // dim at 1-4M rows (profiles/r01/tuning.md): short rows need more blocks, 1024 wants one more than 768.
-static uint32_t blocks_per_cu(uint32_t dim) {
+static uint32_t blocks_per_cu(uint32_t dim, bool rows16 = false) {
     static int env = -1;
     if (env < 0) {
         const char *e = getenv("CX_SCAN_BLOCKS_PER_CU");
@@ -440,6 +440,7 @@ static uint32_t blocks_per_cu(uint32_t dim) {
         if (env > 8) env = 8;
     }
     if (env) return (uint32_t)env;
+    if (rows16) return dim <= 256 ? 5 : 4;   // bf16 store, 1M x 768 / 1024: 4 blocks per CU 0.83 / 0.82 of the peak, 2: 0.80 / 0.72
     if (dim <= 128) return 5;
     if (dim <= 256) return 4;
     if (dim <= 384) return 2;
@@ -449,9 +450,9 @@ static uint32_t blocks_per_cu(uint32_t dim) {
     return 2;
 }
 
-uint32_t scan_grid_blocks(uint32_t n_rows, uint32_t dim) {
+uint32_t scan_grid_blocks(uint32_t n_rows, uint32_t dim, bool rows16) {
     uint32_t want = (n_rows + 3u) / 4u;  // at least one row per wave
-    uint32_t cap = (uint32_t)num_cus() * blocks_per_cu(dim);
+    uint32_t cap = (uint32_t)num_cus() * blocks_per_cu(dim, rows16);
     if (want < 1u) want = 1u;
     return want < cap ? want : cap;
 }
@@ -509,8 +510,19 @@ static void dispatch_scan(const ScanArgs &a, uint32_t grid, int ks, bool nt, hip
                 case 256: return launch_fixed16<256, 32, 8, MODE>(a, grid, ks, nt, s);
                 case 384: return launch_fixed16<384, 16, 4, MODE>(a, grid, ks, nt, s);
                 case 512: return launch_fixed16<512, 64, 8, MODE>(a, grid, ks, nt, s);
-                case 768: return launch_fixed16<768, 32, 4, MODE>(a, grid, ks, nt, s);
-                case 1024: return launch_fixed16<1024, 64, 4, MODE>(a, grid, ks, nt, s);
+                case 768: {
+                    static const int r16 = getenv("CX_SCAN16_R") ? atoi(getenv("CX_SCAN16_R")) : 4;  // tuning knob
+                    if (r16 == 2) return launch_fixed16<768, 32, 2, MODE>(a, grid, ks, nt, s);
+                    if (r16 == 8) return launch_fixed16<768, 32, 8, MODE>(a, grid, ks, nt, s);
+                    if (r16 == 16) return launch_fixed16<768, 16, 4, MODE>(a, grid, ks, nt, s);
+                    return launch_fixed16<768, 32, 4, MODE>(a, grid, ks, nt, s);
+                }
+                case 1024: {
+                    static const int r16 = getenv("CX_SCAN16_R") ? atoi(getenv("CX_SCAN16_R")) : 4;
+                    if (r16 == 2) return launch_fixed16<1024, 64, 2, MODE>(a, grid, ks, nt, s);
+                    if (r16 == 8) return launch_fixed16<1024, 64, 8, MODE>(a, grid, ks, nt, s);
+                    return launch_fixed16<1024, 64, 4, MODE>(a, grid, ks, nt, s);
+                }
                 case 1536: return launch_fixed16<1536, 64, 2, MODE>(a, grid, ks, nt, s);
                 default: break;
             }
@@ -554,7 +566,7 @@ int launch_scan_topk(const ScanArgs &a, const MergeArgs &m, bool nontemporal, hi
                      hipEvent_t ev1) {
     if (a.k > TOPK_MAX) return set_err(CX_ERR_VALIDATION, "launch_scan_topk: k=%u exceeds %u", a.k, TOPK_MAX);
     const int ks = a.k <= 64 ? 1 : (a.k <= 128 ? 2 : 4);
-    const uint32_t grid = scan_grid_blocks(a.n_rows, a.dim);
+    const uint32_t grid = scan_grid_blocks(a.n_rows, a.dim, a.rows16 != nullptr);
     if (m.n_lists != grid) return set_err(CX_ERR_VALIDATION, "launch_scan_topk: scratch sized for %u lists, grid is %u", m.n_lists, grid);
     if (ev0) CX_HIP(hipEventRecord(ev0, stream));
     dispatch_scan<0>(a, grid, ks, nontemporal, stream);
@@ -695,7 +707,7 @@ int launch_dense_topk(const float *d_dense, uint32_t stride, uint32_t n_rows, ui
 }
 
 int launch_scan_dense(const ScanArgs &a, bool nontemporal, hipStream_t stream) {
-    const uint32_t grid = scan_grid_blocks(a.n_rows, a.dim);
+    const uint32_t grid = scan_grid_blocks(a.n_rows, a.dim, a.rows16 != nullptr);
     dispatch_scan<1>(a, grid, 1, nontemporal, stream);
     CX_HIP(hipGetLastError());
     return CX_OK;
