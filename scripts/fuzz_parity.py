@@ -14,7 +14,15 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=120.0)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--big", action="store_true", help="corpora of 50k-300k rows at 384/768-d: many compactions per list, several query groups")
+ap.add_argument("--dtype", default="f32", help="bf16: the index is a bf16 row store (cx_create_ex) and the oracle is fed the rounded rows")
 a = ap.parse_args()
+
+
+def stored(x):   # what the index keeps of a row
+    if a.dtype != "bf16":
+        return x
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    return ((((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32)).view(np.float32).reshape(x.shape)
 O.build()
 rng = np.random.default_rng(a.seed)
 t_end = time.time() + a.seconds
@@ -30,8 +38,8 @@ while time.time() < t_end:
     if rng.random() < 0.2 and n > 10:
         rows = rows.copy(); rows[n // 2:] = rows[: n - n // 2]                # every row twice: ties everywhere
     ids = ids_for(n)
-    h = hip.HipIndex(d); h.insert_batch(ids, rows)
-    o = O.OracleIndex(d); o.insert_batch(ids, rows)
+    h = hip.HipIndex(d, dtype=a.dtype); h.insert_batch(ids, rows)
+    o = O.OracleIndex(d); o.insert_batch(ids, stored(rows))
     for r in rng.integers(0, n, int(rng.integers(0, 6))):
         h.remove(ids[r].tobytes()); o.remove(ids[r].tobytes())
     hf = of = None
@@ -47,14 +55,14 @@ while time.time() < t_end:
         nq = int(rng.choice([33, 64, 65, 130]))
         rows = O.synth_rows(n, d, seed_rows=int(rng.integers(1, 1 << 30)))
         ids = ids_for(n)
-        h = hip.HipIndex(d); h.insert_batch(ids, rows)
-        o = O.OracleIndex(d); o.insert_batch(ids, rows)
+        h = hip.HipIndex(d, dtype=a.dtype); h.insert_batch(ids, rows)
+        o = O.OracleIndex(d); o.insert_batch(ids, stored(rows))
         for r in rng.integers(0, n, 5):
             h.remove(ids[r].tobytes()); o.remove(ids[r].tobytes())
         hf = of = None
     qs = O.synth_queries(max(n, 64), d, nq, seed_centres=int(rng.integers(1, 1 << 30)))
     lut = {ids[i].tobytes(): i for i in range(n)}
-    what = f"case n={n} d={d} k={k} nq={nq} filter={hf is not None}"
+    what = f"case n={n} d={d} k={k} nq={nq} filter={hf is not None} dtype={a.dtype}"
     try:
         bi, bs, bd, bc = h.search_batch_arrays(qs, k, hf)
         exp_all = o.search_batch(qs, k, of, n_threads=16) if a.big else None

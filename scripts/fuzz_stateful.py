@@ -14,7 +14,15 @@ from conftest import assert_topk_parity, ids_for, SCORE_TOL
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=120.0)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--dtype", default="f32", help="bf16: a bf16 row store (cx_create_ex); the oracle is fed the rounded rows")
 a = ap.parse_args()
+
+
+def stored(x):   # what the index keeps of a row
+    if a.dtype != "bf16":
+        return x
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    return ((((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32)).view(np.float32).reshape(np.shape(x))
 O.build()
 rng = np.random.default_rng(a.seed)
 t_end = time.time() + a.seconds
@@ -24,7 +32,7 @@ while time.time() < t_end:
     pool_n = int(rng.integers(50, 6000))
     pool = O.synth_rows(pool_n, d, seed_rows=int(rng.integers(1, 1 << 30)))
     pids = ids_for(pool_n, salt=int(rng.integers(0, 1000)))
-    h, o = hip.HipIndex(d), O.OracleIndex(d)
+    h, o = hip.HipIndex(d, dtype=a.dtype), O.OracleIndex(d)
     live = {}                       # id bytes -> current vector
     log = []
 
@@ -70,10 +78,10 @@ while time.time() < t_end:
                 idx = rng.integers(0, pool_n, m)
                 idx = np.unique(idx)
                 if rng.random() < 0.5:
-                    h.insert_batch(pids[idx], pool[idx]); o.insert_batch(pids[idx], pool[idx])
+                    h.insert_batch(pids[idx], pool[idx]); o.insert_batch(pids[idx], stored(pool[idx]))
                 else:
                     for i in idx[:50]:
-                        h.insert(pids[i].tobytes(), pool[i]); o.insert(pids[i].tobytes(), pool[i])
+                        h.insert(pids[i].tobytes(), pool[i]); o.insert(pids[i].tobytes(), stored(pool[i]))
                     idx = idx[:50]
                 for i in idx: live[pids[i].tobytes()] = i
                 log.append(("insert", len(idx)))
@@ -81,7 +89,7 @@ while time.time() < t_end:
                 keys = list(live)
                 for kk in [keys[int(t)] for t in rng.integers(0, len(keys), min(len(keys), int(rng.integers(1, 30))))]:
                     j = int(rng.integers(0, pool_n))                     # upsert: a known id gets another vector, keeps its row
-                    h.insert(kk, pool[j]); o.insert(kk, pool[j]); live[kk] = j
+                    h.insert(kk, pool[j]); o.insert(kk, stored(pool[j])); live[kk] = j
                 log.append(("upsert",))
             elif op < 0.8:
                 keys = list(live)

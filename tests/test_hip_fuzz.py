@@ -19,6 +19,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ("fuzz_parity.py", ["--seconds", "12", "--seed", "107"], {"CX_BATCHG_FILTER_MIN": "300", "CX_BATCH2": "0"}),
     ("fuzz_parity.py", ["--seconds", "8", "--seed", "108"], {"CX_BATCHG_FILTER_MIN": "300", "CX_BATCHG_SAMPLE_STEP": "7", "CX_BATCHG_CAND_CAP": "1"}),  # short lists: overflow -> dense fallback
     ("fuzz_stateful.py", ["--seconds", "8", "--seed", "109"], {"CX_BATCHG_FILTER_MIN": "300", "CX_BATCH2": "0"}),
+    # bf16 row stores: the same fuzzers, the oracle fed the rounded rows
+    ("fuzz_parity.py", ["--seconds", "10", "--seed", "110", "--dtype", "bf16"], {}),
+    ("fuzz_parity.py", ["--seconds", "8", "--seed", "111", "--dtype", "bf16"], {"CX_BATCHG_FILTER_MIN": "300"}),
+    ("fuzz_stateful.py", ["--seconds", "8", "--seed", "112", "--dtype", "bf16"], {}),
     ("fuzz_autolink.py", ["--seconds", "12", "--seed", "103"], {}),
     ("fuzz_autolink.py", ["--seconds", "10", "--seed", "106"], {"CX_PAIR_CAND_CAP": "24"}),     # most rows on the exact path
     ("fuzz_stateful.py", ["--seconds", "10", "--seed", "104"], {}),
