@@ -48,10 +48,11 @@ class Cortex:
         self.hooks: List[Callable[[Node, str], None]] = []
 
     @classmethod
-    def open(cls, storage, embedding, devices: Optional[Sequence[int]] = None) -> "Cortex":
+    def open(cls, storage, embedding, devices: Optional[Sequence[int]] = None, dtype: str = "f32") -> "Cortex":
         """api.rs:50-82.  devices: None / one device -> HipIndex; several -> ShardedHipIndex (one shard per device)."""
         dim = embedding.dimension()
-        idx = HipIndex(dim, devices[0] if devices else 0) if not devices or len(devices) == 1 else ShardedHipIndex(dim, devices)
+        # dtype "bf16": a bf16 row store (cx_create_ex) — half the HBM per embedding, results for the rounded vectors
+        idx = HipIndex(dim, devices[0] if devices else 0, dtype=dtype) if not devices or len(devices) == 1 else ShardedHipIndex(dim, devices, dtype=dtype)
         any_ = False
         for node in storage.list_nodes():                      # NodeFilter::new(): deleted nodes are not listed
             if node.embedding is not None:
