@@ -481,7 +481,7 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
                 mc.n_lists = bgrid * (cb / k_eff);
                 mc.seg_counts = counts;
                 mc.seg_len = cb;
-                if (int rc = launch_merge_batch(mc, m, s, false)) return rc;
+                if (int rc = launch_cand_select(mc, m, overflow, s)) return rc;
                 // 3. the exact fallback below runs only if some list overflowed
                 run_if = overflow;
                 e0 = e1 = nullptr;

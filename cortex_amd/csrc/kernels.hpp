@@ -108,6 +108,9 @@ int launch_batch_scan(BatchArgs a, uint32_t grid, hipStream_t stream);
 // second stage for nq queries at once: query q's lists are part[q*n_lists*k ...], outputs at [q*k]; sorted_lists = false:
 // the lists are unordered sets with empty (0) slots anywhere (batchg's candidate lists)
 int launch_merge_batch(const MergeArgs &m, uint32_t nq, hipStream_t stream, bool sorted_lists = true);
+// segmented candidate lists (m.seg_counts / m.seg_len set) -> top k, live entries held in registers; *d_redo is set (never
+// cleared) when a query has more live entries than that path holds — batchg passes its overflow flag: the dense pass redoes it
+int launch_cand_select(const MergeArgs &m, uint32_t nq, uint32_t *d_redo, hipStream_t stream);
 
 // ---- batched search for the other row widths (batchg.hip): dense cosines for <= 64 queries, then top-k ----
 bool batchg_supported(uint32_t dim, uint32_t k);       // dim % 128 == 0, dim <= 4096, k <= 256

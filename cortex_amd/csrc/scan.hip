@@ -621,6 +621,78 @@ __global__ __launch_bounds__(256) void dense_topk_kernel(const float *dense, uin
     block_merge_store<KS>(top, k, part_keys + base, part_sims + base);
 }
 
+// For the 256 threads that own a histogram bin: the number of entries in the bins ABOVE the thread's own.  Suffix sums
+// inside each of the four waves by shuffles, then the waves' totals through four LDS words — every thread summing up to
+// 255 bins itself took ~12 us per pass.  Called by every thread of the block (it contains a barrier); wtot: 4 uint32 of LDS.
+__device__ inline uint32_t bins_above(const uint32_t *hist, uint32_t tid, uint32_t *wtot, uint32_t &mine) {
+    uint32_t suf = 0;
+    mine = 0;
+    if (tid < 256u) {
+        mine = hist[tid];
+        suf = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_down(suf, off, 64);
+            if ((tid & 63u) + (uint32_t)off < 64u) suf += t;
+        }
+        if ((tid & 63u) == 0u) wtot[tid >> 6] = suf;
+    }
+    __syncthreads();
+    uint32_t above = suf - mine;
+    if (tid < 256u)
+        for (uint32_t w = (tid >> 6) + 1u; w < 4u; w++) above += wtot[w];
+    return above;
+}
+
+// Block-wide exact selection over keys the threads hold in REGISTERS (0 = empty): the value of the k-th largest key,
+// counting duplicates, or 0 when fewer than k keys are set.  A radix walk from bit `hi` down to bit `lo` (multiples of 8),
+// one 256-bin LDS histogram and four barriers per byte — no global memory, so a pass costs a microsecond instead of a
+// round trip per element.  Every thread of the block must call it; sh: 264 uint32 of LDS.
+template <int NV>
+__device__ inline uint64_t block_select_kth(const uint64_t (&key)[NV], uint32_t k, int hi, int lo, uint32_t *sh) {
+    uint32_t *hist = sh;                      // [256]
+    uint32_t *s_need = sh + 256, *s_found = sh + 257, *s_bin = sh + 258, *s_ok = sh + 259, *wtot = sh + 260;
+    const uint32_t tid = threadIdx.x;
+    uint64_t prefix = 0ull, mask = 0ull;
+    if (tid == 0) { *s_need = k; *s_ok = 1u; }
+    for (int shift = hi; shift >= lo; shift -= 8) {
+        if (tid < 256) hist[tid] = 0;
+        if (tid == 0) *s_found = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NV; u++) {
+            const bool act = key[u] != 0ull && (key[u] & mask) == prefix;
+            const uint32_t bin = (uint32_t)(key[u] >> shift) & 255u;
+            const uint64_t am = __ballot(act);
+            if (am == 0ull) continue;
+            // leading bytes of score keys are nearly constant: a wave that lands in one bin adds its count once
+            const int first = __ffsll((unsigned long long)am) - 1;
+            const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, first);
+            if (__ballot(act && bin == b0) == am) {
+                if ((int)(tid & 63u) == first) atomicAdd(&hist[b0], (uint32_t)__popcll(am));
+            } else if (act) {
+                atomicAdd(&hist[bin], 1u);
+            }
+        }
+        __syncthreads();
+        {
+            uint32_t mine;
+            const uint32_t above = bins_above(hist, tid, wtot, mine);
+            const uint32_t need = *s_need;
+            if (tid < 256 && above < need && need <= above + mine) { *s_bin = tid; *s_found = need - above; }   // found: the new need (>= 1)
+        }
+        __syncthreads();
+        const uint32_t found = *s_found;
+        if (!found) { if (tid == 0) *s_ok = 0u; break; }   // uniform: every thread reads the same LDS word
+        prefix |= (uint64_t)(*s_bin) << shift;
+        mask |= 0xFFull << shift;
+        __syncthreads();
+        if (tid == 0) *s_need = found;
+    }
+    __syncthreads();
+    return *s_ok ? prefix : 0ull;
+}
+
 // tau_ord[q] = score_ord of the k-th largest score among the cosines dense[q][0 .. n) of rows that pass the filter (0 when
 // fewer than k do): a block-wide radix
 // select over the 32-bit ordinals, one block per query, most significant byte first — a bound needs no list.  (The
@@ -628,7 +700,7 @@ __global__ __launch_bounds__(256) void dense_topk_kernel(const float *dense, uin
 // pass it prepares.)
 __global__ __launch_bounds__(1024) void bound_select_kernel(const float *dense, uint32_t stride, uint32_t n, uint32_t k, uint32_t *tau_ord,
                                                            const DevFilter flt, uint32_t tile_rows, uint32_t tile_step) {
-    __shared__ uint32_t hist[256];
+    __shared__ uint32_t hist[256], wtot[4];
     __shared__ uint32_t s_prefix, s_mask, s_need, s_found_all, s_found;
     const uint32_t tid = threadIdx.x, NT = 1024;
     if (n < k) { if (tid == 0) tau_ord[blockIdx.x] = 0u; return; }
@@ -663,12 +735,11 @@ __global__ __launch_bounds__(1024) void bound_select_kernel(const float *dense, 
             }
         }
         __syncthreads();
-        if (tid < 256) {   // the bin that holds the need-th largest of the values still in play
+        {   // the bin that holds the need-th largest of the values still in play
+            uint32_t mine;
+            const uint32_t above = bins_above(hist, tid, wtot, mine);
             const uint32_t need = s_need;
-            uint32_t above = 0;
-            for (uint32_t b = tid + 1; b < 256; b++) above += hist[b];
-            const uint32_t mine = hist[tid];
-            if (above < need && need <= above + mine) {
+            if (tid < 256 && above < need && need <= above + mine) {
                 s_prefix = prefix | (tid << shift);
                 s_mask = mask | (0xFFu << shift);
                 s_need = need - above;
@@ -681,10 +752,35 @@ __global__ __launch_bounds__(1024) void bound_select_kernel(const float *dense, 
     }
     if (tid == 0) tau_ord[blockIdx.x] = s_found_all ? s_prefix : 0u;
 }
+// The same for samples of up to NV * 1024 columns: every thread keeps its NV ordinals in registers, read once
+// (bound_select_kernel re-reads the sample in each of its four passes: 36 us at 16k columns, this 10).
+template <int NV>
+__global__ __launch_bounds__(1024) void bound_select_reg_kernel(const float *dense, uint32_t stride, uint32_t n, uint32_t k, uint32_t *tau_ord,
+                                                               const DevFilter flt, uint32_t tile_rows, uint32_t tile_step) {
+    __shared__ uint32_t sh[264];
+    const uint32_t tid = threadIdx.x;
+    const float *d = dense + (size_t)blockIdx.x * stride;
+    float v[NV];
+#pragma unroll
+    for (int u = 0; u < NV; u++) { const uint32_t e = tid + (uint32_t)u * 1024u; v[u] = e < n ? d[e] : 0.0f; }
+    uint64_t key[NV];
+#pragma unroll
+    for (int u = 0; u < NV; u++) {
+        const uint32_t e = tid + (uint32_t)u * 1024u;
+        bool live = e < n;
+        if (live && !flt.trivial) live = row_passes(flt, (e / tile_rows) * tile_step * tile_rows + e % tile_rows);
+        key[u] = live ? ((uint64_t)score_ord(score_of(distance_of(v[u]))) << 32) | 1ull : 0ull;   // ordinals are >= 1: never an empty key
+    }
+    const uint64_t t = block_select_kth<NV>(key, k, 56, 32, sh);
+    if (tid == 0) tau_ord[blockIdx.x] = (uint32_t)(t >> 32);
+}
+
 int launch_bound_select(const float *d_dense, uint32_t stride, uint32_t n, uint32_t nq, uint32_t k, uint32_t *tau_ord, const DevFilter &flt,
                         uint32_t tile_rows, uint32_t tile_step, hipStream_t stream) {
     if (!nq || !k) return CX_OK;
-    hipLaunchKernelGGL(bound_select_kernel, dim3(nq), dim3(1024), 0, stream, d_dense, stride, n, k, tau_ord, flt, tile_rows, tile_step);
+    if (n <= 16u * 1024u) hipLaunchKernelGGL(bound_select_reg_kernel<16>, dim3(nq), dim3(1024), 0, stream, d_dense, stride, n, k, tau_ord, flt, tile_rows, tile_step);
+    else if (n <= 32u * 1024u) hipLaunchKernelGGL(bound_select_reg_kernel<32>, dim3(nq), dim3(1024), 0, stream, d_dense, stride, n, k, tau_ord, flt, tile_rows, tile_step);
+    else hipLaunchKernelGGL(bound_select_kernel, dim3(nq), dim3(1024), 0, stream, d_dense, stride, n, k, tau_ord, flt, tile_rows, tile_step);
     CX_HIP(hipGetLastError());
     return CX_OK;
 }
@@ -734,7 +830,7 @@ __global__ __launch_bounds__(1024) void merge_radix_kernel(const MergeArgs m0) {
     m.out_scores += (size_t)blockIdx.x * m0.k;
     m.out_dists += (size_t)blockIdx.x * m0.k;
     m.out_count += blockIdx.x;
-    __shared__ uint32_t hist[256];
+    __shared__ uint32_t hist[256], wtot[4];
     __shared__ uint64_t surv_k[MERGE_RADIX_CAP];
     __shared__ float surv_s[MERGE_RADIX_CAP];
     __shared__ uint64_t s_prefix, s_mask;
@@ -776,12 +872,11 @@ __global__ __launch_bounds__(1024) void merge_radix_kernel(const MergeArgs m0) {
             }
         }
         __syncthreads();
-        if (tid < 256) {   // the bin that holds the need-th largest of the keys still in play
+        {   // the bin that holds the need-th largest of the keys still in play
+            uint32_t mine;
+            const uint32_t above = bins_above(hist, tid, wtot, mine);
             const uint32_t need = s_need;
-            uint32_t above = 0;
-            for (uint32_t b = tid + 1; b < 256; b++) above += hist[b];
-            const uint32_t mine = hist[tid];
-            if (above < need && need <= above + mine) {
+            if (tid < 256 && above < need && need <= above + mine) {
                 s_prefix = prefix | ((uint64_t)tid << shift);
                 s_mask = mask | (0xFFull << shift);
                 s_need = need - above;
@@ -822,6 +917,97 @@ __global__ __launch_bounds__(1024) void merge_radix_kernel(const MergeArgs m0) {
         }
     }
     if (tid == 0) *m.out_count = S < k ? S : k;
+}
+
+// batchg's candidate lists ([segments][seg_len] slots per query, the first seg_counts[segment] of each set) -> the final
+// top k, one block per query.  The live entries (a few hundred to a few thousand) go into registers through a prefix sum of
+// the counts, block_select_kth finds the k-th key exactly, and the <= k survivors are ranked against each other — one
+// read of the lists instead of the radix merge's pass-by-pass re-reads (29 us at k = 10, 40 at k = 100: now ~10).
+// More than NV * 1024 live entries (a weak bound and a wide list): *redo is set — the caller passes batchg's overflow flag,
+// so the exact dense pass queued behind does the batch again.
+template <int NV>
+__global__ __launch_bounds__(1024) void cand_select_kernel(const MergeArgs m0, uint32_t *redo) {
+    __shared__ uint32_t offs[1025];
+    __shared__ uint32_t sh[264];
+    __shared__ uint64_t surv_k[256 + 64];
+    __shared__ float surv_s[256 + 64];
+    __shared__ uint32_t s_n;
+    const uint32_t tid = threadIdx.x, q = blockIdx.x;
+    const uint32_t k = m0.k, slots = m0.n_lists * k, n_seg = slots / m0.seg_len;   // n_seg <= 1024 (checked by the launcher)
+    const uint32_t *counts = m0.seg_counts + (size_t)q * n_seg;
+    const uint64_t *keys = m0.part_keys + (size_t)q * slots;
+    const float *sims = m0.part_sims + (size_t)q * slots;
+    // exclusive prefix sum of the segment counts (Hillis-Steele over <= 1024 values)
+    uint32_t c = tid < n_seg ? counts[tid] : 0u;
+    if (c > m0.seg_len) c = m0.seg_len;
+    offs[tid + 1u > 1024u ? 1024u : tid + 1u] = c;
+    if (tid == 0) { offs[0] = 0u; s_n = 0u; }
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {
+        const uint32_t v = (tid + 1u > d) ? offs[tid + 1u - d] : 0u;
+        __syncthreads();
+        if (tid + 1u > d) offs[tid + 1u] += v;
+        __syncthreads();
+    }
+    const uint32_t total = offs[n_seg < 1024u ? n_seg : 1024u];
+    if (total > (uint32_t)NV * 1024u) {   // uniform
+        if (tid == 0) *redo = 1u;
+        return;
+    }
+    uint64_t key[NV];
+    float sim[NV];
+#pragma unroll
+    for (int u = 0; u < NV; u++) {
+        const uint32_t ci = tid + (uint32_t)u * 1024u;
+        key[u] = 0ull;
+        sim[u] = 0.0f;
+        if (ci < total) {
+            uint32_t lo = 0, hi = n_seg;   // the segment with offs[seg] <= ci < offs[seg + 1]
+            while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (offs[mid] <= ci) lo = mid; else hi = mid; }
+            const size_t at = (size_t)lo * m0.seg_len + (ci - offs[lo]);
+            key[u] = keys[at];
+            sim[u] = sims[at];
+        }
+    }
+    const uint64_t t = block_select_kth<NV>(key, k, 56, 0, sh);   // 0: fewer than k entries — all of them are results
+    const uint64_t low = t ? t : 1ull;
+#pragma unroll
+    for (int u = 0; u < NV; u++)
+        if (key[u] >= low && key[u] != 0ull) {   // keys are unique (the row is part of the key): exactly min(k, total) survivors
+            const uint32_t pos = atomicAdd(&s_n, 1u);
+            if (pos < 256u + 64u) { surv_k[pos] = key[u]; surv_s[pos] = sim[u]; }
+        }
+    __syncthreads();
+    const uint32_t S = s_n < 256u + 64u ? s_n : 256u + 64u;
+    uint32_t *out_rows = m0.out_rows + (size_t)q * k;
+    float *out_scores = m0.out_scores + (size_t)q * k, *out_dists = m0.out_dists + (size_t)q * k;
+    for (uint32_t i = tid; i < S; i += 1024u) {
+        const uint64_t ki = surv_k[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < S; j++) rank += surv_k[j] > ki ? 1u : 0u;
+        if (rank < k) {
+            const float dist = distance_of(surv_s[i]);
+            out_rows[rank] = key_row(ki);
+            out_dists[rank] = dist;
+            out_scores[rank] = score_of(dist);
+        }
+    }
+    if (tid == 0) m0.out_count[q] = S < k ? S : k;
+}
+
+// the candidate lists of nq queries -> top k each; *d_redo (not cleared here) is set when a query has more live entries
+// than the register path holds: the caller redoes the batch some other way
+int launch_cand_select(const MergeArgs &m, uint32_t nq, uint32_t *d_redo, hipStream_t stream) {
+    if (!nq || !m.k) return CX_OK;
+    if (!m.seg_counts || !m.seg_len || !d_redo) return set_err(CX_ERR_VALIDATION, "cand_select: segmented lists expected");
+    const uint32_t n_seg = m.n_lists * m.k / m.seg_len;
+    if (n_seg > 1024u || m.k > 256u) return launch_merge_batch(m, nq, stream, false);
+    // expected live entries per query: k x the sample step (64 up to k = 32, 32 beyond): 2k / 3.2k (k = 100) / 8k (k = 256)
+    if (m.k <= 32) hipLaunchKernelGGL(cand_select_kernel<4>, dim3(nq), dim3(1024), 0, stream, m, d_redo);
+    else if (m.k <= 128) hipLaunchKernelGGL(cand_select_kernel<8>, dim3(nq), dim3(1024), 0, stream, m, d_redo);
+    else hipLaunchKernelGGL(cand_select_kernel<16>, dim3(nq), dim3(1024), 0, stream, m, d_redo);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
 }
 
 // SEQ = false: shard p's rows are local, part_base[p] makes them global and ties resolve by (part, slot) — parts are
