@@ -209,7 +209,7 @@ def test_pass_sees_upserts_and_removes(hip, oracle):
                   oracle_scores(o2, allrows), "after mutations")
 
 
-@pytest.mark.parametrize("n,d,thr", [(2500, 768, 0.92), (1500, 384, 0.92), (400, 100, 0.9)])
+@pytest.mark.parametrize("n,d,thr", [(1800, 768, 0.92), (1500, 384, 0.92), (400, 100, 0.9)])
 def test_dedup_scan_matches_oracle(hip, oracle, n, d, thr):
     rows = oracle.synth_rows(n, d)
     h, o, ids = build(hip, oracle, rows)
