@@ -44,7 +44,7 @@ for src, dst in (("bench.json", f"bench_{rnd}.json"), ("bench_steps20_warmup5.js
                  ("autolink_mfma_utilisation.json", "autolink_100kx768_mfma_utilisation.json"),
                  ("batch_trace_kernel_stats.csv", "batch64_1.25Mx768_kernel_stats.csv"), ("batch.json", "batch64_1.25Mx768_bench.json"),
                  ("b1024_trace_kernel_stats.csv", "batch64_1Mx1024_kernel_stats.csv"), ("batch64_1Mx1024.json", "batch64_1Mx1024_bench.json"),
-                 ("batch64_other_shapes.jsonl", "batch64_other_shapes.jsonl"), ("top100_lists_100kx768.log", "top100_lists_100kx768.log"),
+                 ("batch64_other_shapes.jsonl", "batch64_other_shapes.jsonl"), ("single_query_bf16_store.jsonl", "single_query_bf16_store.jsonl"), ("top100_lists_100kx768.log", "top100_lists_100kx768.log"),
                  ("read_shape_probe.log", "read_shape_probe.log"), ("mfma_shape_probe.log", "mfma_shape_probe.log")):
     cp(src, dst)
 if not os.path.exists(os.path.join(S, "cold_start_probe.json")) and os.path.exists(os.path.join(ROOT, "gpurun_out", "cold_probe.json")):

@@ -17,7 +17,8 @@ step lists; timeout -k 10 200 python3 $R/scripts/bench_lists.py 100000 768 > $O/
 step batch1024-trace; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/b1024_trace -- python3 $R/scripts/bench_batch_dim.py --rows 1000000 --dim 1024 > $O/batch64_1Mx1024.json 2> $O/b1024_trace.err || { tail -5 $O/b1024_trace.err; exit 1; }
 step batch1024-fetch; timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/b1024_fetch -- python3 $R/scripts/bench_batch_dim.py --rows 1000000 --dim 1024 --steps 5 > $O/b1024_fetch.json 2> $O/b1024_fetch.err || { tail -5 $O/b1024_fetch.err; exit 1; }
 step batch1024-write; timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/b1024_write -- python3 $R/scripts/bench_batch_dim.py --rows 1000000 --dim 1024 --steps 5 > $O/b1024_write.json 2> $O/b1024_write.err || { tail -5 $O/b1024_write.err; exit 1; }
-step batch-shapes; for a in "4000000 1024 10" "1250000 768 100" "2000000 512 10" "1000000 1536 10"; do set -- $a; timeout -k 10 200 python3 $R/scripts/bench_batch_dim.py --rows $1 --dim $2 --k $3 --steps 10 2>/dev/null; done > $O/batch64_other_shapes.jsonl
+step batch-shapes; for a in "4000000 1024 10 f32" "1000000 1024 100 f32" "1000000 1024 256 f32" "1250000 768 100 f32" "1250000 384 100 f32" "2000000 512 10 f32" "1000000 1536 10 f32" "1000000 1024 10 bf16" "6250000 1024 10 bf16" "1250000 768 100 bf16"; do set -- $a; timeout -k 10 200 python3 $R/scripts/bench_batch_dim.py --rows $1 --dim $2 --k $3 --dtype $4 --steps 10 2>/dev/null; done > $O/batch64_other_shapes.jsonl
+step single-bf16; for a in "1000000 768" "1000000 1024" "1000000 384"; do set -- $a; timeout -k 10 200 python3 $R/scripts/bench_batch_dim.py --rows $1 --dim $2 --single --steps 200 --dtype bf16 2>/dev/null; done > $O/single_query_bf16_store.jsonl
 # the stand-alone probes behind profiles/rNN/tuning.md section 4 (built here if the snapshot has no binaries)
 step probes; P=$R/scripts/probes
 [ -x $P/_shape_probe ] || (cd $P && hipcc --offload-arch=gfx950 -O3 -std=c++17 -o _shape_probe shape_probe.hip 2>/dev/null)
