@@ -274,20 +274,24 @@ __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArg
     constexpr uint32_t HL_CAP = 256;                                    // pairs per wave; flushed when full
     uint32_t *hl = reinterpret_cast<uint32_t *>(smem) + wave * (2u * HL_CAP);
     uint32_t nh = 0;                                                     // wave-uniform
-    auto flush = [&]() {
-        uint32_t slot[HL_CAP / 64], ii[HL_CAP / 64], jj[HL_CAP / 64];
+    auto flush = [&]() {   // the list holds (i, j) once; a mirrored tile also enters i into j's list
+        uint32_t slot[HL_CAP / 64], slot2[HL_CAP / 64], ii[HL_CAP / 64], jj[HL_CAP / 64];
 #pragma unroll
         for (uint32_t t = 0; t < HL_CAP / 64; t++) {
             const uint32_t idx = lane + 64u * t;
             slot[t] = a.cap;
+            slot2[t] = a.cap;
             if (idx < nh) {
                 ii[t] = hl[2u * idx]; jj[t] = hl[2u * idx + 1u];
                 slot[t] = atomicAdd(a.cand_cnt + ii[t], 1u);
+                if (mirror) slot2[t] = atomicAdd(a.cand_cnt + jj[t], 1u);
             }
         }
 #pragma unroll
-        for (uint32_t t = 0; t < HL_CAP / 64; t++)
+        for (uint32_t t = 0; t < HL_CAP / 64; t++) {
             if (slot[t] < a.cap) a.cand[(size_t)ii[t] * a.cap + slot[t]] = jj[t];
+            if (slot2[t] < a.cap) a.cand[(size_t)jj[t] * a.cap + slot2[t]] = ii[t];
+        }
         nh = 0;
     };
     // Hits are rare (a handful per 128x64 wave tile), so the 128 accumulator values are screened 16 at a time
@@ -308,28 +312,32 @@ __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArg
         }
     unsigned long long t2b = 0;
     if constexpr (DIAG) t2b = __builtin_readcyclecounter();
+    // Walk of a 32x32 tile with a hit: 16 compares into a per-lane bit mask (straight-line), then only the lanes that
+    // hold a hit loop over their bits and take list positions from the wave's LDS counter.  (One ballot and one
+    // wave-uniform branch per element — 16 per tile — cost ~650 cycles per tile with a hit: 3.5-5k of a tile's 38k.)
+    uint32_t *wave_nh = reinterpret_cast<uint32_t *>(smem) + 8u * (2u * HL_CAP);   // [8] hits of each wave
+    if (lane == 0) wave_nh[wave] = 0u;
 #pragma unroll
     for (uint32_t m = 0; m < 4; m++)
 #pragma unroll
         for (uint32_t n = 0; n < 2; n++) {
             if (!((strips >> (m * 2u + n)) & 1u)) continue;
             const uint32_t j = j0 + wn * 64u + n * 32u + fr;
+            const uint32_t ibase = i0 + wm * 128u + m * 32u + 4u * fq;
+            uint32_t mask = 0;
 #pragma unroll
             for (uint32_t e = 0; e < 16; e++) {
-                const uint32_t i = i0 + wm * 128u + m * 32u + 8u * (e >> 2) + 4u * fq + (e & 3u);
-                const bool hit = acc[m][n][e] >= a.thr_lo && i < a.n_scan && j < a.n_rows;
-                const uint64_t bm = __ballot(hit);
-                if (bm == 0ull) continue;
-                const uint32_t per = mirror ? 2u : 1u;   // symmetric pass (n_scan == n_rows): (i, j) also stands for (j, i)
-                const uint32_t cnt = (uint32_t)__popcll(bm) * per;
-                if (nh + cnt <= HL_CAP) {
-                    if (hit) {
-                        const uint32_t pos = nh + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull)) * per;
-                        hl[2u * pos] = i; hl[2u * pos + 1u] = j;
-                        if (mirror) { hl[2u * pos + 2u] = j; hl[2u * pos + 3u] = i; }
-                    }
-                    nh += cnt;
-                } else if (hit) {   // list full (a block of near-duplicates): this position pays its own round trip
+                const uint32_t i = ibase + 8u * (e >> 2) + (e & 3u);
+                mask |= (acc[m][n][e] >= a.thr_lo && i < a.n_scan && j < a.n_rows) ? (1u << e) : 0u;
+            }
+            while (mask) {
+                const uint32_t e = (uint32_t)__builtin_ctz(mask);
+                mask &= mask - 1u;
+                const uint32_t i = ibase + 8u * (e >> 2) + (e & 3u);
+                const uint32_t pos = atomicAdd(&wave_nh[wave], 1u);   // LDS
+                if (pos < HL_CAP) {
+                    hl[2u * pos] = i; hl[2u * pos + 1u] = j;
+                } else {   // list full (a block of near-duplicates): this hit pays its own round trip
                     const uint32_t s_f = atomicAdd(a.cand_cnt + i, 1u);
                     uint32_t s_r = a.cap;
                     if (mirror) s_r = atomicAdd(a.cand_cnt + j, 1u);
@@ -338,6 +346,15 @@ __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArg
                 }
             }
         }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_nh[wave]);
+        nh = c < HL_CAP ? c : HL_CAP;
+    }
+    // Hand-over: the slot atomics of the whole list go out back to back and are waited for once.  (Writing the hits with
+    // plain stores into a per-tile region and assigning slots in a second kernel was no faster, 6.85 ms against 6.77: a block
+    // keeps its CU until its last store is acknowledged just as long as until its last atomic returns — 2.5-5k cycles under
+    // this load; only work of a next tile could hide that, and the persistent form lost more elsewhere.)
     if (nh) flush();
     if constexpr (DIAG) {
         const unsigned long long t3 = __builtin_readcyclecounter();
