@@ -101,6 +101,10 @@ def lib():
         L.cxo_hnsw_build.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_uint64]
         L.cxo_hnsw_search.restype = C.c_size_t
         L.cxo_hnsw_search.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+        L.cxo_hnsw_build_mt.restype = C.c_void_p
+        L.cxo_hnsw_build_mt.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int]
+        L.cxo_hnsw_search_batch.restype = None
+        L.cxo_hnsw_search_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.cxo_hnsw_dist_evals.restype = C.c_uint64
         L.cxo_hnsw_dist_evals.argtypes = [C.c_void_p]
         L.cxo_hnsw_free.argtypes = [C.c_void_p]
@@ -313,11 +317,26 @@ class HnswBaseline:
     """CPU HNSW restatement (oracle/cortex_hnsw.c): a REPORTED BASELINE for the reference's approximate path
     (instant-distance 0.6.1, not in /root/reference).  Parity unpinned — never used as a checker."""
 
-    def __init__(self, rows: np.ndarray, M: int = 32, M0: int = 64, ef_construction: int = 100, seed: int = 1):
+    def __init__(self, rows: np.ndarray, M: int = 32, M0: int = 64, ef_construction: int = 100, seed: int = 1, n_threads: int = 1):
+        """n_threads > 1: the concurrent build (the reference builds with rayon, index.rs:430)."""
         self._L = lib()
         self.rows = _f32(rows)
-        self._h = self._L.cxo_hnsw_build(self.rows.ctypes.data, self.rows.shape[0], self.rows.shape[1], M, M0,
-                                         ef_construction, seed)
+        if n_threads > 1:
+            self._h = self._L.cxo_hnsw_build_mt(self.rows.ctypes.data, self.rows.shape[0], self.rows.shape[1], M, M0,
+                                                ef_construction, seed, n_threads)
+        else:
+            self._h = self._L.cxo_hnsw_build(self.rows.ctypes.data, self.rows.shape[0], self.rows.shape[1], M, M0,
+                                             ef_construction, seed)
+
+    def search_batch(self, queries, k: int, ef_search: int = 100, n_threads: int = 1):
+        """-> (rows [nq][k] u32, dist [nq][k] f32, counts [nq])"""
+        qs = _f32(queries)
+        nq = qs.shape[0]
+        rows = np.zeros((nq, max(1, k)), dtype=np.uint32)
+        dist = np.zeros((nq, max(1, k)), dtype=np.float32)
+        counts = np.zeros(nq, dtype=np.uintp)
+        self._L.cxo_hnsw_search_batch(self._h, qs.ctypes.data, nq, k, ef_search, n_threads, rows.ctypes.data, dist.ctypes.data, counts.ctypes.data)
+        return rows, dist, counts
 
     def search(self, query, k: int, ef_search: int = 100):
         q = _f32(query)

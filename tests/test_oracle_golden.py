@@ -103,3 +103,12 @@ def test_hnsw_baseline_restatement_has_high_recall(oracle):
         hits += len(set(r.tolist()) & set(e["row"].tolist()))
         assert np.all(np.diff(dist) >= 0)
     assert hits / (len(qs) * k) > 0.9
+    # the concurrent build + parallel batch search (what bench.py times on all host cores): a working ANN too
+    hm = oracle.HnswBaseline(rows, n_threads=4)
+    r, dist, cnt = hm.search_batch(qs, k, 100, n_threads=4)
+    hits = 0
+    for i, q in enumerate(qs):
+        e = ix.search(q, k)
+        hits += len(set(r[i, :cnt[i]].tolist()) & set(e["row"].tolist()))
+        assert np.all(np.diff(dist[i, :cnt[i]]) >= 0)
+    assert hits / (len(qs) * k) > 0.9
