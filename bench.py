@@ -310,10 +310,10 @@ def cpu_baseline(ix, gen: torch.Tensor, queries: torch.Tensor, n: int, d: int, k
             if int(r) in want or abs(float(sc) - kth) <= 5e-5:
                 bh += 1
     # the reference's approximate path (index.rs:342-371 over instant-distance 0.6.1) at the headline's width: the first
-    # 100k rows of the corpus, built on all host cores like the reference's rayon build (index.rs:430; ~30 s on 16 cores —
-    # the full 1M would take several minutes), queried one at a time (Cortex::search) and as one parallel batch
+    # 50k rows of the corpus, built on all host cores like the reference's rayon build (index.rs:430; 100k rows took 99 s
+    # on the GPU box's 16 cores, the full 1M would take half an hour), queried one at a time (Cortex::search) and as one parallel batch
     # (search_batch, index.rs:390-410); recall against the exact oracle on the same slice
-    hn = min(n, 100_000)
+    hn = min(n, 50_000)
     rows_s = gen[:hn].cpu().numpy()
     t5 = time.perf_counter()
     hidx = O.HnswBaseline(rows_s, n_threads=cores)
