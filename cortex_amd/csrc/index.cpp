@@ -360,7 +360,9 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
     static const uint32_t filter_min = getenv("CX_BATCHG_FILTER_MIN") ? (uint32_t)atoi(getenv("CX_BATCHG_FILTER_MIN")) : 262144u;
     // wide lists (k > 32) on a large unfiltered store: batchg.hip's bound + candidates pass runs at 0.71-0.75 of the HBM
     // peak whatever k is, batch2_kernel's in-kernel wide lists at 0.40-0.49 (1.25M x 384 / 768, k = 100)
-    const bool wide_to_bg = k_eff > 32 && bg_ok && filter_ok && n >= filter_min && batchg_supported(ix->dim, k_eff);
+    // (1.25M rows, per step: k = 100 at 768 / 384-d 0.82 / 0.51 ms against 1.02 / 0.64; k = 32: 0.78 / 0.46 against 0.81 / 0.58; k = 20
+    // at 384-d 0.44 against 0.48; k = 10: 0.77 / 0.45 against 0.65 / 0.43 — batch2's fused lists win while they are short)
+    const bool wide_to_bg = (k_eff > 32 || (ix->dim <= 384 && k_eff >= 20)) && bg_ok && filter_ok && n >= filter_min && batchg_supported(ix->dim, k_eff);
     if (b2_ok && ix->dtype == 0 && !wide_to_bg && topk_path && no_tails && nq >= (uint64_t)batch_min && k_eff >= 1 && batch_supported(ix->dim, k_eff)) {
         if (int rc = ensure_norms(ix, s)) return rc;
         const uint32_t qpp = batch_queries_per_pass(ix->dim, k_eff, nq);
