@@ -89,7 +89,7 @@ def test_threshold_filters_removes_and_rebuild(hip, oracle):
 
 
 @pytest.mark.parametrize("n,d,k,nq", [(5000, 1024, 10, 64), (3001, 768, 100, 70), (777, 512, 32, 7), (40, 1024, 40, 70),
-                                      (1300, 640, 10, 9), (2100, 384, 10, 33)])
+                                      (1300, 640, 10, 9), (2100, 384, 10, 33), (900, 2048, 10, 70), (300, 4096, 5, 9), (257, 128, 256, 64)])
 def test_search_batch_matches_oracle_on_rounded_rows(hip, oracle, n, d, k, nq):
     rows = oracle.synth_rows(n, d)
     qs = oracle.synth_queries(n, d, nq)

@@ -318,6 +318,8 @@ def test_concurrent_filtered_readers(hip, oracle):
     (40, 1024, 40, 70),      # k == n: fewer rows than one tile
     (1300, 640, 10, 9),      # dim % 128 == 0 is all batchg.hip asks for
     (700, 128, 64, 33),
+    (900, 2048, 10, 70),     # the widest rows batchg.hip takes
+    (300, 4096, 5, 9),
 ])
 def test_search_batch_matches_oracle(hip, oracle, n, d, k, nq):
     rows = oracle.synth_rows(n, d)
