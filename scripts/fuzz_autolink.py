@@ -14,7 +14,15 @@ from test_hip_autolink import compare_edges, per_node, oracle_scores
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=120.0)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--dtype", default="f32", help="bf16: a bf16 row store (cx_create_ex); the oracle is fed the rounded rows")
 a = ap.parse_args()
+
+
+def stored(x):   # what the index keeps of a row
+    if a.dtype != "bf16":
+        return x
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    return ((((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32)).view(np.float32).reshape(np.shape(x))
 O.build()
 rng = np.random.default_rng(a.seed)
 t_end = time.time() + a.seconds
@@ -27,7 +35,8 @@ while time.time() < t_end:
     topk = int(rng.choice([100, 100, 10, 256]))
     rows = O.synth_rows(n, d, seed_rows=int(rng.integers(1, 1 << 30)))
     ids = ids_for(n)
-    h = hip.HipIndex(d); h.insert_batch(ids, rows)
+    h = hip.HipIndex(d, dtype=a.dtype); h.insert_batch(ids, rows)
+    rows = stored(rows)                       # from here on "the rows" are what the index holds
     o = O.OracleIndex(d); o.insert_batch(ids, rows)
     for r in rng.integers(0, n, int(rng.integers(0, 4))):
         h.remove(ids[r].tobytes()); o.remove(ids[r].tobytes())

@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ("fuzz_parity.py", ["--seconds", "6", "--seed", "110", "--dtype", "bf16"], {}),
     ("fuzz_parity.py", ["--seconds", "5", "--seed", "111", "--dtype", "bf16"], {"CX_BATCHG_FILTER_MIN": "300"}),
     ("fuzz_stateful.py", ["--seconds", "5", "--seed", "112", "--dtype", "bf16"], {}),
+    ("fuzz_autolink.py", ["--seconds", "6", "--seed", "113", "--dtype", "bf16"], {}),
     ("fuzz_autolink.py", ["--seconds", "7", "--seed", "103"], {}),
     ("fuzz_autolink.py", ["--seconds", "6", "--seed", "106"], {"CX_PAIR_CAND_CAP": "24"}),     # most rows on the exact path
     ("fuzz_stateful.py", ["--seconds", "6", "--seed", "104"], {}),
