@@ -89,3 +89,16 @@ def test_poisoned_result_block_is_an_error_not_an_index():
     assert chk() == 2 and b"5 entries" in L.cx_last_error()
     counts[2] = 0xFFFFFFFF
     assert chk() == 2
+
+
+def test_storage_dtype_codes_match_the_header():
+    """cx_create_ex's dtype codes: the header's CX_DTYPE_* against the ctypes mirror's table (cortex_amd/index.py)."""
+    import re
+    from cortex_amd.index import _dtype_code
+    hdr = open(os.path.join(ROOT, "include", "cortex_hip.h")).read()
+    codes = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"#define\s+CX_DTYPE_(\w+)\s+(\d+)", hdr)}
+    assert codes == {"f32": 0, "bf16": 1}
+    for name, code in codes.items():
+        assert _dtype_code(name) == code
+    with pytest.raises(Exception):
+        _dtype_code("fp8")
