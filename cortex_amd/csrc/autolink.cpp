@@ -30,8 +30,8 @@ int ensure_shadow(const cx_index *ix, hipStream_t s) {
         ix->shadow_cap = 0;
         const uint64_t cap = std::max<uint64_t>(n, ix->cap);
         CX_HIP(hipMalloc((void **)&ix->d_shadow, cap * ix->dim * sizeof(uint16_t) + 64));
-        if (tiled) {   // whole 16-row blocks, zero beyond the last row
-            const size_t bytes = (size_t)((cap + 15) / 16) * 16 * ix->dim * sizeof(uint16_t);
+        if (tiled) {   // whole 256-row tiles (the persistent filter kernel reads its last panel unclamped), zero beyond the last row
+            const size_t bytes = (size_t)((cap + 255) / 256) * 256 * ix->dim * sizeof(uint16_t);
             CX_HIP(hipMalloc((void **)&ix->d_shadow_t, bytes));
             CX_HIP(hipMemsetAsync(ix->d_shadow_t, 0, bytes, s));
         }
@@ -74,6 +74,9 @@ struct PassScratch {
     uint32_t *d_list_rows = nullptr, *d_list_cnt = nullptr, *d_counts = nullptr, *d_ident = nullptr;
     float *d_list_scores = nullptr, *d_list_dists = nullptr, *d_pair_sims = nullptr;
     size_t c_pair_sims = 0;
+    uint64_t *d_pairs = nullptr;       // persistent filter kernel: hits as (i | j << 32) pairs, before pair_scatter_kernel
+    uint32_t *d_pair_ctl = nullptr;    // [16]: pairs written, pairs lost, per-XCD tile tickets
+    size_t c_pairs = 0, c_pair_ctl = 0;
     uint64_t *d_offsets = nullptr, *d_exist_off = nullptr;
     uint32_t *d_exist_to = nullptr;
     size_t c_exist_off = 0, c_exist_to = 0;
@@ -89,7 +92,7 @@ struct PassScratch {
         (void)hipFree(d_list_rows); (void)hipFree(d_list_cnt); (void)hipFree(d_counts); (void)hipFree(d_ident);
         (void)hipFree(d_list_scores); (void)hipFree(d_list_dists); (void)hipFree(d_offsets); (void)hipFree(d_pair_sims);
         (void)hipFree(d_deleted); (void)hipFree(d_temp); (void)hipFree(d_from); (void)hipFree(d_to); (void)hipFree(d_w);
-        (void)hipFree(d_exist_off); (void)hipFree(d_exist_to);
+        (void)hipFree(d_exist_off); (void)hipFree(d_exist_to); (void)hipFree(d_pairs); (void)hipFree(d_pair_ctl);
     }
 };
 
@@ -182,6 +185,7 @@ struct CycleInputs {
     bool lists_only = false;
     uint32_t min_count = 0;
     uint32_t cand_cap = 0;      // candidate slots per scanned row; 0 = cand_cap()
+    bool no_persist = false;    // the retry of a pass whose pair buffer ran over: pair_filter256_kernel instead
 };
 
 int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, const uint32_t *scan_rows,
@@ -245,6 +249,8 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
         if (int rc = ensure_dev(ps.d_cand, ps.c_cand, (size_t)chunk * cap)) return rc;
         // phases are timed over all chunks: filter launches first would need all scratch at once, so
         // filter+rescore alternate per chunk and the two event pairs bracket their sums approximately
+        bool used_persist = false;
+        uint32_t pairs_lost = 0;
         for (uint32_t lo = 0; lo < n_scan; lo += chunk) {
             const uint32_t m = std::min<uint32_t>(chunk, n_scan - lo);
             CX_HIP(hipMemsetAsync(ps.d_cand_cnt, 0, (size_t)m * 4, s));
@@ -296,8 +302,22 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
                 f.scan_rows = ps.d_ident;
             }
             static const int stream_ok = getenv("CX_PAIR_STREAM") ? atoi(getenv("CX_PAIR_STREAM")) : 1;
+            const int persist_ok = getenv("CX_PAIR_PERSIST") ? atoi(getenv("CX_PAIR_PERSIST")) : 1;   // read per call: tests switch it
+            bool persist = false;
+            if (big && persist_ok && !cyc.no_persist) {   // persistent blocks (allpairs_p.hip): hits leave the GEMM as pairs
+                const size_t pair_cap = (size_t)std::min<uint64_t>((uint64_t)m * cap / 2u, 128ull << 20);
+                if (int rc = ensure_dev(ps.d_pairs, ps.c_pairs, pair_cap)) return rc;
+                if (int rc = ensure_dev(ps.d_pair_ctl, ps.c_pair_ctl, (size_t)16)) return rc;
+                f.pairs = ps.d_pairs;
+                f.pair_ctl = ps.d_pair_ctl;
+                f.pair_cap = (uint32_t)pair_cap;
+                persist = pair_filter_p_supported(f);
+            }
             if (!big && stream_ok && pair_filter_stream_supported(f)) {
                 if (int rc = launch_pair_filter_stream(f, s)) return rc;
+            } else if (persist) {
+                if (int rc = launch_pair_filter_p(f, s)) return rc;
+                used_persist = true;
             } else if (int rc = big ? launch_pair_filter256(f, s) : launch_pair_filter(f, s)) return rc;
             if (phase_ms && lo == 0) CX_HIP(hipEventRecord(ev[2], s));
             RescoreArgs r;
@@ -323,12 +343,25 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
                 r.pair_sims = ps.d_pair_sims;
             }
             if (int rc = launch_rescore(r, s)) return rc;
+            if (used_persist && n_scan > chunk) {   // the control words are reused by the next chunk
+                uint32_t lost = 0;
+                CX_HIP(hipMemcpyAsync(&lost, ps.d_pair_ctl + 1, 4, hipMemcpyDeviceToHost, s));
+                CX_HIP(hipStreamSynchronize(s));
+                pairs_lost |= lost;
+            }
         }
         if (phase_ms && n_scan > chunk) CX_HIP(hipEventRecord(ev[2], s));  // multi-chunk: only the total is meaningful
         if (phase_ms) CX_HIP(hipEventRecord(ev[3], s));
         std::vector<uint32_t> of(n_scan);
         CX_HIP(hipMemcpyAsync(of.data(), ps.d_overflow, (size_t)n_scan * 4, hipMemcpyDeviceToHost, s));
+        if (used_persist && n_scan <= chunk) CX_HIP(hipMemcpyAsync(&pairs_lost, ps.d_pair_ctl + 1, 4, hipMemcpyDeviceToHost, s));
         CX_HIP(hipStreamSynchronize(s));
+        if (pairs_lost) {   // more hits than the pair buffer holds (a threshold far below the data's): the per-row path has no such limit
+            if (phase_ms) for (auto &e : ev) (void)hipEventDestroy(e);
+            CycleInputs again = cyc;
+            again.no_persist = true;
+            return pass_core(ix, c, ps, n_scan64, scan_rows, topk, threshold, max_edges, deleted, dedup, again, total, phase_ms);
+        }
         if (cyc.min_count) {   // short lists: the threshold hid part of this row's top-k
             std::vector<uint32_t> cnt(n_scan);
             CX_HIP(hipMemcpyAsync(cnt.data(), ps.d_list_cnt, (size_t)n_scan * 4, hipMemcpyDeviceToHost, s));

@@ -170,12 +170,20 @@ struct PairFilterArgs {
     const uint32_t *tile_list;  // symmetric only: (ti << 16) | tj of every live tile, in launch order
     uint32_t n_tiles;           // entries in tile_list
     unsigned long long *diag;   // CX_PAIR_DIAG=1 only: [tiles][4] cycle stamps (prologue, main loop, epilogue)
+    // persistent kernel only (allpairs_p.hip): hits leave the GEMM as (i | j << 32) pairs, pair_scatter_kernel fills cand
+    uint64_t *pairs;            // [pair_cap]
+    uint32_t *pair_ctl;         // [16] zeroed by the launcher: [0] pairs written, [1] pairs lost (pair_cap too small), [8 + x] tile tickets of XCD x
+    uint32_t pair_cap;
 };
 // live tiles of the symmetric pass in L2-friendly order (host side); tile = 128 rows
 void pair_filter_tile_list(uint32_t n_rows, std::vector<uint32_t> &out);
 // 256x256-tile variant for large scan sets (allpairs256.hip); tile list with 256-row tiles
 void pair_filter256_tile_list(uint32_t n_rows, std::vector<uint32_t> &out);
 int launch_pair_filter256(const PairFilterArgs &a, hipStream_t stream);
+// persistent blocks, LDS ring running through the tile boundaries, hits handed over as pairs (allpairs_p.hip); scanned
+// rows = the shard's rows in order (tiled shadow both sides), dim % 64 == 0, dim >= 384
+bool pair_filter_p_supported(const PairFilterArgs &a);
+int launch_pair_filter_p(const PairFilterArgs &a, hipStream_t stream);
 int launch_pair_filter(const PairFilterArgs &a, hipStream_t stream);
 // scan sets of <= 64 rows (streaming ingest): scanned rows in registers, the shard's shadow streamed tile by tile
 bool pair_filter_stream_supported(const PairFilterArgs &a);

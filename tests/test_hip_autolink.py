@@ -401,6 +401,38 @@ print("|".join(out))
     assert res[0] == res[1] == res[2] == res[3] and int(res[0].split()[0]) > 100000, res
 
 
+@pytest.mark.parametrize("env", [
+    {"CX_PAIR_P_GRID": "8"},                              # one block per XCD: each walks ~10-30 tiles, statically dealt
+    {"CX_PAIR_P_GRID": "8", "CX_PAIR_P_DYN": "1"},        # the same with s_atomic_add tile claims
+    {"CX_PAIR_P_GRID": "16", "CX_PAIR_P_WAVES": "4"},     # one 512-register wave per SIMD
+    {},                                                   # the launch the product uses (one block per CU)
+])
+def test_persistent_filter_kernel_equals_the_per_tile_kernel(hip, oracle, monkeypatch, env):
+    """allpairs_p.hip: persistent blocks whose LDS ring runs through the tile boundaries and whose hits leave the GEMM as
+    pairs.  With few blocks every block walks many tiles (the boundary code), at threshold 0.3 a tile holds more hits
+    than the LDS list (flush + direct appends).  Both filters feed the same exact rescore, so the edges must be the
+    same bytes as pair_filter256_kernel's, and equal to the oracle's (auto_linker.rs:215-264)."""
+    for n, d, thr in ((5000, 768, 0.85), (4000, 384, 0.3), (2100, 1024, 0.75)):
+        rows = oracle.synth_rows(n, d)
+        h, o, ids = build(hip, oracle, rows)
+        thr32 = float(np.float32(thr))
+        monkeypatch.setenv("CX_PAIR_PERSIST", "0")
+        ref = h.autolink_pass_rows(None, 100, thr32, 50)
+        monkeypatch.setenv("CX_PAIR_PERSIST", "1")
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = h.autolink_pass_rows(None, 100, thr32, 50)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert len(ref[0]) > 1000
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b), f"n={n} d={d} thr={thr} env={env}"
+        if d == 768:
+            e = o.autolink_pass(np.arange(n), 100, thr32, 50, n_threads=8)
+            compare_edges(per_node(*got), per_node(e["from_row"], e["to_row"], e["weight"]), thr32, oracle_scores(o, rows),
+                          f"persistent n={n}")
+
+
 def test_removed_rows_are_not_scanned(hip, oracle):
     """A row removed from the index has no embedding any more: as a scanned node it proposes nothing
     (auto_linker.rs:217-218 skips nodes without an embedding), whether every row is scanned or it is named in the
