@@ -128,6 +128,7 @@ SIGNATURES = {
     "cx_sharded_search_decayed": (C.c_int, [_P, _P, _U64, _U64, _U64, _P, _P, C.c_float, C.c_int64, _U32, _P, _P, _P, _P]),
     "cx_profile_enable": (C.c_int, [_P, C.c_int]),
     "cx_profile_read": (C.c_int, [_P, _P, _P, C.c_int]),
+    "cx_autolink_filter_profile": (C.c_int, [_P, _P]),
     "cx_device_rows": (_P, [_P]),
     # include/cortex_hip_synth.h
     "cx_synth_fill_dev": (C.c_int, [C.c_int, _P, _U64, _U64, _U64, _U64, _U64, _U64, _U32, _U32]),

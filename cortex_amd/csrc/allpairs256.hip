@@ -385,7 +385,8 @@ int launch_tile_shadow(const uint16_t *shadow, uint16_t *shadow_t, uint32_t row_
 }
 
 void pair_filter256_tile_list(uint32_t n_rows, std::vector<uint32_t> &out) {
-    const uint32_t tiles = (n_rows + p256::BM - 1) / p256::BM, GS = 4;
+    // GS I-panels stay in the XCD's L2 while the J-panels stream past them: a tile fetches 1 / GS of a J-panel from beyond L2
+    const uint32_t tiles = (n_rows + p256::BM - 1) / p256::BM, GS = getenv("CX_PAIR_GS") ? (uint32_t)std::max(1, atoi(getenv("CX_PAIR_GS"))) : 4u;
     out.clear();
     out.reserve((size_t)tiles * (tiles + 1) / 2);
     for (uint32_t g0 = 0; g0 < tiles; g0 += GS) {
@@ -403,7 +404,9 @@ static int launch256(const PairFilterArgs &a, uint32_t tiles, hipStream_t stream
     if (first_use_on_device(attr_devices))
         CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_filter256_kernel<DIAG, SCHED, TA, NS>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if (a.ev_begin) CX_HIP(hipEventRecord((hipEvent_t)a.ev_begin, stream));
     hipLaunchKernelGGL((pair_filter256_kernel<DIAG, SCHED, TA, NS>), dim3(tiles), dim3(512), lds, stream, a);
+    if (a.ev_end) CX_HIP(hipEventRecord((hipEvent_t)a.ev_end, stream));
     CX_HIP(hipGetLastError());
     return CX_OK;
 }

@@ -2,52 +2,64 @@
 //
 // Same contract as pair_filter256_kernel (allpairs256.hip): bf16 shadow rows in, candidate columns out, no score
 // matrix; replaces the per-node search loop of AutoLinker::run_cycle (linker/auto_linker.rs:215-264) and of
-// DedupScanner::scan (linker/dedup.rs:65-127).  Same 256x256x32 K-step on the same 4-slot LDS ring.  What changes is
-// everything AROUND the K loop, which at dim 768 (24 K-steps per tile) was 15 % of every tile (profiles/r02/tuning.md §2):
+// DedupScanner::scan (linker/dedup.rs:65-127).  Same 256x256x32 K-step on the same 4-slot LDS ring, 8 waves as
+// 2 (M) x 4 (N) of 128 x 64.  What changes is everything AROUND the K loop, which at dim 768 (24 K-steps per tile)
+// was a quarter of every tile (profiles/r03/tuning.md §1):
 //
 //  - one block per CU for the whole launch; a block walks its tiles and the LDS ring runs THROUGH the tile
 //    boundaries: the last three K-steps of a tile issue the LDS-DMAs of the next tile's first three, the last one
-//    reads the next tile's first fragments — no prologue, no relaunch, no cold ring (prologue: 1.85k of 38k cycles);
-//  - the first K-step of a tile starts its accumulators from the MFMA's inline 0 (no 128-register clear);
-//  - hits do not leave the CU inside the tile: (i, j) pairs go to a list in LDS (24 KiB behind the ring) and the list is
-//    written out — ONE returning atomic per block for the space, coalesced 8-byte stores — only when it holds more than
-//    1,024 pairs, every ~30-60 tiles.  A tile's epilogue is then VALU + LDS work only; it never waits for an
-//    acknowledgement from L2 (2.5-5k cycles per tile under this load, the largest part of the old epilogue).
-//    pair_scatter_kernel turns the pairs into the per-row candidate lists the exact rescore reads (both directions
-//    for the mirrored tiles of the symmetric pass);
-//  - tiles are dealt to blocks in list order inside each XCD's contiguous share of the tile list, so that the blocks
-//    running at any moment on an XCD work on neighbouring tiles and share panels in its L2: statically interleaved
-//    (block b of the XCD takes entries b, b + 32, ...) or claimed with s_atomic_add (returns through lgkmcnt, not
-//    through the in-order vmcnt queue the ring's counted waits live on; profiles/r02/tuning.md §7).
-//
-// vmcnt is one in-order queue per wave (MI355X_MICROARCH.md): a global store or returning atomic issued by a wave that
-// also issues the ring's LDS-DMAs delays its next counted wait by the store's acknowledgement.  That is why nothing in
-// the steady state writes global memory, and why the rare flush simply drains.
+//    reads the next tile's first fragments — no prologue, no relaunch, no cold ring;
+//  - the first K-step of a tile starts its accumulators from the MFMA's inline 0 (no 128-register clear); the last
+//    one runs 32x32 tile by 32x32 tile and screens each finished accumulator (running maximum, one ballot) under the
+//    MFMAs of the next ones;
+//  - a hit costs its wave one LDS record, not a walk: the LANES that hold a value over the threshold (a handful per
+//    tile) copy their 16 accumulator values of that 32x32 tile + its coordinates into a record (80 B) behind the ring;
+//    ONE wave picks the tile's records up during the next tile's second K-step — one record per lane, 16 compares,
+//    (i, j) pairs appended to a list in LDS — while its SIMD partner and the other SIMDs keep computing.  Walking a
+//    hit tile where it was found (16 compares + mask + list positions on all 64 lanes of the wave, the other seven
+//    waves waiting at the next barrier for the one with the most hits) was 11.6 % of the kernel's cycles;
+//  - the pair list leaves the CU only when it holds more than 1,024 pairs (every ~50 tiles): ONE returning atomic per
+//    block for the space, coalesced 8-byte stores.  pair_scatter_kernel turns the pairs into the per-row candidate
+//    lists the exact rescore reads (both directions for the mirrored tiles of the symmetric pass).  Nothing in the
+//    steady state writes global memory: vmcnt is ONE in-order queue per wave (MI355X_MICROARCH.md), so a store or
+//    returning atomic issued between the ring's LDS-DMAs delays the next counted wait by its acknowledgement
+//    (2.5-5k cycles under this load — per tile, in the per-tile kernel);
+//  - tiles are dealt in list order inside each XCD's contiguous share of the tile list, so that the blocks running
+//    at any moment on an XCD work on neighbouring tiles and share panels in its L2: claimed with s_atomic_add
+//    (returns through lgkmcnt, not through vmcnt; issued at K-step 1, looked at at K-step 6) or, as a measurement
+//    arm, statically interleaved (block b of the XCD takes entries b, b + 32, ...).
 #include "kernels.hpp"
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <vector>
 
 namespace cx {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace pp {
-constexpr int BM = 256, BN = 256, BK = 32, NS = 4, PF = 3;
+constexpr int BM = 256, BN = 256, BK = 32, NS = 4, PF = 3, WAVES = 8;
 constexpr int OP_BYTES = BM * BK * 2;          // 16 KiB per operand per slot
 constexpr int SLOT_BYTES = 2 * OP_BYTES;       // 32 KiB
 constexpr int RING_BYTES = NS * SLOT_BYTES;    // 128 KiB
-constexpr uint32_t HL_CAP = 3072;              // pairs the block's list holds (24 KiB)
+constexpr uint32_t HL_CAP = 2560;              // pairs the block's list holds (20 KiB)
 constexpr uint32_t HL_FLUSH = 1024;            // written out at the next check once it holds more than this
+constexpr uint32_t REC_PER_WAVE = 16;          // hit-lane records per wave and tile (80 B each: 16 accumulator values, i base, j)
+constexpr uint32_t REC_CAP = REC_PER_WAVE * WAVES;
+constexpr uint32_t REC_BYTES = 80;
 constexpr int HL_OFF = RING_BYTES;
-constexpr int CTL_OFF = HL_OFF + (int)HL_CAP * 8;   // [0] pairs in the list, [1] next tile (dynamic claims), [2] flush base
-constexpr int LDS_BYTES = CTL_OFF + 64;
+constexpr int REC_OFF = HL_OFF + (int)HL_CAP * 8;
+constexpr int CTL_OFF = REC_OFF + (int)(REC_CAP * REC_BYTES);   // [0] pairs in the list, [1] next tile, [2] flush base, [8 + w] records of wave w
+constexpr int LDS_BYTES = CTL_OFF + 64;   // 16 control words
+static_assert(LDS_BYTES <= 160 * 1024, "LDS of a CU");
 // same LDS image as allpairs256.hip: 16-byte piece p of a 64-byte row at p ^ (row >> 3 & 3)
 __device__ inline uint32_t off(uint32_t row, uint32_t piece) { return row * 64u + ((piece ^ ((row >> 3) & 3u)) << 4); }
-// LDS control words and the hit list are touched through inline assembly: hipcc tracks every in-flight LDS-DMA as a
-// pending LDS write and puts `s_waitcnt vmcnt(0)` in front of any LDS access it cannot tell apart from the ring —
+// LDS control words, records and the pair list are touched through inline assembly: hipcc tracks every in-flight LDS-DMA
+// as a pending LDS write and puts `s_waitcnt vmcnt(0)` in front of any LDS access it cannot tell apart from the ring —
 // a drain of the next tile's K-steps in every epilogue (seen in the ISA of the first version); volatile C++ accesses
 // went through flat_load/flat_store for the same words.  Addresses are byte offsets in LDS.
 __device__ inline uint32_t lds_read_u32(uint32_t addr) {
@@ -59,6 +71,7 @@ __device__ inline void lds_write_u32(uint32_t addr, uint32_t v) {
     asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" :: "v"(addr), "v"(v) : "memory");
 }
 __device__ inline void lds_write_u64(uint32_t addr, uint64_t v) { asm volatile("ds_write_b64 %0, %1" :: "v"(addr), "v"(v) : "memory"); }
+__device__ inline void lds_write_f32x4(uint32_t addr, f32x4 v) { asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(v) : "memory"); }
 __device__ inline uint32_t lds_add_rtn_u32(uint32_t addr, uint32_t v) {
     uint32_t r;
     asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(addr), "v"(v) : "memory");
@@ -73,23 +86,24 @@ __device__ inline uint32_t scalar_load_u32(const uint32_t *p) {
 }
 }  // namespace pp
 
-// WAVES = 8: 2 (M) x 4 (N) waves of 128 x 64, two per SIMD (256 registers each).
-// WAVES = 4: 2 x 2 waves of 128 x 128, one per SIMD (512 registers, accumulators in the upper half).
-template <int WAVES, bool DYN>
-__global__ __launch_bounds__(WAVES * 64) void pair_filter_p_kernel(const PairFilterArgs a) {
+// ARM: 0 = the product; measurement arms (results invalid): 1 = hits are found and dropped (what the hand-over costs),
+// 2 = no LDS-DMA inside the K loop, 3 = no fragment reads, 4 = no barriers, 5 = no counted waits and no barriers
+template <bool DYN, bool DIAG, int ARM>
+__global__ __launch_bounds__(pp::WAVES * 64) void pair_filter_p_kernel(const PairFilterArgs a) {
     using namespace pp;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int WN = WAVES == 8 ? 4 : 2;            // waves along N
-    constexpr int MT = 4, NT = (BN / WN) / 32;        // 32x32 tiles per wave: 4 x 2 or 4 x 4
+    constexpr int WN = 4;                             // waves along N
+    constexpr int MT = 4, NT = (BN / WN) / 32;        // 32x32 tiles per wave: 4 x 2
     constexpr int NPW = 16 / WAVES;                   // 16-row pieces of each operand a wave loads per K-step
     constexpr int ND = 2 * NPW;                       // LDS-DMA instructions per wave and K-step
     constexpr int NM = MT * NT * 2;                   // MFMAs per wave and K-step
+    static_assert(ND == 4 && NM == 16, "one DMA or fragment read after each MFMA");
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const uint32_t wm = wave / WN, wn = wave % WN;
     const uint32_t KT = a.dim / BK;
     const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char *)smem;   // LDS byte address of smem
-    const uint32_t ctl = lds0 + CTL_OFF, hla = lds0 + HL_OFF;
+    const uint32_t ctl = lds0 + CTL_OFF, hla = lds0 + HL_OFF, reca = lds0 + REC_OFF;
     const uint64_t *hl = reinterpret_cast<const uint64_t *>(smem + HL_OFF);
 
     // this block's share of the tile order: XCD x (blocks x, x + 8, ... share one) owns a contiguous eighth
@@ -125,17 +139,16 @@ __global__ __launch_bounds__(WAVES * 64) void pair_filter_p_kernel(const PairFil
 
     // tile claims.  static: entries local, local + per_xcd, ... of the share.  dynamic: tickets of the XCD's counter.
     uint32_t my = local;                 // position inside the share
+    if (tid < 16u) lds_write_u32(ctl + 4u * tid, 0u);
     if constexpr (DYN) {
         uint32_t v = 1;
         if (wave == 0) {
             asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(v) : "s"(a.pair_ctl + 8u + xcd) : "memory");
             if (lane == 0) lds_write_u32(ctl + 4u, v);
         }
-        if (tid == 0) lds_write_u32(ctl, 0u);
         __syncthreads();
         my = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_read_u32(ctl + 4u));
     } else {
-        if (tid == 0) lds_write_u32(ctl, 0u);
         __syncthreads();
     }
     if (my >= count) return;   // block-uniform
@@ -148,12 +161,13 @@ __global__ __launch_bounds__(WAVES * 64) void pair_filter_p_kernel(const PairFil
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                          (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
     };
-    auto wait_ring = [&]() {   // all but this wave's youngest K-step of DMAs have landed
-        if constexpr (ND == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    };
+    auto wait_ring = [&]() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); };   // all but this wave's youngest K-step of DMAs have landed
 
     f32x16 acc[MT][NT];
+    float mxs[MT * NT];        // per lane: largest of its 16 values of each 32x32 tile (set by the tile's last K-step)
+    uint32_t strips = 0;       // 32x32 tiles of this wave with a hit somewhere
+    uint32_t cur_i0 = 0;       // first scanned row of the tile whose records are waiting to be picked up
+    unsigned long long c_vm = 0, c_bar = 0, c_main = 0, c_epi = 0, c_hook = 0;   // DIAG: cycles in the counted waits, barriers, K loops, epilogues, hooks
     const uint32_t fr = lane & 31u, fq = lane >> 5;
     uint32_t fo[2];
 #pragma unroll
@@ -163,47 +177,38 @@ __global__ __launch_bounds__(WAVES * 64) void pair_filter_p_kernel(const PairFil
     auto rdA = [&](uint32_t slot, int m, int h) { return *reinterpret_cast<const bf16x8 *>(smem + (slot * SLOT_BYTES + baseA + fo[h]) + m * 2048); };
     auto rdB = [&](uint32_t slot, int n, int h) { return *reinterpret_cast<const bf16x8 *>(smem + (slot * SLOT_BYTES + baseB + fo[h]) + n * 2048); };
 
-    // One K-step (g = steps since the block started: ring slot g & 3; kt = step inside the tile): the MFMAs of step kt
-    // on the fragments read during the step before, and after each MFMA one other instruction of the step — the
-    // LDS-DMAs of step kt + 3 (the NEXT tile's when kt + 3 >= KT) and the fragment reads of step kt + 1 (the next tile's
-    // step 0 when kt is the last) — then the counted wait and the raw barrier (allpairs256.hip: RAW / WAR argument).
-    auto step = [&](auto first_tag, uint32_t g, uint32_t kt, const Desc &cur, const Desc &nxt, const bf16x8 *fa, const bf16x8 *fb,
-                    bf16x8 *na, bf16x8 *nb) {
-        constexpr bool FIRST = decltype(first_tag)::value;
-        const uint32_t dslot = (g + PF) & 3u, rslot = (g + 1u) & 3u;
-        const bool in_cur = kt + PF < KT;
-        Desc dd;
-        dd.A = in_cur ? cur.A : nxt.A;
-        dd.B = in_cur ? cur.B : nxt.B;
-        const uint32_t kk = in_cur ? kt + PF : kt + PF - KT;
-        __builtin_amdgcn_sched_barrier(0);
-        int di = 0, ri = 0;
+    auto screen_tile = [&](int t) {
+        const int m = t / NT, n = t % NT;
+        float mx = acc[m][n][0];
 #pragma unroll
-        for (int idx = 0; idx < NM; idx++) {
-            const int h = idx / (MT * NT), m = (idx / NT) % MT, n = idx % NT;
-            if (FIRST && h == 0) {
-                f32x16 z;
-#pragma unroll
-                for (int e = 0; e < 16; e++) z[e] = 0.0f;
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m * 2 + h], fb[n * 2 + h], z, 0, 0, 0);
-            } else {
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m * 2 + h], fb[n * 2 + h], acc[m][n], 0, 0, 0);
-            }
-            // WAVES = 8: 16 MFMAs, 4 DMAs + 12 reads: one per MFMA.  WAVES = 4: 32 MFMAs, 8 DMAs + 16 reads: three per four.
-            const bool want_dma = (idx % 4) == 0 && di < ND;
-            const bool want_read = !want_dma && (WAVES == 8 || (idx % 4) != 3) && ri < (MT + NT) * 2;
-            if (want_dma) {
-                dma(dslot, kk, dd, di);
-                di++;
-            } else if (want_read) {
-                if (ri < NT * 2) nb[ri] = rdB(rslot, ri >> 1, ri & 1);
-                else na[ri - NT * 2] = rdA(rslot, (ri - NT * 2) >> 1, (ri - NT * 2) & 1);
-                ri++;
-            }
-            __builtin_amdgcn_sched_barrier(0);
+        for (uint32_t e = 1; e < 16; e++) mx = fmaxf(mx, acc[m][n][e]);
+        mxs[t] = mx;
+        strips |= __ballot(mx >= a.thr_lo) != 0ull ? 1u << t : 0u;
+    };
+    // one pair into the block's list; a full list (a block of near-duplicates inside one tile) sends it straight out
+    auto append_pair = [&](uint32_t i, uint32_t j) {
+        const uint64_t v = (uint64_t)i | ((uint64_t)j << 32);
+        const uint32_t pos = lds_add_rtn_u32(ctl, 1u);
+        if (pos < HL_CAP) {
+            lds_write_u64(hla + pos * 8u, v);
+        } else {
+            const uint32_t p = atomicAdd(a.pair_ctl, 1u);
+            if (p < a.pair_cap) a.pairs[p] = v;
+            else a.pair_ctl[1] = 1u;
         }
-        wait_ring();
-        __builtin_amdgcn_s_barrier();
+    };
+    // the 16 values of one lane of a 32x32 tile: register e holds row ibase + 8 (e / 4) + e % 4 (ibase includes 4 (lane >> 5))
+    auto emit_lane = [&](const float *v, uint32_t ibase, uint32_t j) {
+        uint32_t mask = 0;
+#pragma unroll
+        for (uint32_t e = 0; e < 16; e++) mask |= v[e] >= a.thr_lo ? 1u << e : 0u;
+        if (j >= a.n_rows) mask = 0;
+        while (mask) {
+            const uint32_t e = (uint32_t)__builtin_ctz(mask);
+            mask &= mask - 1u;
+            const uint32_t i = ibase + 8u * (e >> 2) + (e & 3u);
+            if (i < a.n_scan) append_pair(i, j);
+        }
     };
 
     // the list goes out: space from ONE returning atomic, coalesced 8-byte stores.  Block-uniform; drains (rare).
@@ -218,61 +223,179 @@ __global__ __launch_bounds__(WAVES * 64) void pair_filter_p_kernel(const PairFil
         if (tid == 0) lds_write_u32(ctl, 0u);
     };
 
-    // epilogue of a tile: screen the accumulators (running maximum + one ballot per 32x32 tile), walk only the tiles
-    // with a hit somewhere in the wave, append (i, j) to the block's list.  No global memory, no barrier.
-    auto epilogue = [&](const Desc &cur) {
-        uint32_t strips = 0;
+    // A 32x32 tile with a hit: the lanes that hold a value over the threshold leave a record each in the wave's own 16
+    // slots — no returning LDS operation, no wait: the LDS is busy with the ring's traffic and a round trip costs 300-600
+    // cycles here.  Called from INSIDE the tile's last K-step, right after the tile was screened, so that the writes drain
+    // under the remaining MFMAs (issued behind the step's barrier, the next step's first `s_waitcnt lgkmcnt(0)` — the
+    // compiler's wait for its fragment reads — waited for them instead: 1-2k cycles per tile).
+    uint32_t rec_base = 0;     // records this wave has written for the current tile
+    auto record_tile = [&](int t, const Desc &cur) {
+        if constexpr (ARM == 1) { asm volatile("" :: "s"(strips)); return; }
+        if (!((strips >> t) & 1u)) return;
+        const int m = t / NT, n = t % NT;
+        const bool mine = mxs[t] >= a.thr_lo;
+        const unsigned long long bal = __ballot(mine);
+        const uint32_t j = cur.j0 + wn * (NT * 32u) + (uint32_t)n * 32u + fr;
+        const uint32_t ibase = cur.i0 + wm * 128u + (uint32_t)m * 32u + 4u * fq;
+        if (mine) {
+            const uint32_t slot = rec_base + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
+            if (slot < REC_PER_WAVE) {
+                const uint32_t ra = reca + (wave * REC_PER_WAVE + slot) * REC_BYTES;
+                lds_write_f32x4(ra, __builtin_shufflevector(acc[m][n], acc[m][n], 0, 1, 2, 3));
+                lds_write_f32x4(ra + 16u, __builtin_shufflevector(acc[m][n], acc[m][n], 4, 5, 6, 7));
+                lds_write_f32x4(ra + 32u, __builtin_shufflevector(acc[m][n], acc[m][n], 8, 9, 10, 11));
+                lds_write_f32x4(ra + 48u, __builtin_shufflevector(acc[m][n], acc[m][n], 12, 13, 14, 15));
+                lds_write_u64(ra + 64u, (uint64_t)ibase | ((uint64_t)j << 32));
+            } else {   // more hit lanes in this wave's part of the tile than records: this lane walks its values here
+                float v[16];
 #pragma unroll
-        for (uint32_t m = 0; m < MT; m++)
-#pragma unroll
-            for (uint32_t n = 0; n < NT; n++) {
-                float mx = acc[m][n][0];
-#pragma unroll
-                for (uint32_t e = 1; e < 16; e++) mx = fmaxf(mx, acc[m][n][e]);
-                strips |= __ballot(mx >= a.thr_lo) != 0ull ? 1u << (m * NT + n) : 0u;
+                for (int e = 0; e < 16; e++) v[e] = acc[m][n][e];
+                emit_lane(v, ibase, j);
             }
-        if (!strips) return;
+        }
+        rec_base += (uint32_t)__builtin_popcountll(bal);
+    };
+    auto publish_records = [&]() {   // before the last K-step's barrier: drains while the wave waits for the others
+        if constexpr (ARM == 1) return;
+        if (rec_base && lane == 0)
+            asm volatile("ds_write_b32 %0, %1" :: "v"(ctl + 32u + 4u * wave), "v"(rec_base < REC_PER_WAVE ? rec_base : REC_PER_WAVE) : "memory");
+        rec_base = 0;
+    };
+    // One K-step (g = steps since the block started: ring slot g & 3; kt = step inside the tile): the MFMAs of step kt
+    // on the fragments read during the step before, and after each MFMA one other instruction of the step — the
+    // LDS-DMAs of step kt + 3 (the NEXT tile's when kt + 3 >= KT) and the fragment reads of step kt + 1 (the next tile's
+    // step 0 when kt is the last) — then the counted wait and the raw barrier (allpairs256.hip: RAW / WAR argument).
+    // KIND 1 = first step of a tile (accumulators start from the inline 0), 2 = last (tile by tile, screening under the MFMAs).
+    auto step = [&](auto kind_tag, uint32_t g, uint32_t kt, const Desc &cur, const Desc &nxt, const bf16x8 *fa, const bf16x8 *fb,
+                    bf16x8 *na, bf16x8 *nb) {
+        constexpr int KIND = decltype(kind_tag)::value;
+        constexpr bool FIRST = KIND == 1, LAST = KIND == 2;
+        const uint32_t dslot = (g + PF) & 3u, rslot = (g + 1u) & 3u;
+        const bool in_cur = kt + PF < KT;
+        Desc dd;
+        dd.A = in_cur ? cur.A : nxt.A;
+        dd.B = in_cur ? cur.B : nxt.B;
+        const uint32_t kk = in_cur ? kt + PF : kt + PF - KT;
+        __builtin_amdgcn_sched_barrier(0);
+        int di = 0, ri = 0;
 #pragma unroll
-        for (uint32_t m = 0; m < MT; m++)
+        for (int idx = 0; idx < NM; idx++) {
+            int h = idx / (MT * NT), m = (idx / NT) % MT, n = idx % NT;
+            if (LAST) {   // tile by tile: (m, n) is final after its second MFMA
+                h = idx & 1;
+                m = (idx >> 1) / NT;
+                n = (idx >> 1) % NT;
+            }
+            if (FIRST && h == 0) {
+                f32x16 z;
 #pragma unroll
-            for (uint32_t n = 0; n < NT; n++) {
-                if (!((strips >> (m * NT + n)) & 1u)) continue;
-                // C layout of the 32x32 tile: register e of lane l holds row 8 (e / 4) + 4 (l >> 5) + e % 4, column l & 31
-                const uint32_t j = cur.j0 + wn * (NT * 32u) + n * 32u + fr;
-                const uint32_t ibase = cur.i0 + wm * 128u + m * 32u + 4u * fq;
-                uint32_t mask = 0;
-#pragma unroll
-                for (uint32_t e = 0; e < 16; e++) {
-                    const uint32_t i = ibase + 8u * (e >> 2) + (e & 3u);
-                    mask |= (acc[m][n][e] >= a.thr_lo && i < a.n_scan && j < a.n_rows) ? (1u << e) : 0u;
+                for (int e = 0; e < 16; e++) z[e] = 0.0f;
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m * 2 + h], fb[n * 2 + h], z, 0, 0, 0);
+            } else {
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m * 2 + h], fb[n * 2 + h], acc[m][n], 0, 0, 0);
+            }
+            if ((idx % 4) == 0) {
+                if constexpr (ARM != 2) dma(dslot, kk, dd, di);
+                di++;
+            } else {
+                if constexpr (ARM != 3) {
+                    if (ri < NT * 2) nb[ri] = rdB(rslot, ri >> 1, ri & 1);
+                    else na[ri - NT * 2] = rdA(rslot, (ri - NT * 2) >> 1, (ri - NT * 2) & 1);
                 }
-                // lanes with a hit take list positions round by round: one LDS atomic per round for the whole wave
-                for (;;) {
-                    const unsigned long long act = __ballot(mask != 0u);
-                    if (!act) break;
-                    const uint32_t n_act = (uint32_t)__builtin_popcountll(act);
-                    const uint32_t leader = (uint32_t)__builtin_ctzll(act);
-                    uint32_t base = 0;
-                    if (lane == leader) base = lds_add_rtn_u32(ctl, n_act);
-                    base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
-                    if (!mask) continue;
-                    const uint32_t e = (uint32_t)__builtin_ctz(mask);
-                    mask &= mask - 1u;
-                    const uint32_t i = ibase + 8u * (e >> 2) + (e & 3u);
-                    const uint64_t v = (uint64_t)i | ((uint64_t)j << 32);
-                    const uint32_t pos = base + (uint32_t)__builtin_popcountll(act & ((1ull << lane) - 1ull));
+                ri++;
+            }
+            if (LAST && (idx & 1) && idx >= 3) {   // finished one pair of MFMAs ago: screened, and its hit lanes recorded, under this pair
+                screen_tile((idx >> 1) - 1);
+                record_tile((idx >> 1) - 1, cur);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (LAST) {
+            screen_tile(MT * NT - 1);
+            record_tile(MT * NT - 1, cur);
+            publish_records();
+        }
+        unsigned long long w0 = 0, w1 = 0;
+        if constexpr (DIAG) { asm volatile("s_nop 0" :: "v"(acc[MT - 1][NT - 1][15])); w0 = __builtin_readcyclecounter(); }
+        if constexpr (ARM != 5) wait_ring();
+        if constexpr (DIAG) w1 = __builtin_readcyclecounter();
+        if constexpr (ARM != 4 && ARM != 5) __builtin_amdgcn_s_barrier();
+        if constexpr (DIAG) { const unsigned long long w2 = __builtin_readcyclecounter(); c_vm += w1 - w0; c_bar += w2 - w1; }
+    };
+
+    // the records of the tile before: one per lane of ONE wave (every wave has passed a barrier since the last record was
+    // written), while the partner wave on its SIMD and the other SIMDs compute
+    auto pick_up_records = [&](uint32_t turn) {
+        if (wave != (turn & 7u)) return;
+        // Two LDS round trips in all (each 300-600 cycles under the ring's traffic): every lane reads the counts and BOTH of
+        // its record slots at once (lane l: slots l and l + 64; a slot without a record reads stale bytes and is masked),
+        // then takes the list positions of all its hits with one atomic.  The partner wave's 16 MFMAs cover about that long.
+        const uint32_t s0 = lane, s1 = lane + 64u;
+        f32x4 q[8];
+        uint64_t hd0, hd1;
+        uint32_t c0, c1;
+        asm volatile("ds_read_b32 %10, %12\n\tds_read_b32 %11, %13\n\t"
+                     "ds_read_b128 %0, %14\n\tds_read_b128 %1, %14 offset:16\n\tds_read_b128 %2, %14 offset:32\n\tds_read_b128 %3, %14 offset:48\n\t"
+                     "ds_read_b64 %8, %14 offset:64\n\t"
+                     "ds_read_b128 %4, %15\n\tds_read_b128 %5, %15 offset:16\n\tds_read_b128 %6, %15 offset:32\n\tds_read_b128 %7, %15 offset:48\n\t"
+                     "ds_read_b64 %9, %15 offset:64\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7]), "=&v"(hd0), "=&v"(hd1),
+                       "=&v"(c0), "=&v"(c1)
+                     : "v"(ctl + 32u + 4u * (s0 / REC_PER_WAVE)), "v"(ctl + 32u + 4u * (s1 / REC_PER_WAVE)), "v"(reca + s0 * REC_BYTES), "v"(reca + s1 * REC_BYTES)
+                     : "memory");
+        if (lane < 8u) asm volatile("ds_write_b32 %0, %1" :: "v"(ctl + 32u + 4u * lane), "v"(0u) : "memory");   // this wave has them all: the counts start over
+        uint32_t mask[2] = {0u, 0u};
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) mask[r] |= q[r * 4 + e / 4][e % 4] >= a.thr_lo ? 1u << e : 0u;
+        }
+        if (!((s0 % REC_PER_WAVE) < c0) || (uint32_t)(hd0 >> 32) >= a.n_rows) mask[0] = 0u;
+        if (!((s1 % REC_PER_WAVE) < c1) || (uint32_t)(hd1 >> 32) >= a.n_rows) mask[1] = 0u;
+        if (a.n_scan - cur_i0 < (uint32_t)BM) {   // the last panel of scanned rows: rows beyond n_scan are not pairs
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const uint32_t ib = (uint32_t)(r ? hd1 : hd0);
+#pragma unroll
+                for (uint32_t e = 0; e < 16; e++)
+                    if (ib + 8u * (e >> 2) + (e & 3u) >= a.n_scan) mask[r] &= ~(1u << e);
+            }
+        }
+        const uint32_t n_mine = (uint32_t)__builtin_popcount(mask[0]) + (uint32_t)__builtin_popcount(mask[1]);
+        if (n_mine) {
+            uint32_t pos = lds_add_rtn_u32(ctl, n_mine);
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const uint64_t hd = r ? hd1 : hd0;
+                uint32_t mk = mask[r];
+                while (mk) {
+                    const uint32_t e = (uint32_t)__builtin_ctz(mk);
+                    mk &= mk - 1u;
+                    const uint64_t v = (uint64_t)((uint32_t)hd + 8u * (e >> 2) + (e & 3u)) | (hd & 0xFFFFFFFF00000000ull);
                     if (pos < HL_CAP) {
                         lds_write_u64(hla + pos * 8u, v);
-                    } else {   // list full inside one tile (a block of near-duplicates): this hit pays its own round trip
+                    } else {
                         const uint32_t p = atomicAdd(a.pair_ctl, 1u);
                         if (p < a.pair_cap) a.pairs[p] = v;
                         else a.pair_ctl[1] = 1u;
                     }
+                    pos++;
                 }
             }
+        }
     };
 
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
     // ---- the block's life
+    // block 0 stamps the shader clock against the 100 MHz reference around its whole life (two scalar reads per launch):
+    // what the chip's power management lets this kernel run at is half of every MFMA utilisation figure (tuning.md)
+    unsigned long long t_clk = 0, t_ref = 0;
+    if (blockIdx.x == 0) {
+        t_clk = __builtin_amdgcn_s_memtime();
+        t_ref = __builtin_amdgcn_s_memrealtime();
+    }
     const uint32_t stride = per_xcd;
     Desc cur = make_desc(first + my), nxt = cur;
 #pragma unroll
@@ -287,7 +410,7 @@ __global__ __launch_bounds__(WAVES * 64) void pair_filter_p_kernel(const PairFil
 #pragma unroll
         for (int r = 0; r < MT * 2; r++) fa0[r] = rdA(0u, r >> 1, r & 1);
     }
-    uint32_t g = 0;
+    uint32_t g = 0, turn = 0;
     for (;;) {
         uint32_t nmy;
         bool more;
@@ -297,45 +420,66 @@ __global__ __launch_bounds__(WAVES * 64) void pair_filter_p_kernel(const PairFil
             nxt = make_desc(first + (more ? nmy : my));
         }
         uint32_t ticket = 1;
-        step(std::true_type{}, g, 0u, cur, nxt, fa0, fb0, fa1, fb1);
-        if constexpr (DYN) {   // claim the next tile: issued here, looked at four K-steps later
+        unsigned long long d0 = 0, d1 = 0, d2 = 0;
+        if constexpr (DIAG) d0 = __builtin_readcyclecounter();
+        strips = 0;
+        step(K1{}, g, 0u, cur, nxt, fa0, fb0, fa1, fb1);
+        if constexpr (DYN) {   // claim the next tile: issued here, looked at five K-steps later
             if (wave == 0) asm volatile("s_atomic_add %0, %1, 0x0 glc" : "+s"(ticket) : "s"(a.pair_ctl + 8u + xcd) : "memory");
         }
-        step(std::false_type{}, g + 1u, 1u, cur, nxt, fa1, fb1, fa0, fb0);
-        {   // every wave has passed a barrier since the last append: the count is the same for all of them
+        step(K0{}, g + 1u, 1u, cur, nxt, fa1, fb1, fa0, fb0);
+        pick_up_records(turn++);
+        step(K0{}, g + 2u, 2u, cur, nxt, fa0, fb0, fa1, fb1);
+        step(K0{}, g + 3u, 3u, cur, nxt, fa1, fb1, fa0, fb0);
+        {   // every wave has passed two barriers since the last append: the count is the same for all of them
             const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_read_u32(ctl));
             if (cnt > HL_FLUSH) flush(cnt < HL_CAP ? cnt : HL_CAP);
         }
-        uint32_t kt = 2;
+        step(K0{}, g + 4u, 4u, cur, nxt, fa0, fb0, fa1, fb1);
+        step(K0{}, g + 5u, 5u, cur, nxt, fa1, fb1, fa0, fb0);
         if constexpr (DYN) {
-            for (; kt < 6; kt += 2) {
-                step(std::false_type{}, g + kt, kt, cur, nxt, fa0, fb0, fa1, fb1);
-                step(std::false_type{}, g + kt + 1u, kt + 1u, cur, nxt, fa1, fb1, fa0, fb0);
-            }
             if (wave == 0) {
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ticket) :: "memory");
                 if (lane == 0) lds_write_u32(ctl + 4u, ticket);
             }
-            for (; kt < 8; kt += 2) {
-                step(std::false_type{}, g + kt, kt, cur, nxt, fa0, fb0, fa1, fb1);
-                step(std::false_type{}, g + kt + 1u, kt + 1u, cur, nxt, fa1, fb1, fa0, fb0);
-            }
+        }
+        step(K0{}, g + 6u, 6u, cur, nxt, fa0, fb0, fa1, fb1);
+        step(K0{}, g + 7u, 7u, cur, nxt, fa1, fb1, fa0, fb0);
+        if constexpr (DYN) {
             nmy = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_read_u32(ctl + 4u));
             more = nmy < count;
             nxt = make_desc(first + (more ? nmy : my));
         }
-        for (; kt < KT; kt += 2) {
-            step(std::false_type{}, g + kt, kt, cur, nxt, fa0, fb0, fa1, fb1);
-            step(std::false_type{}, g + kt + 1u, kt + 1u, cur, nxt, fa1, fb1, fa0, fb0);
+        uint32_t kt = 8;
+        for (; kt + 2u < KT; kt += 2) {
+            step(K0{}, g + kt, kt, cur, nxt, fa0, fb0, fa1, fb1);
+            step(K0{}, g + kt + 1u, kt + 1u, cur, nxt, fa1, fb1, fa0, fb0);
         }
+        step(K0{}, g + kt, kt, cur, nxt, fa0, fb0, fa1, fb1);
+        step(K2{}, g + kt + 1u, kt + 1u, cur, nxt, fa1, fb1, fa0, fb0);
         g += KT;
-        epilogue(cur);
+        if constexpr (DIAG) { d1 = __builtin_readcyclecounter(); d2 = d1; c_main += d1 - d0; c_epi += d2 - d1; }
+        cur_i0 = cur.i0;
         if (!more) break;
         cur = nxt;
         my = nmy;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy DMAs of the tile that never came
     __syncthreads();
+    pick_up_records(0u);
+    __syncthreads();
+    if constexpr (DIAG) {
+        if (lane == 0) {
+            unsigned long long *o = a.diag + ((size_t)blockIdx.x * WAVES + wave) * 8;
+            o[0] = c_main; o[1] = c_epi; o[2] = c_vm; o[3] = c_bar; o[4] = g / KT; o[5] = c_hook;
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(a.pair_ctl + 16);
+        o[0] = __builtin_amdgcn_s_memtime() - t_clk;
+        o[1] = __builtin_amdgcn_s_memrealtime() - t_ref;
+        a.pair_ctl[20] = g / KT;   // tiles this block walked
+    }
     {
         const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_read_u32(ctl));
         if (cnt) flush(cnt < HL_CAP ? cnt : HL_CAP);
@@ -361,18 +505,39 @@ __global__ __launch_bounds__(256) void pair_scatter_kernel(const uint64_t *pairs
 }
 
 bool pair_filter_p_supported(const PairFilterArgs &a) {
-    // rows scanned in order from the tiled shadow; >= 12 K-steps (the claim hooks sit at steps 1, 6 and 8)
+    // rows scanned in order from the tiled shadow; >= 12 K-steps (the hooks of a tile sit behind its steps 1, 3, 5 and 7)
     return a.shadow_t && !a.shadow_q && !a.scan_rows && a.dim % 64u == 0 && a.dim >= 384u && a.pairs && a.pair_ctl && a.pair_cap;
 }
 
-template <int WAVES, bool DYN>
+template <bool DYN, bool DIAG = false, int ARM = 0>
 static int launch_p(const PairFilterArgs &a, uint32_t grid, hipStream_t stream) {
     static std::atomic<uint64_t> attr_devices{0};
     if (first_use_on_device(attr_devices))
-        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_filter_p_kernel<WAVES, DYN>),
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_filter_p_kernel<DYN, DIAG, ARM>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS_BYTES));
-    hipLaunchKernelGGL((pair_filter_p_kernel<WAVES, DYN>), dim3(grid), dim3(WAVES * 64), pp::LDS_BYTES, stream, a);
+    if (a.ev_begin) CX_HIP(hipEventRecord((hipEvent_t)a.ev_begin, stream));
+    hipLaunchKernelGGL((pair_filter_p_kernel<DYN, DIAG, ARM>), dim3(grid), dim3(pp::WAVES * 64), pp::LDS_BYTES, stream, a);
+    if (a.ev_end) CX_HIP(hipEventRecord((hipEvent_t)a.ev_end, stream));
     CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+
+// CX_PAIR_DIAG: per-phase cycles (s_memtime; the stamps themselves cost ~6 %), results still valid
+static int launch_p_diag(const PairFilterArgs &a, uint32_t grid, bool dyn, hipStream_t stream) {
+    PairFilterArgs d = a;
+    const size_t n = (size_t)grid * 8 * 8;
+    CX_HIP(hipMalloc((void **)&d.diag, n * 8));
+    CX_HIP(hipMemsetAsync(d.diag, 0, n * 8, stream));
+    if (int rc = dyn ? launch_p<true, true>(d, grid, stream) : launch_p<false, true>(d, grid, stream)) return rc;
+    CX_HIP(hipStreamSynchronize(stream));
+    std::vector<unsigned long long> h(n);
+    CX_HIP(hipMemcpy(h.data(), d.diag, n * 8, hipMemcpyDeviceToHost));
+    CX_HIP(hipFree(d.diag));
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    for (size_t w = 0; w < (size_t)grid * 8; w++) for (int p = 0; p < 6; p++) s[p] += (double)h[w * 8 + p];
+    const double nt = s[4] > 0 ? s[4] : 1.0;   // wave-tiles
+    fprintf(stderr, "[pair_p diag] %.0f wave-tiles; cycles per tile and wave: K loop %.0f (counted waits %.0f, barriers %.0f), epilogue %.0f\n",
+            nt, s[0] / nt, s[2] / nt, s[3] / nt, s[1] / nt);
     return CX_OK;
 }
 
@@ -388,16 +553,31 @@ int launch_pair_filter_p(const PairFilterArgs &a, hipStream_t stream) {
     const int grid_env = getenv("CX_PAIR_P_GRID") ? atoi(getenv("CX_PAIR_P_GRID")) : 0;
     uint32_t grid = (uint32_t)(grid_env > 0 ? grid_env : cus);
     grid = std::max<uint32_t>(8u, grid / 8u * 8u);   // one block per CU, a whole number per XCD
-    CX_HIP(hipMemsetAsync(a.pair_ctl, 0, 64, stream));
-    const int waves = getenv("CX_PAIR_P_WAVES") ? atoi(getenv("CX_PAIR_P_WAVES")) : 8;
-    const int dyn = getenv("CX_PAIR_P_DYN") ? atoi(getenv("CX_PAIR_P_DYN")) : 0;
+    CX_HIP(hipMemsetAsync(a.pair_ctl, 0, 128, stream));
+    const int dyn = getenv("CX_PAIR_P_DYN") ? atoi(getenv("CX_PAIR_P_DYN")) : 1;   // tile claims: 1 s_atomic_add tickets, 0 static interleave
+    const int arm = getenv("CX_PAIR_P_ARM") ? atoi(getenv("CX_PAIR_P_ARM")) : 0;
     int rc;
-    if (waves == 4) rc = dyn ? launch_p<4, true>(a, grid, stream) : launch_p<4, false>(a, grid, stream);
-    else rc = dyn ? launch_p<8, true>(a, grid, stream) : launch_p<8, false>(a, grid, stream);
+    if (getenv("CX_PAIR_DIAG")) rc = launch_p_diag(a, grid, dyn != 0, stream);
+    else if (arm == 1) rc = launch_p<true, false, 1>(a, grid, stream);
+    else if (arm == 2) rc = launch_p<true, false, 2>(a, grid, stream);
+    else if (arm == 3) rc = launch_p<true, false, 3>(a, grid, stream);
+    else if (arm == 4) rc = launch_p<true, false, 4>(a, grid, stream);
+    else if (arm == 5) rc = launch_p<true, false, 5>(a, grid, stream);
+    else rc = dyn ? launch_p<true>(a, grid, stream) : launch_p<false>(a, grid, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(pair_scatter_kernel, dim3(1024), dim3(256), 0, stream, a.pairs, a.pair_ctl, a.pair_cap, a.cand_cnt, a.cand, a.cap,
                        a.symmetric);
     CX_HIP(hipGetLastError());
+    if (getenv("CX_PAIR_P_CLOCK")) {   // measurement: the clock block 0 saw, pairs handed over
+        uint32_t h[32];
+        CX_HIP(hipStreamSynchronize(stream));
+        CX_HIP(hipMemcpy(h, a.pair_ctl, sizeof h, hipMemcpyDeviceToHost));
+        unsigned long long clk, ref;
+        memcpy(&clk, h + 16, 8);
+        memcpy(&ref, h + 18, 8);
+        fprintf(stderr, "[pair_p] block 0: %llu shader cycles in %.3f ms = %.3f GHz, %u tiles; %u pairs%s\n", clk, (double)ref / 1.0e5,
+                ref ? (double)clk / (double)ref * 0.1 : 0.0, h[20], h[0], h[1] ? " (pair buffer overflow)" : "");
+    }
     return CX_OK;
 }
 

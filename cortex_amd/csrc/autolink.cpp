@@ -74,6 +74,7 @@ struct PassScratch {
     uint32_t *d_list_rows = nullptr, *d_list_cnt = nullptr, *d_counts = nullptr, *d_ident = nullptr;
     float *d_list_scores = nullptr, *d_list_dists = nullptr, *d_pair_sims = nullptr;
     size_t c_pair_sims = 0;
+    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;   // around the filter GEMM kernel alone (timed passes)
     uint64_t *d_pairs = nullptr;       // persistent filter kernel: hits as (i | j << 32) pairs, before pair_scatter_kernel
     uint32_t *d_pair_ctl = nullptr;    // [16]: pairs written, pairs lost, per-XCD tile tickets
     size_t c_pairs = 0, c_pair_ctl = 0;
@@ -93,6 +94,8 @@ struct PassScratch {
         (void)hipFree(d_list_scores); (void)hipFree(d_list_dists); (void)hipFree(d_offsets); (void)hipFree(d_pair_sims);
         (void)hipFree(d_deleted); (void)hipFree(d_temp); (void)hipFree(d_from); (void)hipFree(d_to); (void)hipFree(d_w);
         (void)hipFree(d_exist_off); (void)hipFree(d_exist_to); (void)hipFree(d_pairs); (void)hipFree(d_pair_ctl);
+        if (ev_k0) (void)hipEventDestroy(ev_k0);
+        if (ev_k1) (void)hipEventDestroy(ev_k1);
     }
 };
 
@@ -241,6 +244,8 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
     if (phase_ms) CX_HIP(hipEventRecord(ev[0], s));
 
     std::vector<uint32_t> redo;  // scanned positions that must take the exact scan path
+    int prof_kind = 2;
+    uint64_t prof_tiles = 0;
     if (mfma_path) {
         if (int rc = ensure_shadow(ix, s)) return rc;
         if (phase_ms) CX_HIP(hipEventRecord(ev[1], s));
@@ -251,6 +256,8 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
         // filter+rescore alternate per chunk and the two event pairs bracket their sums approximately
         bool used_persist = false;
         uint32_t pairs_lost = 0;
+        int filter_kind = 2;
+        uint64_t filter_tiles = 0;
         for (uint32_t lo = 0; lo < n_scan; lo += chunk) {
             const uint32_t m = std::min<uint32_t>(chunk, n_scan - lo);
             CX_HIP(hipMemsetAsync(ps.d_cand_cnt, 0, (size_t)m * 4, s));
@@ -307,18 +314,29 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
             if (big && persist_ok && !cyc.no_persist) {   // persistent blocks (allpairs_p.hip): hits leave the GEMM as pairs
                 const size_t pair_cap = (size_t)std::min<uint64_t>((uint64_t)m * cap / 2u, 128ull << 20);
                 if (int rc = ensure_dev(ps.d_pairs, ps.c_pairs, pair_cap)) return rc;
-                if (int rc = ensure_dev(ps.d_pair_ctl, ps.c_pair_ctl, (size_t)16)) return rc;
+                if (int rc = ensure_dev(ps.d_pair_ctl, ps.c_pair_ctl, (size_t)32)) return rc;
                 f.pairs = ps.d_pairs;
                 f.pair_ctl = ps.d_pair_ctl;
                 f.pair_cap = (uint32_t)pair_cap;
                 persist = pair_filter_p_supported(f);
             }
+            if (phase_ms && lo == 0) {   // the GEMM kernel alone, for cx_autolink_filter_profile
+                if (!ps.ev_k0) { CX_HIP(hipEventCreate(&ps.ev_k0)); CX_HIP(hipEventCreate(&ps.ev_k1)); }
+                f.ev_begin = ps.ev_k0;
+                f.ev_end = ps.ev_k1;
+            }
             if (!big && stream_ok && pair_filter_stream_supported(f)) {
                 if (int rc = launch_pair_filter_stream(f, s)) return rc;
+                filter_kind = 2;
             } else if (persist) {
                 if (int rc = launch_pair_filter_p(f, s)) return rc;
                 used_persist = true;
-            } else if (int rc = big ? launch_pair_filter256(f, s) : launch_pair_filter(f, s)) return rc;
+                filter_kind = 1;
+            } else {
+                if (int rc = big ? launch_pair_filter256(f, s) : launch_pair_filter(f, s)) return rc;
+                filter_kind = big ? 0 : 2;
+            }
+            if (lo == 0) filter_tiles = f.symmetric ? f.n_tiles : (uint64_t)((m + 255u) / 256u) * ((n_rows + 255u) / 256u);
             if (phase_ms && lo == 0) CX_HIP(hipEventRecord(ev[2], s));
             RescoreArgs r;
             memset(&r, 0, sizeof r);
@@ -350,6 +368,8 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
                 pairs_lost |= lost;
             }
         }
+        prof_kind = filter_kind;
+        prof_tiles = filter_tiles;
         if (phase_ms && n_scan > chunk) CX_HIP(hipEventRecord(ev[2], s));  // multi-chunk: only the total is meaningful
         if (phase_ms) CX_HIP(hipEventRecord(ev[3], s));
         std::vector<uint32_t> of(n_scan);
@@ -453,6 +473,24 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
             phase_ms[p] = ms;
         }
         for (auto &e : ev) (void)hipEventDestroy(e);
+        std::lock_guard<std::mutex> g(ix->shadow_mu);
+        for (double &v : ix->filter_prof) v = 0.0;
+        if (mfma_path && prof_kind != 2 && ps.ev_k0) {
+            float ms = 0.0f;
+            CX_HIP(hipEventElapsedTime(&ms, ps.ev_k0, ps.ev_k1));
+            ix->filter_prof[0] = ms;
+            ix->filter_prof[1] = 2.0 * 256.0 * 256.0 * (double)ix->dim * (double)prof_tiles;
+            ix->filter_prof[2] = (double)prof_tiles;
+            ix->filter_prof[3] = (double)prof_kind;
+            if (prof_kind == 1) {
+                uint32_t h[32];
+                CX_HIP(hipMemcpy(h, ps.d_pair_ctl, sizeof h, hipMemcpyDeviceToHost));
+                unsigned long long clk, ref;
+                memcpy(&clk, h + 16, 8);
+                memcpy(&ref, h + 18, 8);
+                ix->filter_prof[4] = ref ? (double)clk / (double)ref * 0.1 : 0.0;
+            }
+        }
     }
     *total = n_edges;
     return CX_OK;
@@ -546,6 +584,13 @@ int cx_autolink_pass_timed(const cx_index *ix, uint64_t n_scan, const uint32_t *
     cyc.max_edges_per_cycle = max_edges_per_cycle;
     return pass_core(ix, lease.c, ps, n_scan, scan_rows, (uint32_t)std::min<uint64_t>(topk, 0xFFFFFFFFull), threshold,
                      (uint32_t)std::min<uint64_t>(max_edges_per_node, 0xFFFFFFFFull), nullptr, false, cyc, n_edges, phase_ms);
+} catch (...) { return cx::on_exception(); }
+
+int cx_autolink_filter_profile(const cx_index *ix, double out[5]) try {
+    if (!ix || !out) return set_err(CX_ERR_VALIDATION, "null argument");
+    std::lock_guard<std::mutex> g(ix->shadow_mu);
+    for (int i = 0; i < 5; i++) out[i] = ix->filter_prof[i];
+    return CX_OK;
 } catch (...) { return cx::on_exception(); }
 
 /* Ordered neighbour lists of nq external vectors against this shard (the multi-GPU building block of the

@@ -172,6 +172,8 @@ struct cx_index {
     mutable char *d_split = nullptr;
     mutable uint32_t *d_tile_list = nullptr;   // live tiles of the symmetric all-pairs pass, cached per row count
     mutable uint32_t tile_list_rows = 0, tile_list_n = 0, tile_list_big = 0;
+    // cx_autolink_filter_profile: the filter GEMM of the last timed all-pairs pass (under shadow_mu)
+    mutable double filter_prof[5] = {0, 0, 0, 0, 0};
     // measurement (cx_profile_*): event pairs around the scan kernel
     bool profiling = false;
     mutable std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;

@@ -172,8 +172,9 @@ struct PairFilterArgs {
     unsigned long long *diag;   // CX_PAIR_DIAG=1 only: [tiles][4] cycle stamps (prologue, main loop, epilogue)
     // persistent kernel only (allpairs_p.hip): hits leave the GEMM as (i | j << 32) pairs, pair_scatter_kernel fills cand
     uint64_t *pairs;            // [pair_cap]
-    uint32_t *pair_ctl;         // [16] zeroed by the launcher: [0] pairs written, [1] pairs lost (pair_cap too small), [8 + x] tile tickets of XCD x
+    uint32_t *pair_ctl;         // [32] zeroed by the launcher: [0] pairs written, [1] pairs lost (pair_cap too small), [8 + x] tile tickets of XCD x, [16..20] block 0's clock stamps
     uint32_t pair_cap;
+    void *ev_begin, *ev_end;    // optional hipEvent_t pair recorded around the GEMM kernel alone (256-tile and persistent kernels)
 };
 // live tiles of the symmetric pass in L2-friendly order (host side); tile = 128 rows
 void pair_filter_tile_list(uint32_t n_rows, std::vector<uint32_t> &out);

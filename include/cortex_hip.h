@@ -460,6 +460,14 @@ int cx_profile_enable(cx_index *ix, int on);
  * reset; waits for the recorded events. */
 int cx_profile_read(cx_index *ix, double *kernel_ms_sum, uint64_t *launches, int reset);
 
+/* The MFMA filter GEMM of the most recent TIMED all-pairs pass on this index (cx_autolink_pass_timed), for bench.py's
+ * MFMA roofline: out[0] = duration of the GEMM kernel alone in ms (HIP events around that one launch, on its stream),
+ * out[1] = flops its MFMAs executed (2 x 256 x 256 x dim per tile launched: symmetric passes launch tiles tj >= ti only),
+ * out[2] = tiles, out[3] = which kernel ran (0 pair_filter256_kernel, 1 pair_filter_p_kernel, 2 the 128-tile / stream
+ * kernels: out[1] = 0 then), out[4] = shader clock in GHz a block of the persistent kernel measured over its life
+ * (s_memtime against the 100 MHz reference; 0 if not measured).  All zero before the first timed pass. */
+int cx_autolink_filter_profile(const cx_index *ix, double out[5]);
+
 /* raw device pointer to the f32 row store (row-major, cx_dimension floats per
  * row) — read-only view for tools and tests */
 const float *cx_device_rows(const cx_index *ix);

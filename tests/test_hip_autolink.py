@@ -402,15 +402,15 @@ print("|".join(out))
 
 
 @pytest.mark.parametrize("env", [
-    {"CX_PAIR_P_GRID": "8"},                              # one block per XCD: each walks ~10-30 tiles, statically dealt
-    {"CX_PAIR_P_GRID": "8", "CX_PAIR_P_DYN": "1"},        # the same with s_atomic_add tile claims
-    {"CX_PAIR_P_GRID": "16", "CX_PAIR_P_WAVES": "4"},     # one 512-register wave per SIMD
+    {"CX_PAIR_P_GRID": "8"},                              # one block per XCD: each walks ~10-30 tiles, claimed with s_atomic_add
+    {"CX_PAIR_P_GRID": "8", "CX_PAIR_P_DYN": "0"},        # the same, statically dealt
+    {"CX_PAIR_P_GRID": "24"},
     {},                                                   # the launch the product uses (one block per CU)
 ])
 def test_persistent_filter_kernel_equals_the_per_tile_kernel(hip, oracle, monkeypatch, env):
     """allpairs_p.hip: persistent blocks whose LDS ring runs through the tile boundaries and whose hits leave the GEMM as
-    pairs.  With few blocks every block walks many tiles (the boundary code), at threshold 0.3 a tile holds more hits
-    than the LDS list (flush + direct appends).  Both filters feed the same exact rescore, so the edges must be the
+    records -> pairs.  With few blocks every block walks many tiles (the boundary code), at threshold 0.3 a tile holds
+    more hit lanes than records and more hits than the LDS list (in-place walk, flush, direct appends).  Both filters feed the same exact rescore, so the edges must be the
     same bytes as pair_filter256_kernel's, and equal to the oracle's (auto_linker.rs:215-264)."""
     for n, d, thr in ((5000, 768, 0.85), (4000, 384, 0.3), (2100, 1024, 0.75)):
         rows = oracle.synth_rows(n, d)
