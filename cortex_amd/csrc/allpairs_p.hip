@@ -42,20 +42,37 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace pp {
-constexpr int BM = 256, BN = 256, BK = 32, NS = 4, PF = 3, WAVES = 8;
-constexpr int OP_BYTES = BM * BK * 2;          // 16 KiB per operand per slot
-constexpr int SLOT_BYTES = 2 * OP_BYTES;       // 32 KiB
-constexpr int RING_BYTES = NS * SLOT_BYTES;    // 128 KiB
-constexpr uint32_t HL_CAP = 2560;              // pairs the block's list holds (20 KiB)
-constexpr uint32_t HL_FLUSH = 1024;            // written out at the next check once it holds more than this
-constexpr uint32_t REC_PER_WAVE = 16;          // hit-lane records per wave and tile (80 B each: 16 accumulator values, i base, j)
-constexpr uint32_t REC_CAP = REC_PER_WAVE * WAVES;
-constexpr uint32_t REC_BYTES = 80;
-constexpr int HL_OFF = RING_BYTES;
-constexpr int REC_OFF = HL_OFF + (int)HL_CAP * 8;
-constexpr int CTL_OFF = REC_OFF + (int)(REC_CAP * REC_BYTES);   // [0] pairs in the list, [1] next tile, [2] flush base, [8 + w] records of wave w
-constexpr int LDS_BYTES = CTL_OFF + 64;   // 16 control words
-static_assert(LDS_BYTES <= 160 * 1024, "LDS of a CU");
+constexpr int BN = 256, BK = 32;
+constexpr uint32_t REC_BYTES = 80;             // a hit lane's record: its 16 accumulator values of a 32x32 tile, i base, j
+// Block shape: BM = 256 scanned rows x 256 rows, 8 waves (2 x 4 of 128 x 64), one block per CU, 4-slot ring.
+// (Measured and dropped, profiles/r03/tuning.md §1.4: 128 x 256 tiles on 4-wave blocks, TWO independent blocks per CU on
+// 3-slot rings, so that a block's barrier stalls only its own wave of each SIMD.  The barriers did cost less — 6 % of the
+// cycles instead of 28 % — but a 128 x 256 tile moves +50 % bytes per flop from L2 to LDS and its LDS-DMAs then cost 20 %
+// instead of 15 %: 6.0 ms against 5.7.  On a 3-slot ring the DMA of step t + 3 also targets the slot whose fragment reads
+// were issued only one step earlier: a late ds_read can lose the race against an L2-hit DMA, which showed as a handful of
+// missing hits in one test run in four.)
+template <int BM_>
+struct Cfg {
+    static constexpr int BM = BM_;
+    static constexpr int WAVES = BM_ / 32;                   // 8 | 4
+    // PF = 3 K-steps of DMA ahead: what a wave issues in step t is waited for at the end of step t + 1 (the counted wait
+    // leaves only the youngest step in flight) and read as fragments in step t + 2 — it is the data of step t + 3 — and
+    // goes into the slot of step t - 1, whose fragments were read during step t - 2 and consumed in step t - 1.
+    static constexpr int NS = 4, PF = 3;
+    static constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BN * BK * 2;
+    static constexpr int SLOT_BYTES = A_BYTES + B_BYTES;     // 32 | 24 KiB
+    static constexpr int RING_BYTES = NS * SLOT_BYTES;       // 128 | 72 KiB
+    static constexpr int NDA = (BM_ / 16) / WAVES, NDB = (BN / 16) / WAVES, ND = NDA + NDB;   // LDS-DMAs per wave and K-step: 2 + 2 | 2 + 4
+    static constexpr uint32_t HL_CAP = BM_ == 256 ? 2560 : 640;      // pairs the block's list holds
+    static constexpr uint32_t HL_FLUSH = BM_ == 256 ? 1024 : 256;    // written out at the next check once it holds more than this
+    static constexpr uint32_t REC_PER_WAVE = BM_ == 256 ? 16 : 8;    // hit-lane records per wave and tile
+    static constexpr uint32_t REC_CAP = REC_PER_WAVE * WAVES;
+    static constexpr int HL_OFF = RING_BYTES;
+    static constexpr int REC_OFF = HL_OFF + (int)HL_CAP * 8;
+    static constexpr int CTL_OFF = REC_OFF + (int)(REC_CAP * REC_BYTES);   // [0] pairs in the list, [1] next tile, [2] flush base, [8 + w] records of wave w
+    static constexpr int LDS_BYTES = CTL_OFF + 64;
+    static_assert(BM_ == 256 && LDS_BYTES <= 160 * 1024, "one block per CU");
+};
 // same LDS image as allpairs256.hip: 16-byte piece p of a 64-byte row at p ^ (row >> 3 & 3)
 __device__ inline uint32_t off(uint32_t row, uint32_t piece) { return row * 64u + ((piece ^ ((row >> 3) & 3u)) << 4); }
 // LDS control words, records and the pair list are touched through inline assembly: hipcc tracks every in-flight LDS-DMA
@@ -88,16 +105,19 @@ __device__ inline uint32_t scalar_load_u32(const uint32_t *p) {
 
 // ARM: 0 = the product; measurement arms (results invalid): 1 = hits are found and dropped (what the hand-over costs),
 // 2 = no LDS-DMA inside the K loop, 3 = no fragment reads, 4 = no barriers, 5 = no counted waits and no barriers
-template <bool DYN, bool DIAG, int ARM>
-__global__ __launch_bounds__(pp::WAVES * 64) void pair_filter_p_kernel(const PairFilterArgs a) {
+template <int BM, bool DYN, bool DIAG, int ARM>
+__global__ __launch_bounds__(pp::Cfg<BM>::WAVES * 64, 2) void pair_filter_p_kernel(const PairFilterArgs a) {
     using namespace pp;
+    using C = Cfg<BM>;
+    constexpr int WAVES = C::WAVES, NS = C::NS, PF = C::PF, SLOT_BYTES = C::SLOT_BYTES, ND = C::ND, NDA = C::NDA, NDB = C::NDB;
+    constexpr uint32_t HL_CAP = C::HL_CAP, HL_FLUSH = C::HL_FLUSH, REC_PER_WAVE = C::REC_PER_WAVE, REC_CAP = C::REC_CAP;
+    constexpr int HL_OFF = C::HL_OFF, REC_OFF = C::REC_OFF, CTL_OFF = C::CTL_OFF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int WN = 4;                             // waves along N
     constexpr int MT = 4, NT = (BN / WN) / 32;        // 32x32 tiles per wave: 4 x 2
-    constexpr int NPW = 16 / WAVES;                   // 16-row pieces of each operand a wave loads per K-step
-    constexpr int ND = 2 * NPW;                       // LDS-DMA instructions per wave and K-step
     constexpr int NM = MT * NT * 2;                   // MFMAs per wave and K-step
-    static_assert(ND == 4 && NM == 16, "one DMA or fragment read after each MFMA");
+    constexpr int NR = (MT + NT) * 2;                 // fragment reads per wave and K-step
+    static_assert(NM == 16 && (ND == 4 || ND == 6), "the K-step's interleave");
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const uint32_t wm = wave / WN, wn = wave % WN;
@@ -121,8 +141,8 @@ __global__ __launch_bounds__(pp::WAVES * 64) void pair_filter_p_kernel(const Pai
             const uint32_t t = scalar_load_u32(a.tile_list + idx);
             ti = t >> 16;
             tj = t & 0xFFFFu;
-        } else {   // 4 I-panels per J-panel, as pair_filter256_kernel
-            const uint32_t GS = 4u, per_group = GS * tiles_j;
+        } else {   // 1,024 scanned rows of I-panels per J-panel, as pair_filter256_kernel
+            const uint32_t GS = 1024u / BM, per_group = GS * tiles_j;
             const uint32_t group = idx / per_group, first_i = group * GS;
             const uint32_t gsz = (tiles_i - first_i) < GS ? (tiles_i - first_i) : GS;
             ti = first_i + (idx % per_group) % gsz;
@@ -132,8 +152,8 @@ __global__ __launch_bounds__(pp::WAVES * 64) void pair_filter_p_kernel(const Pai
         d.i0 = ti * BM;
         d.j0 = tj * BN;
         // the tiled shadow is padded to whole 256-row tiles (ensure_shadow): no clamping of the last panel
-        d.A = reinterpret_cast<const char *>(a.shadow_t) + (size_t)(d.i0 / 16u + wave * NPW) * KT * 1024u;
-        d.B = reinterpret_cast<const char *>(a.shadow_t) + (size_t)(d.j0 / 16u + wave * NPW) * KT * 1024u;
+        d.A = reinterpret_cast<const char *>(a.shadow_t) + (size_t)(d.i0 / 16u + wave * NDA) * KT * 1024u;
+        d.B = reinterpret_cast<const char *>(a.shadow_t) + (size_t)(d.j0 / 16u + wave * NDB) * KT * 1024u;
         return d;
     };
 
@@ -154,14 +174,20 @@ __global__ __launch_bounds__(pp::WAVES * 64) void pair_filter_p_kernel(const Pai
     if (my >= count) return;   // block-uniform
 
     const uint32_t voff = lane * 16u;
-    auto dma = [&](uint32_t slot, uint32_t kk, const Desc &d, int which) {   // which: 2 q + (0 A | 1 B)
-        const int q = which >> 1;
-        char *dst = smem + slot * SLOT_BYTES + ((which & 1) ? OP_BYTES : 0) + (wave * NPW + (uint32_t)q) * 1024u;
-        const char *src = ((which & 1) ? d.B : d.A) + ((size_t)q * KT + kk) * 1024u + voff;
+    // the wave's ND pieces of a K-step: A pieces wave * NDA + q, B pieces wave * NDB + q, B and A alternating
+    auto dma = [&](uint32_t slot, uint32_t kk, const Desc &d, int which) {
+        constexpr int per_a = ND / NDA;                       // every per_a-th instruction is an A piece
+        const bool is_a = which % per_a == 0;
+        const int q = is_a ? which / per_a : which - which / per_a - 1;
+        char *dst = smem + slot * SLOT_BYTES + (is_a ? (wave * NDA + (uint32_t)q) * 1024u : C::A_BYTES + (wave * NDB + (uint32_t)q) * 1024u);
+        const char *src = (is_a ? d.A : d.B) + ((size_t)q * KT + kk) * 1024u + voff;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                          (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
     };
-    auto wait_ring = [&]() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); };   // all but this wave's youngest K-step of DMAs have landed
+    auto wait_ring = [&]() {   // all but this wave's youngest K-step of DMAs have landed
+        if constexpr (ND == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    };
 
     f32x16 acc[MT][NT];
     float mxs[MT * NT];        // per lane: largest of its 16 values of each 32x32 tile (set by the tile's last K-step)
@@ -172,7 +198,7 @@ __global__ __launch_bounds__(pp::WAVES * 64) void pair_filter_p_kernel(const Pai
     uint32_t fo[2];
 #pragma unroll
     for (uint32_t h = 0; h < 2; h++) fo[h] = off(fr, 2u * h + fq);
-    const uint32_t baseA = wm * 128u * 64u, baseB = OP_BYTES + wn * (NT * 32u) * 64u;
+    const uint32_t baseA = wm * 128u * 64u, baseB = C::A_BYTES + wn * (NT * 32u) * 64u;
     bf16x8 fa0[MT * 2], fb0[NT * 2], fa1[MT * 2], fb1[NT * 2];
     auto rdA = [&](uint32_t slot, int m, int h) { return *reinterpret_cast<const bf16x8 *>(smem + (slot * SLOT_BYTES + baseA + fo[h]) + m * 2048); };
     auto rdB = [&](uint32_t slot, int n, int h) { return *reinterpret_cast<const bf16x8 *>(smem + (slot * SLOT_BYTES + baseB + fo[h]) + n * 2048); };
@@ -270,7 +296,7 @@ __global__ __launch_bounds__(pp::WAVES * 64) void pair_filter_p_kernel(const Pai
                     bf16x8 *na, bf16x8 *nb) {
         constexpr int KIND = decltype(kind_tag)::value;
         constexpr bool FIRST = KIND == 1, LAST = KIND == 2;
-        const uint32_t dslot = (g + PF) & 3u, rslot = (g + 1u) & 3u;
+        const uint32_t dslot = (g + PF) % NS, rslot = (g + 1u) % NS;
         const bool in_cur = kt + PF < KT;
         Desc dd;
         dd.A = in_cur ? cur.A : nxt.A;
@@ -294,15 +320,19 @@ __global__ __launch_bounds__(pp::WAVES * 64) void pair_filter_p_kernel(const Pai
             } else {
                 acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m * 2 + h], fb[n * 2 + h], acc[m][n], 0, 0, 0);
             }
-            if ((idx % 4) == 0) {
-                if constexpr (ARM != 2) dma(dslot, kk, dd, di);
-                di++;
-            } else {
-                if constexpr (ARM != 3) {
-                    if (ri < NT * 2) nb[ri] = rdB(rslot, ri >> 1, ri & 1);
-                    else na[ri - NT * 2] = rdA(rslot, (ri - NT * 2) >> 1, (ri - NT * 2) & 1);
+            // the step's ND DMAs and NR fragment reads, spread evenly behind the 16 MFMAs (ND = 4: one each; ND = 6: two of the
+            // MFMAs are followed by two); op k is a DMA when k * ND mod (ND + NR) < ND
+            for (int k = idx * (ND + NR) / NM; k < (idx + 1) * (ND + NR) / NM; k++) {
+                if ((k * ND) % (ND + NR) < ND) {
+                    if constexpr (ARM != 2) dma(dslot, kk, dd, di);
+                    di++;
+                } else {
+                    if constexpr (ARM != 3) {
+                        if (ri < NT * 2) nb[ri] = rdB(rslot, ri >> 1, ri & 1);
+                        else na[ri - NT * 2] = rdA(rslot, (ri - NT * 2) >> 1, (ri - NT * 2) & 1);
+                    }
+                    ri++;
                 }
-                ri++;
             }
             if (LAST && (idx & 1) && idx >= 3) {   // finished one pair of MFMAs ago: screened, and its hit lanes recorded, under this pair
                 screen_tile((idx >> 1) - 1);
@@ -326,11 +356,11 @@ __global__ __launch_bounds__(pp::WAVES * 64) void pair_filter_p_kernel(const Pai
     // the records of the tile before: one per lane of ONE wave (every wave has passed a barrier since the last record was
     // written), while the partner wave on its SIMD and the other SIMDs compute
     auto pick_up_records = [&](uint32_t turn) {
-        if (wave != (turn & 7u)) return;
+        if (wave != turn % WAVES) return;
         // Two LDS round trips in all (each 300-600 cycles under the ring's traffic): every lane reads the counts and BOTH of
         // its record slots at once (lane l: slots l and l + 64; a slot without a record reads stale bytes and is masked),
         // then takes the list positions of all its hits with one atomic.  The partner wave's 16 MFMAs cover about that long.
-        const uint32_t s0 = lane, s1 = lane + 64u;
+        const uint32_t s0 = lane % REC_CAP, s1 = (lane + 64u) % REC_CAP;   // REC_CAP = 128: two slots per lane; 32: lanes 0-31 one slot each
         f32x4 q[8];
         uint64_t hd0, hd1;
         uint32_t c0, c1;
@@ -343,15 +373,15 @@ __global__ __launch_bounds__(pp::WAVES * 64) void pair_filter_p_kernel(const Pai
                        "=&v"(c0), "=&v"(c1)
                      : "v"(ctl + 32u + 4u * (s0 / REC_PER_WAVE)), "v"(ctl + 32u + 4u * (s1 / REC_PER_WAVE)), "v"(reca + s0 * REC_BYTES), "v"(reca + s1 * REC_BYTES)
                      : "memory");
-        if (lane < 8u) asm volatile("ds_write_b32 %0, %1" :: "v"(ctl + 32u + 4u * lane), "v"(0u) : "memory");   // this wave has them all: the counts start over
+        if (lane < (uint32_t)WAVES) asm volatile("ds_write_b32 %0, %1" :: "v"(ctl + 32u + 4u * lane), "v"(0u) : "memory");   // this wave has them all: the counts start over
         uint32_t mask[2] = {0u, 0u};
 #pragma unroll
         for (int r = 0; r < 2; r++) {
 #pragma unroll
             for (int e = 0; e < 16; e++) mask[r] |= q[r * 4 + e / 4][e % 4] >= a.thr_lo ? 1u << e : 0u;
         }
-        if (!((s0 % REC_PER_WAVE) < c0) || (uint32_t)(hd0 >> 32) >= a.n_rows) mask[0] = 0u;
-        if (!((s1 % REC_PER_WAVE) < c1) || (uint32_t)(hd1 >> 32) >= a.n_rows) mask[1] = 0u;
+        if (!((s0 % REC_PER_WAVE) < c0) || (uint32_t)(hd0 >> 32) >= a.n_rows || lane >= REC_CAP) mask[0] = 0u;
+        if (!((s1 % REC_PER_WAVE) < c1) || (uint32_t)(hd1 >> 32) >= a.n_rows || REC_CAP <= 64u) mask[1] = 0u;
         if (a.n_scan - cur_i0 < (uint32_t)BM) {   // the last panel of scanned rows: rows beyond n_scan are not pairs
 #pragma unroll
             for (int r = 0; r < 2; r++) {
@@ -429,6 +459,9 @@ __global__ __launch_bounds__(pp::WAVES * 64) void pair_filter_p_kernel(const Pai
         }
         step(K0{}, g + 1u, 1u, cur, nxt, fa1, fb1, fa0, fb0);
         pick_up_records(turn++);
+        // The first eight steps are written out: with the hooks inside a loop over pairs of steps (`if (kt == 2)` ...) the
+        // kernel spills fewer scalar registers (12 against 41) but runs 5 % more cycles — the waits hipcc places where
+        // control flow joins inside the loop are not the counted ones.
         step(K0{}, g + 2u, 2u, cur, nxt, fa0, fb0, fa1, fb1);
         step(K0{}, g + 3u, 3u, cur, nxt, fa1, fb1, fa0, fb0);
         {   // every wave has passed two barriers since the last append: the count is the same for all of them
@@ -464,9 +497,12 @@ __global__ __launch_bounds__(pp::WAVES * 64) void pair_filter_p_kernel(const Pai
         cur = nxt;
         my = nmy;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy DMAs of the tile that never came
+    // the dummy DMAs of the tile that never came; and this wave's last records (inline assembly: hipcc's own wait before the
+    // barrier does not know them) must be in LDS before another wave reads them behind the barrier
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     pick_up_records(0u);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
     if constexpr (DIAG) {
         if (lane == 0) {
@@ -486,18 +522,20 @@ __global__ __launch_bounds__(pp::WAVES * 64) void pair_filter_p_kernel(const Pai
     }
 }
 
-// pairs -> the per-row candidate lists the exact rescore reads; a pair of a mirrored tile (symmetric pass, ti != tj)
-// enters both rows' lists
+// pairs -> the per-row candidate lists the exact rescore reads.  Symmetric pass, blocks of 2^shift rows: a pair inside a
+// diagonal block was found in both orders by the tile that computed the block; a pair above the diagonal enters both rows'
+// lists; a pair below it (the 128 x 256 tiles' second column block on odd panels) is the mirror of one found elsewhere
 __global__ __launch_bounds__(256) void pair_scatter_kernel(const uint64_t *pairs, const uint32_t *pair_ctl, uint32_t pair_cap,
-                                                           uint32_t *cand_cnt, uint32_t *cand, uint32_t cap, uint32_t symmetric) {
+                                                           uint32_t *cand_cnt, uint32_t *cand, uint32_t cap, uint32_t symmetric, uint32_t shift) {
     const uint32_t total = pair_ctl[0];
     const uint32_t n = total < pair_cap ? total : pair_cap;
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
         const uint64_t v = pairs[t];
         const uint32_t i = (uint32_t)v, j = (uint32_t)(v >> 32);
+        if (symmetric && (j >> shift) < (i >> shift)) continue;
         const uint32_t s = atomicAdd(cand_cnt + i, 1u);
         if (s < cap) cand[(size_t)i * cap + s] = j;
-        if (symmetric && (i >> 8) != (j >> 8)) {
+        if (symmetric && (i >> shift) != (j >> shift)) {
             const uint32_t s2 = atomicAdd(cand_cnt + j, 1u);
             if (s2 < cap) cand[(size_t)j * cap + s2] = i;
         }
@@ -509,26 +547,28 @@ bool pair_filter_p_supported(const PairFilterArgs &a) {
     return a.shadow_t && !a.shadow_q && !a.scan_rows && a.dim % 64u == 0 && a.dim >= 384u && a.pairs && a.pair_ctl && a.pair_cap;
 }
 
-template <bool DYN, bool DIAG = false, int ARM = 0>
+template <int BM, bool DYN, bool DIAG = false, int ARM = 0>
 static int launch_p(const PairFilterArgs &a, uint32_t grid, hipStream_t stream) {
+    using C = pp::Cfg<BM>;
     static std::atomic<uint64_t> attr_devices{0};
     if (first_use_on_device(attr_devices))
-        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_filter_p_kernel<DYN, DIAG, ARM>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS_BYTES));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_filter_p_kernel<BM, DYN, DIAG, ARM>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     if (a.ev_begin) CX_HIP(hipEventRecord((hipEvent_t)a.ev_begin, stream));
-    hipLaunchKernelGGL((pair_filter_p_kernel<DYN, DIAG, ARM>), dim3(grid), dim3(pp::WAVES * 64), pp::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((pair_filter_p_kernel<BM, DYN, DIAG, ARM>), dim3(grid), dim3(C::WAVES * 64), C::LDS_BYTES, stream, a);
     if (a.ev_end) CX_HIP(hipEventRecord((hipEvent_t)a.ev_end, stream));
     CX_HIP(hipGetLastError());
     return CX_OK;
 }
 
 // CX_PAIR_DIAG: per-phase cycles (s_memtime; the stamps themselves cost ~6 %), results still valid
+template <int BM>
 static int launch_p_diag(const PairFilterArgs &a, uint32_t grid, bool dyn, hipStream_t stream) {
     PairFilterArgs d = a;
     const size_t n = (size_t)grid * 8 * 8;
     CX_HIP(hipMalloc((void **)&d.diag, n * 8));
     CX_HIP(hipMemsetAsync(d.diag, 0, n * 8, stream));
-    if (int rc = dyn ? launch_p<true, true>(d, grid, stream) : launch_p<false, true>(d, grid, stream)) return rc;
+    if (int rc = dyn ? launch_p<BM, true, true>(d, grid, stream) : launch_p<BM, false, true>(d, grid, stream)) return rc;
     CX_HIP(hipStreamSynchronize(stream));
     std::vector<unsigned long long> h(n);
     CX_HIP(hipMemcpy(h.data(), d.diag, n * 8, hipMemcpyDeviceToHost));
@@ -536,37 +576,57 @@ static int launch_p_diag(const PairFilterArgs &a, uint32_t grid, bool dyn, hipSt
     double s[6] = {0, 0, 0, 0, 0, 0};
     for (size_t w = 0; w < (size_t)grid * 8; w++) for (int p = 0; p < 6; p++) s[p] += (double)h[w * 8 + p];
     const double nt = s[4] > 0 ? s[4] : 1.0;   // wave-tiles
-    fprintf(stderr, "[pair_p diag] %.0f wave-tiles; cycles per tile and wave: K loop %.0f (counted waits %.0f, barriers %.0f), epilogue %.0f\n",
-            nt, s[0] / nt, s[2] / nt, s[3] / nt, s[1] / nt);
+    fprintf(stderr, "[pair_p diag] %.0f wave-tiles; cycles per tile and wave: K loop %.0f (counted waits %.0f, barriers %.0f)\n",
+            nt, s[0] / nt, s[2] / nt, s[3] / nt);
     return CX_OK;
 }
 
-int launch_pair_filter_p(const PairFilterArgs &a, hipStream_t stream) {
-    using namespace pp;
-    if (!pair_filter_p_supported(a)) return set_err(CX_ERR_VALIDATION, "persistent pair filter: unsupported arguments");
-    if (!a.n_scan || !a.n_rows) return CX_OK;
-    if (a.symmetric && (!a.tile_list || (a.n_rows + BM - 1) / BM > 0xFFFFu))
-        return set_err(CX_ERR_VALIDATION, "persistent pair filter: symmetric pass needs a tile list");
-    const uint64_t tiles = a.symmetric ? a.n_tiles : (uint64_t)((a.n_scan + BM - 1) / BM) * ((a.n_rows + BN - 1) / BN);
-    if (tiles > 0x7FFFFFFFull) return set_err(CX_ERR_VALIDATION, "persistent pair filter: too many tiles");
+uint32_t pair_filter_p_block_rows() { return 256u; }   // scanned rows per tile
+
+// live tiles of the symmetric pass for tiles of bm scanned rows x 256 rows: (ti << 16) | tj with the tile's last column
+// at or beyond its first row, GS I-panels (1,024 scanned rows) per J-panel as pair_filter256_tile_list
+void pair_filter_p_tile_list(uint32_t n_rows, uint32_t bm, std::vector<uint32_t> &out) {
+    const uint32_t tiles_i = (n_rows + bm - 1) / bm, tiles_j = (n_rows + 255u) / 256u, GS = 1024u / bm;
+    out.clear();
+    for (uint32_t g0 = 0; g0 < tiles_i; g0 += GS) {
+        const uint32_t g1 = std::min(g0 + GS, tiles_i);
+        for (uint32_t tj = (uint32_t)((uint64_t)g0 * bm / 256u); tj < tiles_j; tj++)
+            for (uint32_t ti = g0; ti < g1; ti++)
+                if ((uint64_t)tj * 256u + 255u >= (uint64_t)ti * bm) out.push_back((ti << 16) | tj);
+    }
+}
+
+template <int BM>
+static int launch_cfg(const PairFilterArgs &a, hipStream_t stream) {
+    using C = pp::Cfg<BM>;
     const int cus = (int)device_cus();
     const int grid_env = getenv("CX_PAIR_P_GRID") ? atoi(getenv("CX_PAIR_P_GRID")) : 0;
-    uint32_t grid = (uint32_t)(grid_env > 0 ? grid_env : cus);
-    grid = std::max<uint32_t>(8u, grid / 8u * 8u);   // one block per CU, a whole number per XCD
-    CX_HIP(hipMemsetAsync(a.pair_ctl, 0, 128, stream));
+    uint32_t grid = (uint32_t)(grid_env > 0 ? grid_env : cus * (256 / BM));
+    grid = std::max<uint32_t>(8u, grid / 8u * 8u);   // 256 / BM blocks per CU, a whole number per XCD
     const int dyn = getenv("CX_PAIR_P_DYN") ? atoi(getenv("CX_PAIR_P_DYN")) : 1;   // tile claims: 1 s_atomic_add tickets, 0 static interleave
     const int arm = getenv("CX_PAIR_P_ARM") ? atoi(getenv("CX_PAIR_P_ARM")) : 0;
-    int rc;
-    if (getenv("CX_PAIR_DIAG")) rc = launch_p_diag(a, grid, dyn != 0, stream);
-    else if (arm == 1) rc = launch_p<true, false, 1>(a, grid, stream);
-    else if (arm == 2) rc = launch_p<true, false, 2>(a, grid, stream);
-    else if (arm == 3) rc = launch_p<true, false, 3>(a, grid, stream);
-    else if (arm == 4) rc = launch_p<true, false, 4>(a, grid, stream);
-    else if (arm == 5) rc = launch_p<true, false, 5>(a, grid, stream);
-    else rc = dyn ? launch_p<true>(a, grid, stream) : launch_p<false>(a, grid, stream);
-    if (rc) return rc;
+    (void)sizeof(C);
+    if (getenv("CX_PAIR_DIAG")) return launch_p_diag<BM>(a, grid, dyn != 0, stream);
+    switch (arm) {
+        case 1: return launch_p<BM, true, false, 1>(a, grid, stream);
+        case 2: return launch_p<BM, true, false, 2>(a, grid, stream);
+        case 4: return launch_p<BM, true, false, 4>(a, grid, stream);
+        default: return dyn ? launch_p<BM, true>(a, grid, stream) : launch_p<BM, false>(a, grid, stream);
+    }
+}
+
+int launch_pair_filter_p(const PairFilterArgs &a, hipStream_t stream) {
+    if (!pair_filter_p_supported(a)) return set_err(CX_ERR_VALIDATION, "persistent pair filter: unsupported arguments");
+    if (!a.n_scan || !a.n_rows) return CX_OK;
+    const uint32_t bm = 256u;
+    if (a.symmetric && (!a.tile_list || (a.n_rows + bm - 1) / bm > 0xFFFFu))
+        return set_err(CX_ERR_VALIDATION, "persistent pair filter: symmetric pass needs a tile list");
+    const uint64_t tiles = a.symmetric ? a.n_tiles : (uint64_t)((a.n_scan + bm - 1) / bm) * ((a.n_rows + 255u) / 256u);
+    if (tiles > 0x7FFFFFFFull) return set_err(CX_ERR_VALIDATION, "persistent pair filter: too many tiles");
+    CX_HIP(hipMemsetAsync(a.pair_ctl, 0, 128, stream));
+    if (int rc = launch_cfg<256>(a, stream)) return rc;
     hipLaunchKernelGGL(pair_scatter_kernel, dim3(1024), dim3(256), 0, stream, a.pairs, a.pair_ctl, a.pair_cap, a.cand_cnt, a.cand, a.cap,
-                       a.symmetric);
+                       a.symmetric, 8u);
     CX_HIP(hipGetLastError());
     if (getenv("CX_PAIR_P_CLOCK")) {   // measurement: the clock block 0 saw, pairs handed over
         uint32_t h[32];

@@ -246,6 +246,7 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
     std::vector<uint32_t> redo;  // scanned positions that must take the exact scan path
     int prof_kind = 2;
     uint64_t prof_tiles = 0;
+    uint32_t prof_bm = 256;
     if (mfma_path) {
         if (int rc = ensure_shadow(ix, s)) return rc;
         if (phase_ms) CX_HIP(hipEventRecord(ev[1], s));
@@ -258,6 +259,7 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
         uint32_t pairs_lost = 0;
         int filter_kind = 2;
         uint64_t filter_tiles = 0;
+        uint32_t filter_bm = 256;
         for (uint32_t lo = 0; lo < n_scan; lo += chunk) {
             const uint32_t m = std::min<uint32_t>(chunk, n_scan - lo);
             CX_HIP(hipMemsetAsync(ps.d_cand_cnt, 0, (size_t)m * 4, s));
@@ -281,13 +283,26 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
             f.symmetric = (sym_ok && !scan_rows && lo == 0 && m == n_rows && (n_rows + 127u) / 128u <= 0xFFFFu) ? 1u : 0u;
             f.tile_list = nullptr;
             f.n_tiles = 0;
+            const int persist_ok = getenv("CX_PAIR_PERSIST") ? atoi(getenv("CX_PAIR_PERSIST")) : 1;   // read per call: tests switch it
+            bool persist = false;
+            if (big && persist_ok && !cyc.no_persist) {   // persistent blocks (allpairs_p.hip): hits leave the GEMM as pairs
+                const size_t pair_cap = (size_t)std::min<uint64_t>((uint64_t)m * cap / 2u, 128ull << 20);
+                if (int rc = ensure_dev(ps.d_pairs, ps.c_pairs, pair_cap)) return rc;
+                if (int rc = ensure_dev(ps.d_pair_ctl, ps.c_pair_ctl, (size_t)32)) return rc;
+                f.pairs = ps.d_pairs;
+                f.pair_ctl = ps.d_pair_ctl;
+                f.pair_cap = (uint32_t)pair_cap;
+                f.block_rows = pair_filter_p_block_rows();
+                persist = pair_filter_p_supported(f);
+            }
+            const uint32_t tile_kind = !big ? 0u : (persist ? f.block_rows : 256u);   // which tile list: 128^2 kernel, or bm x 256 tiles
             if (f.symmetric) {
                 std::lock_guard<std::mutex> g(ix->shadow_mu);
-                if (ix->tile_list_rows != n_rows || !ix->d_tile_list || ix->tile_list_big != (big ? 1u : 0u)) {
+                if (ix->tile_list_rows != n_rows || !ix->d_tile_list || ix->tile_list_big != tile_kind) {
                     std::vector<uint32_t> tl;
-                    if (big) pair_filter256_tile_list(n_rows, tl);
+                    if (big) pair_filter_p_tile_list(n_rows, tile_kind, tl);   // bm = 256: the order of pair_filter256_tile_list
                     else pair_filter_tile_list(n_rows, tl);
-                    ix->tile_list_big = big ? 1u : 0u;
+                    ix->tile_list_big = tile_kind;
                     if (ix->d_tile_list) CX_HIP(hipFree(ix->d_tile_list));
                     ix->d_tile_list = nullptr;
                     CX_HIP(hipMalloc((void **)&ix->d_tile_list, tl.size() * 4));
@@ -309,17 +324,6 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
                 f.scan_rows = ps.d_ident;
             }
             static const int stream_ok = getenv("CX_PAIR_STREAM") ? atoi(getenv("CX_PAIR_STREAM")) : 1;
-            const int persist_ok = getenv("CX_PAIR_PERSIST") ? atoi(getenv("CX_PAIR_PERSIST")) : 1;   // read per call: tests switch it
-            bool persist = false;
-            if (big && persist_ok && !cyc.no_persist) {   // persistent blocks (allpairs_p.hip): hits leave the GEMM as pairs
-                const size_t pair_cap = (size_t)std::min<uint64_t>((uint64_t)m * cap / 2u, 128ull << 20);
-                if (int rc = ensure_dev(ps.d_pairs, ps.c_pairs, pair_cap)) return rc;
-                if (int rc = ensure_dev(ps.d_pair_ctl, ps.c_pair_ctl, (size_t)32)) return rc;
-                f.pairs = ps.d_pairs;
-                f.pair_ctl = ps.d_pair_ctl;
-                f.pair_cap = (uint32_t)pair_cap;
-                persist = pair_filter_p_supported(f);
-            }
             if (phase_ms && lo == 0) {   // the GEMM kernel alone, for cx_autolink_filter_profile
                 if (!ps.ev_k0) { CX_HIP(hipEventCreate(&ps.ev_k0)); CX_HIP(hipEventCreate(&ps.ev_k1)); }
                 f.ev_begin = ps.ev_k0;
@@ -336,7 +340,8 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
                 if (int rc = big ? launch_pair_filter256(f, s) : launch_pair_filter(f, s)) return rc;
                 filter_kind = big ? 0 : 2;
             }
-            if (lo == 0) filter_tiles = f.symmetric ? f.n_tiles : (uint64_t)((m + 255u) / 256u) * ((n_rows + 255u) / 256u);
+            filter_bm = persist ? f.block_rows : 256u;
+            if (lo == 0) filter_tiles = f.symmetric ? f.n_tiles : (uint64_t)((m + filter_bm - 1u) / filter_bm) * ((n_rows + 255u) / 256u);
             if (phase_ms && lo == 0) CX_HIP(hipEventRecord(ev[2], s));
             RescoreArgs r;
             memset(&r, 0, sizeof r);
@@ -370,6 +375,7 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
         }
         prof_kind = filter_kind;
         prof_tiles = filter_tiles;
+        prof_bm = filter_bm;
         if (phase_ms && n_scan > chunk) CX_HIP(hipEventRecord(ev[2], s));  // multi-chunk: only the total is meaningful
         if (phase_ms) CX_HIP(hipEventRecord(ev[3], s));
         std::vector<uint32_t> of(n_scan);
@@ -479,7 +485,7 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
             float ms = 0.0f;
             CX_HIP(hipEventElapsedTime(&ms, ps.ev_k0, ps.ev_k1));
             ix->filter_prof[0] = ms;
-            ix->filter_prof[1] = 2.0 * 256.0 * 256.0 * (double)ix->dim * (double)prof_tiles;
+            ix->filter_prof[1] = 2.0 * (double)prof_bm * 256.0 * (double)ix->dim * (double)prof_tiles;
             ix->filter_prof[2] = (double)prof_tiles;
             ix->filter_prof[3] = (double)prof_kind;
             if (prof_kind == 1) {

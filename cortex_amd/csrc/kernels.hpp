@@ -174,6 +174,7 @@ struct PairFilterArgs {
     uint64_t *pairs;            // [pair_cap]
     uint32_t *pair_ctl;         // [32] zeroed by the launcher: [0] pairs written, [1] pairs lost (pair_cap too small), [8 + x] tile tickets of XCD x, [16..20] block 0's clock stamps
     uint32_t pair_cap;
+    uint32_t block_rows;        // persistent kernel: scanned rows per tile, 256 (default) or 128 (pair_filter_p_block_rows)
     void *ev_begin, *ev_end;    // optional hipEvent_t pair recorded around the GEMM kernel alone (256-tile and persistent kernels)
 };
 // live tiles of the symmetric pass in L2-friendly order (host side); tile = 128 rows
@@ -184,6 +185,8 @@ int launch_pair_filter256(const PairFilterArgs &a, hipStream_t stream);
 // persistent blocks, LDS ring running through the tile boundaries, hits handed over as pairs (allpairs_p.hip); scanned
 // rows = the shard's rows in order (tiled shadow both sides), dim % 64 == 0, dim >= 384
 bool pair_filter_p_supported(const PairFilterArgs &a);
+uint32_t pair_filter_p_block_rows();
+void pair_filter_p_tile_list(uint32_t n_rows, uint32_t bm, std::vector<uint32_t> &out);
 int launch_pair_filter_p(const PairFilterArgs &a, hipStream_t stream);
 int launch_pair_filter(const PairFilterArgs &a, hipStream_t stream);
 // scan sets of <= 64 rows (streaming ingest): scanned rows in registers, the shard's shadow streamed tile by tile
