@@ -219,15 +219,23 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
         CX_HIP(hipMemcpyAsync(ps.d_deleted, deleted, n_rows, hipMemcpyHostToDevice, s));
         d_deleted = ps.d_deleted;
     }
-    // existing edges of the scanned nodes: validated, each node's segment sorted (the rules kernel bisects it)
+    // existing edges of the scanned nodes: validated here; sorted per node (the rules kernel bisects a node's segment) and
+    // uploaded by stage_existing() below, AFTER the filter and the rescore are queued — the host's share of a rescan
+    // (4 ms of copying and sorting at 100k nodes) then runs beside the GPU's instead of in front of it, and the device does
+    // not idle (and clock down: tuning.md) between the passes of a cycle loop
     std::vector<uint32_t> exist_sorted;
+    bool exist_staged = false;
     if (cyc.existing_offsets) {
         const uint64_t *eo = cyc.existing_offsets;
         if (eo[0] != 0) return set_err(CX_ERR_VALIDATION, "autolink: existing_offsets[0] must be 0");
         for (uint32_t i = 0; i < n_scan; i++)
             if (eo[i + 1] < eo[i]) return set_err(CX_ERR_VALIDATION, "autolink: existing_offsets decrease at node %u", i);
+        if (eo[n_scan] && !cyc.existing_to) return set_err(CX_ERR_VALIDATION, "autolink: existing_to is null");
+    }
+    auto stage_existing = [&]() -> int {
+        if (!cyc.existing_offsets || exist_staged || dedup) return CX_OK;
+        const uint64_t *eo = cyc.existing_offsets;
         const uint64_t n_exist = eo[n_scan];
-        if (n_exist && !cyc.existing_to) return set_err(CX_ERR_VALIDATION, "autolink: existing_to is null");
         exist_sorted.assign(cyc.existing_to, cyc.existing_to + n_exist);
         for (uint32_t i = 0; i < n_scan; i++)
             if (eo[i + 1] - eo[i] > 1) std::sort(exist_sorted.begin() + eo[i], exist_sorted.begin() + eo[i + 1]);
@@ -235,7 +243,9 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
         if (int rc = ensure_dev(ps.d_exist_to, ps.c_exist_to, (size_t)std::max<uint64_t>(n_exist, 1))) return rc;
         CX_HIP(hipMemcpyAsync(ps.d_exist_off, eo, ((size_t)n_scan + 1) * 8, hipMemcpyHostToDevice, s));
         if (n_exist) CX_HIP(hipMemcpyAsync(ps.d_exist_to, exist_sorted.data(), (size_t)n_exist * 4, hipMemcpyHostToDevice, s));
-    }
+        exist_staged = true;
+        return CX_OK;
+    };
     if (int rc = ensure_dev(ps.d_list_rows, ps.c_list_rows, (size_t)n_scan * topk)) return rc;
     if (int rc = ensure_dev(ps.d_list_scores, ps.c_list_scores, (size_t)n_scan * topk)) return rc;
     if (int rc = ensure_dev(ps.d_list_cnt, ps.c_list_cnt, (size_t)n_scan)) return rc;
@@ -378,6 +388,8 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
         prof_bm = filter_bm;
         if (phase_ms && n_scan > chunk) CX_HIP(hipEventRecord(ev[2], s));  // multi-chunk: only the total is meaningful
         if (phase_ms) CX_HIP(hipEventRecord(ev[3], s));
+        if (!cyc.lists_only)
+            if (int rc = stage_existing()) return rc;   // host work under the queued filter + rescore (before any copy that waits for them)
         std::vector<uint32_t> of(n_scan);
         CX_HIP(hipMemcpyAsync(of.data(), ps.d_overflow, (size_t)n_scan * 4, hipMemcpyDeviceToHost, s));
         if (used_persist && n_scan <= chunk) CX_HIP(hipMemcpyAsync(&pairs_lost, ps.d_pair_ctl + 1, 4, hipMemcpyDeviceToHost, s));
@@ -416,6 +428,7 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
         return CX_OK;
     }
     // link rules: count, exclusive scan, emit
+    if (int rc = stage_existing()) return rc;   // (the exact-path-only passes come here without having staged it)
     if (int rc = ensure_dev(ps.d_counts, ps.c_counts, (size_t)n_scan)) return rc;
     if (int rc = ensure_dev(ps.d_offsets, ps.c_offsets, (size_t)n_scan)) return rc;
     const size_t tb = scan_temp_bytes(n_scan);
@@ -439,7 +452,86 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
     l.dedup = dedup ? 1u : 0u;
     l.threshold = threshold;
     l.counts = ps.d_counts;
+    // dedup.rs:85-87 is search_threshold: no k.  A scanned row whose list is full at topk with its tail still at or above
+    // the threshold ("dense": a cluster of more than topk near-duplicates) gets its COMPLETE list from the exact threshold
+    // path (dense keys + radix sort, what cx_search_threshold runs), the reference's walk over it on the host, and its
+    // pairs spliced into the device output at the row's offset — never CX_ERR_CAPACITY for data reasons.
+    std::vector<uint32_t> dense;                 // scan positions
+    std::vector<uint64_t> dense_src_off;         // CSR over the dense rows' pairs
+    std::vector<uint32_t> dense_to;
+    std::vector<float> dense_w;
+    if (dedup) {
+        std::vector<uint32_t> cnt(n_scan);
+        std::vector<float> tail(n_scan);
+        CX_HIP(hipMemcpyAsync(cnt.data(), ps.d_list_cnt, (size_t)n_scan * 4, hipMemcpyDeviceToHost, s));
+        CX_HIP(hipMemcpy2DAsync(tail.data(), 4, ps.d_list_scores + (topk - 1), (size_t)topk * 4, 4, n_scan, hipMemcpyDeviceToHost, s));   // ONE copy of the last column
+        CX_HIP(hipStreamSynchronize(s));
+        for (uint32_t i = 0; i < n_scan; i++)
+            if (cnt[i] >= topk && tail[i] >= threshold) dense.push_back(i);   // lists from the exact path are not thresholded: the tail decides
+    }
+    if (!dense.empty()) {
+        DevFilter flt;
+        memset(&flt, 0, sizeof flt);
+        flt.meta = ix->d_meta;
+        flt.agent = ix->d_agent;
+        RedoScratch &rs = ps.redo;
+        const uint32_t blk = (uint32_t)std::min<size_t>(64, dense.size());
+        if (int rc = ensure_dev(rs.d_vec, rs.c_vec, (size_t)blk * ix->dim)) return rc;
+        if (int rc = ensure_dev(rs.d_src, rs.c_src, (size_t)blk)) return rc;
+        if (int rc = ensure_dev(rs.d_rows, rs.c_rows, (size_t)n_rows)) return rc;
+        if (int rc = ensure_dev(rs.d_scores, rs.c_scores, (size_t)n_rows)) return rc;
+        if (int rc = ensure_dev(rs.d_dists, rs.c_dists, (size_t)n_rows)) return rc;
+        if (int rc = ensure_dev(rs.d_cnt, rs.c_cnt, (size_t)1)) return rc;
+        std::vector<uint32_t> src(blk), h_rows(n_rows);
+        std::vector<float> h_scores(n_rows);
+        dense_src_off.push_back(0);
+        for (size_t lo = 0; lo < dense.size(); lo += blk) {
+            const uint32_t m = (uint32_t)std::min<size_t>(blk, dense.size() - lo);
+            for (uint32_t t = 0; t < m; t++) src[t] = scan_rows ? scan_rows[dense[lo + t]] : dense[lo + t];
+            CX_HIP(hipMemcpyAsync(rs.d_src, src.data(), (size_t)m * 4, hipMemcpyHostToDevice, s));
+            if (int rc = (ix->dtype == 1 ? launch_gather_rows(ix->rows16(), rs.d_vec, rs.d_src, m, ix->dim, s) : launch_gather_rows(ix->d_rows, rs.d_vec, rs.d_src, m, ix->dim, s))) return rc;
+            for (uint32_t t = 0; t < m; t++) {
+                if (int rc = search_core(ix, c, rs.d_vec + (size_t)t * ix->dim, nullptr, 1, n_rows, flt, threshold, true, rs.d_rows, rs.d_scores,
+                                         rs.d_dists, rs.d_cnt, s))
+                    return rc;
+                uint32_t got = 0;
+                CX_HIP(hipMemcpyAsync(&got, rs.d_cnt, 4, hipMemcpyDeviceToHost, s));
+                CX_HIP(hipStreamSynchronize(s));
+                if (got > n_rows) return set_err(CX_ERR_DEVICE, "dedup: threshold list of %u entries in an index of %u rows", got, n_rows);
+                CX_HIP(hipMemcpyAsync(h_rows.data(), rs.d_rows, (size_t)got * 4, hipMemcpyDeviceToHost, s));
+                CX_HIP(hipMemcpyAsync(h_scores.data(), rs.d_scores, (size_t)got * 4, hipMemcpyDeviceToHost, s));
+                CX_HIP(hipStreamSynchronize(s));
+                const uint32_t self = src[t];
+                for (uint32_t r = 0; r < got; r++) {   // dedup.rs:89-113, as link_rules_kernel walks a list
+                    const uint32_t j = h_rows[r];
+                    if (j >= n_rows) return set_err(CX_ERR_DEVICE, "dedup: device list names row %u of %u", j, n_rows);
+                    if (j == self) continue;
+                    if (j < self && !(deleted && deleted[j])) continue;   // the pair was reported when j was scanned
+                    if (!(h_scores[r] >= threshold)) continue;
+                    dense_to.push_back(j);
+                    dense_w.push_back(h_scores[r]);
+                }
+                dense_src_off.push_back(dense_to.size());
+            }
+        }
+        // the dense rows' truncated lists emit nothing; their counts are the host's
+        if (int rc = ensure_dev(rs.d_pos, rs.c_pos, dense.size())) return rc;
+        CX_HIP(hipMemcpyAsync(rs.d_pos, dense.data(), dense.size() * 4, hipMemcpyHostToDevice, s));
+        if (int rc = launch_patch_u32(ps.d_list_cnt, rs.d_pos, nullptr, 0u, (uint32_t)dense.size(), s)) return rc;
+    }
     if (int rc = launch_link_rules(l, false, s)) return rc;
+    std::vector<uint32_t> dense_cnt(dense.size());
+    if (!dense.empty()) {
+        RedoScratch &rs = ps.redo;
+        for (size_t t = 0; t < dense.size(); t++) {
+            const uint64_t c64 = dense_src_off[t + 1] - dense_src_off[t];
+            if (c64 > 0xFFFFFFFFull) return set_err(CX_ERR_CAPACITY, "dedup: too many pairs for one row");
+            dense_cnt[t] = (uint32_t)c64;
+        }
+        if (int rc = ensure_dev(rs.d_cnt2, rs.c_cnt2, dense.size())) return rc;
+        CX_HIP(hipMemcpyAsync(rs.d_cnt2, dense_cnt.data(), dense.size() * 4, hipMemcpyHostToDevice, s));
+        if (int rc = launch_patch_u32(ps.d_counts, rs.d_pos, rs.d_cnt2, 0u, (uint32_t)dense.size(), s)) return rc;
+    }
     if (int rc = launch_exclusive_scan(ps.d_counts, ps.d_offsets, n_scan, ps.d_temp, tb, s)) return rc;
     uint64_t last_off = 0;
     uint32_t last_cnt = 0;
@@ -456,22 +548,32 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
         l.out_to = ps.d_to;
         l.out_weight = ps.d_w;
         if (int rc = launch_link_rules(l, true, s)) return rc;
+        if (!dense.empty() && !dense_to.empty()) {   // splice: segment t of (dense_to, dense_w) -> the output at offsets[dense[t]]
+            RedoScratch &rs = ps.redo;
+            std::vector<uint32_t> from_row(dense.size());
+            for (size_t t = 0; t < dense.size(); t++) from_row[t] = scan_rows ? scan_rows[dense[t]] : dense[t];
+            uint64_t *d_src_off = nullptr;
+            uint32_t *d_to_h = nullptr, *d_from_row = nullptr;
+            float *d_w_h = nullptr;
+            CX_HIP(hipMalloc((void **)&d_src_off, (dense.size() + 1) * 8));
+            CX_HIP(hipMalloc((void **)&d_from_row, dense.size() * 4));
+            CX_HIP(hipMalloc((void **)&d_to_h, dense_to.size() * 4));
+            CX_HIP(hipMalloc((void **)&d_w_h, dense_w.size() * 4));
+            hipError_t e1 = hipMemcpyAsync(d_src_off, dense_src_off.data(), (dense.size() + 1) * 8, hipMemcpyHostToDevice, s);
+            hipError_t e2 = hipMemcpyAsync(d_from_row, from_row.data(), dense.size() * 4, hipMemcpyHostToDevice, s);
+            hipError_t e3 = hipMemcpyAsync(d_to_h, dense_to.data(), dense_to.size() * 4, hipMemcpyHostToDevice, s);
+            hipError_t e4 = hipMemcpyAsync(d_w_h, dense_w.data(), dense_w.size() * 4, hipMemcpyHostToDevice, s);
+            int rc = (e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess && e4 == hipSuccess)
+                         ? launch_copy_edge_segments(ps.d_offsets, rs.d_pos, d_src_off, d_from_row, d_to_h, d_w_h, (uint32_t)dense.size(), ps.d_from,
+                                                     ps.d_to, ps.d_w, s)
+                         : set_err(CX_ERR_DEVICE, "dedup: staging the dense rows' pairs failed");
+            (void)hipStreamSynchronize(s);
+            (void)hipFree(d_src_off); (void)hipFree(d_from_row); (void)hipFree(d_to_h); (void)hipFree(d_w_h);
+            if (rc) return rc;
+        }
     }
     if (phase_ms) CX_HIP(hipEventRecord(ev[4], s));
     CX_HIP(hipStreamSynchronize(s));
-    if (dedup) {
-        // search_threshold has no k: a list that is full at topk may hide further neighbours above the threshold
-        std::vector<uint32_t> cnt(n_scan);
-        CX_HIP(hipMemcpy(cnt.data(), ps.d_list_cnt, (size_t)n_scan * 4, hipMemcpyDeviceToHost));
-        for (uint32_t i = 0; i < n_scan; i++) {
-            if (cnt[i] < topk) continue;
-            float last = 0.0f;  // lists from the exact path are not thresholded: full only matters if the tail still passes
-            CX_HIP(hipMemcpy(&last, ps.d_list_scores + (size_t)i * topk + (topk - 1), 4, hipMemcpyDeviceToHost));
-            if (last >= threshold)
-                return set_err(CX_ERR_CAPACITY, "dedup: row %u has %u or more neighbours above the threshold; "
-                               "scan it with cx_search_threshold", scan_rows ? scan_rows[i] : i, topk);
-        }
-    }
     if (phase_ms) {
         for (int p = 0; p < 4; p++) {
             float ms = 0.0f;

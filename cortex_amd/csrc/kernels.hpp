@@ -247,6 +247,13 @@ int launch_scatter_lists(const uint32_t *src_rows, const float *src_scores, cons
                          const uint32_t *d_pos, uint32_t n, uint32_t k_src, uint32_t k_dst, uint32_t *dst_rows,
                          float *dst_scores, float *dst_dists, uint32_t *dst_cnt, hipStream_t stream);
 
+// dst[d_idx[i]] = d_val ? d_val[i] : value, i < n
+int launch_patch_u32(uint32_t *dst, const uint32_t *d_idx, const uint32_t *d_val, uint32_t value, uint32_t n, hipStream_t stream);
+// edge segments t = 0 .. n_seg: (to, w)[src_off[t] .. src_off[t + 1]) -> out_* at dst_off[seg_pos[t]], out_from = from_row[t]
+int launch_copy_edge_segments(const uint64_t *d_dst_off, const uint32_t *d_seg_pos, const uint64_t *d_src_off, const uint32_t *d_from_row,
+                              const uint32_t *d_to, const float *d_w, uint32_t n_seg, uint32_t *out_from, uint32_t *out_to, float *out_w,
+                              hipStream_t stream);
+
 // |row|^2 of rows [row_lo, row_hi) -> norms[row] (one wave per row)
 int launch_row_norms(const float *rows, float *norms, uint32_t row_lo, uint32_t row_hi, uint32_t dim, hipStream_t stream);
 int launch_row_norms(const uint16_t *rows, float *norms, uint32_t row_lo, uint32_t row_hi, uint32_t dim, hipStream_t stream);

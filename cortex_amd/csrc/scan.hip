@@ -1289,4 +1289,39 @@ int launch_gather_rows(const float *src, uint16_t *dst, const uint32_t *d_src_ro
     return gather_rows_t(src, dst, d_src_rows, n_dst, dim, stream);
 }
 
+
+// dst[idx[i]] = val ? val[i] : value  (a handful of rows of a per-row array: the dedup pass's dense rows)
+__global__ void patch_u32_kernel(uint32_t *dst, const uint32_t *idx, const uint32_t *val, uint32_t value, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[idx[i]] = val ? val[i] : value;
+}
+int launch_patch_u32(uint32_t *dst, const uint32_t *d_idx, const uint32_t *d_val, uint32_t value, uint32_t n, hipStream_t stream) {
+    if (!n) return CX_OK;
+    hipLaunchKernelGGL(patch_u32_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, dst, d_idx, d_val, value, n);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+
+// segment t of (to, w) [src_off[t], src_off[t + 1]) -> out_* at dst_off[seg_pos[t]] ..., out_from = from_row[t]: one block per segment
+__global__ __launch_bounds__(256) void copy_edge_segments_kernel(const uint64_t *dst_off, const uint32_t *seg_pos, const uint64_t *src_off,
+                                                                 const uint32_t *from_row, const uint32_t *to, const float *w, uint32_t *out_from,
+                                                                 uint32_t *out_to, float *out_w) {
+    const uint32_t t = blockIdx.x;
+    const uint64_t lo = src_off[t], n = src_off[t + 1] - lo, base = dst_off[seg_pos[t]];
+    for (uint64_t e = threadIdx.x; e < n; e += blockDim.x) {
+        out_from[base + e] = from_row[t];
+        out_to[base + e] = to[lo + e];
+        out_w[base + e] = w[lo + e];
+    }
+}
+int launch_copy_edge_segments(const uint64_t *d_dst_off, const uint32_t *d_seg_pos, const uint64_t *d_src_off, const uint32_t *d_from_row,
+                              const uint32_t *d_to, const float *d_w, uint32_t n_seg, uint32_t *out_from, uint32_t *out_to, float *out_w,
+                              hipStream_t stream) {
+    if (!n_seg) return CX_OK;
+    hipLaunchKernelGGL(copy_edge_segments_kernel, dim3(n_seg), dim3(256), 0, stream, d_dst_off, d_seg_pos, d_src_off, d_from_row, d_to, d_w, out_from,
+                       out_to, out_w);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+
 }  // namespace cx

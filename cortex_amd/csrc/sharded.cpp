@@ -324,6 +324,33 @@ int hits_of(const cx_sharded *h, size_t s, const uint8_t *ids, const float *sc, 
 
 }  // namespace
 
+namespace {
+// every neighbour of the query with score >= threshold over all shards, best first (score desc, global row asc): the
+// shards' own threshold searches (count-then-fill, like any caller of cx_search_threshold) merged on the host
+int threshold_hits(const cx_sharded *h, const float *query, uint64_t len, float threshold, const cx_filter *filter, std::vector<Hit> &all) {
+    std::vector<std::vector<Hit>> parts;
+    if (int rc = fan_out_host(h, parts, [&](size_t s, std::vector<Hit> &out) -> int {
+            const cx_index *ix = h->shards[s];
+            if (cx_len(ix) == 0) return CX_OK;
+            uint64_t c = 256;
+            for (;;) {
+                std::vector<uint8_t> ids(16 * c);
+                std::vector<float> sc(c), di(c);
+                uint64_t n = 0, need = 0;
+                const int rc = cx_search_threshold(ix, query, len, threshold, filter, c, ids.data(), sc.data(), di.data(), &n, &need);
+                if (rc == CX_ERR_CAPACITY && need > c) { c = need; continue; }
+                if (rc) return rc;
+                return hits_of(h, s, ids.data(), sc.data(), di.data(), n, out);
+            }
+        }))
+        return rc;
+    all.clear();
+    for (auto &p : parts) all.insert(all.end(), p.begin(), p.end());
+    std::sort(all.begin(), all.end(), hit_better);
+    return CX_OK;
+}
+}  // namespace
+
 extern "C" {
 
 cx_sharded *cx_sharded_create(uint32_t dimension, uint32_t n_shards, const int *device_ids) {
@@ -556,25 +583,8 @@ int cx_sharded_search_threshold(const cx_sharded *h, const float *query, uint64_
     *n_out = 0;
     if (n_needed) *n_needed = 0;
     if (h->n_alive == 0) return CX_OK;
-    std::vector<std::vector<Hit>> parts;
-    if (int rc = fan_out_host(h, parts, [&](size_t s, std::vector<Hit> &out) -> int {
-            const cx_index *ix = h->shards[s];
-            if (cx_len(ix) == 0) return CX_OK;
-            uint64_t c = 256;
-            for (;;) {   // count-then-fill, like any caller of cx_search_threshold
-                std::vector<uint8_t> ids(16 * c);
-                std::vector<float> sc(c), di(c);
-                uint64_t n = 0, need = 0;
-                const int rc = cx_search_threshold(ix, query, len, threshold, filter, c, ids.data(), sc.data(), di.data(), &n, &need);
-                if (rc == CX_ERR_CAPACITY && need > c) { c = need; continue; }
-                if (rc) return rc;
-                return hits_of(h, s, ids.data(), sc.data(), di.data(), n, out);
-            }
-        }))
-        return rc;
     std::vector<Hit> all;
-    for (auto &p : parts) all.insert(all.end(), p.begin(), p.end());
-    std::sort(all.begin(), all.end(), hit_better);
+    if (int rc = threshold_hits(h, query, len, threshold, filter, all)) return rc;
     if (n_needed) *n_needed = all.size();
     const uint64_t take = std::min<uint64_t>(all.size(), cap);
     if (take && (!out_ids || !out_scores || !out_distances)) return set_err(CX_ERR_VALIDATION, "null output buffer");
@@ -770,6 +780,25 @@ int link_pass_sharded(const cx_sharded *h, const std::vector<uint32_t> &scan, co
             a.existing_offsets = root->d_exist_off;
             a.existing_to = root->d_exist_to;
         }
+        // dedup.rs:85-87 is search_threshold — no k: a merged list that is full at topk with its tail still at or above the
+        // threshold hides neighbours.  Such rows ("dense") emit nothing on the device; their complete lists come from the
+        // shards' threshold searches and are walked here (autolink.cpp does the same for one index).
+        std::vector<uint32_t> dense;   // positions in the block
+        if (dedup) {
+            std::vector<uint32_t> cnt(m);
+            std::vector<float> tail(m);
+            CX_HIP(hipMemcpyAsync(cnt.data(), L + 3 * n, (size_t)m * 4, hipMemcpyDeviceToHost, root->stream));
+            CX_HIP(hipMemcpy2DAsync(tail.data(), 4, reinterpret_cast<const float *>(L + n) + (topk - 1), (size_t)topk * 4, 4, m, hipMemcpyDeviceToHost,
+                                    root->stream));
+            CX_HIP(hipStreamSynchronize(root->stream));
+            for (uint32_t i = 0; i < m; i++)
+                if (cnt[i] >= topk && tail[i] >= threshold) dense.push_back(i);
+            if (!dense.empty()) {
+                if (int rc = ensure_dev(root->d_exist_to, root->c_exist_to, dense.size())) return rc;   // free in a dedup pass: the dense positions
+                CX_HIP(hipMemcpyAsync(root->d_exist_to, dense.data(), dense.size() * 4, hipMemcpyHostToDevice, root->stream));
+                if (int rc = launch_patch_u32(L + 3 * n, root->d_exist_to, nullptr, 0u, (uint32_t)dense.size(), root->stream)) return rc;
+            }
+        }
         if (int rc = launch_link_rules(a, false, root->stream)) return rc;
         if (int rc = launch_exclusive_scan(root->d_counts, root->d_offsets, m, root->d_temp, tb, root->stream)) return rc;
         uint64_t last_off = 0;
@@ -778,6 +807,7 @@ int link_pass_sharded(const cx_sharded *h, const std::vector<uint32_t> &scan, co
         CX_HIP(hipMemcpyAsync(&last_cnt, root->d_counts + (m - 1), 4, hipMemcpyDeviceToHost, root->stream));
         CX_HIP(hipStreamSynchronize(root->stream));
         const uint64_t n_edges = std::min<uint64_t>(last_off + last_cnt, a.max_total);
+        const size_t at = o_from.size();
         if (n_edges) {
             if (int rc = ensure_dev(root->d_from, root->c_from, (size_t)n_edges)) return rc;
             if (int rc = ensure_dev(root->d_to, root->c_to, (size_t)n_edges)) return rc;
@@ -787,7 +817,6 @@ int link_pass_sharded(const cx_sharded *h, const std::vector<uint32_t> &scan, co
             a.out_to = root->d_to;
             a.out_weight = root->d_w;
             if (int rc = launch_link_rules(a, true, root->stream)) return rc;
-            const size_t at = o_from.size();
             o_from.resize(at + n_edges); o_to.resize(at + n_edges); o_w.resize(at + n_edges);
             CX_HIP(hipMemcpyAsync(o_from.data() + at, root->d_from, n_edges * 4, hipMemcpyDeviceToHost, root->stream));
             CX_HIP(hipMemcpyAsync(o_to.data() + at, root->d_to, n_edges * 4, hipMemcpyDeviceToHost, root->stream));
@@ -799,16 +828,39 @@ int link_pass_sharded(const cx_sharded *h, const std::vector<uint32_t> &scan, co
                                    (unsigned long long)n_seq);
             emitted += n_edges;
         }
-        if (dedup) {   // search_threshold has no k: a list that is full at topk may hide neighbours above the threshold
-            std::vector<uint32_t> cnt(m);
-            CX_HIP(hipMemcpy(cnt.data(), L + 3 * n, (size_t)m * 4, hipMemcpyDeviceToHost));
+        if (!dense.empty()) {   // splice the dense rows' pairs into the block's edges, in scan order
+            std::vector<uint64_t> off(m);
+            CX_HIP(hipMemcpy(off.data(), root->d_offsets, (size_t)m * 8, hipMemcpyDeviceToHost));
+            std::vector<uint32_t> b_from(o_from.begin() + at, o_from.end()), b_to(o_to.begin() + at, o_to.end());
+            std::vector<float> b_w(o_w.begin() + at, o_w.end());
+            o_from.resize(at); o_to.resize(at); o_w.resize(at);
+            std::vector<float> vec(dim);
+            std::vector<Hit> all;
+            size_t di = 0;
             for (uint32_t i = 0; i < m; i++) {
-                if (cnt[i] < topk) continue;
-                float last = 0.0f;
-                CX_HIP(hipMemcpy(&last, reinterpret_cast<float *>(L + n) + (size_t)i * topk + (topk - 1), 4, hipMemcpyDeviceToHost));
-                if (last >= threshold)
-                    return set_err(CX_ERR_CAPACITY, "dedup: row %u has %u or more neighbours above the threshold; scan it with "
-                                   "cx_sharded_search_threshold", scan[lo + i], topk);
+                const uint64_t lo_e = off[i], hi_e = i + 1 < m ? off[i + 1] : b_from.size();
+                if (di < dense.size() && dense[di] == i) {
+                    di++;
+                    const uint32_t self = scan[lo + i], sh = h->seq_shard[self];
+                    const cx_index *ix = h->shards[sh];
+                    LinkShard &l = *ls[sh];
+                    CX_HIP(hipSetDevice(l.device));
+                    if (int rc = cx_copy_rows_dev(ix, h->seq_row[self], 1, l.d_q, l.stream)) return rc;
+                    CX_HIP(hipMemcpyAsync(vec.data(), l.d_q, (size_t)dim * 4, hipMemcpyDeviceToHost, l.stream));
+                    CX_HIP(hipStreamSynchronize(l.stream));
+                    CX_HIP(hipSetDevice(h->root));
+                    if (int rc = threshold_hits(h, vec.data(), dim, threshold, nullptr, all)) return rc;
+                    for (const Hit &x : all) {   // dedup.rs:89-113 as link_rules_kernel walks a list
+                        if (x.seq == self) continue;
+                        if (x.seq < self && !(deleted && deleted[x.seq])) continue;
+                        if (!(x.score >= threshold)) continue;
+                        o_from.push_back(self); o_to.push_back(x.seq); o_w.push_back(x.score);
+                    }
+                } else {
+                    o_from.insert(o_from.end(), b_from.begin() + lo_e, b_from.begin() + hi_e);
+                    o_to.insert(o_to.end(), b_to.begin() + lo_e, b_to.begin() + hi_e);
+                    o_w.insert(o_w.end(), b_w.begin() + lo_e, b_w.begin() + hi_e);
+                }
             }
         }
     }

@@ -77,13 +77,8 @@ while time.time() < t_end:
         assert all(pos[order[i]] <= pos[order[i + 1]] for i in range(len(order) - 1)), f"{what}: edges not in scan order"
         if rng.random() < 0.4:   # DedupScanner::scan (dedup.rs:65-127) over the same index
             dthr = float(np.float32(rng.choice([0.92, 0.85, 0.97])))
-            try:
-                pa, pb, psim = h.dedup_scan_rows(dthr, deleted)
-            except hip.CortexError as ce:
-                if "or more neighbours above the threshold" not in str(ce):
-                    raise
-                pa = None          # a row with >= 256 duplicates: the pass asks for cx_search_threshold, by contract
-            if pa is not None:
+            pa, pb, psim = h.dedup_scan_rows(dthr, deleted)   # no neighbour cap (dedup.rs:85-87): dense rows take the threshold path
+            if True:
                 wd = o.dedup_scan(np.float32(dthr), deleted)
                 got_p = {(int(x), int(y)): float(z) for x, y, z in zip(pa, pb, psim)}
                 exp_p = {(int(e["from_row"]), int(e["to_row"])): float(e["weight"]) for e in wd}

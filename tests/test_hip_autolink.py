@@ -230,6 +230,44 @@ def test_dedup_scan_matches_oracle(hip, oracle, n, d, thr):
             assert not np.any(deleted[a])                         # deleted nodes are never the scanning side
 
 
+def _with_duplicate_cluster(oracle, n, d, members, seed=21):
+    """synthetic rows with `members` near-copies of one vector spread over the store (a re-imported corpus, boilerplate nodes)"""
+    rows = oracle.synth_rows(n, d).copy()
+    rng = np.random.default_rng(seed)
+    where = np.sort(rng.choice(n, size=members, replace=False))
+    base = rows[where[0]].copy()
+    rows[where] = base[None, :] + rng.normal(0.0, 0.02 / np.sqrt(d), size=(members, d)).astype(np.float32)
+    rows[where[5]] = base                      # and one exact duplicate
+    return rows, where
+
+
+@pytest.mark.parametrize("n,d,members", [(1600, 384, 400), (900, 768, 300)])
+def test_dedup_scan_has_no_neighbour_cap(hip, oracle, n, d, members):
+    """dedup.rs:85-87 calls search_threshold: a node with more near-duplicates than the pass's lists are wide (256) still
+    reports every pair.  A cluster of 300-400 near-copies (~45k-80k pairs): pair for pair what cxo_dedup_scan reports."""
+    rows, where = _with_duplicate_cluster(oracle, n, d, members)
+    h, o, ids = build(hip, oracle, rows)
+    thr = float(np.float32(0.92))
+    rng = np.random.default_rng(4)
+    for deleted in (None, (rng.random(n) < 0.05).astype(np.uint8)):
+        a, b, s = h.dedup_scan_rows(thr, deleted)
+        e = o.dedup_scan(thr, deleted)
+        got = {(int(x), int(y)): float(z) for x, y, z in zip(a, b, s)}
+        exp = {(int(x), int(y)): float(z) for x, y, z in zip(e["from_row"], e["to_row"], e["weight"])}
+        assert len(exp) > members * (members - 1) // 2 * 0.8
+        for p in set(got) ^ set(exp):
+            sc = got.get(p, exp.get(p))
+            assert abs(sc - np.float32(thr)) <= SCORE_TOL, f"pair {p} score {sc} not a threshold tie"
+        for p in set(got) & set(exp):
+            assert abs(got[p] - exp[p]) <= SCORE_TOL
+        assert len(got) == len(a), "a pair was reported twice"
+        assert np.all(np.diff(a.astype(np.int64)) >= 0)          # scan (row) order
+        # inside one scanned row: best first, like search_threshold's list
+        for node in where[:3]:
+            sel = s[a == node]
+            assert np.all(np.diff(sel) <= 0)
+
+
 def test_linker_mirror_returns_reference_shaped_edges(hip, oracle):
     from cortex_amd import SimilarityConfig
     from cortex_amd.linker import autolink_similarity_edges, dedup_scan

@@ -179,6 +179,35 @@ def test_sharded_linker_passes_equal_single_index(hip, oracle, n, d, shards):
     assert len(b[0]) > 0 and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
 
 
+def test_sharded_dedup_has_no_neighbour_cap(hip, oracle):
+    """cx_sharded_dedup_scan_rows with a 400-row cluster of near-copies (more than the 256 a merged list holds): the same
+    pairs, in the same order, as one index over the same rows (dedup.rs:85-87 has no k), hence as the oracle."""
+    n, d, members = 3000, 384, 400
+    rows = oracle.synth_rows(n, d).copy()
+    rng = np.random.default_rng(21)
+    where = np.sort(rng.choice(n, size=members, replace=False))
+    rows[where] = rows[where[0]][None, :] + rng.normal(0.0, 0.02 / np.sqrt(d), size=(members, d)).astype(np.float32)
+    ids = ids_for(n)
+    one = hip.HipIndex(d); one.insert_batch(ids, rows)
+    sh = hip.ShardedHipIndex(d, [0, 0, 0]); sh.insert_batch(ids, rows)
+    thr = float(np.float32(0.92))
+    deleted = (rng.random(n) < 0.05).astype(np.uint8)
+    for dl in (None, deleted):
+        a = sh.dedup_scan_rows(thr, dl)
+        b = one.dedup_scan_rows(thr, dl)
+        assert len(b[0]) > members * (members - 1) // 2 * 0.8
+        assert np.array_equal(a[0], b[0])
+        # dense rows come from the shards' scan kernels, the others from the rescore kernel: same pairs, scores within the tolerance
+        pa = sorted(zip(a[0].tolist(), a[1].tolist())); pb = sorted(zip(b[0].tolist(), b[1].tolist()))
+        assert pa == pb
+        sa = dict(zip(zip(a[0].tolist(), a[1].tolist()), a[2].tolist())); sb = dict(zip(zip(b[0].tolist(), b[1].tolist()), b[2].tolist()))
+        assert max(abs(sa[k] - sb[k]) for k in sa) <= 5e-5
+    o = oracle.OracleIndex(d); o.insert_batch(ids, rows)
+    e = o.dedup_scan(thr, None)
+    g = sh.dedup_scan_rows(thr, None)
+    assert sorted(zip(g[0].tolist(), g[1].tolist())) == sorted(zip(e["from_row"].tolist(), e["to_row"].tolist()))
+
+
 def test_sharded_concurrent_readers_and_empty_shards(hip, oracle):
     d = 384
     sh = hip.ShardedHipIndex(d, [0, 0, 0, 0])
