@@ -127,7 +127,12 @@ __global__ __launch_bounds__(pp::Cfg<BM>::WAVES * 64, 2) void pair_filter_p_kern
     const uint64_t *hl = reinterpret_cast<const uint64_t *>(smem + HL_OFF);
 
     // this block's share of the tile order: XCD x (blocks x, x + 8, ... share one) owns a contiguous eighth
-    const uint32_t tiles_i = (a.n_scan + BM - 1) / BM, tiles_j = (a.n_rows + BN - 1) / BN;
+    // scanned row i is the shard's row scan_lo + i; tiles start at the 32-row boundary at or below scan_lo — the tiled
+    // shadow's pieces are 16 rows, but their 16-byte pieces are pre-swizzled with (row >> 3) & 3 of the GLOBAL row, which
+    // equals the LDS tile's own row bits only from a multiple of 32 — and the rows in front of scan_lo fall out with the
+    // `i < n_scan` test (unsigned wrap)
+    const uint32_t scan_shift = a.scan_lo % 32u, scan_blk0 = a.scan_lo / 32u * 2u;
+    const uint32_t tiles_i = (a.n_scan + scan_shift + BM - 1) / BM, tiles_j = (a.n_rows + BN - 1) / BN;
     const uint32_t T = a.symmetric ? a.n_tiles : tiles_i * tiles_j;
     const uint32_t xcd = blockIdx.x % 8u, local = blockIdx.x / 8u, per_xcd = gridDim.x / 8u;
     const uint32_t tq = T / 8u, tr = T % 8u;
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(pp::Cfg<BM>::WAVES * 64, 2) void pair_filter_p_kern
         d.i0 = ti * BM;
         d.j0 = tj * BN;
         // the tiled shadow is padded to whole 256-row tiles (ensure_shadow): no clamping of the last panel
-        d.A = reinterpret_cast<const char *>(a.shadow_t) + (size_t)(d.i0 / 16u + wave * NDA) * KT * 1024u;
+        d.A = reinterpret_cast<const char *>(a.shadow_t) + (size_t)(scan_blk0 + d.i0 / 16u + wave * NDA) * KT * 1024u;
         d.B = reinterpret_cast<const char *>(a.shadow_t) + (size_t)(d.j0 / 16u + wave * NDB) * KT * 1024u;
         return d;
     };
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(pp::Cfg<BM>::WAVES * 64, 2) void pair_filter_p_kern
         const bool mine = mxs[t] >= a.thr_lo;
         const unsigned long long bal = __ballot(mine);
         const uint32_t j = cur.j0 + wn * (NT * 32u) + (uint32_t)n * 32u + fr;
-        const uint32_t ibase = cur.i0 + wm * 128u + (uint32_t)m * 32u + 4u * fq;
+        const uint32_t ibase = cur.i0 + wm * 128u + (uint32_t)m * 32u + 4u * fq - scan_shift;   // scan position (wraps for the rows in front of scan_lo)
         if (mine) {
             const uint32_t slot = rec_base + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
             if (slot < REC_PER_WAVE) {
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(pp::Cfg<BM>::WAVES * 64, 2) void pair_filter_p_kern
         }
         if (!((s0 % REC_PER_WAVE) < c0) || (uint32_t)(hd0 >> 32) >= a.n_rows || lane >= REC_CAP) mask[0] = 0u;
         if (!((s1 % REC_PER_WAVE) < c1) || (uint32_t)(hd1 >> 32) >= a.n_rows || REC_CAP <= 64u) mask[1] = 0u;
-        if (a.n_scan - cur_i0 < (uint32_t)BM) {   // the last panel of scanned rows: rows beyond n_scan are not pairs
+        if (a.n_scan + scan_shift - cur_i0 < (uint32_t)BM || (scan_shift && cur_i0 == 0u)) {   // the first / last panel of scanned rows: rows outside [0, n_scan) are not pairs
 #pragma unroll
             for (int r = 0; r < 2; r++) {
                 const uint32_t ib = (uint32_t)(r ? hd1 : hd0);
@@ -491,7 +496,7 @@ __global__ __launch_bounds__(pp::Cfg<BM>::WAVES * 64, 2) void pair_filter_p_kern
         step(K0{}, g + kt, kt, cur, nxt, fa0, fb0, fa1, fb1);
         step(K2{}, g + kt + 1u, kt + 1u, cur, nxt, fa1, fb1, fa0, fb0);
         g += KT;
-        if constexpr (DIAG) { d1 = __builtin_readcyclecounter(); d2 = d1; c_main += d1 - d0; c_epi += d2 - d1; }
+        if constexpr (DIAG) { d1 = __builtin_readcyclecounter(); d2 = d1; c_main += d1 - d0; c_epi += d2 - d1; c_hook += (unsigned long long)__builtin_popcount(strips); }
         cur_i0 = cur.i0;
         if (!more) break;
         cur = nxt;
@@ -543,8 +548,10 @@ __global__ __launch_bounds__(256) void pair_scatter_kernel(const uint64_t *pairs
 }
 
 bool pair_filter_p_supported(const PairFilterArgs &a) {
-    // rows scanned in order from the tiled shadow; >= 12 K-steps (the hooks of a tile sit behind its steps 1, 3, 5 and 7)
-    return a.shadow_t && !a.shadow_q && !a.scan_rows && a.dim % 64u == 0 && a.dim >= 384u && a.pairs && a.pair_ctl && a.pair_cap;
+    // a contiguous range of the shard's rows scanned in order from the tiled shadow; >= 12 K-steps (the hooks of a tile sit
+    // behind its steps 1, 3, 5 and 7)
+    return a.shadow_t && !a.shadow_q && (!a.scan_rows || a.scan_contig) && (uint64_t)a.scan_lo + a.n_scan <= a.n_rows && a.dim % 64u == 0 &&
+           a.dim >= 384u && a.pairs && a.pair_ctl && a.pair_cap;
 }
 
 template <int BM, bool DYN, bool DIAG = false, int ARM = 0>
@@ -576,8 +583,8 @@ static int launch_p_diag(const PairFilterArgs &a, uint32_t grid, bool dyn, hipSt
     double s[6] = {0, 0, 0, 0, 0, 0};
     for (size_t w = 0; w < (size_t)grid * 8; w++) for (int p = 0; p < 6; p++) s[p] += (double)h[w * 8 + p];
     const double nt = s[4] > 0 ? s[4] : 1.0;   // wave-tiles
-    fprintf(stderr, "[pair_p diag] %.0f wave-tiles; cycles per tile and wave: K loop %.0f (counted waits %.0f, barriers %.0f)\n",
-            nt, s[0] / nt, s[2] / nt, s[3] / nt);
+    fprintf(stderr, "[pair_p diag] %.0f wave-tiles, %.0f 32x32 tiles with a hit; cycles per tile and wave: K loop %.0f (counted waits %.0f, barriers %.0f)\n",
+            nt, s[5], s[0] / nt, s[2] / nt, s[3] / nt);
     return CX_OK;
 }
 
@@ -621,7 +628,7 @@ int launch_pair_filter_p(const PairFilterArgs &a, hipStream_t stream) {
     const uint32_t bm = 256u;
     if (a.symmetric && (!a.tile_list || (a.n_rows + bm - 1) / bm > 0xFFFFu))
         return set_err(CX_ERR_VALIDATION, "persistent pair filter: symmetric pass needs a tile list");
-    const uint64_t tiles = a.symmetric ? a.n_tiles : (uint64_t)((a.n_scan + bm - 1) / bm) * ((a.n_rows + 255u) / 256u);
+    const uint64_t tiles = a.symmetric ? a.n_tiles : (uint64_t)((a.n_scan + a.scan_lo % 32u + bm - 1) / bm) * ((a.n_rows + 255u) / 256u);
     if (tiles > 0x7FFFFFFFull) return set_err(CX_ERR_VALIDATION, "persistent pair filter: too many tiles");
     CX_HIP(hipMemsetAsync(a.pair_ctl, 0, 128, stream));
     if (int rc = launch_cfg<256>(a, stream)) return rc;

@@ -303,6 +303,17 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
                 f.pair_ctl = ps.d_pair_ctl;
                 f.pair_cap = (uint32_t)pair_cap;
                 f.block_rows = pair_filter_p_block_rows();
+                // the scanned rows as a range of the shard: all of them, or a run of consecutive rows (an ingest tick's batch)
+                f.scan_lo = 0;
+                f.scan_contig = 0;
+                if (scan_rows) {
+                    bool run = true;
+                    for (uint32_t i = 1; i < m && run; i++) run = scan_rows[lo + i] == scan_rows[lo] + i;
+                    if (run) { f.scan_lo = scan_rows[lo]; f.scan_contig = 1; }
+                } else {
+                    f.scan_lo = lo;
+                    f.scan_contig = 1;   // (a later chunk's materialised identity rows are exactly this range)
+                }
                 persist = pair_filter_p_supported(f);
             }
             const uint32_t tile_kind = !big ? 0u : (persist ? f.block_rows : 256u);   // which tile list: 128^2 kernel, or bm x 256 tiles
@@ -351,7 +362,7 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
                 filter_kind = big ? 0 : 2;
             }
             filter_bm = persist ? f.block_rows : 256u;
-            if (lo == 0) filter_tiles = f.symmetric ? f.n_tiles : (uint64_t)((m + filter_bm - 1u) / filter_bm) * ((n_rows + 255u) / 256u);
+            if (lo == 0) filter_tiles = f.symmetric ? f.n_tiles : (uint64_t)((m + (persist ? f.scan_lo % 32u : 0u) + filter_bm - 1u) / filter_bm) * ((n_rows + 255u) / 256u);
             if (phase_ms && lo == 0) CX_HIP(hipEventRecord(ev[2], s));
             RescoreArgs r;
             memset(&r, 0, sizeof r);

@@ -174,6 +174,9 @@ struct PairFilterArgs {
     uint64_t *pairs;            // [pair_cap]
     uint32_t *pair_ctl;         // [32] zeroed by the launcher: [0] pairs written, [1] pairs lost (pair_cap too small), [8 + x] tile tickets of XCD x, [16..20] block 0's clock stamps
     uint32_t pair_cap;
+    uint32_t scan_lo;           // persistent kernel: the scanned rows are the shard's rows scan_lo .. scan_lo + n_scan in order (0 with
+                                // scan_rows == null; with scan_contig set, scan_rows[i] == scan_lo + i and the kernel ignores the array)
+    uint32_t scan_contig;
     uint32_t block_rows;        // persistent kernel: scanned rows per tile, 256 (default) or 128 (pair_filter_p_block_rows)
     void *ev_begin, *ev_end;    // optional hipEvent_t pair recorded around the GEMM kernel alone (256-tile and persistent kernels)
 };

@@ -469,6 +469,21 @@ def test_persistent_filter_kernel_equals_the_per_tile_kernel(hip, oracle, monkey
             e = o.autolink_pass(np.arange(n), 100, thr32, 50, n_threads=8)
             compare_edges(per_node(*got), per_node(e["from_row"], e["to_row"], e["weight"]), thr32, oracle_scores(o, rows),
                           f"persistent n={n}")
+        # a run of consecutive rows (an ingest tick's batch) is a range of the tiled shadow too: starts that are not on a
+        # 32-row boundary (the swizzle period of the tiled shadow), in an odd 16-row block, and a range that ends the store
+        for lo_s, m_s in ((1003, 700), (n - 533, 533), (16 * 77, 300)):
+            scan = np.arange(lo_s, lo_s + m_s, dtype=np.uint32)
+            monkeypatch.setenv("CX_PAIR_PERSIST", "0")
+            ref = h.autolink_pass_rows(scan, 100, thr32, 50)
+            monkeypatch.setenv("CX_PAIR_PERSIST", "1")
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            got = h.autolink_pass_rows(scan, 100, thr32, 50)
+            for k in env:
+                monkeypatch.delenv(k)
+            assert len(ref[0]) > 100
+            for a, b in zip(got, ref):
+                assert np.array_equal(a, b), f"range scan [{lo_s}, {lo_s + m_s}) n={n} d={d} thr={thr} env={env}"
 
 
 def test_removed_rows_are_not_scanned(hip, oracle):

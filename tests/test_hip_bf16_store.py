@@ -146,6 +146,46 @@ def test_autolink_pass_on_rounded_rows(hip, oracle, n, d):
     assert abs(len(a) - len(ed)) <= max(2, len(ed) // 200)   # pairs within SCORE_TOL of the threshold may differ
 
 
+@pytest.mark.parametrize("batch", [64, 500])
+def test_streaming_ingest_tick_links_the_appended_rows(hip, oracle, batch):
+    """BASELINE configs[4] as the reference runs it (auto_linker.rs:378-398 -> :220-221): a batch of NEW rows is inserted
+    into a bf16 store (cx_upsert_batch_dev: rounded once, on the device), the shadow and its tiled copy grow by exactly
+    those rows, and the pass links exactly those rows against the whole store — their own batch included.  Edges must be
+    the reference's for the rounded vectors.  64 rows take the streaming filter kernel, 500 the 256-tile kernel; two
+    ticks in a row, with an in-place upsert of an old row between them (the shadow's stale list)."""
+    import torch
+    from test_hip_autolink import compare_edges, oracle_scores, per_node
+    n0, d = 3000, 1024
+    allrows = oracle.synth_rows(n0 + 2 * batch, d)
+    ids = ids_for(n0 + 2 * batch)
+    h = hip.HipIndex(d, dtype="bf16")
+    h.reserve(n0 + 2 * batch)
+    h.insert_batch(ids[:n0], allrows[:n0])
+    o = oracle.OracleIndex(d)
+    o.insert_batch(ids[:n0], bf16_round(allrows[:n0]))
+    thr = float(np.float32(0.85))
+    h.autolink_pass_rows(np.arange(n0 - 64, n0, dtype=np.uint32), 100, thr, 50)       # the shadow exists before the ticks
+    lo = n0
+    for tick in range(2):
+        new = allrows[lo:lo + batch]
+        dev = torch.from_numpy(new).to("cuda:0")
+        h.insert_batch_dev(ids[lo:lo + batch], dev.data_ptr(), batch, d)
+        o.insert_batch(ids[lo:lo + batch], bf16_round(new))
+        scan = np.arange(lo, lo + batch, dtype=np.uint32)
+        fr, to, w = h.autolink_pass_rows(scan, 100, thr, 50)
+        e = o.autolink_pass(scan, 100, thr, 50, n_threads=8)
+        got, exp = per_node(fr, to, w), per_node(e["from_row"], e["to_row"], e["weight"])
+        assert len(exp) > 0 and set(got) <= set(int(x) for x in scan)
+        compare_edges(got, exp, thr, oracle_scores(o, bf16_round(allrows[:lo + batch])), f"ingest tick {tick} batch {batch}")
+        assert any(int(t) >= lo for t in to), "no edge inside the new batch: the pass did not see the appended rows as neighbours"
+        lo += batch
+        if tick == 0:     # an old row changes in place: its shadow row (and tiled copy) must be refreshed before the next tick
+            allrows[7] = allrows[lo + 3] * np.float32(1.5)      # now a near-copy of a row of the NEXT batch
+            h.insert(ids[7].tobytes(), allrows[7])
+            o.insert(ids[7].tobytes(), bf16_round(allrows[7:8])[0])
+    assert 7 in set(int(t) for t in to), "the upserted row is not a neighbour of its near-copy: stale shadow"
+
+
 def test_save_load_round_trip(hip, oracle, tmp_path):
     n, d = 1500, 384
     rows = oracle.synth_rows(n, d)
