@@ -297,7 +297,10 @@ __global__ __launch_bounds__(256, 2) void batchg_kernel(const BatchGArgs a) {
         const uint32_t q = (uint32_t)g * 16u + j;
         nqv[g] = sqrtf(q < a.nq ? a.qq[q] : 1.0f);
         tauv[g] = (FILTER && q < a.nq) ? a.tau_ord[q] : 0u;
-        thrv[g] = tauv[g] > 1u ? __uint_as_float(tauv[g] - 2u) - 1e-4f : -__builtin_inff();   // bound 0 / NaN: every pair is a candidate
+        // no bound (0), NaN (1) or a sampled k-th best of 0.0 (2: the clamp of a non-positive cosine): every pair is a candidate.
+        // With a bound of 0.0 a cut at dot < -1e-4 |q||r| dropped rows whose score also clamps to 0.0 — equal to the bound,
+        // legitimate under (score desc, row asc) — so ties at 0 could resolve differently from the scan paths (round-2 ADVICE)
+        thrv[g] = tauv[g] > 2u ? __uint_as_float(tauv[g] - 2u) - 1e-4f : -__builtin_inff();
     }
     const __attribute__((address_space(4))) float *norms_c = (const __attribute__((address_space(4))) float *)a.norms;
     auto epilogue = [&](uint32_t tile) {

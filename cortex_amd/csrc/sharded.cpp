@@ -13,6 +13,9 @@
 //             pinned host memory, one host wait.
 // No ring, no collective library: the exchange is P small posted writes (the payload is latency-bound).
 // The multi-PROCESS variant (one rank per GPU, RCCL all-gather) is cortex_amd/sharded.py, used by bench.py.
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <memory>
 #include <thread>
 
@@ -63,6 +66,7 @@ struct LinkShard {
     float *d_q = nullptr;                                  // [LINK_BLOCK][dim] the block's vectors on this device
     uint32_t *d_rows = nullptr, *d_cnt = nullptr, *d_src = nullptr, *d_pos = nullptr;
     float *d_scores = nullptr, *d_dists = nullptr;
+    size_t c_q = 0, c_rows = 0, c_cnt = 0, c_src = 0, c_pos = 0, c_scores = 0, c_dists = 0;
     ~LinkShard() {
         (void)hipSetDevice(device);
         (void)hipFree(d_q); (void)hipFree(d_rows); (void)hipFree(d_cnt); (void)hipFree(d_src); (void)hipFree(d_pos);
@@ -71,6 +75,67 @@ struct LinkShard {
         if (done) (void)hipEventDestroy(done);
         if (stream) (void)hipStreamDestroy(stream);
     }
+};
+// The per-shard streams and scratch of one linker pass.  They live in the handle's pool, not in the call: every shard
+// index keeps one Ctx (with its device scratch) per stream handle it has been called on until cx_destroy, so a fresh
+// stream per pass — once per linker cycle in a long-running server — leaked HBM without bound (round-2 ADVICE).
+struct LinkSet {
+    std::vector<std::unique_ptr<LinkShard>> ls;
+};
+
+// One enqueue thread per shard, alive as long as the handle: a search's per-shard work (query upload, filter, kernel
+// launches, publish — ~10 us of host time each) is queued on all shards at once instead of one shard after the other
+// from the caller's thread (8 shards: 80 us in front of a 0.5 ms scan).  Callers (`&self`, concurrent) push one job per
+// shard and wait for their own jobs; a worker runs the jobs of its shard in arrival order.
+class ShardWorkers {
+public:
+    explicit ShardWorkers(size_t n) : q_(n) {
+        for (size_t s = 0; s < n; s++) th_.emplace_back([this, s] { loop(s); });
+    }
+    ~ShardWorkers() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    // runs job(s) for every s in [0, n) on shard s's thread; returns when all are done
+    void run_all(size_t n, const std::function<void(size_t)> &job) {
+        struct Latch { std::mutex m; std::condition_variable c; size_t left; } latch;
+        latch.left = n;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            for (size_t s = 0; s < n; s++)
+                q_[s].push_back([&job, &latch, s] {
+                    job(s);
+                    std::lock_guard<std::mutex> g2(latch.m);
+                    if (--latch.left == 0) latch.c.notify_one();
+                });
+        }
+        cv_.notify_all();
+        std::unique_lock<std::mutex> l(latch.m);
+        latch.c.wait(l, [&] { return latch.left == 0; });
+    }
+private:
+    void loop(size_t s) {
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> l(mu_);
+                cv_.wait(l, [&] { return stop_ || !q_[s].empty(); });
+                if (q_[s].empty()) return;
+                f = std::move(q_[s].front());
+                q_[s].pop_front();
+            }
+            f();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<std::deque<std::function<void()>>> q_;
+    std::vector<std::thread> th_;
+    bool stop_ = false;
 };
 
 }  // namespace
@@ -95,6 +160,8 @@ struct cx_sharded {
     std::vector<size_t> c_gseq, n_gseq_up;       // capacity / rows uploaded
     mutable std::mutex mu;
     mutable std::vector<RootCtx *> pool;
+    mutable std::vector<LinkSet *> link_pool;   // streams + scratch of the linker passes (as many sets as passes ever ran at once)
+    mutable std::unique_ptr<ShardWorkers> workers;   // per-shard enqueue threads (created with the handle when it has more than one shard)
 };
 
 namespace {
@@ -179,35 +246,52 @@ int upsert_impl(cx_sharded *h, uint64_t n, const uint8_t *ids, const float *embs
         const uint64_t room = h->block - h->n_fresh % h->block;
         const uint64_t run_start = i;
         const uint64_t first_row = cx_row_count(h->shards[s]);
+        // The run of new ids that goes to shard s: found WITHOUT touching the handle, committed only for the rows the shard
+        // then holds.  (Round-2 ADVICE: bookkeeping written before a shard call that failed — a hipMalloc in grow_rows is
+        // enough — left ids live in the handle but absent from the shard, and the retry appended rows d_gseq did not cover.)
+        std::unordered_map<IdKey, uint64_t, IdHash> in_run;
         while (i < n && i - run_start < room) {
             const IdKey kk = id_key(ids + 16 * i);
-            if (h->map.find(kk) != h->map.end()) break;    // a known id, or a repeat inside this run
-            const uint32_t seq = (uint32_t)h->seq_shard.size();
-            h->map.emplace(kk, seq);
-            h->seq_ids.insert(h->seq_ids.end(), ids + 16 * i, ids + 16 * i + 16);
-            h->seq_shard.push_back((uint32_t)s);
-            h->seq_row.push_back((uint32_t)(first_row + (i - run_start)));
-            h->seq_alive.push_back(1);
-            h->h_gseq[s].push_back(seq);
-            h->n_alive++;
-            h->n_fresh++;
-            if (!h->pending_meta.empty()) {     // metadata that arrived before the vector: hand it to the shard first
+            if (h->map.find(kk) != h->map.end() || in_run.count(kk)) break;    // a known id, or a repeat inside this run
+            in_run.emplace(kk, i);
+            if (!h->pending_meta.empty()) {     // metadata that arrived before the vector: the shard keeps it pending until the row exists
                 auto pm = h->pending_meta.find(kk);
-                if (pm != h->pending_meta.end()) {
-                    (void)cx_set_metadata(h->shards[s], ids + 16 * i, pm->second.first, pm->second.second);
-                    h->pending_meta.erase(pm);
-                }
+                if (pm != h->pending_meta.end()) (void)cx_set_metadata(h->shards[s], ids + 16 * i, pm->second.first, pm->second.second);
             }
             i++;
         }
         const uint64_t m = i - run_start;
-        rc = on_device ? cx_upsert_batch_dev(h->shards[s], m, ids + 16 * run_start, embs + run_start * len, len)
-                       : cx_upsert_batch(h->shards[s], m, ids + 16 * run_start, embs + run_start * len, len);
-        if (rc == CX_OK && cx_row_count(h->shards[s]) != first_row + m)
-            rc = set_err(CX_ERR_DEVICE, "sharded: shard %zu holds %llu rows after an append of %llu to %llu", s,
-                         (unsigned long long)cx_row_count(h->shards[s]), (unsigned long long)m, (unsigned long long)first_row);
+        static const long fail_at = getenv("CX_SHARD_FAIL_UPSERT") ? atol(getenv("CX_SHARD_FAIL_UPSERT")) : -1;   // fault injection (tests): the N-th shard append fails
+        static std::atomic<long> appends{0};
+        if (fail_at >= 0 && appends.fetch_add(1) == fail_at) rc = set_err(CX_ERR_DEVICE, "injected failure of a shard append (CX_SHARD_FAIL_UPSERT)");
+        else
+            rc = on_device ? cx_upsert_batch_dev(h->shards[s], m, ids + 16 * run_start, embs + run_start * len, len)
+                           : cx_upsert_batch(h->shards[s], m, ids + 16 * run_start, embs + run_start * len, len);
+        const uint64_t now = cx_row_count(h->shards[s]);
+        const uint64_t held = now >= first_row ? std::min<uint64_t>(now - first_row, m) : 0;   // all of them, or what a failed call got as far as
+        for (uint64_t t = 0; t < held; t++) {
+            const uint64_t src = run_start + t;
+            const IdKey kk = id_key(ids + 16 * src);
+            const uint32_t seq = (uint32_t)h->seq_shard.size();
+            h->map.emplace(kk, seq);
+            h->seq_ids.insert(h->seq_ids.end(), ids + 16 * src, ids + 16 * src + 16);
+            h->seq_shard.push_back((uint32_t)s);
+            h->seq_row.push_back((uint32_t)(first_row + t));
+            h->seq_alive.push_back(1);
+            h->h_gseq[s].push_back(seq);
+            h->n_alive++;
+            h->n_fresh++;
+            h->pending_meta.erase(kk);
+        }
+        if (rc == CX_OK && now != first_row + m)
+            rc = set_err(CX_ERR_DEVICE, "sharded: shard %zu holds %llu rows after an append of %llu to %llu", s, (unsigned long long)now,
+                         (unsigned long long)m, (unsigned long long)first_row);
     }
-    for (size_t s = 0; s < P && rc == CX_OK; s++) rc = upload_gseq(h, s);
+    // the device copies of the row maps cover every row a shard holds, also when the call fails half way
+    for (size_t s = 0; s < P; s++) {
+        const int rc2 = upload_gseq(h, s);
+        if (rc == CX_OK) rc = rc2;
+    }
     return rc;
 }
 
@@ -249,36 +333,66 @@ int search_device_path(const cx_sharded *h, RootCtx *root, uint64_t nq, const fl
     uint32_t *gather = h->p2p ? root->d_gather : root->h_gather;
     if (int rc = ensure_host_block(root, nq, k, hb)) return rc;
     std::vector<std::unique_ptr<CtxLease>> leases(P);
-    for (size_t s = 0; s < P; s++) {
-        const cx_index *ix = h->shards[s];
-        uint32_t *part = gather + s * words;
-        if (ix->n_rows == 0) {   // an empty shard contributes empty lists
-            CX_HIP(hipSetDevice(h->root));
-            if (h->p2p) CX_HIP(hipMemsetAsync(part + 3 * nq * k, 0, nq * 4, root->stream));
-            else memset(part + 3 * nq * k, 0, nq * 4);
-            continue;
+    // whatever a failed call left queued on the shard streams writes into the root's pooled gather buffer: it must have
+    // finished before the leases (and the root's) go back to their pools (round-2 ADVICE)
+    struct DrainOnError {
+        std::vector<std::unique_ptr<CtxLease>> &l;
+        bool armed = true;
+        ~DrainOnError() {
+            if (!armed) return;
+            for (auto &x : l)
+                if (x && x->c) { (void)hipSetDevice(x->ix->device); (void)hipStreamSynchronize(x->c->stream); }
         }
-        if (int rc = use_device(ix)) return rc;
-        leases[s].reset(new CtxLease(ix));
-        Ctx *c = leases[s]->c;
-        if (!c) return CX_ERR_DEVICE;
-        const uint32_t k_eff = (uint32_t)std::min<uint64_t>(k, ix->n_rows);
-        std::vector<float> tails;
-        if (int rc = stage_queries(ix, c, nq, queries, len, tails)) return rc;
-        FilterUpload fu;
-        if (int rc = build_filter(ix, c, filter, c->stream, fu)) return rc;
-        const size_t entries = (size_t)nq * k_eff, cpad = (size_t)((nq + 3) / 4 * 4);
-        if (int rc = ensure_dev(c->d_out_rows, c->or_cap, cpad + 3 * entries)) return rc;
-        uint32_t *l_counts = c->d_out_rows, *l_rows = c->d_out_rows + cpad;
-        float *l_scores = reinterpret_cast<float *>(l_rows + entries), *l_dists = l_scores + entries;
-        if (int rc = search_core(ix, c, c->d_query, tails.data(), nq, k_eff, fu.f, 0.0f, false, l_rows, l_scores, l_dists, l_counts,
-                                 c->stream))
-            return rc;
-        if (int rc = launch_publish_part(l_rows, l_scores, l_dists, l_counts, h->d_gseq[s], (uint32_t)nq, k_eff, k,
-                                         (uint32_t)ix->n_rows, part, c->stream))
-            return rc;
-        CX_HIP(hipEventRecord(root->ev[s], c->stream));
+    } drain{leases};
+    std::vector<int> rcs(P, CX_OK);
+    std::vector<std::string> msgs(P);
+    auto enqueue = [&](size_t s) {   // everything one shard contributes, queued on its own stream
+        auto body = [&]() -> int {
+            const cx_index *ix = h->shards[s];
+            uint32_t *part = gather + s * words;
+            if (ix->n_rows == 0) {   // an empty shard contributes empty lists
+                if (!h->p2p) { memset(part + 3 * nq * k, 0, nq * 4); return CX_OK; }
+                CX_HIP(hipSetDevice(h->root));
+                CX_HIP(hipMemsetAsync(part + 3 * nq * k, 0, nq * 4, root->stream));
+                return CX_OK;
+            }
+            if (int rc = use_device(ix)) return rc;
+            leases[s].reset(new CtxLease(ix));
+            Ctx *c = leases[s]->c;
+            if (!c) return CX_ERR_DEVICE;
+            const uint32_t k_eff = (uint32_t)std::min<uint64_t>(k, ix->n_rows);
+            std::vector<float> tails;
+            if (int rc = stage_queries(ix, c, nq, queries, len, tails)) return rc;
+            FilterUpload fu;
+            if (int rc = build_filter(ix, c, filter, c->stream, fu)) return rc;
+            const size_t entries = (size_t)nq * k_eff, cpad = (size_t)((nq + 3) / 4 * 4);
+            if (int rc = ensure_dev(c->d_out_rows, c->or_cap, cpad + 3 * entries)) return rc;
+            uint32_t *l_counts = c->d_out_rows, *l_rows = c->d_out_rows + cpad;
+            float *l_scores = reinterpret_cast<float *>(l_rows + entries), *l_dists = l_scores + entries;
+            if (int rc = search_core(ix, c, c->d_query, tails.data(), nq, k_eff, fu.f, 0.0f, false, l_rows, l_scores, l_dists, l_counts,
+                                     c->stream))
+                return rc;
+            if (int rc = launch_publish_part(l_rows, l_scores, l_dists, l_counts, h->d_gseq[s], (uint32_t)nq, k_eff, k,
+                                             (uint32_t)ix->n_rows, part, c->stream))
+                return rc;
+            CX_HIP(hipEventRecord(root->ev[s], c->stream));
+            return CX_OK;
+        };
+        try {
+            rcs[s] = body();
+            if (rcs[s] != CX_OK) msgs[s] = err_buf();   // the message is thread-local: carry it out
+        } catch (...) { rcs[s] = on_exception(); msgs[s] = err_buf(); }
+    };
+    // empty shards touch the root stream: keep those on this thread; the others go to their shards' enqueue threads
+    if (h->workers) {
+        h->workers->run_all(P, [&](size_t s) { if (h->shards[s]->n_rows) enqueue(s); });
+        for (size_t s = 0; s < P; s++)
+            if (!h->shards[s]->n_rows) enqueue(s);
+    } else {
+        for (size_t s = 0; s < P; s++) enqueue(s);
     }
+    for (size_t s = 0; s < P; s++)
+        if (rcs[s] != CX_OK) return set_err(rcs[s], "%s", msgs[s].c_str());
     CX_HIP(hipSetDevice(h->root));
     for (size_t s = 0; s < P; s++)
         if (leases[s]) CX_HIP(hipStreamWaitEvent(root->stream, root->ev[s], 0));
@@ -288,6 +402,7 @@ int search_device_path(const cx_sharded *h, RootCtx *root, uint64_t nq, const fl
                                         hb.counts, root->stream))
         return rc;
     CX_HIP(hipStreamSynchronize(root->stream));   // the shard streams are behind it (event waits): their leases may go back
+    drain.armed = false;
     return check_result_block(hb.counts, hb.rows, nq, k, k, h->seq_shard.size());
 }
 
@@ -387,12 +502,16 @@ cx_sharded *cx_sharded_create_ex(uint32_t dimension, uint32_t n_shards, const in
             if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) h->p2p = false;
             (void)hipGetLastError();
         }
+    if (h->shards.size() > 1 && !(getenv("CX_SHARD_ENQUEUE_THREADS") && atoi(getenv("CX_SHARD_ENQUEUE_THREADS")) == 0))
+        h->workers.reset(new ShardWorkers(h->shards.size()));
     return h.release();
 } catch (...) { cx::on_exception(); return nullptr; }
 
 void cx_sharded_destroy(cx_sharded *h) {
     if (!h) return;
+    h->workers.reset();
     for (RootCtx *c : h->pool) delete c;
+    for (LinkSet *l : h->link_pool) delete l;
     for (size_t s = 0; s < h->shards.size(); s++) {
         (void)hipSetDevice(h->devices[s]);
         (void)hipFree(h->d_gseq[s]);
@@ -424,10 +543,11 @@ int cx_sharded_remove(cx_sharded *h, const uint8_t id[16]) try {
     auto it = h->map.find(id_key(id));
     if (it == h->map.end()) return CX_OK;
     const uint32_t seq = it->second;
+    if (int rc = cx_remove(h->shards[h->seq_shard[seq]], id)) return rc;   // the shard first: a failure leaves the handle as it was
     h->map.erase(it);
     h->seq_alive[seq] = 0;
     h->n_alive--;
-    return cx_remove(h->shards[h->seq_shard[seq]], id);
+    return CX_OK;
 } catch (...) { return cx::on_exception(); }
 
 int cx_sharded_set_metadata(cx_sharded *h, const uint8_t id[16], uint32_t kind_code, uint32_t agent_code) try {
@@ -627,23 +747,46 @@ int link_pass_sharded(const cx_sharded *h, const std::vector<uint32_t> &scan, co
     if (!root) return CX_ERR_DEVICE;
     const uint32_t blk = (uint32_t)std::min<size_t>(LINK_BLOCK, scan.size());
     const size_t words = part_words(blk, topk);
-    // per-shard scratch of this call
-    std::vector<std::unique_ptr<LinkShard>> ls(P);
+    // per-shard streams and scratch: a set from the handle's pool (grow-only)
+    struct LinkLease {
+        const cx_sharded *h;
+        LinkSet *set = nullptr;
+        explicit LinkLease(const cx_sharded *hh) : h(hh) {
+            std::lock_guard<std::mutex> g(h->mu);
+            if (!h->link_pool.empty()) { set = h->link_pool.back(); h->link_pool.pop_back(); }
+        }
+        ~LinkLease() {
+            if (!set) return;
+            for (auto &l : set->ls)   // whatever an error path left queued must not outlive the lease
+                if (l && l->stream) { (void)hipSetDevice(l->device); (void)hipStreamSynchronize(l->stream); }
+            std::lock_guard<std::mutex> g(h->mu);
+            h->link_pool.push_back(set);
+        }
+    } lease(h);
+    if (!lease.set) {
+        lease.set = new LinkSet();
+        lease.set->ls.resize(P);
+    }
+    std::vector<std::unique_ptr<LinkShard>> &ls = lease.set->ls;
     for (size_t s = 0; s < P; s++) {
-        ls[s].reset(new LinkShard());
+        if (!ls[s]) {
+            ls[s].reset(new LinkShard());
+            LinkShard &l = *ls[s];
+            l.device = h->devices[s];
+            CX_HIP(hipSetDevice(l.device));
+            CX_HIP(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+            CX_HIP(hipEventCreateWithFlags(&l.scattered, hipEventDisableTiming));
+            CX_HIP(hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
+        }
         LinkShard &l = *ls[s];
-        l.device = h->devices[s];
         CX_HIP(hipSetDevice(l.device));
-        CX_HIP(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
-        CX_HIP(hipEventCreateWithFlags(&l.scattered, hipEventDisableTiming));
-        CX_HIP(hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
-        CX_HIP(hipMalloc((void **)&l.d_q, (size_t)blk * std::max(dim, 1u) * sizeof(float)));
-        CX_HIP(hipMalloc((void **)&l.d_rows, (size_t)blk * topk * 4));
-        CX_HIP(hipMalloc((void **)&l.d_scores, (size_t)blk * topk * 4));
-        CX_HIP(hipMalloc((void **)&l.d_dists, (size_t)blk * topk * 4));
-        CX_HIP(hipMalloc((void **)&l.d_cnt, (size_t)blk * 4));
-        CX_HIP(hipMalloc((void **)&l.d_src, (size_t)blk * 4));
-        CX_HIP(hipMalloc((void **)&l.d_pos, (size_t)blk * 4));
+        if (int rc = ensure_dev(l.d_q, l.c_q, (size_t)blk * std::max(dim, 1u))) return rc;
+        if (int rc = ensure_dev(l.d_rows, l.c_rows, (size_t)blk * topk)) return rc;
+        if (int rc = ensure_dev(l.d_scores, l.c_scores, (size_t)blk * topk)) return rc;
+        if (int rc = ensure_dev(l.d_dists, l.c_dists, (size_t)blk * topk)) return rc;
+        if (int rc = ensure_dev(l.d_cnt, l.c_cnt, (size_t)blk)) return rc;
+        if (int rc = ensure_dev(l.d_src, l.c_src, (size_t)blk)) return rc;
+        if (int rc = ensure_dev(l.d_pos, l.c_pos, (size_t)blk)) return rc;
     }
     CX_HIP(hipSetDevice(h->root));
     if (int rc = ensure_dev(root->d_gather, root->c_gather, P * words)) return rc;

@@ -714,6 +714,22 @@ for n, d, k, nq in [(3001, 768, 10, 70), (1520, 768, 100, 9), (9100, 1024, 10, 6
                 assert m == len(e["row"]), (m, len(e["row"]))
                 got = np.array([lut[g.tobytes()] for g in bi[i, :m]], dtype=np.int64)
                 assert_topk_parity(got, bs[i, :m], e["row"], e["score"], what="filtered n=%%d d=%%d k=%%d q%%d" %% (n, d, k, i))
+# fewer than k rows with a positive cosine: the k-th best score is the clamped 0.0, and the rows tied at 0 must come out in the
+# declared order (row ascending) whichever path ran — batch == single scan == oracle, id for id (round-2 ADVICE, batchg.hip)
+n, d, k = 4000, 1024, 10
+rng = np.random.default_rng(8)
+rows = np.abs(rng.normal(size=(n, d))).astype(np.float32)            # the positive orthant
+qs = -np.abs(rng.normal(size=(8, d))).astype(np.float32)             # cosine < 0 with every row ...
+for t in range(6): rows[100 + 37 * t] = -rows[100 + 37 * t]          # ... but six
+ids = ids_for(n); lut = {ids[i].tobytes(): i for i in range(n)}
+h = cortex_amd.HipIndex(d); h.insert_batch(ids, rows)
+o = oracle.OracleIndex(d); o.insert_batch(ids, rows)
+bi, bs, bd, bc = h.search_batch_arrays(qs, k)
+for i in range(len(qs)):
+    e = o.search(qs[i], k); si, ss, sd = h.search_arrays(qs[i], k)
+    got = [lut[g.tobytes()] for g in bi[i, :int(bc[i])]]
+    assert got == [lut[g.tobytes()] for g in si] == [int(r) for r in e["row"]], (i, got, e["row"])
+    assert int((bs[i, :k] > 0).sum()) == 6
 print("ok")
 """ % ((os.path.dirname(os.path.dirname(os.path.abspath(__file__))),) * 2)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))

@@ -208,6 +208,69 @@ def test_sharded_dedup_has_no_neighbour_cap(hip, oracle):
     assert sorted(zip(g[0].tolist(), g[1].tolist())) == sorted(zip(e["from_row"].tolist(), e["to_row"].tolist()))
 
 
+def test_failed_shard_append_leaves_the_handle_consistent(hip):
+    """Round-2 ADVICE: a shard append that fails (a hipMalloc in grow_rows is enough; here injected with
+    CX_SHARD_FAIL_UPSERT) must not leave ids live in the handle but absent from the shard.  The failed call reports the
+    error, the rows placed before it stay, a retry of the SAME batch places the rest, and the index then answers like a
+    single index over the same rows.  The switch is read once per process: a child process."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+import cortex_amd
+from oracle import oracle as O
+O.build()
+n, d = 3000, 384
+rows = O.synth_rows(n, d)
+rng = np.random.default_rng(1000); ids = rng.integers(0, 256, size=(n, 16), dtype=np.uint8)
+ids[:, 8:] = np.arange(n, dtype=np.uint64).astype(">u8").view(np.uint8).reshape(n, 8)
+sh = cortex_amd.ShardedHipIndex(d, [0, 0, 0])
+try:
+    sh.insert_batch(ids, rows)                  # 6 placement blocks of 512: the third append fails
+    print("NOERROR")
+except cortex_amd.CortexError as e:
+    assert "injected failure" in str(e), str(e)
+assert len(sh) == 1024 and sh.row_count() == 1024, (len(sh), sh.row_count())
+sh.insert_batch(ids, rows)                      # the retry: known ids rewrite in place, the rest is appended
+assert len(sh) == n and sh.row_count() == n
+one = cortex_amd.HipIndex(d); one.insert_batch(ids, rows)
+for q in (rows[5], rows[1500], rows[2999]):
+    a, b = sh.search_arrays(q, 20), one.search_arrays(q, 20)
+    assert np.array_equal(a[0], b[0]) and np.allclose(a[1], b[1], atol=1e-6)
+fr = sh.autolink_pass_rows(None, 100, float(np.float32(0.85)), 50)
+fo = one.autolink_pass_rows(None, 100, float(np.float32(0.85)), 50)
+assert len(fo[0]) > 100 and np.array_equal(fr[0], fo[0]) and np.array_equal(fr[1], fo[1])
+print("OK")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CX_SHARD_FAIL_UPSERT="2", CX_SHARD_PLACEMENT_BLOCK="512")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == "OK", (r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_linker_passes_do_not_leak_per_stream_scratch(hip, oracle):
+    """Round-2 ADVICE: the sharded linker passes ran on fresh streams every call, and every shard keeps one scratch context
+    per stream it has been called on: a pass per linker cycle leaked HBM without bound.  The streams now live in the
+    handle: free device memory stays flat over repeated passes."""
+    import torch
+    n, d = 6000, 384
+    rows = oracle.synth_rows(n, d)
+    sh = hip.ShardedHipIndex(d, [0, 0, 0]); sh.insert_batch(ids_for(n), rows)
+    scan = np.arange(0, 3000, dtype=np.uint32)
+    for _ in range(3):
+        sh.topk_lists_rows(20, scan)
+        sh.autolink_pass_rows(scan, 100, float(np.float32(0.85)), 50)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(25):
+        sh.topk_lists_rows(20, scan)
+        sh.autolink_pass_rows(scan, 100, float(np.float32(0.85)), 50)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < (8 << 20), f"{(free0 - free1) >> 20} MiB of device memory gone after 25 more passes"
+
+
 def test_sharded_concurrent_readers_and_empty_shards(hip, oracle):
     d = 384
     sh = hip.ShardedHipIndex(d, [0, 0, 0, 0])
