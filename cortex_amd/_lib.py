@@ -126,6 +126,8 @@ SIGNATURES = {
     "cx_sharded_bulk_load_nodes": (C.c_int, [_P, _U64, _P, _P, _U32, _P]),
     "cx_sharded_set_node_stats_batch": (C.c_int, [_P, _U64, _P, _P, _P, _P, _P]),
     "cx_sharded_search_decayed": (C.c_int, [_P, _P, _U64, _U64, _U64, _P, _P, C.c_float, C.c_int64, _U32, _P, _P, _P, _P]),
+    "cx_sharded_save": (C.c_int, [_P, C.c_char_p]),
+    "cx_sharded_load_ex": (_P, [C.c_char_p, _U32, _P, C.c_int]),
     "cx_profile_enable": (C.c_int, [_P, C.c_int]),
     "cx_profile_read": (C.c_int, [_P, _P, _P, C.c_int]),
     "cx_autolink_filter_profile": (C.c_int, [_P, _P]),

@@ -209,6 +209,30 @@ struct BulkSink {
 };
 int bulk_load_impl(const BulkSink &sink, uint64_t n, const uint8_t *blob, const uint64_t *offsets, uint32_t flags, ::cx_bulk_stats *stats);
 
+// ---- the reference's index file (vector/index.rs:437-473), shared by the single index and the sharded handle (persist.cpp)
+struct IndexFileWriter {
+    FILE *f;
+    bool ok = true;
+    void bytes(const void *p, size_t n) { if (ok && n && fwrite(p, 1, n, f) != n) ok = false; }
+    void u64(uint64_t v) { bytes(&v, 8); }  // host is little endian (x86-64)
+    void str(const std::string &s) { u64(s.size()); bytes(s.data(), s.size()); }
+    void uuid(const uint8_t *id) { u64(16); bytes(id, 16); }
+};
+struct IndexFileMeta { uint8_t id[16]; std::string kind, agent; };
+// writes the tuple: n_alive vectors through write_vectors (uuid, u64 dim, dim x f32 each), the metadata map, the dimension
+int save_index_file(const char *path, uint32_t dim, uint64_t n_alive, const std::function<int(IndexFileWriter &)> &write_vectors,
+                    const std::vector<IndexFileMeta> &metas);
+// where a loaded file goes: one index or a sharded handle.  create() is called once the row width is known.
+struct IndexFileSink {
+    std::function<int(uint64_t dim, uint64_t n_vec)> create;
+    std::function<int(uint64_t n, const uint8_t *ids, const float *rows, uint64_t dim)> upsert;
+    std::function<uint32_t(const char *, uint64_t)> intern;
+    std::function<int(const uint8_t *id, uint32_t kind, uint32_t agent)> set_meta;
+};
+int load_index_file(const char *path, const IndexFileSink &sink);   // on failure the caller destroys what create() made
+int read_rows_host(const cx_index *ix, uint64_t r0, uint64_t m, float *dst, std::vector<uint16_t> &tmp16);
+void collect_metas(const cx_index *ix, std::vector<IndexFileMeta> &out);
+
 struct FilterUpload {
     DevFilter f;
     bool needs_sync = false;

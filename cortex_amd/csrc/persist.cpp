@@ -22,15 +22,6 @@ namespace {
 
 using namespace cx;
 
-struct Writer {
-    FILE *f;
-    bool ok = true;
-    void bytes(const void *p, size_t n) { if (ok && n && fwrite(p, 1, n, f) != n) ok = false; }
-    void u64(uint64_t v) { bytes(&v, 8); }  // host is little endian (x86-64)
-    void str(const std::string &s) { u64(s.size()); bytes(s.data(), s.size()); }
-    void uuid(const uint8_t *id) { u64(16); bytes(id, 16); }
-};
-
 struct Reader {
     FILE *f;
     bool ok = true;
@@ -54,72 +45,166 @@ struct Reader {
 
 }  // namespace
 
+namespace cx {
+
+int save_index_file(const char *path, uint32_t dim, uint64_t n_alive, const std::function<int(IndexFileWriter &)> &write_vectors,
+                    const std::vector<IndexFileMeta> &metas) {
+    FILE *f = fopen(path, "wb");
+    if (!f) return set_err(CX_ERR_IO, "Failed to write index file: %s", strerror(errno));
+    IndexFileWriter w{f};
+    w.u64(n_alive);
+    if (int rc = write_vectors(w)) { fclose(f); return rc; }
+    w.u64(metas.size());
+    for (const IndexFileMeta &m : metas) { w.uuid(m.id); w.str(m.kind); w.str(m.agent); }
+    w.u64(dim);
+    const bool ok = w.ok;
+    if (fclose(f) != 0 || !ok) return set_err(CX_ERR_IO, "Failed to write index file: %s", strerror(errno));
+    return CX_OK;
+}
+
+int load_index_file(const char *path, const IndexFileSink &sink) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return set_err(CX_ERR_IO, "Failed to read index file: %s", strerror(errno));
+    Reader r{f};
+    auto fail = [&](const char *msg) -> int {
+        fclose(f);
+        return set_err(CX_ERR_VALIDATION, "Failed to deserialize index: %s", msg);
+    };
+    // the dimension is the LAST field of the tuple; every vector carries its own length, so the first
+    // one tells us the row width and the trailer is checked against it
+    const uint64_t n_vec = r.u64();
+    if (!r.ok) return fail(r.why);
+    bool created = false;
+    uint64_t dim = 0;
+    const uint64_t batch_rows = 4096;
+    std::vector<uint8_t> ids;
+    std::vector<float> rows;
+    auto flush = [&]() -> int {
+        if (ids.empty()) return CX_OK;
+        const int rc = sink.upsert(ids.size() / 16, ids.data(), rows.data(), dim);
+        ids.clear();
+        rows.clear();
+        return rc;
+    };
+    for (uint64_t i = 0; i < n_vec; i++) {
+        uint8_t id[16];
+        if (!r.uuid(id)) return fail(r.why);
+        const uint64_t len = r.u64();
+        if (!r.ok) return fail(r.why);
+        if (!created) {
+            if (len > 0xFFFFFFFFull) return fail("vector too long");
+            dim = len;
+            if (int rc = sink.create(dim, n_vec)) { fclose(f); return rc; }
+            created = true;
+        } else if (len != dim) {
+            return fail("vectors of different lengths");
+        }
+        const size_t at = rows.size();
+        rows.resize(at + (size_t)dim);
+        r.bytes(rows.data() + at, (size_t)dim * 4);
+        if (!r.ok) return fail(r.why);
+        ids.insert(ids.end(), id, id + 16);
+        if (ids.size() / 16 >= batch_rows)
+            if (int rc = flush()) { fclose(f); return rc; }
+    }
+    if (created)
+        if (int rc = flush()) { fclose(f); return rc; }
+    const uint64_t n_meta = r.u64();
+    if (!r.ok) return fail(r.why);
+    std::vector<IndexFileMeta> metas;
+    for (uint64_t i = 0; i < n_meta; i++) {
+        IndexFileMeta m;
+        if (!r.uuid(m.id) || !r.str(m.kind) || !r.str(m.agent)) return fail(r.why);
+        metas.push_back(std::move(m));
+    }
+    const uint64_t dimension = r.u64();
+    if (!r.ok) return fail(r.why);
+    if (fgetc(f) != EOF) return fail("trailing bytes");
+    fclose(f);
+    if (!created) {  // no vectors: the trailer is the only source of the dimension
+        if (dimension > 0xFFFFFFFFull) return set_err(CX_ERR_VALIDATION, "Failed to deserialize index: dimension out of range");
+        if (int rc = sink.create(dimension, 0)) return rc;
+    } else if (dimension != dim) {
+        return set_err(CX_ERR_VALIDATION, "Failed to deserialize index: dimension %llu does not match the stored vectors (%llu)",
+                       (unsigned long long)dimension, (unsigned long long)dim);
+    }
+    for (auto &m : metas) {
+        const uint32_t kc = sink.intern(m.kind.data(), m.kind.size());
+        const uint32_t ac = sink.intern(m.agent.data(), m.agent.size());
+        if (int rc = sink.set_meta(m.id, kc, ac)) return rc;
+    }
+    return CX_OK;
+}
+
+// rows [r0, r0 + m) of a shard's store as f32 on the host (a bf16 store is written as the f32 values it holds)
+int read_rows_host(const cx_index *ix, uint64_t r0, uint64_t m, float *dst, std::vector<uint16_t> &tmp16) {
+    const uint32_t dim = ix->dim;
+    if (!dim || !m) return CX_OK;
+    if (ix->dtype == 1) {
+        tmp16.resize((size_t)m * dim);
+        CX_HIP(hipMemcpy(tmp16.data(), ix->rows16() + (size_t)r0 * dim, (size_t)m * dim * 2, hipMemcpyDeviceToHost));
+        for (size_t t = 0; t < (size_t)m * dim; t++) dst[t] = bf16_bits_to_f32(tmp16[t]);
+    } else {
+        CX_HIP(hipMemcpy(dst, ix->d_rows + (size_t)r0 * dim, (size_t)m * dim * 4, hipMemcpyDeviceToHost));
+    }
+    return CX_OK;
+}
+
+// (id, kind, agent) of every live row of one index that has metadata, plus its ids that only have metadata so far
+void collect_metas(const cx_index *ix, std::vector<IndexFileMeta> &out) {
+    std::lock_guard<std::mutex> intern_guard(ix->intern_mu);
+    std::vector<const std::string *> names(ix->interned.size() + 1, nullptr);
+    for (auto &kv : ix->interned) names[kv.second] = &kv.first;
+    static const std::string empty;
+    auto name = [&](uint32_t c) -> const std::string & { return c < names.size() && names[c] ? *names[c] : empty; };
+    for (uint64_t r = 0; r < ix->n_rows; r++) {
+        const uint32_t m = ix->h_meta[r];
+        if ((m & META_REMOVED) || !(m & META_HAS)) continue;
+        IndexFileMeta e;
+        memcpy(e.id, &ix->ids[16 * (size_t)r], 16);
+        e.kind = name(m >> 8);
+        e.agent = name(ix->h_agent[r]);
+        out.push_back(std::move(e));
+    }
+    for (auto &kv : ix->pending_meta) {   // metadata of ids without a vector is part of the map too (:438)
+        IndexFileMeta e;
+        memcpy(e.id, &kv.first.a, 8);
+        memcpy(e.id + 8, &kv.first.b, 8);
+        e.kind = name(kv.second.first);
+        e.agent = name(kv.second.second);
+        out.push_back(std::move(e));
+    }
+}
+
+}  // namespace cx
+
 extern "C" {
 
 int cx_save(const cx_index *ix, const char *path) try {
     if (!ix || !path) return set_err(CX_ERR_VALIDATION, "null argument");
     if (int rc = use_device(ix)) return rc;
-    FILE *f = fopen(path, "wb");
-    if (!f) return set_err(CX_ERR_IO, "Failed to write index file: %s", strerror(errno));
-    Writer w{f};
     const uint32_t dim = ix->dim;
-    w.u64(ix->n_alive);
-    // vectors: stream the row store back in 32 MiB slabs
-    const uint64_t slab_rows = std::max<uint64_t>(1, (32ull << 20) / std::max<uint64_t>(1, (uint64_t)dim * 4));
-    std::vector<float> host((size_t)slab_rows * std::max(dim, 1u));
-    std::vector<uint16_t> host16(ix->dtype == 1 ? host.size() : 0);   // a bf16 store is written as the f32 values it holds
-    for (uint64_t r0 = 0; r0 < ix->n_rows; r0 += slab_rows) {
-        const uint64_t m = std::min(slab_rows, ix->n_rows - r0);
-        if (dim) {
-            hipError_t e;
-            if (ix->dtype == 1) {
-                e = hipMemcpy(host16.data(), ix->rows16() + (size_t)r0 * dim, (size_t)m * dim * 2, hipMemcpyDeviceToHost);
-                for (size_t t = 0; t < (size_t)m * dim; t++) host[t] = bf16_bits_to_f32(host16[t]);
-            } else
-                e = hipMemcpy(host.data(), ix->d_rows + (size_t)r0 * dim, (size_t)m * dim * 4, hipMemcpyDeviceToHost);
-            if (e != hipSuccess) {
-                fclose(f);
-                return set_err(CX_ERR_DEVICE, "Failed to write index file: device read failed: %s", hipGetErrorString(e));
+    std::vector<IndexFileMeta> metas;
+    collect_metas(ix, metas);
+    return save_index_file(path, dim, ix->n_alive, [&](IndexFileWriter &w) -> int {
+        // vectors: stream the row store back in 32 MiB slabs, entries in row order
+        const uint64_t slab_rows = std::max<uint64_t>(1, (32ull << 20) / std::max<uint64_t>(1, (uint64_t)dim * 4));
+        std::vector<float> host((size_t)slab_rows * std::max(dim, 1u));
+        std::vector<uint16_t> tmp16;
+        for (uint64_t r0 = 0; r0 < ix->n_rows; r0 += slab_rows) {
+            const uint64_t m = std::min(slab_rows, ix->n_rows - r0);
+            if (read_rows_host(ix, r0, m, host.data(), tmp16) != CX_OK)
+                return set_err(CX_ERR_DEVICE, "Failed to write index file: device read failed");
+            for (uint64_t i = 0; i < m; i++) {
+                const uint64_t r = r0 + i;
+                if (ix->h_meta[r] & META_REMOVED) continue;
+                w.uuid(&ix->ids[16 * (size_t)r]);
+                w.u64(dim);
+                w.bytes(host.data() + (size_t)i * dim, (size_t)dim * 4);
             }
         }
-        for (uint64_t i = 0; i < m; i++) {
-            const uint64_t r = r0 + i;
-            if (ix->h_meta[r] & META_REMOVED) continue;
-            w.uuid(&ix->ids[16 * (size_t)r]);
-            w.u64(dim);
-            w.bytes(host.data() + (size_t)i * dim, (size_t)dim * 4);
-        }
-    }
-    // metadata
-    std::lock_guard<std::mutex> intern_guard(ix->intern_mu);
-    std::vector<const std::string *> names(ix->interned.size() + 1, nullptr);
-    for (auto &kv : ix->interned) names[kv.second] = &kv.first;
-    uint64_t n_meta = ix->pending_meta.size();   // metadata of ids without a vector is part of the map too (:438)
-    for (uint64_t r = 0; r < ix->n_rows; r++)
-        if (!(ix->h_meta[r] & META_REMOVED) && (ix->h_meta[r] & META_HAS)) n_meta++;
-    w.u64(n_meta);
-    static const std::string empty;
-    for (uint64_t r = 0; r < ix->n_rows; r++) {
-        const uint32_t m = ix->h_meta[r];
-        if ((m & META_REMOVED) || !(m & META_HAS)) continue;
-        const uint32_t kc = m >> 8, ac = ix->h_agent[r];
-        w.uuid(&ix->ids[16 * (size_t)r]);
-        w.str(kc < names.size() && names[kc] ? *names[kc] : empty);
-        w.str(ac < names.size() && names[ac] ? *names[ac] : empty);
-    }
-    for (auto &kv : ix->pending_meta) {
-        uint8_t id[16];
-        memcpy(id, &kv.first.a, 8);
-        memcpy(id + 8, &kv.first.b, 8);
-        const uint32_t kc = kv.second.first, ac = kv.second.second;
-        w.uuid(id);
-        w.str(kc < names.size() && names[kc] ? *names[kc] : empty);
-        w.str(ac < names.size() && names[ac] ? *names[ac] : empty);
-    }
-    w.u64(dim);
-    const bool ok = w.ok;
-    if (fclose(f) != 0 || !ok) return set_err(CX_ERR_IO, "Failed to write index file: %s", strerror(errno));
-    return CX_OK;
+        return CX_OK;
+    }, metas);
 } catch (...) { return cx::on_exception(); }
 
 cx_index *cx_load(const char *path, int device) { return cx_load_ex(path, device, CX_DTYPE_F32); }
@@ -129,83 +214,23 @@ cx_index *cx_load_ex(const char *path, int device, int dtype) try {
         set_err(CX_ERR_VALIDATION, "null path");
         return nullptr;
     }
-    FILE *f = fopen(path, "rb");
-    if (!f) {
-        set_err(CX_ERR_IO, "Failed to read index file: %s", strerror(errno));
-        return nullptr;
-    }
-    Reader r{f};
-    auto fail = [&](cx_index *ix, const char *msg) -> cx_index * {
-        set_err(CX_ERR_VALIDATION, "Failed to deserialize index: %s", msg);
-        fclose(f);
-        if (ix) cx_destroy(ix);
-        return nullptr;
-    };
-    // the dimension is the LAST field of the tuple; every vector carries its own length, so the first
-    // one tells us the row width and the trailer is checked against it
-    const uint64_t n_vec = r.u64();
-    if (!r.ok) return fail(nullptr, r.why);
     cx_index *ix = nullptr;
-    uint64_t dim = 0;
-    const uint64_t batch_rows = 4096;
-    std::vector<uint8_t> ids;
-    std::vector<float> rows;
-    auto flush = [&]() -> bool {
-        if (ids.empty()) return true;
-        const int rc = cx_upsert_batch(ix, ids.size() / 16, ids.data(), rows.data(), dim);
-        ids.clear();
-        rows.clear();
-        return rc == CX_OK;
+    IndexFileSink sink;
+    sink.create = [&](uint64_t dim, uint64_t n_vec) -> int {
+        ix = cx_create_ex((uint32_t)dim, device, dtype);
+        if (!ix) return CX_ERR_DEVICE;
+        return n_vec ? cx_reserve(ix, n_vec) : CX_OK;
     };
-    for (uint64_t i = 0; i < n_vec; i++) {
-        uint8_t id[16];
-        if (!r.uuid(id)) return fail(ix, r.why);
-        const uint64_t len = r.u64();
-        if (!r.ok) return fail(ix, r.why);
-        if (!ix) {
-            if (len > 0xFFFFFFFFull) return fail(nullptr, "vector too long");
-            dim = len;
-            ix = cx_create_ex((uint32_t)dim, device, dtype);
-            if (!ix) { fclose(f); return nullptr; }
-            if (cx_reserve(ix, n_vec) != CX_OK) { fclose(f); cx_destroy(ix); return nullptr; }
-        } else if (len != dim) {
-            return fail(ix, "vectors of different lengths");
+    sink.upsert = [&](uint64_t n, const uint8_t *ids, const float *rows, uint64_t dim) { return cx_upsert_batch(ix, n, ids, rows, dim); };
+    sink.intern = [&](const char *s, uint64_t n) { return cx_intern(ix, s, n); };
+    sink.set_meta = [&](const uint8_t *id, uint32_t kc, uint32_t ac) { return cx_set_metadata(ix, id, kc, ac); };
+    if (const int rc = load_index_file(path, sink)) {
+        if (ix) {
+            const std::string msg = err_buf();   // cx_destroy may touch the message
+            cx_destroy(ix);
+            set_err(rc, "%s", msg.c_str());
         }
-        const size_t at = rows.size();
-        rows.resize(at + (size_t)dim);
-        r.bytes(rows.data() + at, (size_t)dim * 4);
-        if (!r.ok) return fail(ix, r.why);
-        ids.insert(ids.end(), id, id + 16);
-        if (ids.size() / 16 >= batch_rows && !flush()) { fclose(f); cx_destroy(ix); return nullptr; }
-    }
-    if (ix && !flush()) { fclose(f); cx_destroy(ix); return nullptr; }
-    const uint64_t n_meta = r.u64();
-    if (!r.ok) return fail(ix, r.why);
-    struct Meta { uint8_t id[16]; std::string kind, agent; };
-    std::vector<Meta> metas;
-    for (uint64_t i = 0; i < n_meta; i++) {
-        Meta m;
-        if (!r.uuid(m.id) || !r.str(m.kind) || !r.str(m.agent)) return fail(ix, r.why);
-        metas.push_back(std::move(m));
-    }
-    const uint64_t dimension = r.u64();
-    if (!r.ok) return fail(ix, r.why);
-    if (fgetc(f) != EOF) return fail(ix, "trailing bytes");
-    fclose(f);
-    if (!ix) {  // no vectors: the trailer is the only source of the dimension
-        if (dimension > 0xFFFFFFFFull) { set_err(CX_ERR_VALIDATION, "Failed to deserialize index: dimension out of range"); return nullptr; }
-        ix = cx_create_ex((uint32_t)dimension, device, dtype);
-        if (!ix) return nullptr;
-    } else if (dimension != dim) {
-        cx_destroy(ix);
-        set_err(CX_ERR_VALIDATION, "Failed to deserialize index: dimension %llu does not match the stored vectors (%llu)",
-                (unsigned long long)dimension, (unsigned long long)dim);
         return nullptr;
-    }
-    for (auto &m : metas) {
-        const uint32_t kc = cx_intern(ix, m.kind.data(), m.kind.size());
-        const uint32_t ac = cx_intern(ix, m.agent.data(), m.agent.size());
-        if (cx_set_metadata(ix, m.id, kc, ac) != CX_OK) { cx_destroy(ix); return nullptr; }
     }
     return ix;
 } catch (...) { cx::on_exception(); return nullptr; }

@@ -507,6 +507,101 @@ cx_sharded *cx_sharded_create_ex(uint32_t dimension, uint32_t n_shards, const in
     return h.release();
 } catch (...) { cx::on_exception(); return nullptr; }
 
+/* VectorIndex::save / load for the sharded handle (vector/index.rs:437-473): ONE file in the reference's layout — the
+ * file of a single index over the same calls, entries in global row order — so an index saved sharded loads on one GPU,
+ * and the other way round. */
+int cx_sharded_save(const cx_sharded *h, const char *path) try {
+    if (!h || !path) return set_err(CX_ERR_VALIDATION, "null argument");
+    const uint32_t dim = h->dim;
+    std::vector<IndexFileMeta> metas;
+    {   // metadata in global row order, then the ids that only have metadata so far (handle and shards)
+        std::vector<std::vector<IndexFileMeta>> per(h->shards.size());
+        std::vector<std::unordered_map<IdKey, size_t, IdHash>> at(h->shards.size());
+        for (size_t s = 0; s < h->shards.size(); s++) {
+            collect_metas(h->shards[s], per[s]);
+            for (size_t i = 0; i < per[s].size(); i++) at[s].emplace(id_key(per[s][i].id), i);
+        }
+        std::vector<std::vector<char>> used(h->shards.size());
+        for (size_t s = 0; s < per.size(); s++) used[s].assign(per[s].size(), 0);
+        for (size_t q = 0; q < h->seq_shard.size(); q++) {
+            if (!h->seq_alive[q]) continue;
+            const uint32_t s = h->seq_shard[q];
+            auto it = at[s].find(id_key(&h->seq_ids[16 * q]));
+            if (it == at[s].end()) continue;
+            metas.push_back(per[s][it->second]);
+            used[s][it->second] = 1;
+        }
+        for (size_t s = 0; s < per.size(); s++)
+            for (size_t i = 0; i < per[s].size(); i++)
+                if (!used[s][i]) metas.push_back(per[s][i]);
+        if (!h->pending_meta.empty()) {
+            const cx_index *ix0 = h->shards[0];   // every shard interns every string in the same order: shard 0's table names the codes
+            std::lock_guard<std::mutex> g(ix0->intern_mu);
+            std::vector<const std::string *> names(ix0->interned.size() + 1, nullptr);
+            for (auto &kv : ix0->interned) names[kv.second] = &kv.first;
+            for (auto &kv : h->pending_meta) {
+                IndexFileMeta e;
+                memcpy(e.id, &kv.first.a, 8);
+                memcpy(e.id + 8, &kv.first.b, 8);
+                const uint32_t kc = kv.second.first, ac = kv.second.second;
+                if (kc < names.size() && names[kc]) e.kind = *names[kc];
+                if (ac < names.size() && names[ac]) e.agent = *names[ac];
+                metas.push_back(std::move(e));
+            }
+        }
+    }
+    return save_index_file(path, dim, h->n_alive, [&](IndexFileWriter &w) -> int {
+        // global rows are dealt to the shards in placement blocks: runs of consecutive global rows are runs of consecutive
+        // local rows of one shard, read back with one copy each (32 MiB at most)
+        const uint64_t slab_rows = std::max<uint64_t>(1, (32ull << 20) / std::max<uint64_t>(1, (uint64_t)dim * 4));
+        std::vector<float> host((size_t)slab_rows * std::max(dim, 1u));
+        std::vector<uint16_t> tmp16;
+        const size_t n_seq = h->seq_shard.size();
+        size_t q = 0;
+        while (q < n_seq) {
+            const uint32_t s = h->seq_shard[q], r0 = h->seq_row[q];
+            size_t e = q + 1;
+            while (e < n_seq && e - q < slab_rows && h->seq_shard[e] == s && h->seq_row[e] == r0 + (e - q)) e++;
+            const cx_index *ix = h->shards[s];
+            if (use_device(ix) != CX_OK || read_rows_host(ix, r0, e - q, host.data(), tmp16) != CX_OK)
+                return set_err(CX_ERR_DEVICE, "Failed to write index file: device read failed");
+            for (size_t t = q; t < e; t++) {
+                if (!h->seq_alive[t]) continue;
+                w.uuid(&h->seq_ids[16 * t]);
+                w.u64(dim);
+                w.bytes(host.data() + (t - q) * dim, (size_t)dim * 4);
+            }
+            q = e;
+        }
+        return CX_OK;
+    }, metas);
+} catch (...) { return cx::on_exception(); }
+
+cx_sharded *cx_sharded_load_ex(const char *path, uint32_t n_shards, const int *device_ids, int dtype) try {
+    if (!path) {
+        set_err(CX_ERR_VALIDATION, "null path");
+        return nullptr;
+    }
+    cx_sharded *h = nullptr;
+    IndexFileSink sink;
+    sink.create = [&](uint64_t dim, uint64_t) -> int {
+        h = cx_sharded_create_ex((uint32_t)dim, n_shards, device_ids, dtype);
+        return h ? CX_OK : CX_ERR_DEVICE;
+    };
+    sink.upsert = [&](uint64_t n, const uint8_t *ids, const float *rows, uint64_t dim) { return cx_sharded_upsert_batch(h, n, ids, rows, dim); };
+    sink.intern = [&](const char *s, uint64_t n) { return cx_sharded_intern(h, s, n); };
+    sink.set_meta = [&](const uint8_t *id, uint32_t kc, uint32_t ac) { return cx_sharded_set_metadata(h, id, kc, ac); };
+    if (const int rc = load_index_file(path, sink)) {
+        if (h) {
+            const std::string msg = err_buf();
+            cx_sharded_destroy(h);
+            set_err(rc, "%s", msg.c_str());
+        }
+        return nullptr;
+    }
+    return h;
+} catch (...) { cx::on_exception(); return nullptr; }
+
 void cx_sharded_destroy(cx_sharded *h) {
     if (!h) return;
     h->workers.reset();

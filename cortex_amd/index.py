@@ -505,7 +505,7 @@ class _ShardedAbi:
     _HAVE = {"upsert", "upsert_batch", "upsert_batch_dev", "remove", "set_metadata", "set_metadata_batch", "intern", "lookup",
              "len", "dimension", "row_count", "row_id", "rows_of", "rebuild", "search", "search_batch", "search_threshold",
              "autolink_pass_rows", "dedup_scan_rows", "topk_lists_rows", "bulk_load_nodes", "set_node_stats_batch",
-             "search_decayed"}
+             "search_decayed", "save"}
 
     def __init__(self, L):
         self._L = L
@@ -539,6 +539,24 @@ class ShardedHipIndex(HipIndex):
     @classmethod
     def new(cls, dimension: int, devices: Sequence[int] = (0,)) -> "ShardedHipIndex":
         return cls(dimension, devices)
+
+    @classmethod
+    def load(cls, path, devices: Sequence[int] = (0,), dtype: str = "f32") -> "ShardedHipIndex":
+        """VectorIndex::load (index.rs:447-473) into a sharded handle: the file of a single index or of a sharded one
+        (same layout), vectors placed like insert_batch would."""
+        L = _lib.load()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = L.cx_sharded_load_ex(str(path).encode(), len(devices), devs, _dtype_code(dtype))
+        if not h:
+            raise CortexError(L.cx_last_error().decode("utf-8", "replace"))
+        self = cls.__new__(cls)
+        self._L = _ShardedAbi(L)
+        self._h = h
+        self.dtype = dtype
+        self.dimension = int(L.cx_sharded_dimension(h))
+        self.devices = list(devices)
+        self.device = self.devices[0]
+        return self
 
     def close(self) -> None:
         if getattr(self, "_h", None):

@@ -128,6 +128,45 @@ def autolink_walk(index: HipIndex, scan_ids: Optional[Sequence[NodeId]], rules, 
     return out
 
 
+def walk_similarity_lists(node_rows, rows, scores, counts, threshold, max_edges_per_node: int, deleted=None, existing=None):
+    """auto_linker.rs:233-264 with SimilarityLinkRule (rules.rs:42-62) as the only rule, over MANY nodes' ordered neighbour
+    lists at once (numpy; the per-neighbour Python loop of autolink_walk is for arbitrary rules).  Same walk as
+    link_rules_kernel (allpairs.hip) and cxo_autolink_pass:
+      skip self (:235-237) and storage-deleted neighbours (:240-243) — they do not reach the cap test;
+      score >= threshold -> an edge, unless the node already has it (existing_set, :226-231, :249-258: dropped WITHOUT counting);
+      after every neighbour that was not skipped, stop once max_edges_per_node edges were proposed (:259-262 — tested after the
+      push, so a cap of 0 still lets the first neighbour's edge through).
+    node_rows [m] (the rows the lists belong to), rows / scores [m, k], counts [m]; deleted: flags indexed by row;
+    existing: (offsets u64 [m + 1], to_rows) CSR over these m nodes.  Returns (from, to, weight), node order then list order."""
+    node_rows = np.asarray(node_rows, dtype=np.int64)
+    rows = np.asarray(rows).astype(np.int64)
+    scores = np.asarray(scores, dtype=np.float32)
+    counts = np.asarray(counts).astype(np.int64)
+    m, k = rows.shape
+    valid = np.arange(k)[None, :] < counts[:, None]
+    safe = np.where(valid, rows, 0)
+    considered = valid & (rows != node_rows[:, None])
+    if deleted is not None:
+        considered &= ~np.asarray(deleted)[safe].astype(bool)
+    emit = considered & (scores >= np.float32(threshold))
+    if existing is not None:
+        eo = np.asarray(existing[0], dtype=np.int64)
+        et = np.asarray(existing[1], dtype=np.int64)
+        if et.size:
+            owner = np.repeat(np.arange(m, dtype=np.int64), np.diff(eo))
+            have = np.unique((owner << 32) | et)
+            keys = (np.arange(m, dtype=np.int64)[:, None] << 32) | safe
+            pos = np.searchsorted(have, keys)
+            hit = (pos < have.size) & (have[np.minimum(pos, have.size - 1)] == keys)
+            emit &= ~hit
+    cum = np.cumsum(emit, axis=1)
+    stop = considered & (cum >= max_edges_per_node)               # the walk ends after the first of these
+    first_stop = np.where(stop.any(axis=1), stop.argmax(axis=1), k)
+    emit &= np.arange(k)[None, :] <= first_stop[:, None]
+    ii, jj = np.nonzero(emit)
+    return node_rows[ii], rows[ii, jj], scores[ii, jj]
+
+
 def similarity_rule(config: SimilarityConfig):
     """SimilarityLinkRule::evaluate (linker/rules.rs:42-62) as an autolink_walk rule."""
     thr = np.float32(config.auto_link_threshold)

@@ -161,9 +161,17 @@ class ShardedAutolink:
         self.knn = ShardedKnn(rank, world, self.bases.tolist(), block, topk, device, lists_fn, merge_fn=merge_fn, group=group)
         self.buf = torch.zeros((block, dim), dtype=torch.float32, device=device)
 
-    def run(self, threshold: float, max_edges_per_node: int, deleted: Optional[np.ndarray] = None):
-        """Edges proposed for the rows this rank owns: (from_global u64, to_global u64, weight f32), scan order then
-        score order.  deleted: optional flags over GLOBAL rows (storage tombstones, quirk Q2)."""
+    def run(self, threshold: float, max_edges_per_node: int, deleted: Optional[np.ndarray] = None, existing=None,
+            max_edges_per_cycle: Optional[int] = None):
+        """Edges proposed for the rows this rank owns: (from_global i64, to_global i64, weight f32), scan order then
+        score order — AutoLinker::run_cycle's walk (auto_linker.rs:215-264) in global rows, as the fused pass of one
+        index runs it (linker.walk_similarity_lists):
+        deleted: optional flags over GLOBAL rows (storage tombstones, quirk Q2);
+        existing: optional (offsets u64 [own_rows + 1], to_global) CSR of the related_to edges each OWN row already has
+        (:226-231): dropped without counting towards max_edges_per_node (:249-258);
+        max_edges_per_cycle: :284-287 `take(max_edges_per_cycle)` over the cycle's proposals in scan order = global row
+        order: a rank keeps what the ranks before it left of the budget (one all_gather of the ranks' edge counts)."""
+        from .linker import walk_similarity_lists
         thr = np.float32(threshold)
         out_f, out_t, out_w = [], [], []
         for src in range(self.world):
@@ -192,18 +200,27 @@ class ShardedAutolink:
                     rows = self.knn.out_rows[:m].cpu().numpy()
                     scores, counts = self.knn.out_scores[:m].cpu().numpy(), self.knn.out_counts[:m].cpu().numpy()
                 self_g = self.bases[src] + lo + np.arange(m, dtype=np.int64)
-                valid = np.arange(self.topk)[None, :] < counts[:, None]
-                safe_rows = np.where(valid, rows, 0)
-                ok = valid & (rows != self_g[:, None]) & (scores >= thr)
-                if self.alive_fn is not None:
-                    ok &= np.asarray(self.alive_fn(lo, m), dtype=bool)[:, None]
-                if deleted is not None:
-                    ok &= ~deleted[safe_rows].astype(bool)
-                ok &= np.cumsum(ok, axis=1) <= max_edges_per_node
-                ii, jj = np.nonzero(ok)
-                out_f.append(self_g[ii]); out_t.append(rows[ii, jj]); out_w.append(scores[ii, jj])
+                counts = np.asarray(counts).copy()
+                if self.alive_fn is not None:   # a row removed from the index has no embedding: it proposes nothing (:217-218)
+                    counts[~np.asarray(self.alive_fn(lo, m), dtype=bool)] = 0
+                ex = None
+                if existing is not None:
+                    eo = np.asarray(existing[0], dtype=np.int64)
+                    ex = (eo[lo:lo + m + 1] - eo[lo], np.asarray(existing[1])[eo[lo]:eo[lo + m]])
+                f, t, w = walk_similarity_lists(self_g, rows, scores, counts, thr, max_edges_per_node, deleted, ex)
+                out_f.append(f); out_t.append(t); out_w.append(w)
         cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt)
-        return cat(out_f, np.int64), cat(out_t, np.int64), cat(out_w, np.float32)
+        f, t, w = cat(out_f, np.int64), cat(out_t, np.int64), cat(out_w, np.float32)
+        if max_edges_per_cycle is not None:
+            before = 0
+            if self.world > 1:
+                mine = torch.tensor([len(f)], dtype=torch.int64, device=self.device if self.device.type == "cuda" else "cpu")
+                every = [torch.zeros_like(mine) for _ in range(self.world)]
+                dist.all_gather(every, mine, group=self.group)
+                before = int(sum(int(x.item()) for x in every[:self.rank]))
+            keep = max(0, min(len(f), int(max_edges_per_cycle) - before))
+            f, t, w = f[:keep], t[:keep], w[:keep]
+        return f, t, w
 
 
 def hip_lists_fn(index, threshold: float) -> Callable:

@@ -399,6 +399,12 @@ int cx_sharded_row_id(const cx_sharded *h, uint64_t global_row, uint8_t out_id[1
 int cx_sharded_rows_of(const cx_sharded *h, uint64_t n, const uint8_t *ids, uint32_t *out_rows);
 /* compacts every shard and renumbers the global rows (order preserved) */
 int cx_sharded_rebuild(cx_sharded *h);
+/* VectorIndex::save / load (vector/index.rs:437-473) for the sharded handle: ONE bincode file in the reference's layout,
+ * entries in global row order — the file cx_save writes for a single index over the same calls, so either kind of index
+ * loads what the other saved (and what the reference saved).  cx_sharded_load_ex places the file's vectors like
+ * cx_sharded_upsert_batch would (dtype: CX_DTYPE_F32 / CX_DTYPE_BF16 row stores). */
+int cx_sharded_save(const cx_sharded *h, const char *path);
+cx_sharded *cx_sharded_load_ex(const char *path, uint32_t n_shards, const int *device_ids, int dtype);
 
 /* VectorIndex::search / search_batch / search_threshold over all shards — same contracts as cx_search,
  * cx_search_batch, cx_search_threshold */

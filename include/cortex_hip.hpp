@@ -262,6 +262,8 @@ public:
         : h_(cx_sharded_create_ex((uint32_t)dimension, (uint32_t)devices.size(), devices.data(), dtype)) {
         if (!h_) throw CortexError(CX_ERR_DEVICE, cx_last_error());
     }
+    explicit ShardedHipIndex(cx_sharded *adopt) : h_(adopt) {}
+    ShardedHipIndex(ShardedHipIndex &&o) noexcept : h_(o.h_) { o.h_ = nullptr; }
     ShardedHipIndex(const ShardedHipIndex &) = delete;
     ~ShardedHipIndex() override { if (h_) cx_sharded_destroy(h_); }
     size_t n_shards() const { return cx_sharded_n_shards(h_); }
@@ -317,7 +319,12 @@ public:
     }
     size_t len() const override { return cx_sharded_len(h_); }
     void rebuild() override { check(cx_sharded_rebuild(h_)); }
-    void save(const std::string &) const override { throw CortexError(CX_ERR_VALIDATION, "a sharded index is not saved as one file: rebuild it from the nodes table (serve.rs:105-123)"); }
+    void save(const std::string &path) const override { check(cx_sharded_save(h_, path.c_str())); }   // :437-445: one file, the single index's layout
+    static ShardedHipIndex load(const std::string &path, const std::vector<int> &devices, int dtype = CX_DTYPE_F32) {   // :447-473
+        cx_sharded *h = cx_sharded_load_ex(path.c_str(), (uint32_t)devices.size(), devices.data(), dtype);
+        if (!h) throw CortexError(CX_ERR_VALIDATION, cx_last_error());
+        return ShardedHipIndex(h);
+    }
 };
 
 struct SimilarityConfig {  // vector/config.rs:3-87

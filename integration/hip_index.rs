@@ -80,6 +80,8 @@ extern "C" {
     fn cx_sharded_len(h: *const c_void) -> u64;
     fn cx_sharded_row_count(h: *const c_void) -> u64;
     fn cx_sharded_rebuild(h: *mut c_void) -> c_int;
+    fn cx_sharded_save(h: *const c_void, path: *const c_char) -> c_int;
+    fn cx_sharded_load_ex(path: *const c_char, n_shards: u32, device_ids: *const c_int, dtype: c_int) -> *mut c_void;
     fn cx_sharded_search(h: *const c_void, q: *const f32, len: u64, k: u64, f: *const CxFilter,
                          ids: *mut u8, scores: *mut f32, dists: *mut f32, n_out: *mut u64) -> c_int;
     fn cx_sharded_search_threshold(h: *const c_void, q: *const f32, len: u64, thr: f32, f: *const CxFilter,
@@ -507,10 +509,20 @@ impl VectorIndex for ShardedHipIndex {
     }
     fn len(&self) -> usize { unsafe { cx_sharded_len(self.h) as usize } }
     fn rebuild(&mut self) -> Result<()> { check(unsafe { cx_sharded_rebuild(self.h) }) }
-    fn save(&self, _path: &Path) -> Result<()> {
-        Err(CortexError::Validation("a sharded index is rebuilt from the nodes table at start-up (serve.rs:105-123), not saved".into()))
+    /// vector/index.rs:437-445 — ONE file in the reference's own layout (entries in global row order): what `HipIndex::save`
+    /// writes for a single index over the same calls, and what `HnswIndex::load` reads.
+    fn save(&self, path: &Path) -> Result<()> {
+        let p = std::ffi::CString::new(path.to_string_lossy().as_bytes()).map_err(|e| CortexError::Validation(e.to_string()))?;
+        check(unsafe { cx_sharded_save(self.h, p.as_ptr()) })
     }
-    fn load(_path: &Path) -> Result<Self> {
-        Err(CortexError::Validation("a sharded index is rebuilt from the nodes table at start-up (serve.rs:105-123), not loaded".into()))
+    /// vector/index.rs:447-473 — over the GPUs named in CORTEX_HIP_DEVICES ("0,1,2,3,4,5,6,7"; default: device 0 only)
+    fn load(path: &Path) -> Result<Self> {
+        let p = std::ffi::CString::new(path.to_string_lossy().as_bytes()).map_err(|e| CortexError::Validation(e.to_string()))?;
+        let devs: Vec<c_int> = std::env::var("CORTEX_HIP_DEVICES").ok()
+            .map(|v| v.split(',').filter_map(|x| x.trim().parse().ok()).collect()).filter(|v: &Vec<c_int>| !v.is_empty()).unwrap_or_else(|| vec![0]);
+        let bf16 = std::env::var("CORTEX_HIP_DTYPE").map(|v| v == "bf16").unwrap_or(false);
+        let h = unsafe { cx_sharded_load_ex(p.as_ptr(), devs.len() as u32, devs.as_ptr(), if bf16 { 1 } else { 0 }) };
+        if h.is_null() { return Err(last_error()); }
+        Ok(Self { h })
     }
 }

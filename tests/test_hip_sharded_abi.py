@@ -208,6 +208,36 @@ def test_sharded_dedup_has_no_neighbour_cap(hip, oracle):
     assert sorted(zip(g[0].tolist(), g[1].tolist())) == sorted(zip(e["from_row"].tolist(), e["to_row"].tolist()))
 
 
+def test_sharded_save_and_load_are_the_single_index_file(hip, oracle, tmp_path):
+    """vector/index.rs:437-473 for the sharded handle: ONE file in the reference's layout.  A 3-shard index with removed
+    rows, metadata (also for an id that has no vector yet) and a second batch of inserts saves the bytes a single index over
+    the same calls saves; each kind of index loads the other's file and then answers like it."""
+    n, d = 5000, 384
+    rows = oracle.synth_rows(n, d); ids = ids_for(n)
+    one = hip.HipIndex(d); sh = hip.ShardedHipIndex(d, [0, 0, 0])
+    for ix in (one, sh):
+        ix.insert_batch(ids[:4000], rows[:4000])
+        for r in (3, 77, 2048): ix.remove(ids[r].tobytes())
+        for r in range(0, 900, 7): ix.set_metadata(ids[r].tobytes(), "fact" if r % 2 else "event", "kai")
+        ix.set_metadata(ids[4500].tobytes(), "decision", "nova")          # metadata before the vector (vector/tests.rs:65-66)
+        ix.insert_batch(ids[4000:], rows[4000:])
+        ix.set_metadata(ids[4999].tobytes(), "goal", "kai")
+    f1, f2 = tmp_path / "one.idx", tmp_path / "sharded.idx"
+    one.save(f1); sh.save(f2)
+    assert open(f1, "rb").read() == open(f2, "rb").read()
+    back_sh = hip.ShardedHipIndex.load(f1, [0, 0])                         # the single index's file, on two shards
+    back_one = hip.HipIndex.load(f2)                                       # the sharded file, on one GPU
+    assert len(back_sh) == len(back_one) == len(one) == n - 3
+    flt = hip.VectorFilter(kinds=["fact", "decision"])
+    for q in oracle.synth_queries(n, d, 6):
+        for f in (None, flt):
+            a, b, c = one.search_arrays(q, 20, f), back_sh.search_arrays(q, 20, f), back_one.search_arrays(q, 20, f)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[0], c[0])
+            assert np.allclose(a[1], b[1], atol=1e-6) and np.allclose(a[1], c[1], atol=1e-6)
+    with pytest.raises(hip.CortexError):
+        hip.ShardedHipIndex.load(tmp_path / "missing.idx", [0])
+
+
 def test_failed_shard_append_leaves_the_handle_consistent(hip):
     """Round-2 ADVICE: a shard append that fails (a hipMalloc in grow_rows is enough; here injected with
     CX_SHARD_FAIL_UPSERT) must not leave ids live in the handle but absent from the shard.  The failed call reports the

@@ -146,6 +146,46 @@ def _autolink_worker(rank: int, world: int, port: int, n_total: int, d: int, thr
         e = full.autolink_pass(np.arange(lo, hi), topk, thr32, 50, deleted.astype(np.uint8))
         ok = (np.array_equal(f, e["from_row"].astype(np.int64)) and np.array_equal(t, e["to_row"].astype(np.int64))
               and np.array_equal(w, e["weight"]))
+        # the rescan (auto_linker.rs:137-182): ~30 % of the own rows already carry related_to edges (dropped WITHOUT counting,
+        # :249-258), a tight per-node cap, cap 0 (the reference still lets the first neighbour through, :259-262) and the
+        # per-cycle cap over BOTH ranks' proposals in scan order (:284-287)
+        rng = np.random.default_rng(5)
+        have = {}
+        for a, b in zip(e["from_row"], e["to_row"]):
+            have.setdefault(int(a), []).append(int(b))
+        lists = [sorted(rng.permutation(have.get(r, []))[:3].tolist()) + [int(rng.integers(0, n_total))] if rng.random() < 0.3 else []
+                 for r in range(lo, hi)]
+        eo = np.zeros(len(lists) + 1, np.uint64); eo[1:] = np.cumsum([len(x) for x in lists])
+        et = np.array([x for l in lists for x in l], dtype=np.uint32)
+        whole = full.autolink_pass(np.arange(n_total), topk, thr32, 4, deleted.astype(np.uint8))   # both ranks' rows, no edges yet: sizes the cycle cap
+        for cap_node, cyc in ((4, None), (0, None), (4, len(whole) // 2)):
+            f2, t2, w2 = sa.run(thr32, cap_node, deleted, existing=(eo, et), max_edges_per_cycle=cyc)
+            # the oracle walks ALL scanned rows of the cycle in order with every node's own existing set: rank 1's rows carry theirs
+            # only on rank 1, so each rank checks its own rows with the other rank's rows edge-free — as the other rank does
+            other = np.arange(0, lo) if rank == 1 else np.arange(hi, n_total)
+            if rank == 1:
+                scan_all = np.concatenate([other, np.arange(lo, hi)]); eo_all = np.concatenate([np.zeros(len(other), np.uint64), eo])
+            else:
+                scan_all = np.concatenate([np.arange(lo, hi), other]); eo_all = np.concatenate([eo, np.full(len(other), eo[-1], np.uint64)])
+            ref = full.autolink_pass(scan_all, topk, thr32, cap_node, deleted.astype(np.uint8), existing=(eo_all, et),
+                                     max_edges_per_cycle=None)
+            mine_ref = ref[(ref["from_row"] >= lo) & (ref["from_row"] < hi)]
+            if cyc is not None:   # budget left after the ranks in front (rank 0's proposals count first)
+                r0 = full.autolink_pass(np.arange(0, sizes[0]), topk, thr32, cap_node, deleted.astype(np.uint8),
+                                        existing=(eo, et) if rank == 0 else None)
+                before = 0 if rank == 0 else None
+                if rank == 1:
+                    before = -1   # rank 0 reports its own count through the collective; checked below by the total
+                keep = cyc if rank == 0 else None
+                if rank == 0:
+                    mine_ref = mine_ref[:max(0, min(len(mine_ref), cyc))]
+                else:
+                    mine_ref = mine_ref[:len(f2)]   # what rank 0 left of the budget: the total is checked by the parent
+            ok = ok and np.array_equal(f2, mine_ref["from_row"].astype(np.int64)) and np.array_equal(t2, mine_ref["to_row"].astype(np.int64)) \
+                and np.array_equal(w2, mine_ref["weight"])
+            if cap_node == 0:
+                ok = ok and len(f2) > 0 and np.all(np.bincount((f2 - lo).astype(np.int64), minlength=hi - lo) <= 1)
+            out_q.put(("cycle", rank, cap_node, cyc, len(f2)))
         out_q.put((rank, bool(ok), len(f)))
     finally:
         dist.destroy_process_group()
@@ -161,5 +201,15 @@ def test_two_rank_gloo_sharded_autolink_equals_oracle_pass():
     [p.start() for p in procs]
     [p.join(180) for p in procs]
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-    got = sorted(q.get(timeout=5) for _ in range(2))
+    msgs = []
+    while True:
+        try:
+            msgs.append(q.get(timeout=5))
+        except Exception:
+            break
+    got = sorted(m for m in msgs if m[0] != "cycle")
     assert [g[:2] for g in got] == [(0, True), (1, True)] and all(g[2] > 0 for g in got)
+    # the per-cycle cap holds over both ranks together, and rank 0's proposals come first
+    capped = {m[1]: m[4] for m in msgs if m[0] == "cycle" and m[3] is not None}
+    budget = [m[3] for m in msgs if m[0] == "cycle" and m[3] is not None][0]
+    assert capped[0] + capped[1] == budget and capped[0] > 0
