@@ -64,5 +64,34 @@ torch.cuda.synchronize()
 ms, cnt = ix.profile_read(reset=True)
 print(f"back-to-back 60: avg {ms / cnt * 1e3:.0f} us", flush=True)
 res["b2b_avg_us"] = ms / cnt * 1e3
+
+# Round 3, one remedy tried once: does a trickle of work during the idle gap keep the board where it
+# was?  (a) a 256 MiB read every 5 ms (about 1 % duty) from a side stream while the caller idles for 1 s; (b) the same gap with
+# eight microsecond-scale dummy launches right before the burst; (c) the plain 1 s gap again, for reference on this board.
+import threading
+pad = torch.empty(64 << 20, dtype=torch.float32, device=dev)      # 256 MiB
+side = torch.cuda.Stream(device=dev)
+
+
+def idle_with_trickle(seconds, period):
+    stop = time.perf_counter() + seconds
+    with torch.cuda.stream(side):
+        while time.perf_counter() < stop:
+            pad.sum()
+            side.synchronize()
+            time.sleep(period)
+
+
+time.sleep(1.0)
+res["idle1s_again"] = burst(40, "idle 1s  ")
+idle_with_trickle(1.0, 0.005)
+res["idle1s_trickle_5ms"] = burst(40, "trickle 5")
+idle_with_trickle(1.0, 0.050)
+res["idle1s_trickle_50ms"] = burst(40, "trickle50")
+time.sleep(1.0)
+tiny = torch.empty(1024, dtype=torch.float32, device=dev)
+for _ in range(8):
+    tiny.add_(1.0)
+res["idle1s_then_8_dummy_launches"] = burst(40, "dummies  ")
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(res, open("gpurun_out/cold_probe.json", "w"))
