@@ -206,6 +206,7 @@ def main() -> None:
             "frac": achieved / HBM_PEAK_GBS, "traffic": float(traffic) if traffic else None, "traffic_source": traffic_src,
             "kernel": "cx::scan_kernel" if B < 3 else "cx::batch2_kernel", "avg_kernel_ms": avg_ms, "launches": kern_n,
             "algorithmic_bytes_per_launch": algo_bytes,
+            "step_achieved": algo_bytes / (elapsed / args.steps) / 1e9, "frac_step": algo_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
         },
     }
 
@@ -496,7 +497,9 @@ def config4_leg(L, device: int, dev, n: int = 1_250_000, d: int = 768, k: int = 
             "queries_per_s": steps * B / el, "ms_per_step": el / steps * 1e3,
             "roofline": {"bound": "hbm", "achieved": algo / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": algo / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": kernel, "avg_kernel_ms": avg,
-                         "launches": kern_n, "algorithmic_bytes_per_launch": algo}}
+                         "launches": kern_n, "algorithmic_bytes_per_launch": algo,
+                         "step_achieved": algo / (el / steps) / 1e9, "frac_step": algo / (el / steps) / 1e9 / HBM_PEAK_GBS,
+                         "frac_note": "frac: the dominant kernel's launches alone; frac_step: the same bytes over the whole step (every launch of the step + gaps)"}}
 
 
 def config4_sharded_leg(L, device: int, dev, rank: int, world: int, total: int = 10_000_000, d: int = 768, k: int = 10,
@@ -559,7 +562,9 @@ def config4_sharded_leg(L, device: int, dev, rank: int, world: int, total: int =
             "roofline": {"bound": "hbm", "achieved": algo / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": algo / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": "cx::batch2_kernel", "avg_kernel_ms": avg,
                          "launches": kern_n, "algorithmic_bytes_per_launch": algo,
-                         "note": "rank 0's shard; one launch reads the rank's whole shard once for 64 queries"}}
+                         "step_achieved": algo / (el / steps) / 1e9, "frac_step": algo / (el / steps) / 1e9 / HBM_PEAK_GBS,
+                         "note": "rank 0's shard; one launch reads the rank's whole shard once for 64 queries; frac_step: the same bytes over the "
+                                 "whole step (all-gather and merge included)"}}
 
 
 def config4_one_process_leg(L, n_dev: int, total: int = 10_000_000, d: int = 768, k: int = 10, B: int = 64, steps: int = 20, warmup: int = 5):
@@ -708,7 +713,8 @@ def config2_leg(L, device: int, dev, n: int = 1_000_000, d: int = 384, k: int = 
             "queries_per_s": steps / el, "ms_per_step": el / steps * 1e3,
             "roofline": {"bound": "hbm", "achieved": algo / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": algo / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": "cx::scan_kernel", "avg_kernel_ms": avg,
-                         "launches": kern_n, "algorithmic_bytes_per_launch": algo}}
+                         "launches": kern_n, "algorithmic_bytes_per_launch": algo,
+                         "step_achieved": algo / (el / steps) / 1e9, "frac_step": algo / (el / steps) / 1e9 / HBM_PEAK_GBS}}
 
 
 def mfma_roofline(contract_flops: float, prof: dict, phase_ms: float) -> dict:

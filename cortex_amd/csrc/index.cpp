@@ -429,6 +429,10 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
         // the row stream a fifth of its rate, and launch_dense_topk reads them all back.
         // expected candidates per query = k * step (the sample's k-th best against step times as many rows)
         static const uint32_t step_env = getenv("CX_BATCHG_SAMPLE_STEP") ? (uint32_t)std::max(1, atoi(getenv("CX_BATCHG_SAMPLE_STEP"))) : 0u;
+        // (A coarser sample for big shards — 1 tile in 191 at 6.25M rows instead of 1 in 64 — was tried in round 3 to shorten the
+        // bound: k * step candidates per query then spread widely around their mean of 1,910 and one query of a batch overflowed
+        // cand_select_kernel's 4,096 now and then: the exact dense fallback ran, 4.5 ms instead of 2.4.  The bound got cheaper
+        // another way: launch_bound_topk below.)
         const uint32_t tile_step = step_env ? step_env : (k_eff <= 32u ? 64u : 32u);
         uint32_t s_tiles = 0;
         const uint32_t s_rows = batchg_sample_rows(n, tile_step, &s_tiles, ix->dtype == 1), s_stride = (s_rows + 3u) & ~3u;
@@ -470,7 +474,18 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
                 // 1. the bound: the k-th best score of the sampled tiles
                 uint32_t *counts = c->d_bg_ctl + 80;
                 if (int rc = launch_batchg_pass(ix->rows32(), ix->d_norms, n, ix->dim, m, c->d_qimg, d_qq, c->d_dense, s_stride, tile_step, nullptr, nullptr, s, ix->rows16())) return rc;
-                if (int rc = launch_bound_select(c->d_dense, s_stride, s_rows, m, k_eff, tau, flt, batchg_tile_rows(ix->dtype == 1), tile_step, s)) return rc;
+                // the k-th best score of the sample.  No row filter: the chunked top-k kernels the dense fallback uses (256
+                // blocks per query, then one merge) instead of ONE block per query walking all its sampled scores — 141 us
+                // -> ~25 us at the 97k sampled rows of a 6.25M-row shard, 6 % of that step.  With a filter the sample's
+                // columns have to be mapped back to rows: bound_select_kernel does that.
+                if (flt.trivial && k_eff <= 32u) {   // (wide lists: the chunked kernels' k = 100 lists cost more than the one-block select, 0.94 against 0.83 ms per step)
+                    const uint32_t s_chunks = dense_topk_chunks(s_rows);
+                    if (int rc = launch_dense_topk(c->d_dense, s_stride, s_rows, m, k_eff, flt, c->d_part_keys, c->d_part_sims, s_chunks, s)) return rc;
+                    MergeArgs mb = mg;
+                    mb.n_lists = s_chunks;
+                    if (int rc = launch_merge_batch(mb, m, s)) return rc;
+                    if (int rc = launch_tau_from_lists(mg.out_scores, mg.out_count, m, k_eff, tau, s)) return rc;
+                } else if (int rc = launch_bound_select(c->d_dense, s_stride, s_rows, m, k_eff, tau, flt, batchg_tile_rows(ix->dtype == 1), tile_step, s)) return rc;
                 // 2. every row, candidates only
                 CX_HIP(hipMemsetAsync(overflow, 0, sizeof(uint32_t), s));
                 BatchGFilter f{tau, c->d_cand_keys, c->d_cand_sims, counts, overflow, cb, flt};

@@ -142,6 +142,8 @@ int launch_batchg_pass(const float *rows, const float *norms, uint32_t n_rows, u
 // than k do); column e stands for row (e / tile_rows) * tile_step * tile_rows + e % tile_rows
 int launch_bound_select(const float *d_dense, uint32_t stride, uint32_t n, uint32_t nq, uint32_t k, uint32_t *tau_ord, const DevFilter &flt,
                         uint32_t tile_rows, uint32_t tile_step, hipStream_t stream);
+// tau_ord[q] = score_ord of the k-th entry of query q's ordered list (0: fewer than k entries)
+int launch_tau_from_lists(const float *d_scores, const uint32_t *d_counts, uint32_t nq, uint32_t k, uint32_t *tau_ord, hipStream_t stream);
 uint32_t dense_topk_chunks(uint32_t n_rows);
 int launch_dense_topk(const float *d_dense, uint32_t stride, uint32_t n_rows, uint32_t nq, uint32_t k, const DevFilter &flt,
                       uint64_t *part_keys, float *part_sims, uint32_t chunks, hipStream_t stream, const uint32_t *run_if = nullptr);

@@ -1290,6 +1290,18 @@ int launch_gather_rows(const float *src, uint16_t *dst, const uint32_t *d_src_ro
 }
 
 
+// tau_ord[q] = score_ord of the k-th entry of query q's ordered list (0 = no bound: fewer than k entries)
+__global__ void tau_from_lists_kernel(const float *scores, const uint32_t *counts, uint32_t nq, uint32_t k, uint32_t *tau_ord) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nq) tau_ord[q] = counts[q] >= k ? score_ord(scores[(size_t)q * k + (k - 1u)]) : 0u;
+}
+int launch_tau_from_lists(const float *d_scores, const uint32_t *d_counts, uint32_t nq, uint32_t k, uint32_t *tau_ord, hipStream_t stream) {
+    if (!nq) return CX_OK;
+    hipLaunchKernelGGL(tau_from_lists_kernel, dim3((nq + 63u) / 64u), dim3(64), 0, stream, d_scores, d_counts, nq, k, tau_ord);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+
 // dst[idx[i]] = val ? val[i] : value  (a handful of rows of a per-row array: the dedup pass's dense rows)
 __global__ void patch_u32_kernel(uint32_t *dst, const uint32_t *idx, const uint32_t *val, uint32_t value, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

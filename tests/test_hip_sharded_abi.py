@@ -333,7 +333,7 @@ def test_sharded_concurrent_readers_and_empty_shards(hip, oracle):
     [t.join() for t in ts]
     assert not errs, errs[0]
     with pytest.raises(hip.ValidationError):
-        sh.save("/tmp/x")                                                 # no sharded form: fails loudly
+        sh.profile_enable(True)                                           # an entry point with no sharded form fails loudly
 
 
 def test_sharded_lists_bulk_load_and_decayed_search(hip, oracle, monkeypatch):
