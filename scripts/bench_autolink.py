@@ -24,10 +24,18 @@ for r in range(a.reps + 1):
     t0 = time.perf_counter()
     ne, ph = h.autolink_pass_timed(100, float(np.float32(a.thr)), 50)
     wall = time.perf_counter() - t0
-    if r: res.append((wall, ph, ne))
-wall = min(x[0] for x in res); ph = min(res, key=lambda x: x[0])[1]; ne = res[0][2]
+    if r: res.append((wall, ph, ne, h.autolink_filter_profile()))
+best = min(res, key=lambda x: x[0])
+wall, ph, ne, prof = best
+kms = [x[3]["kernel_ms"] for x in res]
+steady = kms[3:] if len(kms) > 4 else kms
+prof = dict(prof, kernel_ms=sum(steady) / len(steady))     # the average launch behind the clock ramp of the first passes
 flops = 2.0 * n * n * d
+ksec = prof["kernel_ms"] * 1e-3
 print(json.dumps({"rows": n, "dim": d, "thr": a.thr, "edges": ne, "wall_ms": wall * 1e3,
                   "phase_ms": {"shadow": ph[0], "filter_gemm": ph[1], "rescore": ph[2], "rules": ph[3]},
-                  "pairs_per_s": n * n / wall, "gemm_tflops": flops / (ph[1] * 1e-3) / 1e12,
-                  "mfma_frac_of_2.5PF": flops / (ph[1] * 1e-3) / 2.5e15}))
+                  "pairs_per_s": n * n / wall, "filter_kernel": prof["kernel"], "filter_kernel_ms": prof["kernel_ms"], "filter_kernel_ms_every_pass": [round(x, 4) for x in kms], "best_filter_kernel_ms": min(kms),
+                  "executed_flops": prof["executed_flops"], "shader_clock_ghz_in_kernel": prof["shader_clock_ghz"],
+                  "executed_tflops": prof["executed_flops"] / ksec / 1e12 if ksec else None,
+                  "mfma_frac_of_2.5PF_executed": prof["executed_flops"] / ksec / 2.5e15 if ksec else None,
+                  "contract_equivalent_frac_2N2d": flops / ksec / 2.5e15 if ksec else None}))

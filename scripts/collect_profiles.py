@@ -5,7 +5,7 @@ half of a wide coalesced streaming read -> read bytes = FETCH_SIZE * 1024 * 2; W
 import json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 S, D = os.path.join(ROOT, "gpurun_out", "prof_round"), os.path.join(ROOT, "profiles", rnd)
 os.makedirs(D, exist_ok=True)
 CORR = ("MI355X_MICROARCH.md §HBM: counters in KB; gfx950 FETCH_SIZE reports 1/2 of a wide coalesced streaming read -> "
@@ -44,13 +44,13 @@ for src, dst in (("bench.json", f"bench_{rnd}.json"), ("bench_steps20_warmup5.js
                  ("autolink_mfma_utilisation.json", "autolink_100kx768_mfma_utilisation.json"),
                  ("batch_trace_kernel_stats.csv", "batch64_1.25Mx768_kernel_stats.csv"), ("batch.json", "batch64_1.25Mx768_bench.json"),
                  ("b1024_trace_kernel_stats.csv", "batch64_1Mx1024_kernel_stats.csv"), ("batch64_1Mx1024.json", "batch64_1Mx1024_bench.json"),
-                 ("batch64_other_shapes.jsonl", "batch64_other_shapes.jsonl"), ("single_query_bf16_store.jsonl", "single_query_bf16_store.jsonl"), ("top100_lists_100kx768.log", "top100_lists_100kx768.log"),
+                 ("batch64_other_shapes.jsonl", "batch64_other_shapes.jsonl"), ("autolink_legs.json", "autolink_legs_100kx768.json"), ("single_query_bf16_store.jsonl", "single_query_bf16_store.jsonl"), ("top100_lists_100kx768.log", "top100_lists_100kx768.log"),
                  ("read_shape_probe.log", "read_shape_probe.log"), ("mfma_shape_probe.log", "mfma_shape_probe.log")):
     cp(src, dst)
 if not os.path.exists(os.path.join(S, "cold_start_probe.json")) and os.path.exists(os.path.join(ROOT, "gpurun_out", "cold_probe.json")):
     shutil.copy(os.path.join(ROOT, "gpurun_out", "cold_probe.json"), os.path.join(D, "cold_start_probe.json"))
 traffic("knn_1Mx768_pmc_final.json", "scripts/profile_round.sh: rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- "
-        "python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-autolink", "scan_kernel<768", "knn_fetch_summary.json", "knn_write_summary.json",
+        "python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-autolink --no-config4", "scan_kernel<768", "knn_fetch_summary.json", "knn_write_summary.json",
         3_072_000_000, "scan_kernel_hbm_bytes_per_launch")
 traffic("batch64_1.25Mx768_pmc_final.json", "scripts/profile_round.sh: rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 scripts/bench_batch.py --steps 5",
         "batch2_kernel", "batch_fetch_summary.json", None, 1_250_000 * 768 * 4, "batch_kernel_hbm_read_bytes_per_launch")

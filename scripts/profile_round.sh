@@ -13,6 +13,7 @@ step bench; timeout -k 10 700 python3 $R/bench.py > $O/bench.json 2> $O/bench.er
 # the driver's own command line (round 1: 0.77 on the post-idle clock transient; the pre-roll carries the device past it)
 step bench-driver-cmdline; timeout -k 10 300 python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-autolink --no-config4 > $O/bench_steps20_warmup5.json 2> $O/bench_steps20.err || { tail -5 $O/bench_steps20.err; exit 1; }
 step cold-probe; timeout -k 10 200 python3 $R/scripts/cold_probe.py > $O/cold_probe.log 2>&1 && cp $R/gpurun_out/cold_probe.json $O/cold_start_probe.json
+step legs; timeout -k 10 300 python3 $R/scripts/bench_autolink_legs.py > $O/autolink_legs.json 2>/dev/null
 step lists; timeout -k 10 200 python3 $R/scripts/bench_lists.py 100000 768 > $O/top100_lists_100kx768.log 2>&1
 step batch1024-trace; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/b1024_trace -- python3 $R/scripts/bench_batch_dim.py --rows 1000000 --dim 1024 > $O/batch64_1Mx1024.json 2> $O/b1024_trace.err || { tail -5 $O/b1024_trace.err; exit 1; }
 step batch1024-fetch; timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/b1024_fetch -- python3 $R/scripts/bench_batch_dim.py --rows 1000000 --dim 1024 --steps 5 > $O/b1024_fetch.json 2> $O/b1024_fetch.err || { tail -5 $O/b1024_fetch.err; exit 1; }
@@ -24,12 +25,12 @@ step probes; P=$R/scripts/probes
 [ -x $P/_shape_probe ] || (cd $P && hipcc --offload-arch=gfx950 -O3 -std=c++17 -o _shape_probe shape_probe.hip 2>/dev/null)
 [ -x $P/_mfma_shape_probe ] || (cd $P && hipcc --offload-arch=gfx950 -O3 -std=c++17 -o _mfma_shape_probe mfma_shape_probe.hip 2>/dev/null)
 timeout -k 10 120 $P/_shape_probe 1 40 > $O/read_shape_probe.log 2>&1; timeout -k 10 120 $P/_mfma_shape_probe > $O/mfma_shape_probe.log 2>&1
-step knn-trace; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/knn_trace -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-autolink > $O/knn_trace.json 2> $O/knn_trace.err || { tail -5 $O/knn_trace.err; exit 1; }
-step knn-fetch; timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/knn_fetch -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-autolink > $O/knn_fetch.json 2> $O/knn_fetch.err || { tail -5 $O/knn_fetch.err; exit 1; }
-step knn-write; timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/knn_write -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-autolink > $O/knn_write.json 2> $O/knn_write.err || { tail -5 $O/knn_write.err; exit 1; }
-step autolink-trace; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/al_trace -- python3 $R/scripts/bench_autolink.py > $O/autolink.json 2> $O/al_trace.err || { tail -5 $O/al_trace.err; exit 1; }
+step knn-trace; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/knn_trace -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-autolink --no-config4 > $O/knn_trace.json 2> $O/knn_trace.err || { tail -5 $O/knn_trace.err; exit 1; }
+step knn-fetch; timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/knn_fetch -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-autolink --no-config4 > $O/knn_fetch.json 2> $O/knn_fetch.err || { tail -5 $O/knn_fetch.err; exit 1; }
+step knn-write; timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/knn_write -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-autolink --no-config4 > $O/knn_write.json 2> $O/knn_write.err || { tail -5 $O/knn_write.err; exit 1; }
+step autolink-trace; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/al_trace -- python3 $R/scripts/bench_autolink.py --reps 24 > $O/autolink.json 2> $O/al_trace.err || { tail -5 $O/al_trace.err; exit 1; }
 # MFMA pipe utilisation of the all-pairs filter GEMM (north_star: ">= 50 % MFMA utilisation"): counters only, program directly after `--`
-step autolink-mfma; timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/al_mfma -- python3 $R/scripts/bench_autolink.py --reps 2 > $O/al_mfma.json 2> $O/al_mfma.err || { tail -5 $O/al_mfma.err; exit 1; }
+step autolink-mfma; timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/al_mfma -- python3 $R/scripts/bench_autolink.py --reps 24 > $O/al_mfma.json 2> $O/al_mfma.err || { tail -5 $O/al_mfma.err; exit 1; }
 step batch-trace; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/batch_trace -- python3 $R/scripts/bench_batch.py > $O/batch.json 2> $O/batch_trace.err || { tail -5 $O/batch_trace.err; exit 1; }
 step batch-fetch; timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/batch_fetch -- python3 $R/scripts/bench_batch.py --steps 5 > $O/batch_fetch.json 2> $O/batch_fetch.err || { tail -5 $O/batch_fetch.err; exit 1; }
 # keep only the summaries (traces are large)
@@ -43,7 +44,7 @@ for r in csv.DictReader(open(sys.argv[1])):
 print(json.dumps([{"kernel": k[0], "counter": k[1], "sum": v[0], "dispatches": v[1], "per_dispatch": v[0] / v[1]} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]], indent=1))
 PY
 done
-# MFMA utilisation of pair_filter256_kernel: busy cycles (summed over all SIMDs) / (kernel cycles x 256 CUs x 4 SIMDs);
+# MFMA utilisation of pair_filter_p_kernel: busy cycles (summed over all SIMDs) / (kernel cycles x 256 CUs x 4 SIMDs);
 # GRBM_GUI_ACTIVE is reported per XCD and summed over the 8 of them
 python3 - $O/al_mfma_summary.json > $O/autolink_mfma_utilisation.json <<'PY'
 import json, sys
@@ -53,10 +54,10 @@ def per(kern, ctr):
         if kern in r["kernel"] and r["counter"] == ctr:
             return r["per_dispatch"], r["dispatches"]
     return None, 0
-busy, nb = per("pair_filter256_kernel", "SQ_VALU_MFMA_BUSY_CYCLES")
-act, na = per("pair_filter256_kernel", "GRBM_GUI_ACTIVE")
-out = {"command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -- python3 scripts/bench_autolink.py --reps 2",
-       "kernel": "cx::pair_filter256_kernel", "dispatches": nb,
+busy, nb = per("pair_filter_p_kernel", "SQ_VALU_MFMA_BUSY_CYCLES")
+act, na = per("pair_filter_p_kernel", "GRBM_GUI_ACTIVE")
+out = {"command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -- python3 scripts/bench_autolink.py --reps 24",
+       "kernel": "cx::pair_filter_p_kernel", "dispatches": nb,
        "per_launch": {"SQ_VALU_MFMA_BUSY_CYCLES": busy, "GRBM_GUI_ACTIVE_sum_over_8_XCDs": act}}
 if busy and act:
     cyc = act / 8.0
