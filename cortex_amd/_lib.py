@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcortex_hip.so")
+# CORTEX_HIP_LIB: another build of the same library (A/B measurements of a kernel variant on one box); never a fallback
+LIB_PATH = os.environ.get("CORTEX_HIP_LIB") or os.path.join(_HERE, "lib", "libcortex_hip.so")
 
 
 class cx_filter(C.Structure):

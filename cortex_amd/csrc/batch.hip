@@ -499,24 +499,24 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
         auto step = [&](f32x4 (&ld)[C::LOADS], f32x4 &nr) {
             const uint32_t next = tile + gridDim.x;
             // the slots are re-read every 4th tile (agent-scope loads go past the L2) and applied one tile later
-            if ((it & 3u) == 1u) refresh_apply();
+            if ((it & 3u) == 1u && !(a.arm & 16u)) refresh_apply();
             // the slot loads go out BEFORE this step's tile reloads: waiting for them next step then leaves the
             // reloads in flight (vmcnt counts in issue order)
-            if ((it & 3u) == 0u) refresh_issue(it >> 2);
+            if ((it & 3u) == 0u && !(a.arm & 16u)) refresh_issue(it >> 2);
             if constexpr (NBUF == 2) {
                 if (next < n_tiles) {
                     write_tile(ld, nr, buf ^ 1u, next + 2u * gridDim.x);     // buffer last read one tile ago, behind that tile's barrier
                     stamp(t_write);
                 }
                 it++;
-                producer_compact();
+                if (!(a.arm & 8u)) producer_compact();
                 stamp(t_stage);
                 tile_barrier();
                 stamp(t_bar);
                 buf ^= 1u;
             } else {
                 it++;
-                producer_compact();          // while the consumers work on `tile`
+                if (!(a.arm & 8u)) producer_compact();          // while the consumers work on `tile`
                 stamp(t_stage);
                 tile_barrier();              // the consumers are done with the buffer
                 stamp(t_bar);
@@ -612,13 +612,15 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
     const uint32_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - 1u - blockIdx.x) / gridDim.x + 1u : 0u;
     const uint32_t my_steps = (my_tiles + 1u) & ~1u;   // the producers step in pairs
     for (uint32_t st = 0, tile = blockIdx.x; st < my_steps; st++, tile += gridDim.x) {
-        if (wave_dead || tile >= n_tiles) { tile_barrier(); if constexpr (NBUF == 2) buf ^= 1u; else tile_barrier(); continue; }
-        apply_shrink();
+        if (wave_dead || tile >= n_tiles || (a.arm & 4u)) { tile_barrier(); if constexpr (NBUF == 2) buf ^= 1u; else tile_barrier(); continue; }
+        if (!(a.arm & 2u)) apply_shrink();
         stamp(t_stage);
         const char *Thi = tiles + buf * C::TILE_BYTES, *Tlo = Thi + C::IMG_BYTES;
         // epilogue operands are read now, under the MFMA loop, not after it
         const float tsq = c_tsq[qslot];
         const f32x4 rr4 = *reinterpret_cast<const f32x4 *>(c_rr + buf * BT_ROWS + 4u * kq);
+        // (three independent accumulator chains instead of one 36- / 72-deep one: 5 % slower at 384-d, again in round 3 —
+        // the loop is bound by its LDS reads, 4 bytes read per tile byte, not by the MFMA dependency)
         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
         constexpr int CH = 2, NCH = KS / CH;
         static_assert(KS % CH == 0, "dim/32 must be even");
@@ -668,6 +670,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
             const bool maybe = (tsq < 0.0f) | beats | odd;
             mask |= (maybe & live & (row0 + 4u * kq + r < n_rows)) ? (1u << r) : 0u;
         }
+        if (a.arm & 1u) mask = 0u;
         if (__ballot(mask != 0u)) {
             if constexpr (DIAG) n_append_steps++;
 #pragma unroll
@@ -834,6 +837,8 @@ static int launch_batch_d(BatchArgs a, uint32_t grid, hipStream_t stream) {
 int launch_batch_scan(BatchArgs a, uint32_t grid, hipStream_t stream) {
     if (!batch_supported(a.dim, a.k)) return set_err(CX_ERR_VALIDATION, "batch scan: unsupported dim %u / k %u", a.dim, a.k);
     if (a.n_groups == 0) a.n_groups = 1;
+    static const uint32_t arm_env = getenv("CX_BATCH_ARM") ? (uint32_t)atoi(getenv("CX_BATCH_ARM")) : 0u;
+    a.arm = arm_env;
     const uint32_t qpp = a.qpp;
     if (qpp != 64u && !(qpp == 32u && batch_wide_k(a.k))) return set_err(CX_ERR_VALIDATION, "batch scan: %u queries per pass for k = %u", qpp, a.k);
     if (a.nq == 0 || a.nq > qpp * a.n_groups || a.nq <= qpp * (a.n_groups - 1))

@@ -95,6 +95,7 @@ struct BatchArgs {
     float *part_sims;
     unsigned long long *diag;  // diagnostic build only (CX_BATCH_DIAG=1): [grid*4 waves][5] cycle sums
     uint32_t *gslots;       // [n_groups][64][128] zeroed before the launch: cross-block score bound (batch.hip, "global slots")
+    uint32_t arm;           // CX_BATCH_ARM: measurement arms (results invalid): 1 no appends, 2 no shrink check, 4 consumers only keep the barriers, 8 no compaction, 16 no slot refresh
 };
 bool batch_supported(uint32_t dim, uint32_t k);
 uint32_t batch_grid_blocks(uint32_t n_rows);
