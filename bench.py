@@ -618,6 +618,9 @@ def config5_leg(L, device: int, dev, n: int = 6_250_000, d: int = 1024, thr: flo
     bytes), MFMA for batches of 500 (two 256-row panels against the shard)."""
     import cortex_amd
     ticks = 5
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    mem_before = torch.cuda.mem_get_info(dev)[0]
     ix = cortex_amd.HipIndex(d, device=device, dtype="bf16")
     ix.reserve(n + ticks * (64 + 500) + 1024)
     chunk = 1_000_000
@@ -629,9 +632,14 @@ def config5_leg(L, device: int, dev, n: int = 6_250_000, d: int = 1024, thr: flo
         del gen
     t = float(np.float32(thr))
     ix.autolink_pass_timed(100, t, 50, np.arange(n - 64, n, dtype=np.uint32))   # builds the shadow of the resident shard
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    shard_gb = (mem_before - torch.cuda.mem_get_info(dev)[0]) / 1e9
     out = {"workload": f"streaming auto-link ingest into a {n} x {d} bf16 shard ({n * d * 2 / 1e9:.1f} GB of rows + the normalised bf16 shadow the "
                        f"filter streams), threshold {thr}, top-100, 50 edges/node; a tick = insert a batch of new rows + extend the shadow + link the batch",
-           "storage_dtype": "bf16", "ticks_per_batch_size": ticks}
+           "storage_dtype": "bf16", "ticks_per_batch_size": ticks,
+           "shard_device_memory_GB": shard_gb, "shard_device_memory_note": "rows (bf16) + ONE normalised shadow in the filter kernels' tiled layout + norms, ids and scratch; "
+                                                                           "rounds 1-2 kept a row-major shadow as well (+ 12.8 GB)"}
     cur = n
     for b in (64, 500):
         rec = []

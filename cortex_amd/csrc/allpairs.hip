@@ -55,7 +55,7 @@ __device__ inline float wave_sum(float v) {
 
 template <typename S>
 __global__ __launch_bounds__(256) void build_shadow_kernel(const S *rows, uint16_t *shadow, uint32_t row_lo,
-                                                           uint32_t row_hi, uint32_t dim) {
+                                                           uint32_t row_hi, uint32_t dim, uint32_t tiled) {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -68,7 +68,9 @@ __global__ __launch_bounds__(256) void build_shadow_kernel(const S *rows, uint16
         uint16_t *o = shadow + (size_t)r * dim;
         for (uint32_t j = lane; j < dim; j += 64u) {
             const float v = ldf(p + j) * inv;
-            o[j] = (v == v && fabsf(v) <= 3.0e38f) ? f32_to_bf16_rne(v) : (uint16_t)0;
+            const uint16_t b = (v == v && fabsf(v) <= 3.0e38f) ? f32_to_bf16_rne(v) : (uint16_t)0;
+            if (tiled) shadow[tiled_shadow_off(r, j >> 3, dim / 32u) + (j & 7u)] = b;
+            else o[j] = b;
         }
     }
 }
@@ -78,7 +80,7 @@ int launch_build_shadow(const float *rows, uint16_t *shadow, uint32_t row_lo, ui
     if (row_hi <= row_lo) return CX_OK;
     uint32_t grid = (row_hi - row_lo + 3u) / 4u;
     if (grid > 8192u) grid = 8192u;
-    hipLaunchKernelGGL(build_shadow_kernel<float>, dim3(grid), dim3(256), 0, stream, rows, shadow, row_lo, row_hi, dim);
+    hipLaunchKernelGGL(build_shadow_kernel<float>, dim3(grid), dim3(256), 0, stream, rows, shadow, row_lo, row_hi, dim, 0u);
     CX_HIP(hipGetLastError());
     return CX_OK;
 }
@@ -87,7 +89,17 @@ int launch_build_shadow(const uint16_t *rows16, uint16_t *shadow, uint32_t row_l
     if (row_hi <= row_lo) return CX_OK;
     uint32_t grid = (row_hi - row_lo + 3u) / 4u;
     if (grid > 8192u) grid = 8192u;
-    hipLaunchKernelGGL(build_shadow_kernel<uint16_t>, dim3(grid), dim3(256), 0, stream, rows16, shadow, row_lo, row_hi, dim);
+    hipLaunchKernelGGL(build_shadow_kernel<uint16_t>, dim3(grid), dim3(256), 0, stream, rows16, shadow, row_lo, row_hi, dim, 0u);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+int launch_build_shadow_tiled(const float *rows, const uint16_t *rows16, uint16_t *shadow_t, uint32_t row_lo, uint32_t row_hi, uint32_t dim, hipStream_t stream) {
+    if (row_hi <= row_lo) return CX_OK;
+    if (dim % 32u) return set_err(CX_ERR_VALIDATION, "tiled shadow needs dim %% 32 == 0 (got %u)", dim);
+    uint32_t grid = (row_hi - row_lo + 3u) / 4u;
+    if (grid > 8192u) grid = 8192u;
+    if (rows16) hipLaunchKernelGGL(build_shadow_kernel<uint16_t>, dim3(grid), dim3(256), 0, stream, rows16, shadow_t, row_lo, row_hi, dim, 1u);
+    else hipLaunchKernelGGL(build_shadow_kernel<float>, dim3(grid), dim3(256), 0, stream, rows, shadow_t, row_lo, row_hi, dim, 1u);
     CX_HIP(hipGetLastError());
     return CX_OK;
 }
@@ -138,8 +150,13 @@ __global__ __launch_bounds__(256) void pair_filter_kernel(const PairFilterArgs a
     const uint32_t i0 = ti * BM, j0 = tj * BN;
 
     // loader: each wave-level LDS-DMA moves 8 rows x 128 B; 16 per operand tile, 4 per wave
+    // The shard's rows come from the tiled shadow when there is one (dim % 32 == 0: the row-major copy is not kept): a
+    // lane's 16 bytes of K-block kt (64 elements = two K-steps of the tiled layout) sit 2 KiB further per kt, and the 8
+    // rows x 128 B of one instruction are two runs of 512 contiguous bytes instead of eight of 128.
     const uint32_t lrow = lane >> 3, lslot = lane & 7u;
     const uint16_t *srcA[4], *srcB[4];
+    const bool tiled = a.shadow_t != nullptr;
+    const uint32_t stepB = tiled ? 1024u : (uint32_t)BK, stepA = (tiled && !a.shadow_q) ? 1024u : (uint32_t)BK;   // elements per K-block
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const uint32_t r = (wave * 4u + (uint32_t)q) * 8u + lrow;      // row inside the tile
@@ -149,17 +166,19 @@ __global__ __launch_bounds__(256) void pair_filter_kernel(const PairFilterArgs a
         const uint32_t ga = a.scan_rows ? a.scan_rows[gi] : gi;
         uint32_t gb = j0 + r;
         gb = gb < a.n_rows ? gb : a.n_rows - 1u;
-        srcA[q] = (a.shadow_q ? a.shadow_q : a.shadow) + (size_t)ga * a.dim + piece * 8u;
-        srcB[q] = a.shadow + (size_t)gb * a.dim + piece * 8u;
+        if (a.shadow_q) srcA[q] = a.shadow_q + (size_t)ga * a.dim + piece * 8u;
+        else if (tiled) srcA[q] = a.shadow_t + tiled_shadow_off(ga, piece, a.dim / 32u);
+        else srcA[q] = a.shadow + (size_t)ga * a.dim + piece * 8u;
+        srcB[q] = tiled ? a.shadow_t + tiled_shadow_off(gb, piece, a.dim / 32u) : a.shadow + (size_t)gb * a.dim + piece * 8u;
     }
     auto stage = [&](uint32_t buf, uint32_t kt) {
         char *A = smem + buf * 2 * TILE_BYTES, *B = A + TILE_BYTES;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const uint32_t off = (wave * 4u + (uint32_t)q) * 1024u;  // wave-uniform LDS base of this DMA
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcA[q] + kt * BK),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcA[q] + (size_t)kt * stepA),
                                              (__attribute__((address_space(3))) void *)(A + off), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcB[q] + kt * BK),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcB[q] + (size_t)kt * stepB),
                                              (__attribute__((address_space(3))) void *)(B + off), 16, 0, 0);
         }
     };

@@ -99,6 +99,7 @@ __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArg
     // instead of 16 half lines, no line fetched twice by consecutive K-steps — addressed as a wave-uniform base (SGPRs)
     // plus lane * 16: no per-lane 64-bit pointers in the loop (the kernel sits at the 256-VGPR cap).
     const uint32_t last_blk = (a.n_rows - 1u) / 16u;
+    const uint32_t a_step = a.shadow_q ? (uint32_t)BK : 512u;   // elements per K-step of a gathered A row (row-major / tiled)
     const uint32_t voff = lane * 16u;
     const char *sB[2], *sA[2];
     const uint16_t *srcA[2] = {nullptr, nullptr};   // per-lane row pointers, row-major A only
@@ -118,7 +119,9 @@ __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArg
             uint32_t gi = i0 + r;
             gi = gi < a.n_scan ? gi : a.n_scan - 1u;
             const uint32_t ga = a.scan_rows ? a.scan_rows[gi] : gi;
-            srcA[q] = (a.shadow_q ? a.shadow_q : a.shadow) + (size_t)ga * a.dim + piece * 8u;
+            // scanned vectors that are not this shard's rows: row-major (a.shadow_q); this shard's rows in any order: the
+            // tiled shadow, a K-step (32 elements) = 512 elements further
+            srcA[q] = a.shadow_q ? a.shadow_q + (size_t)ga * a.dim + piece * 8u : a.shadow_t + tiled_shadow_off(ga, piece, KT);
             sA[q] = nullptr;
         }
     }
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArg
         const void *src;
         if (which & 1) src = sB[q] + (size_t)kt * 1024u + voff;
         else if constexpr (TA) src = sA[q] + (size_t)kt * 1024u + voff;
-        else src = srcA[q] + kt * BK;
+        else src = srcA[q] + (size_t)kt * a_step;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                          (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
     };
@@ -361,27 +364,6 @@ __global__ __launch_bounds__(512) void pair_filter256_kernel(const PairFilterArg
         if (lane == 0) { unsigned long long *o = a.diag + ((size_t)blockIdx.x * 8 + wave) * 4; o[0] = t1 - t0; o[1] = t2 - t1; o[2] = t3 - t2; o[3] = t3 - t0;
             if (blockIdx.x % 9000 == 5017 % 9000 && wave == 5) printf("[pair256] tile %u: main-loop waits vmcnt %llu barrier %llu; epilogue: screen %llu walk %llu\n", blockIdx.x, c_vm, c_bar, t2b - t2, t3 - t2b); }
     }
-}
-
-__global__ __launch_bounds__(256) void tile_shadow_kernel(const uint16_t *shadow, uint16_t *shadow_t, uint32_t row_lo, uint32_t row_hi, uint32_t dim) {
-    const uint32_t ppr = dim / 8u;   // 16-byte pieces per row
-    const uint64_t n = (uint64_t)(row_hi - row_lo) * ppr;
-    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t r = row_lo + (uint32_t)(t / ppr), p = (uint32_t)(t % ppr);
-        const uint4 v = *reinterpret_cast<const uint4 *>(shadow + (size_t)r * dim + p * 8u);
-        const size_t tile = ((size_t)(r / 16u) * (dim / 32u) + p / 4u) * 512u;
-        *reinterpret_cast<uint4 *>(shadow_t + tile + (r % 16u) * 32u + (((p & 3u) ^ ((r >> 3) & 3u)) << 3)) = v;
-    }
-}
-
-int launch_tile_shadow(const uint16_t *shadow, uint16_t *shadow_t, uint32_t row_lo, uint32_t row_hi, uint32_t dim, hipStream_t stream) {
-    if (row_hi <= row_lo) return CX_OK;
-    if (dim % 32u) return set_err(CX_ERR_VALIDATION, "tiled shadow needs dim %% 32 == 0 (got %u)", dim);
-    const uint64_t n = (uint64_t)(row_hi - row_lo) * (dim / 8u);
-    const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 255u) / 256u, 16384u);
-    hipLaunchKernelGGL(tile_shadow_kernel, dim3(grid), dim3(256), 0, stream, shadow, shadow_t, row_lo, row_hi, dim);
-    CX_HIP(hipGetLastError());
-    return CX_OK;
 }
 
 void pair_filter256_tile_list(uint32_t n_rows, std::vector<uint32_t> &out) {

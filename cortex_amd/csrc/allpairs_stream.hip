@@ -10,6 +10,10 @@
 //    scores against thr - eps; hits go to the scanned row's candidate list (rare);
 //  - one raw barrier per tile (lgkmcnt(0) + s_barrier: the prefetched loads stay in flight); a tile is one 16-row image,
 //    or two for dims <= 512, where one image alone is too little work per barrier.
+//  - Round 3: the shard's rows come from the TILED shadow (kernels.hpp: tiled_shadow_off) — the only copy kept when
+//    dim % 32 == 0.  A 16-row block of it is dim / 32 contiguous KiB, so the producers' loads are as before; the LDS
+//    image keeps this kernel's own swizzle, the producers translate (a lane's 16 bytes are piece x ^ s of row r of
+//    K-step ks, s from bits 3-4 of the global row: bit 4 is the block's parity, one XOR of the LDS address by 32).
 // Same contract as pair_filter_kernel (allpairs.hip): candidate columns out, no score matrix.
 #include "kernels.hpp"
 
@@ -50,34 +54,47 @@ __global__ __launch_bounds__(512) void pair_filter_stream_kernel(const PairFilte
     if (!consumer) {
         // ------------------------------------------------------------------ producer
         f32x4 ldA[LOADS], ldB[LOADS];
+        const bool tiled = a.shadow_t != nullptr;
         uint32_t dst_off[LOADS];   // swizzled LDS offset of this lane's 16 bytes of each 1-KiB piece
 #pragma unroll
         for (uint32_t e = 0; e < LOADS; e++) {
-            const uint32_t o = (pw * LOADS + e) * 1024u + lane * 16u;   // byte offset inside the (row-major) tile
-            const uint32_t row = o / ROW_BYTES;                          // 0 .. ROWS-1: image row / 16, swizzled inside its image
-            dst_off[e] = (row / IMG_ROWS) * IMG_BYTES + t_off<D>(row % IMG_ROWS, (o % ROW_BYTES) >> 4);
+            const uint32_t o = (pw * LOADS + e) * 1024u + lane * 16u;   // byte offset inside the tile as it lies in memory
+            if (tiled) {   // [image][K-step][16 rows x 64 B]: slot x of row r holds piece x ^ ((global row >> 3) & 3)
+                const uint32_t img = o / IMG_BYTES, oi = o % IMG_BYTES, ks = oi >> 10, r = (oi >> 6) & 15u, x = (oi >> 4) & 3u;
+                const uint32_t par = NIMG == 2u ? img : 0u;   // two images per tile: tiles start at even blocks; one: the tile's parity, applied per tile
+                dst_off[e] = img * IMG_BYTES + t_off<D>(r, 4u * ks + (x ^ ((par << 1) | (r >> 3))));
+            } else {
+                const uint32_t row = o / ROW_BYTES;                      // 0 .. ROWS-1: image row / 16, swizzled inside its image
+                dst_off[e] = (row / IMG_ROWS) * IMG_BYTES + t_off<D>(row % IMG_ROWS, (o % ROW_BYTES) >> 4);
+            }
         }
         const uint32_t my_src = pw * LOADS * 1024u + lane * 16u;
-        const char *shadow = reinterpret_cast<const char *>(a.shadow);
+        const char *shadow = reinterpret_cast<const char *>(tiled ? a.shadow_t : a.shadow);
         // the last tile may be ragged: rows past n_rows are read from the last full tile position instead (clamped
         // tile index) — their scores are masked at emit
         auto src_of = [&](uint32_t t) {
             const uint32_t tile = t < n_tiles ? t : n_tiles - 1u;
-            // a ragged last tile would read past the shadow: shift it up to end exactly at the last row
-            const size_t row0 = (size_t)tile * ROWS + ROWS <= a.n_rows ? (size_t)tile * ROWS : (size_t)a.n_rows - ROWS;
+            // row-major: a ragged last tile would read past the shadow: shift it up to end exactly at the last row.
+            // The tiled shadow is allocated in whole 256-row tiles: the last tile is read where it lies
+            const size_t row0 = (tiled || (size_t)tile * ROWS + ROWS <= a.n_rows) ? (size_t)tile * ROWS : (size_t)a.n_rows - ROWS;
             return shadow + row0 * ROW_BYTES + my_src;
+        };
+        auto par_of = [&](uint32_t t) {   // LDS address bit 5 of a one-image tile from an odd 16-row block
+            const uint32_t tile = t < n_tiles ? t : n_tiles - 1u;
+            return (tiled && NIMG == 1u) ? (tile & 1u) << 5 : 0u;
         };
         auto issue_loads = [&](f32x4 (&ld)[LOADS], uint32_t t) {
             const char *base = src_of(t);
 #pragma unroll
             for (uint32_t e = 0; e < LOADS; e++) ld[e] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(base + e * 1024u));
         };
-        auto write_tile = [&](f32x4 (&ld)[LOADS], uint32_t buf, uint32_t reload) {
+        auto write_tile = [&](f32x4 (&ld)[LOADS], uint32_t buf, uint32_t held, uint32_t reload) {   // held: the tile the registers hold
             const char *rbase = src_of(reload);
             char *dst = smem + buf * TILE_BYTES;
+            const uint32_t px = par_of(held);
 #pragma unroll
             for (uint32_t e = 0; e < LOADS; e++) {
-                *reinterpret_cast<f32x4 *>(dst + dst_off[e]) = ld[e];   // store, then reload into the same register
+                *reinterpret_cast<f32x4 *>(dst + (dst_off[e] ^ px)) = ld[e];   // store, then reload into the same register
                 ld[e] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(rbase + e * 1024u));
             }
         };
@@ -85,12 +102,12 @@ __global__ __launch_bounds__(512) void pair_filter_stream_kernel(const PairFilte
         if (my_tiles) {
             issue_loads(ldA, tile);
             issue_loads(ldB, tile + gridDim.x);
-            write_tile(ldA, 0, tile + 2u * gridDim.x);
+            write_tile(ldA, 0, tile, tile + 2u * gridDim.x);
         }
         tile_barrier();
         auto step = [&](f32x4 (&ld)[LOADS]) {
             const uint32_t next = tile + gridDim.x;
-            if (next < n_tiles) write_tile(ld, buf ^ 1u, next + 2u * gridDim.x);
+            if (next < n_tiles) write_tile(ld, buf ^ 1u, next, next + 2u * gridDim.x);
             tile_barrier();
             buf ^= 1u;
             tile += gridDim.x;
@@ -107,13 +124,14 @@ __global__ __launch_bounds__(512) void pair_filter_stream_kernel(const PairFilte
     const uint32_t si = pw * 16u + j;                       // this lane's scanned row (position in the scan set)
     bf16x8 qf[KS];
     {
-        const uint16_t *q_src = a.shadow_q ? a.shadow_q : a.shadow;
         const bool live = si < a.n_scan;
         const uint32_t g = live ? (a.scan_rows ? a.scan_rows[si] : si) : 0u;
-        const bf16x8 *q8 = reinterpret_cast<const bf16x8 *>(q_src + (size_t)g * D);
+        const bool q_tiled = !a.shadow_q && a.shadow_t;   // the scanned rows are rows of this shard: read them where the shard keeps them
+        const uint16_t *q_row = a.shadow_q ? a.shadow_q + (size_t)g * D : (a.shadow ? a.shadow + (size_t)g * D : nullptr);
 #pragma unroll
         for (uint32_t ks = 0; ks < KS; ks++) {
-            qf[ks] = q8[4u * ks + kq];
+            qf[ks] = q_tiled ? *reinterpret_cast<const bf16x8 *>(a.shadow_t + tiled_shadow_off(g, 4u * ks + kq, KS))
+                             : reinterpret_cast<const bf16x8 *>(q_row)[4u * ks + kq];
             if (!live) qf[ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
@@ -126,8 +144,8 @@ __global__ __launch_bounds__(512) void pair_filter_stream_kernel(const PairFilte
     uint32_t buf = 0;
     for (uint32_t st = 0, tile = blockIdx.x; st < my_steps; st++, tile += gridDim.x) {
         if (!wave_live || tile >= n_tiles) { tile_barrier(); buf ^= 1u; continue; }
-        // a ragged last tile was read shifted up (src_of): its row 0 is row n_rows - ROWS
-        const size_t row0 = (size_t)tile * ROWS + ROWS <= a.n_rows ? (size_t)tile * ROWS : (size_t)a.n_rows - ROWS;
+        // row-major shadow: a ragged last tile was read shifted up (src_of): its row 0 is row n_rows - ROWS
+        const size_t row0 = (a.shadow_t || (size_t)tile * ROWS + ROWS <= a.n_rows) ? (size_t)tile * ROWS : (size_t)a.n_rows - ROWS;
         const size_t first_new = (size_t)tile * ROWS;   // rows below this were already covered by the previous tile
 #pragma unroll
         for (uint32_t img = 0; img < NIMG; img++) {
@@ -170,7 +188,7 @@ __global__ __launch_bounds__(512) void pair_filter_stream_kernel(const PairFilte
 }
 
 bool pair_filter_stream_supported(const PairFilterArgs &a) {
-    return a.n_scan >= 1 && a.n_scan <= pstream::MAX_SCAN && !a.symmetric && a.n_rows >= pstream::rows_per_tile(a.dim) &&
+    return a.n_scan >= 1 && a.n_scan <= pstream::MAX_SCAN && !a.symmetric && (a.shadow_t || a.n_rows >= pstream::rows_per_tile(a.dim)) &&
            (a.dim == 384 || a.dim == 512 || a.dim == 768 || a.dim == 1024);
 }
 

@@ -22,6 +22,8 @@ int ensure_shadow(const cx_index *ix, hipStream_t s) {
     std::lock_guard<std::mutex> g(ix->shadow_mu);
     const uint64_t n = ix->n_rows;
     const bool tiled = ix->dim % 32 == 0;
+    // ONE copy of the shadow: the tiled layout every filter kernel reads when dim % 32 == 0 (kernels.hpp:
+    // tiled_shadow_off), the row-major one otherwise.  (Rounds 1-2 kept both: 12.8 GB more per 6.25M x 1024 shard.)
     if (ix->shadow_cap < n) {
         if (ix->d_shadow) CX_HIP(hipFree(ix->d_shadow));
         if (ix->d_shadow_t) CX_HIP(hipFree(ix->d_shadow_t));
@@ -29,27 +31,27 @@ int ensure_shadow(const cx_index *ix, hipStream_t s) {
         ix->d_shadow_t = nullptr;
         ix->shadow_cap = 0;
         const uint64_t cap = std::max<uint64_t>(n, ix->cap);
-        CX_HIP(hipMalloc((void **)&ix->d_shadow, cap * ix->dim * sizeof(uint16_t) + 64));
-        if (tiled) {   // whole 256-row tiles (the persistent filter kernel reads its last panel unclamped), zero beyond the last row
+        if (tiled) {   // whole 256-row tiles (the filter kernels read their last panel unclamped), zero beyond the last row
             const size_t bytes = (size_t)((cap + 255) / 256) * 256 * ix->dim * sizeof(uint16_t);
             CX_HIP(hipMalloc((void **)&ix->d_shadow_t, bytes));
             CX_HIP(hipMemsetAsync(ix->d_shadow_t, 0, bytes, s));
+        } else {
+            CX_HIP(hipMalloc((void **)&ix->d_shadow, cap * ix->dim * sizeof(uint16_t) + 64));
         }
         ix->shadow_cap = cap;
         ix->shadow_rows = 0;
         ix->shadow_stale.clear();
     }
+    auto build = [&](uint32_t lo, uint32_t hi) -> int {
+        if (tiled) return launch_build_shadow_tiled(ix->dtype == 1 ? nullptr : ix->d_rows, ix->dtype == 1 ? ix->rows16() : nullptr, ix->d_shadow_t, lo, hi, ix->dim, s);
+        return ix->dtype == 1 ? launch_build_shadow(ix->rows16(), ix->d_shadow, lo, hi, ix->dim, s) : launch_build_shadow(ix->d_rows, ix->d_shadow, lo, hi, ix->dim, s);
+    };
     for (uint32_t r : ix->shadow_stale)
-        if (r < ix->shadow_rows) {
-            if (int rc = (ix->dtype == 1 ? launch_build_shadow(ix->rows16(), ix->d_shadow, r, r + 1, ix->dim, s) : launch_build_shadow(ix->d_rows, ix->d_shadow, r, r + 1, ix->dim, s))) return rc;
-            if (tiled)
-                if (int rc = launch_tile_shadow(ix->d_shadow, ix->d_shadow_t, r, r + 1, ix->dim, s)) return rc;
-        }
+        if (r < ix->shadow_rows)
+            if (int rc = build(r, r + 1)) return rc;
     ix->shadow_stale.clear();
     if (ix->shadow_rows < n) {
-        if (int rc = (ix->dtype == 1 ? launch_build_shadow(ix->rows16(), ix->d_shadow, (uint32_t)ix->shadow_rows, (uint32_t)n, ix->dim, s) : launch_build_shadow(ix->d_rows, ix->d_shadow, (uint32_t)ix->shadow_rows, (uint32_t)n, ix->dim, s))) return rc;
-        if (tiled)
-            if (int rc = launch_tile_shadow(ix->d_shadow, ix->d_shadow_t, (uint32_t)ix->shadow_rows, (uint32_t)n, ix->dim, s)) return rc;
+        if (int rc = build((uint32_t)ix->shadow_rows, (uint32_t)n)) return rc;
         ix->shadow_rows = n;
     }
     CX_HIP(hipStreamSynchronize(s));

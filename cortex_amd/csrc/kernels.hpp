@@ -152,16 +152,22 @@ int launch_dense_topk(const float *d_dense, uint32_t stride, uint32_t n_rows, ui
 // ---- all-pairs auto-link pass (allpairs.hip) ----
 int launch_build_shadow(const float *rows, uint16_t *shadow, uint32_t row_lo, uint32_t row_hi, uint32_t dim,
                         hipStream_t stream);
+// the same rows straight into the tiled layout (dim % 32 == 0)
+int launch_build_shadow_tiled(const float *rows, const uint16_t *rows16, uint16_t *shadow_t, uint32_t row_lo, uint32_t row_hi, uint32_t dim, hipStream_t stream);
 int launch_build_shadow(const uint16_t *rows16, uint16_t *shadow, uint32_t row_lo, uint32_t row_hi, uint32_t dim,
                         hipStream_t stream);   // bf16 store
 
-// rows [row_lo, row_hi) of a row-major bf16 shadow -> the piece-tiled copy the 256-tile kernel's LDS-DMA reads:
-// element (r, k) -> tile (r / 16, k / 32) of 512 elements, inside at (r % 16) * 32 + (((k % 32) / 8) ^ ((r >> 3) & 3)) * 8 + k % 8
-int launch_tile_shadow(const uint16_t *shadow, uint16_t *shadow_t, uint32_t row_lo, uint32_t row_hi, uint32_t dim, hipStream_t stream);
+
+// Tiled shadow (dim % 32 == 0): [16-row block][K-step of 32 elements][16 rows x 64 B], the four 16-byte pieces of a row's
+// K-step XOR-permuted with bits 3-4 of the row — one LDS-DMA instruction of the 256-tile kernels = 1 KiB of contiguous
+// memory.  Offset, in bf16 elements, of 16-byte piece `piece` (8 elements) of row `row`; kt32 = dim / 32.
+__host__ __device__ inline size_t tiled_shadow_off(uint32_t row, uint32_t piece, uint32_t kt32) {
+    return ((size_t)(row >> 4) * kt32 + (piece >> 2)) * 512u + (row & 15u) * 32u + (((piece & 3u) ^ ((row >> 3) & 3u)) << 3);
+}
 
 struct PairFilterArgs {
-    const uint16_t *shadow;     // [n_rows][dim] bf16, L2-normalised rows (the J operand)
-    const uint16_t *shadow_t;   // the J operand again, cut into 1 KiB LDS-DMA pieces (launch_tile_shadow); null = read `shadow`
+    const uint16_t *shadow;     // [n_rows][dim] bf16, L2-normalised rows (the J operand), row-major: only kept when dim % 32 != 0
+    const uint16_t *shadow_t;   // the J operand in the tiled layout above (every kernel reads it when it is there); null = read `shadow`
     const uint16_t *shadow_q;   // I operand if the scanned vectors are not rows of this shard ([n_scan][dim]); null = shadow
     const uint32_t *scan_rows;  // [n_scan] row of each scanned node, or null = identity
     uint32_t n_scan, n_rows, dim;
