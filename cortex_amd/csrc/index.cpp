@@ -479,15 +479,24 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
                 // -> ~25 us at the 97k sampled rows of a 6.25M-row shard, 6 % of that step.  With a filter the sample's
                 // columns have to be mapped back to rows: bound_select_kernel does that.
                 if (flt.trivial && k_eff <= 32u) {   // (wide lists: the chunked kernels' k = 100 lists cost more than the one-block select, 0.94 against 0.83 ms per step)
-                    const uint32_t s_chunks = dense_topk_chunks(s_rows);
+                    // (2k sampled scores per block, not 16k: 64 blocks walking 15.6k scores each took 40 us of a 0.85 ms step at 1M rows)
+                    // at 6.25M rows (97k sampled) 47 chunks cost 12 us more than 6: a block's fixed cost is the merge of its four waves' lists)
+                    const uint32_t s_chunks = std::min<uint32_t>(std::min<uint32_t>(chunks, 12u), std::max<uint32_t>(1u, s_rows / 2048u));
                     if (int rc = launch_dense_topk(c->d_dense, s_stride, s_rows, m, k_eff, flt, c->d_part_keys, c->d_part_sims, s_chunks, s)) return rc;
                     MergeArgs mb = mg;
                     mb.n_lists = s_chunks;
+                    const bool fused = merge_batch_writes_bound(k_eff, s_chunks);   // the merge writes the bounds and clears the flag itself
+                    if (fused) { mb.bound_out = tau; mb.clear_word = overflow; }
                     if (int rc = launch_merge_batch(mb, m, s)) return rc;
-                    if (int rc = launch_tau_from_lists(mg.out_scores, mg.out_count, m, k_eff, tau, s)) return rc;
-                } else if (int rc = launch_bound_select(c->d_dense, s_stride, s_rows, m, k_eff, tau, flt, batchg_tile_rows(ix->dtype == 1), tile_step, s)) return rc;
+                    if (!fused) {
+                        if (int rc = launch_tau_from_lists(mg.out_scores, mg.out_count, m, k_eff, tau, s)) return rc;
+                        CX_HIP(hipMemsetAsync(overflow, 0, sizeof(uint32_t), s));
+                    }
+                } else {
+                    if (int rc = launch_bound_select(c->d_dense, s_stride, s_rows, m, k_eff, tau, flt, batchg_tile_rows(ix->dtype == 1), tile_step, s)) return rc;
+                    CX_HIP(hipMemsetAsync(overflow, 0, sizeof(uint32_t), s));
+                }
                 // 2. every row, candidates only
-                CX_HIP(hipMemsetAsync(overflow, 0, sizeof(uint32_t), s));
                 BatchGFilter f{tau, c->d_cand_keys, c->d_cand_sims, counts, overflow, cb, flt};
                 if (int rc = prof_begin()) return rc;
                 if (int rc = launch_batchg_pass(ix->rows32(), ix->d_norms, n, ix->dim, m, c->d_qimg, d_qq, nullptr, 0, 1, &f, nullptr, s, ix->rows16())) return rc;

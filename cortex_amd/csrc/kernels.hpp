@@ -21,7 +21,12 @@ struct MergeArgs {
     const uint32_t *run_if = nullptr;   // non-null: the launch does nothing unless *run_if != 0
     const uint32_t *seg_counts = nullptr;   // radix merge of unsorted lists only: [nq][n_lists * k / seg_len] valid entries per segment
     uint32_t seg_len = 0;
+    // merge_small_kernel only (merge_batch_writes_bound): also write score_ord of query q's k-th result to bound_out[q] (0 = fewer
+    // than k results: no bound) and clear *clear_word — batchg's bound and overflow flag without two more stream operations
+    uint32_t *bound_out = nullptr;
+    uint32_t *clear_word = nullptr;
 };
+bool merge_batch_writes_bound(uint32_t k, uint32_t n_lists);
 
 // One single-query scan over the row store.
 struct ScanArgs {

@@ -418,9 +418,14 @@ __device__ inline void merge_small_body(const MergeArgs &m0) {
             m.out_rows[rank] = key_row(ki);
             m.out_dists[rank] = dist;
             m.out_scores[rank] = score_of(dist);
+            if (m.bound_out && rank == k - 1u) m.bound_out[blockIdx.x] = score_ord(score_of(dist));
         }
     }
-    if (tid == 0) *m.out_count = S < k ? S : k;
+    if (tid == 0) {
+        *m.out_count = S < k ? S : k;
+        if (m.bound_out && S < k) m.bound_out[blockIdx.x] = 0u;
+        if (m.clear_word && blockIdx.x == 0) *m.clear_word = 0u;
+    }
 }
 
 __global__ __launch_bounds__(1024) void merge_small_kernel(const MergeArgs m) { merge_small_body<1024>(m); }
@@ -581,6 +586,8 @@ int launch_scan_topk(const ScanArgs &a, const MergeArgs &m, bool nontemporal, hi
     return CX_OK;
 }
 
+bool merge_batch_writes_bound(uint32_t k, uint32_t n_lists) { return k >= 1 && k <= 32 && n_lists <= MERGE_SMALL_MAX_LISTS && !use_old_merge(); }
+
 int launch_merge_batch(const MergeArgs &m, uint32_t nq, hipStream_t stream, bool sorted_lists) {
     if (!nq || !m.k) return CX_OK;
     if (!sorted_lists) hipLaunchKernelGGL(merge_radix_kernel, dim3(nq), dim3(1024), 0, stream, m);   // a selection over all entries
@@ -648,20 +655,25 @@ __device__ inline uint32_t bins_above(const uint32_t *hist, uint32_t tid, uint32
 // counting duplicates, or 0 when fewer than k keys are set.  A radix walk from bit `hi` down to bit `lo` (multiples of 8),
 // one 256-bin LDS histogram and four barriers per byte — no global memory, so a pass costs a microsecond instead of a
 // round trip per element.  Every thread of the block must call it; sh: 264 uint32 of LDS.
-template <int NV>
-__device__ inline uint64_t block_select_kth(const uint64_t (&key)[NV], uint32_t k, int hi, int lo, uint32_t *sh) {
+template <int NV, typename K = uint64_t>
+__device__ inline K block_select_kth(const K (&key)[NV], uint32_t k, int hi, int lo, uint32_t *sh) {
     uint32_t *hist = sh;                      // [256]
     uint32_t *s_need = sh + 256, *s_found = sh + 257, *s_bin = sh + 258, *s_ok = sh + 259, *wtot = sh + 260;
+    // once the bin that holds the answer has no more than 64 keys they are ranked directly by one wave: a walk over 64-bit
+    // keys (score ordinal | ~row) needs two or three histogram passes instead of eight, one over 32-bit ordinals two
+    __shared__ K s_list[64];
+    __shared__ uint32_t s_ln, s_inbin;
+    __shared__ K s_res;
     const uint32_t tid = threadIdx.x;
-    uint64_t prefix = 0ull, mask = 0ull;
+    K prefix = 0, mask = 0;
     if (tid == 0) { *s_need = k; *s_ok = 1u; }
     for (int shift = hi; shift >= lo; shift -= 8) {
         if (tid < 256) hist[tid] = 0;
-        if (tid == 0) *s_found = 0u;
+        if (tid == 0) { *s_found = 0u; s_ln = 0u; }
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < NV; u++) {
-            const bool act = key[u] != 0ull && (key[u] & mask) == prefix;
+            const bool act = key[u] != 0 && (key[u] & mask) == prefix;
             const uint32_t bin = (uint32_t)(key[u] >> shift) & 255u;
             const uint64_t am = __ballot(act);
             if (am == 0ull) continue;
@@ -679,18 +691,36 @@ __device__ inline uint64_t block_select_kth(const uint64_t (&key)[NV], uint32_t 
             uint32_t mine;
             const uint32_t above = bins_above(hist, tid, wtot, mine);
             const uint32_t need = *s_need;
-            if (tid < 256 && above < need && need <= above + mine) { *s_bin = tid; *s_found = need - above; }   // found: the new need (>= 1)
+            if (tid < 256 && above < need && need <= above + mine) { *s_bin = tid; *s_found = need - above; s_inbin = mine; }   // found: the new need (>= 1)
         }
         __syncthreads();
         const uint32_t found = *s_found;
         if (!found) { if (tid == 0) *s_ok = 0u; break; }   // uniform: every thread reads the same LDS word
-        prefix |= (uint64_t)(*s_bin) << shift;
-        mask |= 0xFFull << shift;
+        const uint32_t in_bin = s_inbin;
+        prefix |= (K)(*s_bin) << shift;
+        mask |= (K)0xFF << shift;
+        if (in_bin <= 64u && shift > lo) {   // uniform.  The found-th largest of the bin's keys, ranked by one wave
+#pragma unroll
+            for (int u = 0; u < NV; u++)
+                if (key[u] != 0 && (key[u] & mask) == prefix) s_list[atomicAdd(&s_ln, 1u)] = key[u];
+            __syncthreads();
+            if (tid < 64u) {
+                const K mine_k = tid < in_bin ? s_list[tid] : (K)0;
+                uint32_t rank = 0;   // keys that come before this one: larger, or equal and earlier in the list
+                for (uint32_t j = 0; j < in_bin; j++) {
+                    const K o = s_list[j];
+                    rank += (o > mine_k || (o == mine_k && j < tid)) ? 1u : 0u;
+                }
+                if (tid < in_bin && rank == found - 1u) s_res = mine_k;
+            }
+            __syncthreads();
+            return s_res;
+        }
         __syncthreads();
         if (tid == 0) *s_need = found;
     }
     __syncthreads();
-    return *s_ok ? prefix : 0ull;
+    return *s_ok ? prefix : (K)0;
 }
 
 // tau_ord[q] = score_ord of the k-th largest score among the cosines dense[q][0 .. n) of rows that pass the filter (0 when
@@ -760,19 +790,62 @@ __global__ __launch_bounds__(1024) void bound_select_reg_kernel(const float *den
     __shared__ uint32_t sh[264];
     const uint32_t tid = threadIdx.x;
     const float *d = dense + (size_t)blockIdx.x * stride;
-    float v[NV];
+    uint32_t key[NV];   // 32-bit ordinals (>= 1 for a live score, 0 = empty): 64 per thread fit the 128 registers of a 1024-thread block
+    constexpr int CHK = NV < 16 ? NV : 16;   // loads in flight per thread (all NV at once would need 2 NV registers)
 #pragma unroll
-    for (int u = 0; u < NV; u++) { const uint32_t e = tid + (uint32_t)u * 1024u; v[u] = e < n ? d[e] : 0.0f; }
-    uint64_t key[NV];
+    for (int c = 0; c < NV; c += CHK) {
+        float v[CHK];
 #pragma unroll
-    for (int u = 0; u < NV; u++) {
-        const uint32_t e = tid + (uint32_t)u * 1024u;
-        bool live = e < n;
-        if (live && !flt.trivial) live = row_passes(flt, (e / tile_rows) * tile_step * tile_rows + e % tile_rows);
-        key[u] = live ? ((uint64_t)score_ord(score_of(distance_of(v[u]))) << 32) | 1ull : 0ull;   // ordinals are >= 1: never an empty key
+        for (int u = 0; u < CHK; u++) { const uint32_t e = tid + (uint32_t)(c + u) * 1024u; v[u] = e < n ? d[e] : 0.0f; }
+#pragma unroll
+        for (int u = 0; u < CHK; u++) {
+            const uint32_t e = tid + (uint32_t)(c + u) * 1024u;
+            bool live = e < n;
+            if (live && !flt.trivial) live = row_passes(flt, (e / tile_rows) * tile_step * tile_rows + e % tile_rows);
+            key[c + u] = live ? score_ord(score_of(distance_of(v[u]))) : 0u;
+        }
     }
-    const uint64_t t = block_select_kth<NV>(key, k, 56, 32, sh);
-    if (tid == 0) tau_ord[blockIdx.x] = (uint32_t)(t >> 32);
+    if constexpr (NV <= 8) {
+        const uint32_t t = block_select_kth<NV, uint32_t>(key, k, 24, 0, sh);
+        if (tid == 0) tau_ord[blockIdx.x] = t;
+    } else {
+        // Two stages.  The radix walk costs four passes over every register of every thread (59 us for 39k scores at
+        // k = 100: ballots and scalar bookkeeping per value, not the LDS atomics).  A first walk over 4 values per thread —
+        // a uniform 4,096-column sub-sample — finds a score t0 that about 2.5 k of ALL the scores should reach; one compare
+        // per value collects those into LDS; a second 4-values-per-thread walk over the survivors finds the exact k-th.
+        // Too few survivors (< k): t0 is taken further down the sub-sample; more than the list holds: the full walk.
+        __shared__ uint32_t surv[4096];
+        __shared__ uint32_t s_cnt;
+        const uint32_t sub[4] = {key[0], key[1], key[2], key[3]};
+        uint32_t ksub = (uint32_t)(((uint64_t)k * 4096u * 5u / 2u + n - 1u) / n) + 2u;
+        uint32_t t = 0u;
+        bool done = false;
+        for (int round = 0; round < 4 && !done; round++, ksub *= 2u) {
+            const uint32_t t0 = ksub <= 4096u ? block_select_kth<4, uint32_t>(sub, ksub, 24, 0, sh) : 0u;   // 0: every live score survives
+            __syncthreads();
+            if (tid == 0) s_cnt = 0u;
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < NV; u++)
+                if (key[u] != 0u && key[u] >= t0) {
+                    const uint32_t slot = atomicAdd(&s_cnt, 1u);
+                    if (slot < 4096u) surv[slot] = key[u];
+                }
+            __syncthreads();
+            const uint32_t cnt = s_cnt;   // uniform
+            if (cnt > 4096u) break;       // (a sample full of equal scores): the full walk below
+            if (cnt >= k || t0 == 0u) {
+                uint32_t r[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const uint32_t e = tid + (uint32_t)u * 1024u; r[u] = e < cnt ? surv[e] : 0u; }
+                t = block_select_kth<4, uint32_t>(r, k, 24, 0, sh);   // 0 when fewer than k scores are live at all
+                done = true;
+            }
+            __syncthreads();
+        }
+        if (!done) t = block_select_kth<NV, uint32_t>(key, k, 24, 0, sh);
+        if (tid == 0) tau_ord[blockIdx.x] = t;
+    }
 }
 
 int launch_bound_select(const float *d_dense, uint32_t stride, uint32_t n, uint32_t nq, uint32_t k, uint32_t *tau_ord, const DevFilter &flt,
@@ -780,6 +853,7 @@ int launch_bound_select(const float *d_dense, uint32_t stride, uint32_t n, uint3
     if (!nq || !k) return CX_OK;
     if (n <= 16u * 1024u) hipLaunchKernelGGL(bound_select_reg_kernel<16>, dim3(nq), dim3(1024), 0, stream, d_dense, stride, n, k, tau_ord, flt, tile_rows, tile_step);
     else if (n <= 32u * 1024u) hipLaunchKernelGGL(bound_select_reg_kernel<32>, dim3(nq), dim3(1024), 0, stream, d_dense, stride, n, k, tau_ord, flt, tile_rows, tile_step);
+    else if (n <= 64u * 1024u) hipLaunchKernelGGL(bound_select_reg_kernel<64>, dim3(nq), dim3(1024), 0, stream, d_dense, stride, n, k, tau_ord, flt, tile_rows, tile_step);   // k = 100 at 1.25M x 768: 39k sampled scores, 63 us through the kernel below
     else hipLaunchKernelGGL(bound_select_kernel, dim3(nq), dim3(1024), 0, stream, d_dense, stride, n, k, tau_ord, flt, tile_rows, tile_step);
     CX_HIP(hipGetLastError());
     return CX_OK;
