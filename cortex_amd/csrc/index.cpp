@@ -433,7 +433,17 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
         // bound: k * step candidates per query then spread widely around their mean of 1,910 and one query of a batch overflowed
         // cand_select_kernel's 4,096 now and then: the exact dense fallback ran, 4.5 ms instead of 2.4.  The bound got cheaper
         // another way: launch_bound_topk below.)
-        const uint32_t tile_step = step_env ? step_env : (k_eff <= 32u ? 64u : 32u);
+        // The sample is as coarse as the candidate stage allows: a bound from a 1-in-s sample lets k s candidates per query
+        // through on average, spread with a standard deviation of ~sqrt(k) s; cand_select_kernel holds 4,096 (k <= 32) and
+        // has to stay ~6 sigma above the mean — s = 128 at k = 10, 64 at k = 32 (the 1-in-191 sample that failed above sat
+        // 3.6 sigma under the cap).  A coarser sample is a shorter sample pass (latency-bound: 31 us for 77 tiles, 49 for
+        // 306) and a shorter bound selection (<= 64k sampled scores: in registers, bound_select_reg_kernel).
+        uint32_t tile_step = k_eff <= 32u ? 64u : 32u;
+        if (k_eff <= 32u) {
+            const float room = 4096.0f / ((float)k_eff + 6.0f * sqrtf((float)k_eff));
+            tile_step = room >= 128.0f ? 128u : (room >= 96.0f ? 96u : 64u);
+        }
+        if (step_env) tile_step = step_env;
         uint32_t s_tiles = 0;
         const uint32_t s_rows = batchg_sample_rows(n, tile_step, &s_tiles, ix->dtype == 1), s_stride = (s_rows + 3u) & ~3u;
         const bool filtered = filter_ok && n >= filter_min && s_rows >= k_eff;
@@ -478,7 +488,7 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
                 // blocks per query, then one merge) instead of ONE block per query walking all its sampled scores — 141 us
                 // -> ~25 us at the 97k sampled rows of a 6.25M-row shard, 6 % of that step.  With a filter the sample's
                 // columns have to be mapped back to rows: bound_select_kernel does that.
-                if (flt.trivial && k_eff <= 32u) {   // (wide lists: the chunked kernels' k = 100 lists cost more than the one-block select, 0.94 against 0.83 ms per step)
+                if (flt.trivial && k_eff <= 32u && s_rows > 65536u) {   // more sampled scores than bound_select_reg_kernel holds (wide lists: the chunked kernels' k = 100 lists cost more than the one-block select, 0.94 against 0.83 ms per step)
                     // (2k sampled scores per block, not 16k: 64 blocks walking 15.6k scores each took 40 us of a 0.85 ms step at 1M rows)
                     // at 6.25M rows (97k sampled) 47 chunks cost 12 us more than 6: a block's fixed cost is the merge of its four waves' lists)
                     const uint32_t s_chunks = std::min<uint32_t>(std::min<uint32_t>(chunks, 12u), std::max<uint32_t>(1u, s_rows / 2048u));
