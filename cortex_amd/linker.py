@@ -131,7 +131,7 @@ def autolink_walk(index: HipIndex, scan_ids: Optional[Sequence[NodeId]], rules, 
 def walk_similarity_lists(node_rows, rows, scores, counts, threshold, max_edges_per_node: int, deleted=None, existing=None):
     """auto_linker.rs:233-264 with SimilarityLinkRule (rules.rs:42-62) as the only rule, over MANY nodes' ordered neighbour
     lists at once (numpy; the per-neighbour Python loop of autolink_walk is for arbitrary rules).  Same walk as
-    link_rules_kernel (allpairs.hip) and cxo_autolink_pass:
+    link_rules_kernel (allpairs.hip):
       skip self (:235-237) and storage-deleted neighbours (:240-243) — they do not reach the cap test;
       score >= threshold -> an edge, unless the node already has it (existing_set, :226-231, :249-258: dropped WITHOUT counting);
       after every neighbour that was not skipped, stop once max_edges_per_node edges were proposed (:259-262 — tested after the
