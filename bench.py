@@ -269,6 +269,12 @@ def main() -> None:
         out.setdefault("extra", {})["config2_1M_x_384_k10"] = config2_leg(L, local_rank, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_autolink and B == 1:
         out.setdefault("extra", {})["config4_shard_1.25Mx768_batch64_k10"] = config4_leg(L, local_rank, dev)
+        # the same shard at the reference's default embedding width (384-d, embedding.rs:43-50), short and long lists:
+        # batchq.hip — queries resident in LDS, rows straight into MFMA operands, one service wave per block
+        out["extra"]["batch64_1.25Mx384_k10"] = config4_leg(L, local_rank, dev, d=384, steps=100, kernel="cx::batchq_kernel<384, 4>",
+                                                            shard_note="the reference's default width; one of 8 shards of 10M rows")
+        out["extra"]["batch64_1.25Mx384_k100"] = config4_leg(L, local_rank, dev, d=384, k=100, steps=100, kernel="cx::batchq_kernel<384, 4>",
+                                                             shard_note="the reference's default width, the linker's list length")
     if rank == 0 and world == 1 and not args.no_autolink:
         out.setdefault("extra", {})["autolink_allpairs"] = autolink_leg(L, local_rank, d, args.no_cpu_baseline)
         # the same pass over the bench corpus itself: BASELINE.json's metric names "auto-link pairs/sec at 1Mx768"

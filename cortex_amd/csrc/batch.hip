@@ -18,14 +18,13 @@
 //  - per-block lists go to HBM, one merge block per query finishes (merge_small_kernel / merge_radix_kernel).
 #include <vector>
 
+#include "batch_common.hpp"
 #include "kernels.hpp"
 #include "topk.hpp"
 
 namespace cx {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int BT_ROWS = 16;   // rows per tile
+constexpr int BT_ROWS = SPLIT_TILE_ROWS;   // rows per tile
 constexpr int BT_Q = 64;      // queries per pass (4 waves x 16)
 constexpr uint32_t BATCH_K_WIDE = 104;   // largest k of the wide mode (lists of k + 48 for 32 queries next to two 48 KiB tiles)
 
@@ -33,56 +32,13 @@ constexpr uint32_t BATCH_K_WIDE = 104;   // largest k of the wide mode (lists of
 __device__ inline uint64_t cand_key(uint32_t row, float sim) { return make_key(score_of(distance_of(sim)), row); }
 
 // ---------------------------------------------------------------------------------------------------
-// tile images: a 16-row tile is [hi image | lo image], each 16 rows x D bf16
+// tile images: a 16-row tile is D / 32 K-steps of [hi fragment | lo fragment] (batch_common.hpp), 16 rows x D x 4 bytes
 template <int D>
 struct Batch2Cfg {
-    static constexpr int ROW_BYTES = D * 2;                  // one bf16 image row
-    static constexpr int IMG_BYTES = BT_ROWS * ROW_BYTES;    // hi or lo image of a tile
-    static constexpr int TILE_BYTES = 2 * IMG_BYTES;         // = 16 rows x D x 4 B
+    static constexpr int TILE_BYTES = BT_ROWS * D * 4;
     static constexpr int LOADS = BT_ROWS * D * 4 / 1024 / 4; // 1 KiB wave loads per wave per tile (4 waves)
-    static constexpr int SEGS = D / 256;                     // 1 KiB segments per row
     static_assert(D % 256 == 0 || D == 384, "dim must be 384 or a multiple of 256");
 };
-
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ inline void split4(const f32x4 v, bf16x4_t &hi, bf16x4_t &lo) {
-    // hi = bf16(v) (round to nearest even, NaN stays NaN), lo = bf16(v - hi).  The packed conversion's result is
-    // unpacked with one shift / one mask per pair instead of being converted a second time element by element.
-    const uint32_t p01 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v.x, v.y}, bf16x2_t));
-    const uint32_t p23 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v.z, v.w}, bf16x2_t));
-    const f32x2 b01 = {__uint_as_float(p01 << 16), __uint_as_float(p01 & 0xFFFF0000u)};
-    const f32x2 b23 = {__uint_as_float(p23 << 16), __uint_as_float(p23 & 0xFFFF0000u)};
-    const f32x2 d01 = (f32x2){v.x, v.y} - b01, d23 = (f32x2){v.z, v.w} - b23;   // v_pk_add_f32
-    const uint32_t q01 = __builtin_bit_cast(uint32_t, __builtin_convertvector(d01, bf16x2_t));
-    const uint32_t q23 = __builtin_bit_cast(uint32_t, __builtin_convertvector(d23, bf16x2_t));
-    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    hi = __builtin_bit_cast(bf16x4_t, (u32x2){p01, p23});
-    lo = __builtin_bit_cast(bf16x4_t, (u32x2){q01, q23});
-}
-
-// byte offset of the 8-byte half `half` of 16-byte piece p of row i inside a bf16 image (XOR swizzle
-// inside each 256-byte segment, same involution as the f32 kernel)
-template <int D>
-__device__ inline uint32_t img_off(uint32_t i, uint32_t p, uint32_t half) {
-    return i * Batch2Cfg<D>::ROW_BYTES + (((p & ~15u) | ((p ^ i) & 15u)) << 4) + half * 8u;
-}
-
-// minimum over the 64 lanes, result in every lane (same exchange pattern as wave_sum_dpp)
-__device__ inline uint32_t wave_min_u32(uint32_t v) {
-    uint32_t o;
-    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);  v = o < v ? o : v;
-    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);  v = o < v ? o : v;
-    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true); v = o < v ? o : v;
-    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true); v = o < v ? o : v;
-    o = (uint32_t)__shfl_xor((int)v, 16, 64); v = o < v ? o : v;
-    o = (uint32_t)__shfl_xor((int)v, 32, 64); v = o < v ? o : v;
-    return v;
-}
 
 // sum over the 64 lanes, result in every lane: four DPP steps inside each 16-lane row (VALU rate), then
 // two cross-row exchanges
@@ -578,10 +534,8 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
     qq += __shfl_xor(qq, 16, 64);
     qq += __shfl_xor(qq, 32, 64);
 
-    // A-operand read offsets (hi image; lo image = + IMG_BYTES): lane (i = j, kq) reads piece 4 ks + kq of row i
-    uint32_t a_off[4];
-#pragma unroll
-    for (uint32_t ksl = 0; ksl < 4; ksl++) a_off[ksl] = j * C::ROW_BYTES + ((((4u * ksl + kq) ^ j) & 15u) << 4);
+    // A-operand reads: K-step ks of the tile is [hi fragment | lo fragment], a lane's 16 bytes at 16 * lane
+    const uint32_t a_off = lane * 16u;
 
     unsigned long long n_compact = 0, n_append_steps = 0;   // n_compact: kept for the diag record layout
     // behind a barrier: slide what this wave appended since a producer's compaction snapshot down to k
@@ -615,7 +569,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
         if (wave_dead || tile >= n_tiles || (a.arm & 4u)) { tile_barrier(); if constexpr (NBUF == 2) buf ^= 1u; else tile_barrier(); continue; }
         if (!(a.arm & 2u)) apply_shrink();
         stamp(t_stage);
-        const char *Thi = tiles + buf * C::TILE_BYTES, *Tlo = Thi + C::IMG_BYTES;
+        const char *Thi = tiles + buf * C::TILE_BYTES + a_off, *Tlo = Thi + SPLIT_FRAG_BYTES;
         // epilogue operands are read now, under the MFMA loop, not after it
         const float tsq = c_tsq[qslot];
         const f32x4 rr4 = *reinterpret_cast<const f32x4 *>(c_rr + buf * BT_ROWS + 4u * kq);
@@ -624,8 +578,8 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
         constexpr int CH = 2, NCH = KS / CH;
         static_assert(KS % CH == 0, "dim/32 must be even");
-        auto rdh = [&](int ks) { return *reinterpret_cast<const s16x8 *>(Thi + a_off[ks & 3] + (uint32_t)(ks >> 2) * 256u); };
-        auto rdl = [&](int ks) { return *reinterpret_cast<const s16x8 *>(Tlo + a_off[ks & 3] + (uint32_t)(ks >> 2) * 256u); };
+        auto rdh = [&](int ks) { return *reinterpret_cast<const s16x8 *>(Thi + (uint32_t)ks * SPLIT_STEP_BYTES); };
+        auto rdl = [&](int ks) { return *reinterpret_cast<const s16x8 *>(Tlo + (uint32_t)ks * SPLIT_STEP_BYTES); };
         s16x8 ha[CH], la[CH], hb[CH], lb[CH];
 #pragma unroll
         for (int u = 0; u < CH; u++) { ha[u] = rdh(u); la[u] = rdl(u); }
@@ -714,25 +668,22 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
     }
 }
 
-// rows [row_lo, row_hi) of the f32 store -> the split store: tile t = rows 16 t .. 16 t + 15 as [hi image | lo image],
-// each image 16 rows x D bf16 with the 16-byte pieces of a row XOR-swizzled inside 256-byte segments (img_off) — byte
-// for byte what the consumers read from LDS.  One wave per row.
+// rows [row_lo, row_hi) of the f32 store -> the split store in its fragment-major layout (batch_common.hpp) — byte for
+// byte what the consumers read from LDS and what batchq.hip loads straight into MFMA operand registers.  One wave per row.
 template <int D>
 __global__ __launch_bounds__(256) void build_split_kernel(const float *rows, char *split, uint32_t row_lo, uint32_t row_hi) {
-    using C = Batch2Cfg<D>;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t r = row_lo + wave; r < row_hi; r += n_waves) {
         const f32x4 *src = reinterpret_cast<const f32x4 *>(rows + (size_t)r * D);
-        char *hi_img = split + (size_t)(r / BT_ROWS) * C::TILE_BYTES, *lo_img = hi_img + C::IMG_BYTES;
+        char *tile = split + (size_t)(r / BT_ROWS) * split_tile_bytes(D);
         const uint32_t i = r % BT_ROWS;
         for (uint32_t c4 = lane; c4 < (uint32_t)D / 4u; c4 += 64u) {
             bf16x4_t h, l;
             split4(src[c4], h, l);
-            const uint32_t col = c4 * 4u;
-            const uint32_t o = img_off<D>(i, col >> 3, (col >> 2) & 1u);
-            *reinterpret_cast<bf16x4_t *>(hi_img + o) = h;
-            *reinterpret_cast<bf16x4_t *>(lo_img + o) = l;
+            const uint32_t o = split_piece_off(i, c4 * 4u);
+            *reinterpret_cast<bf16x4_t *>(tile + o) = h;
+            *reinterpret_cast<bf16x4_t *>(tile + o + SPLIT_FRAG_BYTES) = l;
         }
     }
 }

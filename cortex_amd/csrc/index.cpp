@@ -362,6 +362,69 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
     // peak whatever k is, batch2_kernel's in-kernel wide lists at 0.40-0.49 (1.25M x 384 / 768, k = 100)
     // (1.25M rows, per step: k = 100 at 768 / 384-d 0.82 / 0.51 ms against 1.02 / 0.64; k = 32: 0.78 / 0.46 against 0.81 / 0.58; k = 20
     // at 384-d 0.44 against 0.48; k = 10: 0.77 / 0.45 against 0.65 / 0.43 — batch2's fused lists win while they are short)
+    // 384-d (the reference's default embedding width) on a store large enough that every wave gets a few tiles:
+    // batchq.hip — queries resident in LDS, rows straight from the split store into MFMA operands, one shared bound per
+    // query from the first tile on, candidate lists that cannot overflow: two stream operations per 64 queries
+    static const int bq_ok = getenv("CX_BATCHQ") ? atoi(getenv("CX_BATCHQ")) : 1;
+    if (bq_ok && ix->dtype == 0 && topk_path && no_tails && nq >= (uint64_t)batch_min && k_eff >= 1 && batchq_supported(ix->dim, k_eff) &&
+        n >= batchq_min_rows()) {
+        if (int rc = ensure_norms(ix, s)) return rc;
+        if (c->bqc_cap < BQ_CTL_WORDS) {
+            if (int rc = ensure_dev(c->d_bq_ctl, c->bqc_cap, (size_t)BQ_CTL_WORDS)) return rc;
+            CX_HIP(hipMemsetAsync(c->d_bq_ctl, 0, (size_t)BQ_CTL_WORDS * sizeof(uint32_t), s));
+        }
+        if (int rc = ensure_dev(c->d_bq_rows, c->bqr_cap, (size_t)64 * n)) return rc;
+        if (int rc = ensure_dev(c->d_bq_cos, c->bqs_cap, (size_t)64 * n)) return rc;
+        for (uint64_t q0 = 0; q0 < nq; q0 += 64) {
+            const uint32_t m = (uint32_t)std::min<uint64_t>(64, nq - q0);
+            BatchQArgs b;
+            memset(&b, 0, sizeof b);
+            b.split = ix->d_split;
+            b.norms = ix->d_norms;
+            b.queries = d_queries + q0 * ix->dim;
+            b.n_rows = n;
+            b.nq = m;
+            b.dim = ix->dim;
+            b.k = k_eff;
+            b.flt = flt;
+            b.ctl = c->d_bq_ctl;
+            b.cand_rows = c->d_bq_rows;
+            b.cand_cos = c->d_bq_cos;
+            b.cap = n;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (ix->profiling) {
+                CX_HIP(hipEventCreate(&e0));
+                CX_HIP(hipEventCreate(&e1));
+                std::lock_guard<std::mutex> g(ix->mu);
+                ix->prof_events.emplace_back(e0, e1);
+                CX_HIP(hipEventRecord(e0, s));
+            }
+            int rc = launch_batchq_pass(b, s);
+            if (e1) CX_HIP(hipEventRecord(e1, s));
+            static const int bq_diag = getenv("CX_BATCHQ_DIAG") ? atoi(getenv("CX_BATCHQ_DIAG")) : 0;
+            std::vector<uint32_t> dg(128);
+            if (bq_diag && !rc) {   // candidates per query and published bounds of this pass, on stderr
+                CX_HIP(hipStreamSynchronize(s));
+                CX_HIP(hipMemcpy(dg.data(), c->d_bq_ctl + BQ_CTL_BOUND, 128 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            }
+            if (!rc) rc = launch_batchq_select(b, d_rows + q0 * k_eff, d_scores + q0 * k_eff, d_dists + q0 * k_eff, d_counts + q0, s);
+            if (bq_diag && !rc) {
+                std::vector<float> sc((size_t)m * k_eff);
+                CX_HIP(hipStreamSynchronize(s));
+                CX_HIP(hipMemcpy(sc.data(), d_scores + q0 * k_eff, sc.size() * sizeof(float), hipMemcpyDeviceToHost));
+                uint64_t tot = 0; uint32_t mx = 0, nob = 0;
+                for (uint32_t q = 0; q < m; q++) { tot += dg[64 + q]; mx = std::max(mx, dg[64 + q]); nob += dg[q] <= 1u; }
+                fprintf(stderr, "[batchq diag] %u queries: %llu candidates (max %u per query), %u without a bound; (candidates, bound, k-th score):", m, (unsigned long long)tot, mx, nob);
+                for (uint32_t q = 0; q < m && q < 12; q++) { float b0; memcpy(&b0, &dg[q], 4); fprintf(stderr, " (%u, %.3f, %.3f)", dg[64 + q], b0, sc[(size_t)q * k_eff + k_eff - 1]); }
+                fprintf(stderr, "\n");
+            }
+            if (rc) {   // a pass that did not run to its select leaves the control block in an unknown state
+                (void)hipMemsetAsync(c->d_bq_ctl, 0, (size_t)BQ_CTL_WORDS * sizeof(uint32_t), s);
+                return rc;
+            }
+        }
+        return CX_OK;
+    }
     const bool wide_to_bg = (k_eff > 32 || (ix->dim <= 384 && k_eff >= 20)) && bg_ok && filter_ok && n >= filter_min && batchg_supported(ix->dim, k_eff);
     if (b2_ok && ix->dtype == 0 && !wide_to_bg && topk_path && no_tails && nq >= (uint64_t)batch_min && k_eff >= 1 && batch_supported(ix->dim, k_eff)) {
         if (int rc = ensure_norms(ix, s)) return rc;

@@ -70,6 +70,9 @@ struct Ctx {
     uint64_t *d_cand_keys = nullptr; size_t ck_cap = 0; // batchg filter mode: per-block candidate lists [64][grid][cb]
     float *d_cand_sims = nullptr; size_t cs_cap = 0;
     uint32_t *d_bg_ctl = nullptr; size_t bc_cap = 0;   // [64] bounds + [1] overflow flag
+    uint32_t *d_bq_ctl = nullptr; size_t bqc_cap = 0;  // batchq: bound slots, published bounds, list lengths (BQ_CTL_WORDS; zero between passes)
+    uint32_t *d_bq_rows = nullptr; size_t bqr_cap = 0; // batchq: candidate lists [64][rows]: row, cosine
+    float *d_bq_cos = nullptr; size_t bqs_cap = 0;
     uint32_t *d_out_rows = nullptr; size_t or_cap = 0;
     float *d_out_scores = nullptr; size_t os_cap = 0;
     float *d_out_dists = nullptr; size_t od_cap = 0;
@@ -92,6 +95,7 @@ struct Ctx {
     ~Ctx() {
         if (pass_scratch && pass_scratch_free) pass_scratch_free(pass_scratch);
         (void)hipFree(d_dense); (void)hipFree(d_qimg); (void)hipFree(d_cand_keys); (void)hipFree(d_cand_sims); (void)hipFree(d_bg_ctl);
+        (void)hipFree(d_bq_ctl); (void)hipFree(d_bq_rows); (void)hipFree(d_bq_cos);
         (void)hipFree(d_query); (void)hipFree(d_gslots); (void)hipFree(d_part_keys); (void)hipFree(d_part_sims); (void)hipFree(d_out_rows);
         (void)hipFree(d_out_scores); (void)hipFree(d_out_dists); (void)hipFree(d_out_counts); (void)hipFree(d_excl);
         (void)hipFree(d_kinds); (void)hipFree(d_keys); (void)hipFree(d_keys2); (void)hipFree(d_sims); (void)hipFree(d_sims2);

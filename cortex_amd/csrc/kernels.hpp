@@ -91,7 +91,7 @@ struct BatchArgs {
     const float *rows;      // [n_rows][dim]
     const float *queries;   // [nq][dim] in HBM
     const float *norms;     // [n_rows (+16 readable)] |row|^2 (cx_index::d_norms)
-    const char *split;      // bf16 hi/lo copy of the rows, tile by tile in the LDS image layout (cx_index::d_split)
+    const char *split;      // bf16 hi/lo copy of the rows, tile by tile as MFMA fragments (cx_index::d_split, batch_common.hpp)
     uint32_t n_rows, nq, dim, k, capq;
     uint32_t n_groups;      // query groups in this launch (gridDim.y); nq covers all of them
     uint32_t qpp;           // queries per group: batch_queries_per_pass(dim, k, queries of the whole call)
@@ -117,6 +117,30 @@ int launch_merge_batch(const MergeArgs &m, uint32_t nq, hipStream_t stream, bool
 // segmented candidate lists (m.seg_counts / m.seg_len set) -> top k, live entries held in registers; *d_redo is set (never
 // cleared) when a query has more live entries than that path holds — batchg passes its overflow flag: the dense pass redoes it
 int launch_cand_select(const MergeArgs &m, uint32_t nq, uint32_t *d_redo, hipStream_t stream);
+
+// ---- batched search at 384-d, queries resident in LDS, rows straight into MFMA operands (batchq.hip) ----
+constexpr uint32_t BQ_SL = 2048;                      // bound slots per query in the control block, [slot][query] (tile t -> slot t mod BQ_SL)
+constexpr uint32_t BQ_CTL_BOUND = 64 * BQ_SL;         // word offsets inside the control block
+constexpr uint32_t BQ_CTL_CNT = BQ_CTL_BOUND + 64;
+constexpr uint32_t BQ_CTL_NEXT = BQ_CTL_CNT + 64;     // the next unclaimed tile beyond the statically dealt first ones
+constexpr uint32_t BQ_CTL_WORDS = BQ_CTL_NEXT + 16;
+struct BatchQArgs {
+    const char *split;      // cx_index::d_split (batch_common.hpp)
+    const float *norms;     // |row|^2 (cx_index::d_norms, padded)
+    const float *queries;   // [nq][dim] f32 in HBM
+    uint32_t n_rows, nq, dim, k;
+    DevFilter flt;
+    uint32_t *ctl;          // [BQ_CTL_WORDS]: 64 x BQ_SL bound slots | 64 published bounds | 64 list lengths | tile counter; zero between passes
+                            // (the select kernel clears what a pass used)
+    uint32_t *cand_rows;    // [64][cap] candidate lists: row, cosine
+    float *cand_cos;
+    uint32_t cap;           // entries per query: n_rows (every pair is tested once, so a list cannot run over)
+    uint32_t arm;           // CX_BATCHQ_ARM: measurement arms (results invalid): 1 workers drop their hits, 4 the service wave drops them
+};
+bool batchq_supported(uint32_t dim, uint32_t k);
+uint32_t batchq_min_rows();   // fewest rows that take this path (CX_BATCHQ_MIN_ROWS)
+int launch_batchq_pass(const BatchQArgs &a, hipStream_t stream);
+int launch_batchq_select(const BatchQArgs &a, uint32_t *out_rows, float *out_scores, float *out_dists, uint32_t *out_count, hipStream_t stream);
 
 // ---- batched search for the other row widths (batchg.hip): dense cosines for <= 64 queries, then top-k ----
 bool batchg_supported(uint32_t dim, uint32_t k);       // dim % 128 == 0, dim <= 4096, k <= 256

@@ -737,6 +737,78 @@ print("ok")
 
 
 @pytest.mark.gpu
+def test_search_batch_queries_in_lds_kernel():
+    """batchq.hip (384-d stores of >= 131,072 rows by default) at test sizes, against the oracle in its own process: ragged
+    tiles, every k class, several passes, removed rows + metadata + filter, zero rows / zero query, massive ties, fewer tiles
+    than slots (no bound can form: every pair is a candidate), fewer rows with a positive cosine than k."""
+    import subprocess, sys, os
+    code = r"""
+import numpy as np, sys, os
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import cortex_amd
+from oracle import oracle
+from conftest import assert_topk_parity, ids_for
+oracle.build()
+d = 384
+def both(rows):
+    ids = ids_for(len(rows)); lut = {ids[i].tobytes(): i for i in range(len(rows))}
+    h = cortex_amd.HipIndex(d); h.insert_batch(ids, rows)
+    o = oracle.OracleIndex(d); o.insert_batch(ids, rows)
+    return h, o, ids, lut
+def check(h, o, lut, qs, k, hf=None, of=None, what="", exact_ids=False):
+    bi, bs, bd, bc = h.search_batch_arrays(qs, k, hf)
+    for i in range(len(qs)):
+        e = o.search(qs[i], k, of); m = int(bc[i])
+        assert m == len(e["row"]), (what, i, m, len(e["row"]))
+        got = np.array([lut[g.tobytes()] for g in bi[i, :m]], dtype=np.int64)
+        if exact_ids:
+            assert list(map(int, got)) == list(map(int, e["row"])), (what, i, got[:8], e["row"][:8])
+        else:
+            assert_topk_parity(got, bs[i, :m], e["row"], e["score"], what="%%s q%%d" %% (what, i))
+for n, k, nq in [(3001, 10, 100), (40000, 100, 70), (20000, 256, 5), (777, 32, 7), (300, 100, 64), (257, 1, 3), (60000, 10, 64), (9000, 33, 130)]:
+    rows = oracle.synth_rows(n, d); qs = oracle.synth_queries(n, d, nq)
+    h, o, ids, lut = both(rows)
+    check(h, o, lut, qs, k, what="n=%%d k=%%d" %% (n, k))
+    if n == 60000:
+        for r in range(0, n, 3):
+            kind = "fact" if r %% 2 else "event"
+            h.set_metadata(ids[r].tobytes(), kind, "kai"); o.set_metadata(ids[r].tobytes(), kind, "kai")
+        for r in (10, 11, 500, 4097, 59999):
+            h.remove(ids[r].tobytes()); o.remove(ids[r].tobytes())
+        excl = [ids[i].tobytes() for i in (1, 2, 3, 130)]
+        check(h, o, lut, qs, k, what="tombstones")
+        check(h, o, lut, qs, k, cortex_amd.VectorFilter(kinds=["fact"], exclude=excl), oracle.Filter(kinds=["fact"], exclude=excl), what="filtered")
+        # a filter almost nothing passes: the slots never fill, every passing row is a candidate
+        for r in range(0, 40): h.set_metadata(ids[7 * r + 1].tobytes(), "rare", "zed"); o.set_metadata(ids[7 * r + 1].tobytes(), "rare", "zed")
+        check(h, o, lut, qs, 50, cortex_amd.VectorFilter(kinds=["rare"]), oracle.Filter(kinds=["rare"]), what="rare kind")
+# zero rows and a zero query: NaN scores come last, in row order
+n = 5000
+rows = oracle.synth_rows(n, d); rows[[3, 77, 4000]] = 0.0
+qs = oracle.synth_queries(n, d, 9); qs[4] = 0.0
+h, o, ids, lut = both(rows)
+for k in (10, 100): check(h, o, lut, qs, k, what="zeros k=%%d" %% k)
+# 50 distinct vectors repeated: almost every cut falls inside a run of equal scores; ids exact
+n = 40000
+base = oracle.synth_rows(50, d)
+rows = np.ascontiguousarray(base[np.arange(n) %% 50])
+qs = np.ascontiguousarray(base[:16] + 0.05 * oracle.synth_queries(50, d, 16))
+h, o, ids, lut = both(rows)
+for k in (32, 100): check(h, o, lut, qs, k, what="ties k=%%d" %% k, exact_ids=True)
+# fewer than k rows with a positive cosine: rows tied at the clamped 0.0 come out in row order; batch == single scan == oracle
+n, k = 4000, 10
+rng = np.random.default_rng(8)
+rows = np.abs(rng.normal(size=(n, d))).astype(np.float32)
+qs = -np.abs(rng.normal(size=(8, d))).astype(np.float32)
+for t in range(6): rows[100 + 37 * t] = -rows[100 + 37 * t]
+h, o, ids, lut = both(rows)
+check(h, o, lut, qs, k, what="six positive", exact_ids=True)
+print("ok")
+""" % ((os.path.dirname(os.path.dirname(os.path.abspath(__file__))),) * 2)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, CX_BATCHQ_MIN_ROWS="256"))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.gpu
 def test_batched_search_bound_and_candidates_at_scale(hip):
     """400k x 1024 (1.6 GB), 70 queries, k = 10 and 100: batchg.hip's default path at this size — a bound per query from a
     1-in-32 sample of the row tiles, then only the rows that reach it — must return what 70 single-query scans return
