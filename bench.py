@@ -204,7 +204,7 @@ def main() -> None:
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": float(traffic) if traffic else None, "traffic_source": traffic_src,
-            "kernel": "cx::scan_kernel" if B < 3 else "cx::batch2_kernel", "avg_kernel_ms": avg_ms, "launches": kern_n,
+            "kernel": "cx::scan_kernel" if B < 3 else f"cx::batchs_kernel<{d}> (streams the 2-byte screening copy: store-equivalent figures)", "avg_kernel_ms": avg_ms, "launches": kern_n,
             "algorithmic_bytes_per_launch": algo_bytes,
             "step_achieved": algo_bytes / (elapsed / args.steps) / 1e9, "frac_step": algo_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
         },
@@ -269,12 +269,13 @@ def main() -> None:
         out.setdefault("extra", {})["config2_1M_x_384_k10"] = config2_leg(L, local_rank, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_autolink and B == 1:
         out.setdefault("extra", {})["config4_shard_1.25Mx768_batch64_k10"] = config4_leg(L, local_rank, dev)
-        # the same shard at the reference's default embedding width (384-d, embedding.rs:43-50), short and long lists:
-        # batchq.hip — queries resident in LDS, rows straight into MFMA operands, one service wave per block
-        out["extra"]["batch64_1.25Mx384_k10"] = config4_leg(L, local_rank, dev, d=384, steps=100, kernel="cx::batchq_kernel<384, 4>",
+        # the same shard at the reference's default embedding width (384-d, embedding.rs:43-50) and with the linker's lists
+        out["extra"]["batch64_1.25Mx384_k10"] = config4_leg(L, local_rank, dev, d=384, steps=100,
                                                             shard_note="the reference's default width; one of 8 shards of 10M rows")
-        out["extra"]["batch64_1.25Mx384_k100"] = config4_leg(L, local_rank, dev, d=384, k=100, steps=100, kernel="cx::batchq_kernel<384, 4>",
+        out["extra"]["batch64_1.25Mx384_k100"] = config4_leg(L, local_rank, dev, d=384, k=100, steps=100,
                                                              shard_note="the reference's default width, the linker's list length")
+        out["extra"]["batch64_1.25Mx768_k100"] = config4_leg(L, local_rank, dev, k=100, steps=60,
+                                                             shard_note="one of 8 shards of 10M rows, the linker's list length")
     if rank == 0 and world == 1 and not args.no_autolink:
         out.setdefault("extra", {})["autolink_allpairs"] = autolink_leg(L, local_rank, d, args.no_cpu_baseline)
         # the same pass over the bench corpus itself: BASELINE.json's metric names "auto-link pairs/sec at 1Mx768"
@@ -293,9 +294,9 @@ def main() -> None:
         out["extra"]["config5_shard_6.25Mx1024_streaming_ingest"] = config5_leg(L, local_rank, dev)
         # config 5's row width through search_batch: the batched kernel for the widths batch2 has no instance for
         out["extra"]["config5_shard_6.25Mx1024_batch64_k10"] = config4_leg(L, local_rank, dev, n=6_250_000, d=1024, steps=10,
-                                                                           kernel="cx::batchg_kernel<0, true, false>", shard_note="one of 8 shards of config 5's 50M rows, f32 store")
+                                                                           shard_note="one of 8 shards of config 5's 50M rows, f32 store")
         out["extra"]["config5_shard_6.25Mx1024_bf16_batch64_k10"] = config4_leg(L, local_rank, dev, n=6_250_000, d=1024, steps=10, dtype="bf16",
-                                                                                kernel="cx::batchg_kernel<0, true, true>", shard_note="one of 8 shards of config 5's 50M rows, bf16 store")
+                                                                                shard_note="one of 8 shards of config 5's 50M rows, bf16 store")
     if rank == 0:
         print(json.dumps(out), flush=True)
     ix.close()
@@ -461,8 +462,30 @@ def config1_leg(L, device: int, n: int = 10_000, d: int = 384, k: int = 5, nq: i
                                      "note": "restatement of instant-distance 0.6.1 from the HNSW paper; parity unpinned"}}
 
 
+def batch_roofline(n: int, d: int, store_elem_bytes: float, avg_kernel_ms: float, step_s: float, kern_n: int, note: str = "") -> dict:
+    """HBM roofline object of a batched-search leg.  Stores of >= 131,072 rows go through batchs.hip: one launch streams
+    the index's SCREENING copy of the shard once — rows L2-normalised, bf16, MFMA fragment order: n x d x 2 bytes — and the
+    survivors (a few hundred per query) are re-scored exactly from the stored rows.  `achieved` / `frac` are those bytes
+    over the screening kernel's duration (HIP events around the launch), `frac_step` the same bytes over the whole step
+    (re-score, selection, gaps).  The contract's figure (the shard's stored bytes per batch) over the same
+    durations is given beside it as store_equivalent_*: it can exceed the peak because the pass reads half of them (f32
+    stores)."""
+    algo = float(n) * d * 2.0
+    store = float(n) * d * store_elem_bytes
+    avg = avg_kernel_ms
+    return {"bound": "hbm", "achieved": algo / (avg * 1e-3) / 1e9 if avg else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": algo / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS if avg else 0.0, "kernel": f"cx::batchs_kernel<{d}>", "avg_kernel_ms": avg,
+            "launches": kern_n, "algorithmic_bytes_per_launch": algo,
+            "step_achieved": algo / step_s / 1e9, "frac_step": algo / step_s / 1e9 / HBM_PEAK_GBS,
+            "store_bytes_per_launch": store, "store_equivalent_GBs": store / (avg * 1e-3) / 1e9 if avg else 0.0,
+            "store_equivalent_step_GBs": store / step_s / 1e9,
+            "frac_note": "frac: the screening kernel's launches alone over the bytes it streams (the 2-byte screening copy); frac_step: the same "
+                         "bytes over the whole step (exact re-score of the survivors, selection, gaps); store_equivalent_*: the stored rows' "
+                         "bytes (the contract's per-batch figure) over the same durations" + (("; " + note) if note else "")}
+
+
 def config4_leg(L, device: int, dev, n: int = 1_250_000, d: int = 768, k: int = 10, B: int = 64, steps: int = 40,
-                kernel: str = "cx::batch2_kernel", shard_note: str = "one of 8 shards of 10M rows", dtype: str = "f32"):
+                shard_note: str = "one of 8 shards of 10M rows", dtype: str = "f32"):
     """BASELINE configs[3], one GPU's share: 64 queries per step over a 1.25M x 768 f32 shard (10M rows / 8 GPUs),
     k=10 — the batched MFMA kernel the sharded search runs before its all-gather; same measurement as the headline
     (cx_search_batch_dev, HIP events around the kernel)."""
@@ -498,14 +521,9 @@ def config4_leg(L, device: int, dev, n: int = 1_250_000, d: int = 768, k: int = 
     kern_ms, kern_n = ix.profile_read(reset=True)
     ix.close()
     avg = kern_ms / max(1, kern_n)
-    algo = float(n) * d * (2.0 if dtype == "bf16" else 4.0)
     return {"workload": f"cosine kNN k={k}, batch of {B} queries per step, {n} x {d} {dtype} rows ({shard_note})",
             "queries_per_s": steps * B / el, "ms_per_step": el / steps * 1e3,
-            "roofline": {"bound": "hbm", "achieved": algo / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": algo / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": kernel, "avg_kernel_ms": avg,
-                         "launches": kern_n, "algorithmic_bytes_per_launch": algo,
-                         "step_achieved": algo / (el / steps) / 1e9, "frac_step": algo / (el / steps) / 1e9 / HBM_PEAK_GBS,
-                         "frac_note": "frac: the dominant kernel's launches alone; frac_step: the same bytes over the whole step (every launch of the step + gaps)"}}
+            "roofline": batch_roofline(n, d, 2.0 if dtype == "bf16" else 4.0, avg, el / steps, kern_n)}
 
 
 def config4_sharded_leg(L, device: int, dev, rank: int, world: int, total: int = 10_000_000, d: int = 768, k: int = 10,
@@ -561,16 +579,12 @@ def config4_sharded_leg(L, device: int, dev, rank: int, world: int, total: int =
     ix.close()
     torch.cuda.empty_cache()
     avg = kern_ms / max(1, kern_n)
-    algo = float(n) * d * 4.0
     return {"workload": f"cosine kNN k={k}, batches of {B} queries, ONE {total} x {d} f32 corpus row-sharded over {world} GPU(s) "
                         f"({n} rows on this rank), all-gather of partial top-k + merge per batch",
             "scaling": "strong", "n_gpus": world, "queries_per_s": steps * B / el, "ms_per_step": el / steps * 1e3, "steps": steps,
-            "roofline": {"bound": "hbm", "achieved": algo / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": algo / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": "cx::batch2_kernel", "avg_kernel_ms": avg,
-                         "launches": kern_n, "algorithmic_bytes_per_launch": algo,
-                         "step_achieved": algo / (el / steps) / 1e9, "frac_step": algo / (el / steps) / 1e9 / HBM_PEAK_GBS,
-                         "note": "rank 0's shard; one launch reads the rank's whole shard once for 64 queries; frac_step: the same bytes over the "
-                                 "whole step (all-gather and merge included)"}}
+            "roofline": batch_roofline(n, d, 4.0, avg, el / steps, kern_n,
+                                       "rank 0's shard; one launch reads the rank's screening copy once for 64 queries; the step includes the "
+                                       "all-gather and the merge")}
 
 
 def config4_one_process_leg(L, n_dev: int, total: int = 10_000_000, d: int = 768, k: int = 10, B: int = 64, steps: int = 20, warmup: int = 5):
@@ -605,13 +619,15 @@ def config4_one_process_leg(L, n_dev: int, total: int = 10_000_000, d: int = 768
     p2p = bool(sh.peer_to_peer)
     sh.close()
     torch.cuda.empty_cache()
-    by = float(total) * d * 4.0
+    by = float(total) * d * 2.0   # the shards' screening copies (batchs.hip), streamed once per batch
     return {"workload": f"cosine kNN k={k}, batches of {B} queries, ONE {total} x {d} f32 corpus behind cx_sharded_search_batch in one process, "
                         f"one shard on each of {len(devs)} visible GPU(s); host queries in, host ids out",
             "scaling": "strong", "n_gpus": len(devs), "peer_to_peer": p2p, "queries_per_s": steps * B / el, "ms_per_step": el / steps * 1e3, "steps": steps,
             "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS * len(devs), "achieved": by / (el / steps) / 1e9,
                          "frac": by / (el / steps) / 1e9 / (HBM_PEAK_GBS * len(devs)),
-                         "note": "whole step (host API, PCIe and merge included) over the aggregate HBM peak of the GPUs used"}}
+                         "store_equivalent_step_GBs": 2.0 * by / (el / steps) / 1e9,
+                         "note": "whole step (host API, PCIe and merge included): the bytes the screening passes stream (total x d x 2) over the "
+                                 "aggregate HBM peak of the GPUs used; store_equivalent: the f32 rows' bytes over the same time"}}
 
 
 def config5_leg(L, device: int, dev, n: int = 6_250_000, d: int = 1024, thr: float = 0.85):

@@ -669,7 +669,7 @@ __global__ __launch_bounds__(512, 2) void batch2_kernel(const BatchArgs a_in) {
 }
 
 // rows [row_lo, row_hi) of the f32 store -> the split store in its fragment-major layout (batch_common.hpp) — byte for
-// byte what the consumers read from LDS and what batchq.hip loads straight into MFMA operand registers.  One wave per row.
+// byte what the consumers read from LDS.  One wave per row.
 template <int D>
 __global__ __launch_bounds__(256) void build_split_kernel(const float *rows, char *split, uint32_t row_lo, uint32_t row_hi) {
     const uint32_t lane = threadIdx.x & 63u;

@@ -1,13 +1,14 @@
-// batch_common.hpp — what the batched-search kernels share (batch.hip, batchq.hip): the bf16 hi/lo split of an f32 value
-// and the layout of the index's split store (cx_index::d_split).
+// batch_common.hpp — the bf16 hi/lo split of an f32 value and the layout of the index's split store (cx_index::d_split,
+// batch.hip).
 //
 // Split store, "fragment-major": a 16-row tile t (rows 16 t .. 16 t + 15) is D / 32 K-steps of 2 KiB:
 //   [K-step ks: hi fragment 1 KiB | lo fragment 1 KiB], fragment = 64 lanes x 16 bytes, lane = 16 kq + i holding
 //   elements 32 ks + 8 kq .. + 7 of row i as bf16 —
-// byte for byte the A operand of v_mfma_f32_16x16x32_bf16 as its lanes hold it.  A wave that loads 16 bytes per lane at
-// `fragment + 16 lane` gets the operand straight into registers with one fully coalesced 1 KiB access (batchq.hip); a
-// block that copies the tile into LDS linearly reads it back conflict-free with ds_read_b128 at the same offsets
-// (batch.hip).  (Rounds 1-2 kept row-major bf16 images with an XOR swizzle: the same bytes, permuted inside a tile.)
+// byte for byte the A operand of v_mfma_f32_16x16x32_bf16 as its lanes hold it: a block that copies the tile into LDS
+// linearly reads it back conflict-free with ds_read_b128 at `fragment + 16 lane` (batch.hip); a wave that loads 16 bytes
+// per lane at the same offsets gets the operand straight into registers with one fully coalesced 1 KiB access (the layout
+// batchs.hip's screening store uses for its single bf16 fragment per K-step).  (Rounds 1-2 kept row-major bf16 images
+// with an XOR swizzle: the same bytes, permuted inside a tile.)
 #pragma once
 
 #include "common.hpp"

@@ -1,0 +1,768 @@
+// batchs.hip — batched exact search (search_batch, vector/index.rs:390-410; BASELINE config 4's inner loop) as a SCREENING
+// pass over a 2-byte copy of the rows followed by an exact f32 re-score of the survivors — the all-pairs pass's own
+// design (allpairs.hip: bf16 filter with a rigorous error bound, then the reference's arithmetic on what is left)
+// applied to up to 64 queries per pass.
+//
+// The operand: the index keeps, for stores this path serves, a copy of the rows L2-normalised and rounded to bf16, laid out
+// as MFMA A fragments (cx_index::d_nfrag: 16-row tile, K-step of 32, one KiB = 64 lanes x 16 bytes; build_nfrag_kernel).
+// Its dot with a normalised bf16 query is the cosine within eps = 2u + u^2 + 1e-4, u = 2^-8 (autolink.cpp: both operands
+// rounded, unit vectors), so
+//   - a row whose approximate cosine is A has an exact cosine >= A - eps;
+//   - if k different rows have approximate cosines >= A_k, the query's exact k-th best is >= A_k - eps, and a row can
+//     only be among the exact k best if its approximate cosine is >= A_k - 2 eps.
+// The pass therefore streams HALF the bytes of the f32 rows (a quarter of rows + split store), needs ONE
+// v_mfma_f32_16x16x32_bf16 per 16 rows x 16 queries x 32 elements instead of three, tests a pair with one compare,
+// and hands a few hundred survivors per query to the select kernel, which computes their exact cosines from the stored
+// rows (f32 or bf16 store) with sequential-in-lane f32 sums — the scan path's arithmetic class — before it selects.
+// Results are the exact path's: the screening only ever removes rows that cannot be among the k best.
+//
+// Structure of the pass (every choice below was measured on the way; profiles/r03/tuning.md §8): a block is seven WORKER
+// waves and one SERVICE wave.
+//  - A worker does what the single-query scan's waves do, independently of the others: it owns 32-row tiles (two A
+//    fragments), keeps a ring of K-steps (2 KiB each, 8 deep at 768 / 1024-d) in flight across tile boundaries with plain
+//    16-byte buffer loads, reads the four query fragments of a K-step from LDS (64 queries x dim x 2 bytes: 96 KiB at
+//    768-d, 128 KiB at 1024-d) and issues 8 MFMAs.  No barrier after the prologue and NOTHING else in its memory queue:
+//    under a saturated HBM an agent-scope load, a returning atomic or a fence takes 5-15 us to come back and vmcnt retires
+//    in order (one bound refresh per wave and 8 tiles cost the row stream 8 %; per-wave warm-up handshakes 50 us).
+//  - The bound of a query is shared by the whole grid from the first tile on: 2,048 slots per query in HBM, slot
+//    (tile mod 2,048) holds the best approximate cosine seen among the rows of those tiles, so the k-th largest slot value
+//    is A_k whatever the timing.  Every worker's first tile fills a slot (1,792 workers x 32 rows: a 57k-row sample without
+//    a pass of its own); the workers test against the block's copy of the bounds in LDS.
+//  - A pair that passes is a HIT: (row, query, approximate cosine) goes into the worker's ring in LDS.
+//  - The service wave owns everything that talks to the rest of the grid: it writes the block's first-tile maxima to the
+//    slots (plain write-through stores — an atomic max per wave and query, 131k at agent scope, took 75 us; one arrival
+//    counter for 2,048 waves 110 us; a release fence per wave ~75 us), publishes the k-th largest slot value of its
+//    queries (radix walk over four 8-bit digits with an LDS histogram: 2 us; a ballot per bit and value: 13), drains the
+//    hit rings — row filter, candidate list (room for every row: nothing can overflow, no fallback pass exists), the
+//    tile's slot raised —, re-reads and re-publishes the bounds at growing intervals (256 service waves polling the same
+//    256 bytes every few microseconds keep one HBM channel busy with themselves: -8 %), and deals the tiles: the first
+//    one of every worker is static (the sample), the rest are claimed 14 at a time from one grid-wide counter and handed
+//    over through a queue in LDS (blocks do not get equal shares of the HBM: at 5M rows the fastest block took 38 % more
+//    tiles than the slowest; statically dealt tiles left a quarter of the chip idle at the end).
+#include <vector>
+
+#include "batch_common.hpp"
+#include "kernels.hpp"
+#include "select.hpp"
+#include "topk.hpp"
+
+namespace cx {
+
+constexpr uint32_t BS_WORK = 7;        // worker waves per block; the eighth wave is the service wave
+// |approximate - exact cosine| (autolink.cpp: FILTER_EPS)
+constexpr float BS_EPS = 2.0f / 256.0f + 1.0f / 65536.0f + 1.0e-4f;
+
+__device__ inline uint32_t bs_ld_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline uint32_t bs_lds_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ inline uint32_t bs_lds_ld_acq(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ inline void bs_lds_st(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ inline void bs_lds_st_rel(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// A published bound is the bits of an approximate cosine > 0 (the k-th largest slot value A_k); 0 = nothing published
+// yet, BS_NONE = "this query has no bound" (fewer than k slots filled: a zero query, a filter that passes next to nothing).
+constexpr uint32_t BS_NONE = 1u;
+// the test's threshold: a pair is a hit unless its approximate cosine is below A_k - 2 eps.  -inf = every pair passes (no
+// bound, or one so low that rows with a non-positive cosine — all tied at the clamped score 0 — could be among the k best);
+// +inf for a query slot beyond nq
+__device__ inline float bs_thr(uint32_t bits, bool live) {
+    const float t = __uint_as_float(bits) - 2.0f * BS_EPS;
+    return !live ? __builtin_inff() : ((bits <= BS_NONE || !(t > 0.0f)) ? -__builtin_inff() : t);
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// LDS control words
+enum : uint32_t { BSL_HEAD = 0, BSL_TAIL = 8, BSL_ARRIVED = 16, BSL_DONE = 17, BSL_READY = 18, BSL_QHEAD = 19, BSL_QTAIL = 20, BSL_WORDS = 24 };
+constexpr uint32_t BS_TQ = 64;         // entries of the block's tile queue (a power of two)
+constexpr uint32_t BS_CLAIM = 14;      // tiles the service wave claims at a time: two per worker
+constexpr uint32_t BS_NO_TILE = 0xFFFFFFFFu;
+
+template <int D>
+struct BsCfg {
+    static constexpr int KS = D / 32;                                   // K-steps per row
+    static constexpr int P = KS % 8 == 0 ? 8 : (KS % 6 == 0 ? 6 : 4);   // K-steps a worker keeps in flight (2 KiB each)
+    static constexpr uint32_t HB = D > 768 ? 128u : 256u;               // hit-ring entries per worker (a power of two)
+    static constexpr uint32_t T16 = 16u * D * 2u;                       // bytes of a 16-row tile of the fragment store
+    static constexpr size_t LDS = (size_t)KS * 4096u + BSL_WORDS * 4 + (size_t)BS_WORK * HB * 12 + BS_WORK * 64 * 4 + 256 * 4 + 64 * 4 + BS_TQ * 4 + 64 * 4;
+    static_assert(KS % P == 0 && D % 128 == 0 && LDS <= 160u * 1024u, "unsupported row width");
+};
+
+// rows [row_lo, row_hi) -> the fragment store: L2-normalised (zero and non-finite rows become zero rows: allpairs.hip's
+// rule), rounded to bf16, element j of row r at tile (r / 16) x T16 + K-step (j / 32) x 1 KiB + lane (16 (j % 32 / 8) + r % 16)
+// x 16 bytes + (j % 8) x 2.  One wave per row.
+template <typename S>
+__global__ __launch_bounds__(256) void build_nfrag_kernel(const S *rows, uint16_t *nfrag, uint32_t row_lo, uint32_t row_hi, uint32_t dim) {
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u, n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t r = row_lo + wave; r < row_hi; r += n_waves) {
+        const S *p = rows + (size_t)r * dim;
+        float ss = 0.0f;
+        for (uint32_t j = lane; j < dim; j += 64u) { const float x = ldf(p + j); ss += x * x; }
+#pragma unroll
+        for (int x = 1; x < 64; x <<= 1) ss += __shfl_xor(ss, x, 64);
+        const float inv = ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f;
+        uint16_t *tile = nfrag + (size_t)(r >> 4) * 16u * dim;
+        for (uint32_t j = lane; j < dim; j += 64u) {
+            const float v = ldf(p + j) * inv;
+            const uint16_t b = (v == v && fabsf(v) <= 3.0e38f) ? f32_to_bf16_bits(v) : (uint16_t)0;
+            tile[(j >> 5) * 512u + ((((j >> 3) & 3u) << 4) + (r & 15u)) * 8u + (j & 7u)] = b;
+        }
+    }
+}
+
+int launch_build_nfrag(const float *rows, const uint16_t *rows16, uint16_t *nfrag, uint32_t row_lo, uint32_t row_hi, uint32_t dim, hipStream_t stream) {
+    if (row_hi <= row_lo) return CX_OK;
+    uint32_t grid = (row_hi - row_lo + 3u) / 4u;
+    if (grid > 8192u) grid = 8192u;
+    if (rows16) hipLaunchKernelGGL(build_nfrag_kernel<uint16_t>, dim3(grid), dim3(256), 0, stream, rows16, nfrag, row_lo, row_hi, dim);
+    else hipLaunchKernelGGL(build_nfrag_kernel<float>, dim3(grid), dim3(256), 0, stream, rows, nfrag, row_lo, row_hi, dim);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+
+template <int D>
+__global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
+    using C = BsCfg<D>;
+    constexpr int KS = C::KS, P = C::P;
+    constexpr uint32_t HB = C::HB, T16 = C::T16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // LDS: [query fragments: KS x 4 groups x 1 KiB][control words][hit rings: rows | queries | cosines, 7 x HB]
+    //      [warm-up maxima 7 x 64][histogram 256][bounds 64][tile queue][1 / |q|: 64]
+    char *qimg = smem;
+    uint32_t *s_ctl = reinterpret_cast<uint32_t *>(smem + KS * 4096);
+    uint32_t *s_hrow = s_ctl + BSL_WORDS;
+    uint32_t *s_hq = s_hrow + BS_WORK * HB;
+    float *s_hdot = reinterpret_cast<float *>(s_hq + BS_WORK * HB);
+    uint32_t *s_wm = reinterpret_cast<uint32_t *>(s_hdot + BS_WORK * HB);   // [7 workers][64 queries] warm-up maxima
+    uint32_t *s_hist = s_wm + BS_WORK * 64u;                                // [256] the service wave's digit histogram
+    uint32_t *s_bnd = s_hist + 256u;                                        // [64] the block's copy of the published bounds
+    uint32_t *s_tq = s_bnd + 64u;                                           // [BS_TQ] the block's tile queue
+    float *s_inv = reinterpret_cast<float *>(s_tq + BS_TQ);                 // [64] 1 / |q| (prologue)
+    float *s_qqp = s_hdot;                                                  // prologue only: the two halves of every |q|^2
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t j = lane & 15u, kq = lane >> 4;
+    const uint32_t n_rows = a.n_rows, k = a.k, nq = a.nq;
+    const uint32_t n32 = (n_rows + 31u) >> 5;
+    const uint32_t nw = gridDim.x * BS_WORK;                      // worker waves of the grid
+    const uint32_t T_first = blockIdx.x * BS_WORK;                // the block's workers start at tiles T_first .. T_first + 6
+    const uint32_t in_block = T_first >= n32 ? 0u : (n32 - T_first < BS_WORK ? n32 - T_first : BS_WORK);   // workers with a first tile
+    uint32_t *const g_slots = a.ctl, *const g_bound = a.ctl + BS_CTL_BOUND, *const g_cnt = a.ctl + BS_CTL_CNT, *const g_next = a.ctl + BS_CTL_NEXT;
+    const bool worker = wave < BS_WORK;
+    // Tiles: the first nw (one per worker wave: the sample, tile -> slot) are dealt statically; the rest are claimed
+    // BS_CLAIM at a time from one grid-wide counter by the service waves and handed over through a queue in LDS
+    const uint32_t n_static = nw < n32 ? nw : n32;
+    uint32_t claim0 = 0u;
+    if (!worker && lane == 0u) claim0 = atomicAdd(g_next, BS_CLAIM);   // (comes back under the query prologue)
+
+    auto now = [&]() -> uint64_t {   // 100 MHz
+        uint64_t t;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        return t;
+    };
+
+    // ---- workers: the ring.  P K-steps x 2 row fragments of 16 bytes per lane.  A 32-row tile is 2 x T16 contiguous bytes
+    // of the fragment store (the store ends with a spare 16-row tile, so the second half of the last tile exists); one
+    // buffer descriptor per tile — SGPR base, the lane's 16 bytes as the only address VGPR
+    s16x8 ring[P][2];
+    const uint32_t voff = lane * 16u;
+    auto tile_rsrc = [&](uint32_t T) {
+        const uint32_t Tc = (uint32_t)__builtin_amdgcn_readfirstlane((int)(T < n32 ? T : n32 - 1u));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(const_cast<uint16_t *>(a.nfrag)) + (size_t)Tc * (2u * T16), 0, (int)(2u * T16), 0x00020000);
+    };
+    auto issue = [&](s16x8 (&slot)[2], __amdgpu_buffer_rsrc_t rs, int ks) {
+#pragma unroll
+        for (int f = 0; f < 2; f++)
+            slot[f] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff + (ks & 3) * 1024, (int)(f * T16) + (ks >> 2) * 4096, 2 /* nt */));
+    };
+
+    uint32_t T = T_first + wave;
+    const bool has_work = worker && T < n32;
+    __amdgpu_buffer_rsrc_t crs = tile_rsrc(T);
+    if (has_work) {
+#pragma unroll
+        for (int p = 0; p < P; p++) issue(ring[p], crs, p);
+    }
+
+    // ---- prologue (all eight waves): |q|, then the queries normalised, rounded to bf16, as B fragments in LDS: wave w
+    // takes query group w & 3, K-steps of half w >> 2
+    {
+        const uint32_t g = wave & 3u, half = wave >> 2, q = g * 16u + j;
+        const bool live = q < nq;
+        const f32x4 *q4 = reinterpret_cast<const f32x4 *>(a.queries + (size_t)(live ? q : 0u) * D) + half * (KS / 2) * 8;
+        float qq = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < KS / 2; ks++) {
+            const f32x4 v0 = q4[8 * ks + 2 * kq], v1 = q4[8 * ks + 2 * kq + 1];
+            qq += v0.x * v0.x + v0.y * v0.y + v0.z * v0.z + v0.w * v0.w + v1.x * v1.x + v1.y * v1.y + v1.z * v1.z + v1.w * v1.w;
+        }
+        qq += __shfl_xor(qq, 16, 64);
+        qq += __shfl_xor(qq, 32, 64);
+        if (kq == 0u) s_qqp[half * 64u + q] = live ? qq : 0.0f;
+        if (tid < BSL_WORDS) s_ctl[tid] = 0u;
+        if (tid < 64u) s_bnd[tid] = 0u;
+        __syncthreads();
+        if (tid < 64u) {
+            const float ss = s_qqp[tid] + s_qqp[64u + tid];
+            s_inv[tid] = ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f;   // a zero (or non-finite) query: a zero image — it bounds nothing, every row is re-scored
+        }
+        __syncthreads();
+        const float inv = s_inv[q];
+#pragma unroll
+        for (int ks = 0; ks < KS / 2; ks++) {
+            const f32x4 v0 = q4[8 * ks + 2 * kq], v1 = q4[8 * ks + 2 * kq + 1];
+            const float e[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            s16x8 H;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const float v = e[i] * inv;
+                H[i] = (short)((live && v == v && fabsf(v) <= 3.0e38f) ? f32_to_bf16_bits(v) : (uint16_t)0);
+            }
+            *reinterpret_cast<s16x8 *>(qimg + (((uint32_t)ks + half * (KS / 2)) * 4u + g) * 1024u + lane * 16u) = H;
+        }
+    }
+    // the service wave fills the tile queue: tiles n_static + c .. + BS_CLAIM - 1 of a claim c; BS_WORK end marks once
+    // the counter has passed the last tile
+    bool exhausted = false;
+    uint32_t q_head = 0u;
+    auto push_claim = [&](uint32_t c) {   // service wave, all lanes
+        c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+        const uint32_t first = n_static + c;
+        const uint32_t have = first >= n32 ? 0u : (n32 - first < BS_CLAIM ? n32 - first : BS_CLAIM);
+        if (lane < have) bs_lds_st(&s_tq[(q_head + lane) & (BS_TQ - 1u)], first + lane);
+        q_head += have;
+        if (have < BS_CLAIM) {
+            if (lane < BS_WORK) bs_lds_st(&s_tq[(q_head + lane) & (BS_TQ - 1u)], BS_NO_TILE);
+            q_head += BS_WORK;
+            exhausted = true;
+        }
+        if (lane == 0u) bs_lds_st_rel(&s_ctl[BSL_QHEAD], q_head);
+    };
+    if (!worker) push_claim(claim0);
+    __syncthreads();
+
+    if (!worker) {
+        // =============================================================== the service wave
+        // One hit per lane: row filter, candidate list (the exact cosine is the select kernel's), the tile's slot.  Lanes
+        // with the same query take their list positions from ONE atomic add.
+        auto process_hits = [&](bool active, uint32_t row, uint32_t q, float approx) {
+            active = active && row_passes(a.flt, row);
+            row = active ? row : 0u;
+            q = active ? q : 0u;
+            uint64_t same = __ballot(active);
+#pragma unroll
+            for (int b = 0; b < 6; b++) {
+                const uint64_t m = __ballot((q >> b) & 1u);
+                same &= ((q >> b) & 1u) ? m : ~m;
+            }
+            const int leader = __ffsll((unsigned long long)same) - 1;
+            uint32_t base = 0;
+            if (active && (int)lane == leader) base = atomicAdd(g_cnt + q, (uint32_t)__popcll(same));
+            base = (uint32_t)__shfl((int)base, active ? leader : 0, 64);
+            const uint32_t pos = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            if (active && pos < a.cap) a.cand_rows[(size_t)q * a.cap + pos] = row;
+            if (active && approx > 0.0f)
+                __hip_atomic_fetch_max(g_slots + q * BS_SL + ((row >> 5) & (BS_SL - 1u)), __float_as_uint(approx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        // The slots of query q (32 per lane) and the k-th largest of them (a radix walk over four 8-bit digits with a
+        // 256-bin histogram in LDS; one wave: its LDS operations stay in order)
+        constexpr int NV = (int)(BS_SL / 64u);
+        uint32_t v[NV];
+        auto slots_load = [&](uint32_t q) -> uint32_t {   // returns the number of filled slots
+            uint32_t nz = 0;
+#pragma unroll
+            for (int i = 0; i < NV; i++) v[i] = bs_ld_agent(g_slots + q * BS_SL + lane + 64u * i);
+#pragma unroll
+            for (int i = 0; i < NV; i++) nz += (uint32_t)__popcll(__ballot(v[i] != 0u));
+            return nz;
+        };
+        auto slots_kth = [&]() -> uint32_t {   // 0 = fewer than k slots are filled
+            uint32_t prefix = 0u, mask = 0u, need = k;
+#pragma unroll 1
+            for (int shift = 24; shift >= 0; shift -= 8) {
+                *reinterpret_cast<u32x4 *>(s_hist + 4u * lane) = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int i = 0; i < NV; i++)
+                    if (v[i] != 0u && (v[i] & mask) == prefix) atomicAdd(&s_hist[(v[i] >> shift) & 255u], 1u);
+                const u32x4 h = *reinterpret_cast<const u32x4 *>(s_hist + 4u * lane);   // bins 4 lane .. 4 lane + 3
+                const uint32_t mine_tot = h.x + h.y + h.z + h.w;
+                uint32_t suf = mine_tot;   // inclusive suffix sum over the lanes above
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t t = (uint32_t)__shfl_down((int)suf, off, 64);
+                    if (lane + (uint32_t)off < 64u) suf += t;
+                }
+                uint32_t cum = suf - mine_tot;   // entries in bins above this lane's
+                uint32_t bin = 0u, nneed = 0u;
+                bool found = false;
+                const uint32_t hh[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+                for (int b = 3; b >= 0; b--) {
+                    const bool here = !found && cum < need && need <= cum + hh[b];
+                    bin = here ? 4u * lane + (uint32_t)b : bin;
+                    nneed = here ? need - cum : nneed;
+                    found = found || here;
+                    cum += hh[b];
+                }
+                const uint64_t fm = __ballot(found);
+                if (!fm) return 0u;
+                const int src = __ffsll((unsigned long long)fm) - 1;
+                bin = (uint32_t)__builtin_amdgcn_readlane((int)bin, src);
+                need = (uint32_t)__builtin_amdgcn_readlane((int)nneed, src);
+                prefix |= bin << shift;
+                mask |= 0xFFu << shift;
+            }
+            return prefix;
+        };
+        // publisher duty: this block looks after the queries b, b + grid, ... (b = blockIdx mod 64: several blocks per
+        // query when the grid is larger); `min_filled`: publish only once that many slots are in; final: a query whose
+        // slots have not filled by now is declared to have no bound
+        auto publish = [&](uint32_t min_filled, bool final) -> bool {
+            bool all_done = true;
+            for (uint32_t q = blockIdx.x & 63u; q < nq; q += gridDim.x) {
+                const uint32_t nz = slots_load(q);
+                if (nz < min_filled && !final) { all_done = false; continue; }
+                const uint32_t t = slots_kth();
+                if (lane == 0u && (t || final)) __hip_atomic_fetch_max(g_bound + q, t ? t : BS_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!t && !final) all_done = false;
+            }
+            return all_done;
+        };
+
+        // A-C. the warm-up, one polling loop: (A) once the block's workers have left their first tiles' maxima in LDS, write
+        // them to the tiles' slots (plain write-through stores); (B) publish this block's queries as soon as a fraction
+        // of the grid's sample is in the slots; (C) leave when every live query has a bound or a no-bound mark
+        uint32_t bl = 1u;
+        {
+            const uint32_t sample = (nw < n32 ? nw : n32) < BS_SL ? (nw < n32 ? nw : n32) : BS_SL;   // slots the first tiles fill
+            const uint32_t frac = ((blockIdx.x >> 6) & 3u) + 1u;                                      // 1/8, 2/8, 3/8, 4/8
+            const uint32_t want = sample * frac / 8u > k ? sample * frac / 8u : k;
+            bool stored = false, published = false;
+            for (int spin = 0; spin < 4096; spin++) {   // bounded: a few ms
+                if (!stored && bs_lds_ld_acq(&s_ctl[BSL_ARRIVED]) >= in_block) {
+                    stored = true;
+                    if (lane < nq)
+                        for (uint32_t w = 0; w < in_block; w++)
+                            __hip_atomic_store(g_slots + lane * BS_SL + ((T_first + w) & (BS_SL - 1u)), s_wm[w * 64u + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (!published) published = publish(want, spin >= 96);
+                bl = lane < nq ? bs_ld_agent(g_bound + lane) : 1u;
+                if (stored && __ballot(bl == 0u) == 0ull) break;
+                if (published) __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        bs_lds_st(&s_bnd[lane], bl);
+        if (lane == 0u) bs_lds_st_rel(&s_ctl[BSL_READY], 1u);
+        // D. service loop: drain the workers' hit rings, keep the tile queue filled and the block's copy of the bounds
+        // fresh (re-read and re-published 2, 4, 8, ... us apart, then every 128 us: see the head of the file)
+        uint32_t gap = 200u;           // x10 ns
+        uint64_t t_next = now() + gap;
+        for (;;) {
+            uint32_t hd = 0u, tl = 0u;
+            if (lane < BS_WORK) { hd = bs_lds_ld_acq(&s_ctl[BSL_HEAD + lane]); tl = bs_lds_ld(&s_ctl[BSL_TAIL + lane]); }   // (the tails are this wave's own)
+            const uint32_t pend = hd - tl;
+            uint32_t incl = pend;        // inclusive prefix sum over the first lanes
+#pragma unroll
+            for (int off = 1; off < 8; off <<= 1) {
+                const uint32_t t = (uint32_t)__shfl_up((int)incl, off, 64);
+                if (lane >= (uint32_t)off) incl += t;
+            }
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)BS_WORK - 1);
+            const bool busy = total != 0u;
+            if (busy) {   // up to 64 pending entries, taken from the rings in worker order, in one round
+                uint32_t w_of = 0u, first_of = 0u, tail_of = 0u;
+#pragma unroll
+                for (uint32_t w = 0; w < BS_WORK; w++) {
+                    const uint32_t end_w = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)w);
+                    const uint32_t beg_w = end_w - (uint32_t)__builtin_amdgcn_readlane((int)pend, (int)w);
+                    const uint32_t tl_w = (uint32_t)__builtin_amdgcn_readlane((int)tl, (int)w);
+                    if (lane >= beg_w && lane < end_w) { w_of = w; first_of = beg_w; tail_of = tl_w; }
+                }
+                const bool on = lane < total;
+                const uint32_t e = w_of * HB + ((tail_of + lane - first_of) & (HB - 1u));
+                if (!(a.arm & 4u)) process_hits(on, on ? s_hrow[e] : 0u, on ? s_hq[e] : 0u, on ? s_hdot[e] : 0.0f);
+                if (lane < BS_WORK) {
+                    const uint32_t beg = incl - pend;
+                    const uint32_t took = beg >= 64u ? 0u : (incl <= 64u ? pend : 64u - beg);
+                    if (took) bs_lds_st_rel(&s_ctl[BSL_TAIL + lane], tl + took);
+                }
+            }
+            if (!exhausted && (int32_t)(q_head - bs_lds_ld(&s_ctl[BSL_QTAIL])) < (int32_t)BS_CLAIM) {   // fewer than two tiles per worker queued
+                uint32_t c = 0u;
+                if (lane == 0u) c = atomicAdd(g_next, BS_CLAIM);
+                push_claim(c);
+            }
+            const bool workers_done = bs_lds_ld_acq(&s_ctl[BSL_DONE]) >= BS_WORK;
+            const uint64_t t_now = now();
+            if (t_now >= t_next && !workers_done) {
+                bl = bs_ld_agent(g_bound + lane);
+                if (bl > bs_lds_ld(&s_bnd[lane])) bs_lds_st(&s_bnd[lane], bl);
+                if (gap >= 800u) publish(0u, true);
+                gap = gap < 12800u ? gap * 2u : 12800u;
+                t_next = now() + gap;
+            }
+            if (!busy) {
+                if (workers_done) {   // every worker is through; one more look at the rings, then out
+                    bool left = false;
+#pragma unroll 1
+                    for (uint32_t w = 0; w < BS_WORK; w++) left = left || bs_lds_ld_acq(&s_ctl[BSL_HEAD + w]) != bs_lds_ld(&s_ctl[BSL_TAIL + w]);
+                    if (!left) break;
+                } else {
+                    __builtin_amdgcn_s_sleep(64);   // ~2 us
+                }
+            }
+        }
+        return;
+    }
+
+    // =================================================================== worker waves
+    if (!has_work) {
+        if (lane == 0u) __hip_atomic_fetch_add(&s_ctl[BSL_DONE], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;
+    }
+    const char *const my_q = qimg + lane * 16u;
+    uint32_t *const hb_row = s_hrow + wave * HB, *const hb_q = s_hq + wave * HB;
+    float *const hb_dot = s_hdot + wave * HB;
+    uint32_t head = 0;               // entries this wave has put into its hit ring (wave-uniform; s_ctl[BSL_HEAD + wave] mirrors it)
+    bool first = true;
+    bool liveq[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) liveq[g] = 16u * g + j < nq;
+    float thr[4];                    // the threshold of each of the lane's four queries (bs_thr)
+    auto wait_room = [&](uint32_t n) {   // room for n more entries in the ring (the service wave moves the tail)
+        for (int spin = 0; spin < (1 << 20); spin++) {
+            if (head + n - bs_lds_ld_acq(&s_ctl[BSL_TAIL + wave]) <= HB) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+    };
+    // query fragments: [buffer][group]; the next K-step's are read while this one's MFMAs run
+    s16x8 B[2][4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) B[0][g] = *reinterpret_cast<const s16x8 *>(my_q + g * 1024);
+    auto claim = [&]() -> uint32_t {   // the next tile of this wave: an entry of the block's queue
+        uint32_t idx = 0u;
+        if (lane == 0u) idx = __hip_atomic_fetch_add(&s_ctl[BSL_QTAIL], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
+        while ((int32_t)(bs_lds_ld_acq(&s_ctl[BSL_QHEAD]) - idx) <= 0) __builtin_amdgcn_s_sleep(2);   // the service wave always refills: its claims depend on nobody
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)bs_lds_ld(&s_tq[idx & (BS_TQ - 1u)]));
+    };
+
+    while (T != BS_NO_TILE) {
+        const uint32_t Tn = claim();
+        const __amdgpu_buffer_rsrc_t nrs = tile_rsrc(Tn != BS_NO_TILE ? Tn : T);
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int g = 0; g < 4; g++) { acc[g][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; acc[g][1] = acc[g][0]; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const int p = ks % P, cur = ks & 1, nxt = cur ^ 1;
+            const int nks = ks + 1 < KS ? ks + 1 : 0;   // the last step reads the next tile's first query fragments
+#pragma unroll
+            for (int g = 0; g < 4; g++) B[nxt][g] = *reinterpret_cast<const s16x8 *>(my_q + (nks * 4 + g) * 1024);
+            __builtin_amdgcn_sched_barrier(0);
+            const s16x8 h0 = ring[p][0], h1 = ring[p][1];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h0, B[cur][g], acc[g][0], 0, 0, 0);
+                acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1, B[cur][g], acc[g][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the slot is free: K-step ks + P of this tile, or of the next one
+            if (ks + P < KS) issue(ring[p], crs, ks + P);
+            else issue(ring[p], nrs, ks + P - KS);
+        }
+
+        const uint32_t row0 = T * 32u + 4u * kq;   // this lane's rows: row0 + 16 f + r
+        if (first) {
+            // ---- warm-up, once per wave: the tile's best approximate cosine per query into LDS for the service wave,
+            // which fills the grid's slots with them and brings the first bounds back
+            first = false;
+            uint32_t okm = 0;   // bit 4 f + r: row row0 + 16 f + r exists and passes the filter
+            if (a.flt.trivial) {
+#pragma unroll
+                for (uint32_t i = 0; i < 8u; i++) okm |= (row0 + 16u * (i >> 2) + (i & 3u) < n_rows) ? (1u << i) : 0u;
+            } else {
+                // (the one place a worker reads row metadata: once, before its stream has anything to wait for)
+#pragma unroll 1
+                for (uint32_t i = 0; i < 8u; i++) {
+                    const uint32_t row = row0 + 16u * (i >> 2) + (i & 3u);
+                    okm |= (row < n_rows && row_passes(a.flt, row)) ? (1u << i) : 0u;
+                }
+            }
+            uint32_t mine = 0u;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                float mx = 0.0f;
+#pragma unroll
+                for (int f = 0; f < 2; f++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) mx = (((okm >> (4 * f + r)) & 1u) && acc[g][f][r] > mx) ? acc[g][f][r] : mx;
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mine = (kq == (uint32_t)g && 16u * g + j < nq) ? __float_as_uint(mx) : mine;   // lane 16 g + j: query 16 g + j
+            }
+            s_wm[wave * 64u + lane] = mine;
+            if (lane == 0u) __hip_atomic_fetch_add(&s_ctl[BSL_ARRIVED], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int spin = 0; spin < (1 << 16); spin++) {        // bounded: ~30 ms
+                if (bs_lds_ld_acq(&s_ctl[BSL_READY]) != 0u) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; g++) thr[g] = bs_thr(bs_lds_ld(&s_bnd[16 * g + j]), liveq[g]);
+
+        // ---- the test: one compare per pair (a NaN passes); one wave-level branch
+        bool any = false;
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+#pragma unroll
+            for (int f = 0; f < 2; f++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) any |= !(acc[g][f][r] < thr[g]);
+        if (a.arm & 1u) any = false;
+        if (__ballot(any)) {
+            uint32_t hm = 0;             // hit mask (bit (g * 2 + f) * 4 + r)
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+#pragma unroll
+                for (int f = 0; f < 2; f++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const bool hit = !(acc[g][f][r] < thr[g]) & (row0 + 16u * f + r < n_rows) & (16u * g + j < nq);
+                        hm |= hit ? (1u << ((g * 2 + f) * 4 + r)) : 0u;
+                    }
+            const uint32_t mine = (uint32_t)__popc(hm);
+            uint32_t incl = mine;        // inclusive prefix sum over the lanes
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t t = (uint32_t)__shfl_up((int)incl, off, 64);
+                if (lane >= (uint32_t)off) incl += t;
+            }
+            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (tot <= HB / 2u) {
+                wait_room(tot);
+                uint32_t pos = head + incl - mine;
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+#pragma unroll
+                    for (int f = 0; f < 2; f++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            if ((hm >> ((g * 2 + f) * 4 + r)) & 1u) {
+                                const uint32_t e = pos & (HB - 1u);
+                                hb_row[e] = row0 + 16u * f + r;
+                                hb_q[e] = 16u * g + j;
+                                hb_dot[e] = acc[g][f][r];
+                                pos++;
+                            }
+                head += tot;
+                if (lane == 0u) bs_lds_st_rel(&s_ctl[BSL_HEAD + wave], head);
+            } else {
+                // a tile of a query without a bound: one hit per lane and round
+#pragma unroll 1
+                while (__ballot(hm != 0u)) {
+                    const bool on = hm != 0u;
+                    const uint32_t idx = on ? (uint32_t)__ffs((int)hm) - 1u : 0u;
+                    hm &= hm - 1u;
+                    float dot = 0.0f;
+#pragma unroll
+                    for (int g = 0; g < 4; g++)
+#pragma unroll
+                        for (int f = 0; f < 2; f++)
+#pragma unroll
+                            for (int r = 0; r < 4; r++) dot = idx == (uint32_t)((g * 2 + f) * 4 + r) ? acc[g][f][r] : dot;
+                    const uint64_t om = __ballot(on);
+                    const uint32_t n = (uint32_t)__popcll(om);
+                    wait_room(n);
+                    if (on) {
+                        const uint32_t e = (head + (uint32_t)__popcll(om & ((1ull << lane) - 1ull))) & (HB - 1u);
+                        hb_row[e] = row0 + 16u * ((idx >> 2) & 1u) + (idx & 3u);
+                        hb_q[e] = 16u * (idx >> 3) + j;
+                        hb_dot[e] = dot;
+                    }
+                    head += n;
+                    if (lane == 0u) bs_lds_st_rel(&s_ctl[BSL_HEAD + wave], head);
+                }
+            }
+        }
+        // ---- advance
+        T = Tn;
+        crs = nrs;
+    }
+    if (lane == 0u) __hip_atomic_fetch_add(&s_ctl[BSL_DONE], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The exact cosine of every candidate from the stored rows: grid = (slices, queries); a wave takes four candidates at a time
+// (their row reads in flight together: a gathered 3 KiB row per candidate is a latency, not a bandwidth, problem); each
+// lane sums its strided share of dot and |row|^2 in f32 with separately rounded products — the query's share and |q|^2
+// are in registers, computed once per wave —, lanes folded by a butterfly, the reference's epilogue (cosine_from_sums).
+// The value depends on the row and the query only, not on where the candidate sits in the list.
+template <typename S>
+__global__ __launch_bounds__(256) void batchs_rescore_kernel(const BatchSArgs a, const S *rows) {
+#pragma clang fp contract(off)
+    constexpr uint32_t U = 4;
+    const uint32_t q = blockIdx.y, lane = threadIdx.x & 63u;
+    const uint32_t gw = blockIdx.x * 4u + (threadIdx.x >> 6), nwq = gridDim.x * 4u;
+    uint32_t total = a.ctl[BS_CTL_CNT + q];
+    total = total < a.cap ? total : a.cap;
+    if (gw * U >= total) return;
+    const uint32_t *cand = a.cand_rows + (size_t)q * a.cap;
+    float *cosv = a.cand_cos + (size_t)q * a.cap;
+    const uint32_t dim = a.dim, per = dim / 64u;   // dim % 128 == 0: at most 16 elements per lane
+    const float *qv = a.queries + (size_t)q * dim;
+    float ql[16];
+    float qq = 0.0f;
+#pragma unroll
+    for (uint32_t i = 0; i < 16u; i++) {
+        ql[i] = i < per ? qv[lane + 64u * i] : 0.0f;
+        qq += ql[i] * ql[i];
+    }
+#pragma unroll
+    for (int x = 1; x < 64; x <<= 1) qq += __shfl_xor(qq, x, 64);
+    for (uint32_t c = gw * U; c < total; c += nwq * U) {
+        const S *p[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) p[u] = rows + (size_t)cand[c + u < total ? c + u : c] * dim + lane;
+        float dot[U], rr[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) { dot[u] = 0.0f; rr[u] = 0.0f; }
+#pragma unroll
+        for (uint32_t i = 0; i < 16u; i++)
+            if (i < per) {
+                float x[U];
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++) x[u] = ldf(p[u] + 64u * i);
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++) { dot[u] += x[u] * ql[i]; rr[u] += x[u] * x[u]; }
+            }
+#pragma unroll
+        for (int x = 1; x < 64; x <<= 1)
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) { dot[u] += __shfl_xor(dot[u], x, 64); rr[u] += __shfl_xor(rr[u], x, 64); }
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++)
+            if (lane == u && c + u < total) cosv[c + u] = cosine_from_sums(dot[u], qq, rr[u]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Per query: the k best of the re-scored candidates -> results; clears the query's part of the control block for the
+// next pass.  A list of <= NV x 1024
+// entries is held in registers and selected once; a longer one (weak bounds: massive ties, a selective row filter, a
+// zero query) is folded chunk by chunk, the survivors so far riding along — exact whatever the length.
+template <int NV>
+__global__ __launch_bounds__(1024) void batchs_select_kernel(const BatchSArgs a, uint32_t *out_rows, float *out_scores, float *out_dists,
+                                                             uint32_t *out_count) {
+    __shared__ uint32_t sh[264];
+    __shared__ uint64_t surv_k[256 + 64];
+    __shared__ float surv_s[256 + 64];
+    __shared__ uint32_t s_n;
+    const uint32_t tid = threadIdx.x, q = blockIdx.x, k = a.k;
+    uint32_t *const g_slots = a.ctl, *const g_bound = a.ctl + BS_CTL_BOUND, *const g_cnt = a.ctl + BS_CTL_CNT;
+    if (q == 0u && tid == 0u) a.ctl[BS_CTL_NEXT] = 0u;
+    uint32_t total = g_cnt[q];
+    total = total < a.cap ? total : a.cap;
+    const uint32_t *cand = a.cand_rows + (size_t)q * a.cap;
+    const float *cosv = a.cand_cos + (size_t)q * a.cap;
+    constexpr uint32_t CHUNK = (uint32_t)NV * 1024u - 256u;   // room for the survivors so far
+    uint32_t n_surv = 0;
+    for (uint32_t c0 = 0; c0 == 0u || c0 < total; c0 += CHUNK) {
+        const uint32_t cn = total - c0 < CHUNK ? total - c0 : CHUNK;
+        uint64_t key[NV];
+        float sim[NV];
+#pragma unroll
+        for (int u = 0; u < NV; u++) {
+            const uint32_t ci = tid + (uint32_t)u * 1024u;
+            key[u] = 0ull;
+            sim[u] = 0.0f;
+            if (ci < cn) {
+                sim[u] = cosv[c0 + ci];
+                key[u] = make_key(score_of(distance_of(sim[u])), cand[c0 + ci]);
+            } else if (ci - cn < n_surv) {
+                key[u] = surv_k[ci - cn];
+                sim[u] = surv_s[ci - cn];
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_n = 0u;
+        const uint64_t t = block_select_kth<NV>(key, k, 56, 0, sh);   // 0: fewer than k entries — all of them survive
+        const uint64_t low = t ? t : 1ull;
+#pragma unroll
+        for (int u = 0; u < NV; u++)
+            if (key[u] >= low && key[u] != 0ull) {   // keys are unique (the row is part of the key): exactly min(k, live) survivors
+                const uint32_t pos = atomicAdd(&s_n, 1u);
+                if (pos < 256u + 64u) { surv_k[pos] = key[u]; surv_s[pos] = sim[u]; }
+            }
+        __syncthreads();
+        n_surv = s_n < 256u + 64u ? s_n : 256u + 64u;
+    }
+    const uint32_t Sn = n_surv;
+    uint32_t *o_rows = out_rows + (size_t)q * k;
+    float *o_scores = out_scores + (size_t)q * k, *o_dists = out_dists + (size_t)q * k;
+    for (uint32_t i = tid; i < Sn; i += 1024u) {
+        const uint64_t ki = surv_k[i];
+        uint32_t rank = 0;
+        for (uint32_t jj = 0; jj < Sn; jj++) rank += surv_k[jj] > ki ? 1u : 0u;
+        if (rank < k) {
+            const float dist = distance_of(surv_s[i]);
+            o_rows[rank] = key_row(ki);
+            o_dists[rank] = dist;
+            o_scores[rank] = score_of(dist);
+        }
+    }
+    if (tid == 0) { out_count[q] = Sn < k ? Sn : k; g_cnt[q] = 0u; g_bound[q] = 0u; }
+    for (uint32_t s = tid; s < BS_SL; s += 1024u) g_slots[q * BS_SL + s] = 0u;
+}
+
+// ---------------------------------------------------------------------------------------------------
+bool batchs_supported(uint32_t dim, uint32_t k) { return dim >= 128u && dim <= 1024u && dim % 128u == 0u && k >= 1u && k <= 256u; }
+
+uint32_t batchs_min_rows() {
+    static const uint32_t v = getenv("CX_BATCHS_MIN_ROWS") ? (uint32_t)atoi(getenv("CX_BATCHS_MIN_ROWS")) : 131072u;
+    return v;
+}
+
+template <int D>
+static int launch_batchs_d(const BatchSArgs &a, uint32_t grid, hipStream_t stream) {
+    static std::atomic<uint64_t> attr_devices{0};
+    if (first_use_on_device(attr_devices))
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchs_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL((batchs_kernel<D>), dim3(grid), dim3(512), BsCfg<D>::LDS, stream, a);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+
+int launch_batchs_pass(const BatchSArgs &a_in, hipStream_t stream) {
+    BatchSArgs a = a_in;
+    static const uint32_t arm_env = getenv("CX_BATCHS_ARM") ? (uint32_t)atoi(getenv("CX_BATCHS_ARM")) : 0u;
+    a.arm = arm_env;
+    if (!batchs_supported(a.dim, a.k) || a.nq == 0 || a.nq > 64u || a.n_rows == 0)
+        return set_err(CX_ERR_VALIDATION, "batchs: unsupported shape (dim %u, k %u, %u queries, %u rows)", a.dim, a.k, a.nq, a.n_rows);
+    const uint32_t cus = device_cus(), n32 = (a.n_rows + 31u) / 32u;
+    // every worker wave needs a first tile of its own (its warm-up fills a slot); blocks of 7 workers + the service wave
+    uint32_t grid = n32 / BS_WORK;
+    grid = grid < 1u ? 1u : (grid > cus ? cus : grid);
+    switch (a.dim) {
+        case 128: return launch_batchs_d<128>(a, grid, stream);
+        case 256: return launch_batchs_d<256>(a, grid, stream);
+        case 384: return launch_batchs_d<384>(a, grid, stream);
+        case 512: return launch_batchs_d<512>(a, grid, stream);
+        case 640: return launch_batchs_d<640>(a, grid, stream);
+        case 768: return launch_batchs_d<768>(a, grid, stream);
+        case 896: return launch_batchs_d<896>(a, grid, stream);
+        default: return launch_batchs_d<1024>(a, grid, stream);
+    }
+}
+
+int launch_batchs_select(const BatchSArgs &a, uint32_t *out_rows, float *out_scores, float *out_dists, uint32_t *out_count, hipStream_t stream) {
+    const uint32_t slices = 32u;   // 128 waves per query (those past the list's end leave at once): a few hundred to a few thousand candidates
+    if (a.rows16) hipLaunchKernelGGL(batchs_rescore_kernel<uint16_t>, dim3(slices, a.nq), dim3(256), 0, stream, a, a.rows16);
+    else hipLaunchKernelGGL(batchs_rescore_kernel<float>, dim3(slices, a.nq), dim3(256), 0, stream, a, a.rows);
+    if (a.k <= 32u) hipLaunchKernelGGL(batchs_select_kernel<4>, dim3(a.nq), dim3(1024), 0, stream, a, out_rows, out_scores, out_dists, out_count);
+    else hipLaunchKernelGGL(batchs_select_kernel<8>, dim3(a.nq), dim3(1024), 0, stream, a, out_rows, out_scores, out_dists, out_count);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+
+}  // namespace cx

@@ -176,6 +176,7 @@ int upsert_impl(cx_index *ix, uint64_t n, const uint8_t *ids, const float *embs,
         if (it != ix->map.end()) {  // replace in place, row position kept
             if (it->second < ix->shadow_rows) ix->shadow_stale.push_back(it->second);
             if (it->second < ix->norms_rows) ix->norms_stale.push_back(it->second);
+            if (it->second < ix->nfrag_rows) ix->nfrag_stale.push_back(it->second);
             if (int rc = put_rows(it->second, i, 1)) return rc;
             i++;
             continue;
@@ -332,6 +333,40 @@ int ensure_norms(const cx_index *ix, hipStream_t s) {
     return CX_OK;
 }
 
+// The screening copy of the rows (batchs.hip), kept lazily like the norms: whole 16-row tiles plus a spare one (a worker's
+// 32-row tile may start at the last 16-row tile).
+int ensure_nfrag(const cx_index *ix, hipStream_t s) {
+    std::lock_guard<std::mutex> g(ix->nfrag_mu);
+    const uint64_t n = ix->n_rows;
+    bool work = false;
+    if (ix->nfrag_cap < n) {
+        if (ix->d_nfrag) CX_HIP(hipFree(ix->d_nfrag));
+        ix->d_nfrag = nullptr;
+        ix->nfrag_cap = 0;
+        const uint64_t cap = std::max<uint64_t>(n, ix->cap);
+        const size_t bytes = (size_t)((cap + 31) / 16) * 16 * ix->dim * sizeof(uint16_t);
+        CX_HIP(hipMalloc((void **)&ix->d_nfrag, bytes));
+        CX_HIP(hipMemsetAsync(ix->d_nfrag, 0, bytes, s));
+        ix->nfrag_cap = cap;
+        ix->nfrag_rows = 0;
+        ix->nfrag_stale.clear();
+        work = true;
+    }
+    for (uint32_t r : ix->nfrag_stale)
+        if (r < ix->nfrag_rows) {
+            if (int rc = launch_build_nfrag(ix->rows32(), ix->rows16(), ix->d_nfrag, r, r + 1, ix->dim, s)) return rc;
+            work = true;
+        }
+    ix->nfrag_stale.clear();
+    if (ix->nfrag_rows < n) {
+        if (int rc = launch_build_nfrag(ix->rows32(), ix->rows16(), ix->d_nfrag, (uint32_t)ix->nfrag_rows, (uint32_t)n, ix->dim, s)) return rc;
+        ix->nfrag_rows = n;
+        work = true;
+    }
+    if (work) CX_HIP(hipStreamSynchronize(s));
+    return CX_OK;
+}
+
 int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float *tails, uint64_t nq, uint32_t k_eff,
                 const DevFilter &flt, float thr, bool has_thr, uint32_t *d_rows, float *d_scores, float *d_dists,
                 uint32_t *d_counts, hipStream_t s) {
@@ -362,34 +397,34 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
     // peak whatever k is, batch2_kernel's in-kernel wide lists at 0.40-0.49 (1.25M x 384 / 768, k = 100)
     // (1.25M rows, per step: k = 100 at 768 / 384-d 0.82 / 0.51 ms against 1.02 / 0.64; k = 32: 0.78 / 0.46 against 0.81 / 0.58; k = 20
     // at 384-d 0.44 against 0.48; k = 10: 0.77 / 0.45 against 0.65 / 0.43 — batch2's fused lists win while they are short)
-    // 384-d (the reference's default embedding width) on a store large enough that every wave gets a few tiles:
-    // batchq.hip — queries resident in LDS, rows straight from the split store into MFMA operands, one shared bound per
-    // query from the first tile on, candidate lists that cannot overflow: two stream operations per 64 queries
-    static const int bq_ok = getenv("CX_BATCHQ") ? atoi(getenv("CX_BATCHQ")) : 1;
-    if (bq_ok && ix->dtype == 0 && topk_path && no_tails && nq >= (uint64_t)batch_min && k_eff >= 1 && batchq_supported(ix->dim, k_eff) &&
-        n >= batchq_min_rows()) {
-        if (int rc = ensure_norms(ix, s)) return rc;
-        if (c->bqc_cap < BQ_CTL_WORDS) {
-            if (int rc = ensure_dev(c->d_bq_ctl, c->bqc_cap, (size_t)BQ_CTL_WORDS)) return rc;
-            CX_HIP(hipMemsetAsync(c->d_bq_ctl, 0, (size_t)BQ_CTL_WORDS * sizeof(uint32_t), s));
+    // Large stores, every width up to 1024 that is a multiple of 128, both store types: batchs.hip — a screening pass over a
+    // normalised bf16 copy of the rows in MFMA fragment order (half the bytes of the f32 rows, one MFMA per pair instead of
+    // three, a rigorous error bound), the survivors re-scored exactly from the stored rows by the select kernel
+    static const int bs_ok = getenv("CX_BATCHS") ? atoi(getenv("CX_BATCHS")) : 1;
+    if (bs_ok && topk_path && no_tails && nq >= (uint64_t)batch_min && k_eff >= 1 && batchs_supported(ix->dim, k_eff) && n >= batchs_min_rows()) {
+        if (int rc = ensure_nfrag(ix, s)) return rc;
+        if (c->bsc_cap < BS_CTL_WORDS) {
+            if (int rc = ensure_dev(c->d_bs_ctl, c->bsc_cap, (size_t)BS_CTL_WORDS)) return rc;
+            CX_HIP(hipMemsetAsync(c->d_bs_ctl, 0, (size_t)BS_CTL_WORDS * sizeof(uint32_t), s));
         }
-        if (int rc = ensure_dev(c->d_bq_rows, c->bqr_cap, (size_t)64 * n)) return rc;
-        if (int rc = ensure_dev(c->d_bq_cos, c->bqs_cap, (size_t)64 * n)) return rc;
+        if (int rc = ensure_dev(c->d_bs_rows, c->bsr_cap, (size_t)64 * n)) return rc;
+        if (int rc = ensure_dev(c->d_bs_cos, c->bss_cap, (size_t)64 * n)) return rc;
         for (uint64_t q0 = 0; q0 < nq; q0 += 64) {
             const uint32_t m = (uint32_t)std::min<uint64_t>(64, nq - q0);
-            BatchQArgs b;
+            BatchSArgs b;
             memset(&b, 0, sizeof b);
-            b.split = ix->d_split;
-            b.norms = ix->d_norms;
+            b.nfrag = ix->d_nfrag;
             b.queries = d_queries + q0 * ix->dim;
+            b.rows = ix->rows32();
+            b.rows16 = ix->rows16();
             b.n_rows = n;
             b.nq = m;
             b.dim = ix->dim;
             b.k = k_eff;
             b.flt = flt;
-            b.ctl = c->d_bq_ctl;
-            b.cand_rows = c->d_bq_rows;
-            b.cand_cos = c->d_bq_cos;
+            b.ctl = c->d_bs_ctl;
+            b.cand_rows = c->d_bs_rows;
+            b.cand_cos = c->d_bs_cos;
             b.cap = n;
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (ix->profiling) {
@@ -399,27 +434,21 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
                 ix->prof_events.emplace_back(e0, e1);
                 CX_HIP(hipEventRecord(e0, s));
             }
-            int rc = launch_batchq_pass(b, s);
+            int rc = launch_batchs_pass(b, s);
             if (e1) CX_HIP(hipEventRecord(e1, s));
-            static const int bq_diag = getenv("CX_BATCHQ_DIAG") ? atoi(getenv("CX_BATCHQ_DIAG")) : 0;
-            std::vector<uint32_t> dg(128);
-            if (bq_diag && !rc) {   // candidates per query and published bounds of this pass, on stderr
+            static const int bs_diag = getenv("CX_BATCHS_DIAG") ? atoi(getenv("CX_BATCHS_DIAG")) : 0;
+            if (bs_diag && !rc) {   // candidates per query and published bounds of this pass, on stderr
+                std::vector<uint32_t> dg(128);
                 CX_HIP(hipStreamSynchronize(s));
-                CX_HIP(hipMemcpy(dg.data(), c->d_bq_ctl + BQ_CTL_BOUND, 128 * sizeof(uint32_t), hipMemcpyDeviceToHost));
-            }
-            if (!rc) rc = launch_batchq_select(b, d_rows + q0 * k_eff, d_scores + q0 * k_eff, d_dists + q0 * k_eff, d_counts + q0, s);
-            if (bq_diag && !rc) {
-                std::vector<float> sc((size_t)m * k_eff);
-                CX_HIP(hipStreamSynchronize(s));
-                CX_HIP(hipMemcpy(sc.data(), d_scores + q0 * k_eff, sc.size() * sizeof(float), hipMemcpyDeviceToHost));
+                CX_HIP(hipMemcpy(dg.data(), c->d_bs_ctl + BS_CTL_BOUND, 128 * sizeof(uint32_t), hipMemcpyDeviceToHost));
                 uint64_t tot = 0; uint32_t mx = 0, nob = 0;
                 for (uint32_t q = 0; q < m; q++) { tot += dg[64 + q]; mx = std::max(mx, dg[64 + q]); nob += dg[q] <= 1u; }
-                fprintf(stderr, "[batchq diag] %u queries: %llu candidates (max %u per query), %u without a bound; (candidates, bound, k-th score):", m, (unsigned long long)tot, mx, nob);
-                for (uint32_t q = 0; q < m && q < 12; q++) { float b0; memcpy(&b0, &dg[q], 4); fprintf(stderr, " (%u, %.3f, %.3f)", dg[64 + q], b0, sc[(size_t)q * k_eff + k_eff - 1]); }
-                fprintf(stderr, "\n");
+                float b0; memcpy(&b0, &dg[0], 4);
+                fprintf(stderr, "[batchs diag] %u queries: %llu candidates (max %u per query), %u without a bound, bound[0] = %.4f\n", m, (unsigned long long)tot, mx, nob, b0);
             }
+            if (!rc) rc = launch_batchs_select(b, d_rows + q0 * k_eff, d_scores + q0 * k_eff, d_dists + q0 * k_eff, d_counts + q0, s);
             if (rc) {   // a pass that did not run to its select leaves the control block in an unknown state
-                (void)hipMemsetAsync(c->d_bq_ctl, 0, (size_t)BQ_CTL_WORDS * sizeof(uint32_t), s);
+                (void)hipMemsetAsync(c->d_bs_ctl, 0, (size_t)BS_CTL_WORDS * sizeof(uint32_t), s);
                 return rc;
             }
         }
@@ -767,6 +796,7 @@ void cx_destroy(cx_index *ix) {
     (void)hipFree(ix->d_shadow_t);
     (void)hipFree(ix->d_norms);
     (void)hipFree(ix->d_split);
+    (void)hipFree(ix->d_nfrag);
     (void)hipFree(ix->d_tile_list);
     if (ix->up_stream) (void)hipStreamDestroy(ix->up_stream);
     delete ix;
@@ -931,6 +961,8 @@ int cx_rebuild(cx_index *ix) try {
     ix->shadow_stale.clear();
     ix->norms_rows = 0;   // and so are the row norms
     ix->norms_stale.clear();
+    ix->nfrag_rows = 0;   // and the screening copy
+    ix->nfrag_stale.clear();
     return CX_OK;
 } catch (...) { return cx::on_exception(); }
 

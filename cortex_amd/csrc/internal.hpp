@@ -70,9 +70,9 @@ struct Ctx {
     uint64_t *d_cand_keys = nullptr; size_t ck_cap = 0; // batchg filter mode: per-block candidate lists [64][grid][cb]
     float *d_cand_sims = nullptr; size_t cs_cap = 0;
     uint32_t *d_bg_ctl = nullptr; size_t bc_cap = 0;   // [64] bounds + [1] overflow flag
-    uint32_t *d_bq_ctl = nullptr; size_t bqc_cap = 0;  // batchq: bound slots, published bounds, list lengths (BQ_CTL_WORDS; zero between passes)
-    uint32_t *d_bq_rows = nullptr; size_t bqr_cap = 0; // batchq: candidate lists [64][rows]: row, cosine
-    float *d_bq_cos = nullptr; size_t bqs_cap = 0;
+    uint32_t *d_bs_ctl = nullptr; size_t bsc_cap = 0;  // batchs: bound slots, published bounds, list lengths, tile counter (BS_CTL_WORDS; zero between passes)
+    uint32_t *d_bs_rows = nullptr; size_t bsr_cap = 0; // batchs: candidate lists [64][rows]: row, exact cosine
+    float *d_bs_cos = nullptr; size_t bss_cap = 0;
     uint32_t *d_out_rows = nullptr; size_t or_cap = 0;
     float *d_out_scores = nullptr; size_t os_cap = 0;
     float *d_out_dists = nullptr; size_t od_cap = 0;
@@ -95,7 +95,7 @@ struct Ctx {
     ~Ctx() {
         if (pass_scratch && pass_scratch_free) pass_scratch_free(pass_scratch);
         (void)hipFree(d_dense); (void)hipFree(d_qimg); (void)hipFree(d_cand_keys); (void)hipFree(d_cand_sims); (void)hipFree(d_bg_ctl);
-        (void)hipFree(d_bq_ctl); (void)hipFree(d_bq_rows); (void)hipFree(d_bq_cos);
+        (void)hipFree(d_bs_ctl); (void)hipFree(d_bs_rows); (void)hipFree(d_bs_cos);
         (void)hipFree(d_query); (void)hipFree(d_gslots); (void)hipFree(d_part_keys); (void)hipFree(d_part_sims); (void)hipFree(d_out_rows);
         (void)hipFree(d_out_scores); (void)hipFree(d_out_dists); (void)hipFree(d_out_counts); (void)hipFree(d_excl);
         (void)hipFree(d_kinds); (void)hipFree(d_keys); (void)hipFree(d_keys2); (void)hipFree(d_sims); (void)hipFree(d_sims2);
@@ -174,6 +174,13 @@ struct cx_index {
     // bf16 hi/lo split copy of the rows for the batched search (same bytes as the f32 rows, tile-image layout);
     // maintained together with the norms (same validity prefix and stale list)
     mutable char *d_split = nullptr;
+    // rows L2-normalised, rounded to bf16, laid out as MFMA A fragments: the operand of the batched search's screening
+    // pass (batchs.hip); same lazy scheme: rows [0, nfrag_rows) valid, in-place upserts listed in nfrag_stale
+    mutable std::mutex nfrag_mu;
+    mutable uint16_t *d_nfrag = nullptr;
+    mutable uint64_t nfrag_cap = 0;
+    mutable uint64_t nfrag_rows = 0;
+    mutable std::vector<uint32_t> nfrag_stale;
     mutable uint32_t *d_tile_list = nullptr;   // live tiles of the symmetric all-pairs pass, cached per row count
     mutable uint32_t tile_list_rows = 0, tile_list_n = 0, tile_list_big = 0;
     // cx_autolink_filter_profile: the filter GEMM of the last timed all-pairs pass (under shadow_mu)

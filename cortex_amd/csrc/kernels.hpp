@@ -118,29 +118,31 @@ int launch_merge_batch(const MergeArgs &m, uint32_t nq, hipStream_t stream, bool
 // cleared) when a query has more live entries than that path holds — batchg passes its overflow flag: the dense pass redoes it
 int launch_cand_select(const MergeArgs &m, uint32_t nq, uint32_t *d_redo, hipStream_t stream);
 
-// ---- batched search at 384-d, queries resident in LDS, rows straight into MFMA operands (batchq.hip) ----
-constexpr uint32_t BQ_SL = 2048;                      // bound slots per query in the control block, [slot][query] (tile t -> slot t mod BQ_SL)
-constexpr uint32_t BQ_CTL_BOUND = 64 * BQ_SL;         // word offsets inside the control block
-constexpr uint32_t BQ_CTL_CNT = BQ_CTL_BOUND + 64;
-constexpr uint32_t BQ_CTL_NEXT = BQ_CTL_CNT + 64;     // the next unclaimed tile beyond the statically dealt first ones
-constexpr uint32_t BQ_CTL_WORDS = BQ_CTL_NEXT + 16;
-struct BatchQArgs {
-    const char *split;      // cx_index::d_split (batch_common.hpp)
-    const float *norms;     // |row|^2 (cx_index::d_norms, padded)
+// ---- batched search as a bf16 screening pass + exact re-score of the survivors (batchs.hip) ----
+constexpr uint32_t BS_SL = 2048;                      // bound slots per query in the control block (tile t -> slot t mod BS_SL)
+constexpr uint32_t BS_CTL_BOUND = 64 * BS_SL;         // word offsets inside the control block
+constexpr uint32_t BS_CTL_CNT = BS_CTL_BOUND + 64;
+constexpr uint32_t BS_CTL_NEXT = BS_CTL_CNT + 64;     // the next unclaimed tile beyond the statically dealt first ones
+constexpr uint32_t BS_CTL_WORDS = BS_CTL_NEXT + 16;
+struct BatchSArgs {
+    const uint16_t *nfrag;  // cx_index::d_nfrag: rows L2-normalised, bf16, as MFMA A fragments (batchs.hip)
     const float *queries;   // [nq][dim] f32 in HBM
+    const float *rows;      // the f32 store (the re-score reads it); null for a bf16 store
+    const uint16_t *rows16; // the bf16 store
     uint32_t n_rows, nq, dim, k;
     DevFilter flt;
-    uint32_t *ctl;          // [BQ_CTL_WORDS]: 64 x BQ_SL bound slots | 64 published bounds | 64 list lengths | tile counter; zero between passes
-                            // (the select kernel clears what a pass used)
-    uint32_t *cand_rows;    // [64][cap] candidate lists: row, cosine
+    uint32_t *ctl;          // [BS_CTL_WORDS]: 64 x BS_SL bound slots | 64 published bounds | 64 list lengths | tile counter; zero between
+                            // passes (the select kernel clears what a pass used)
+    uint32_t *cand_rows;    // [64][cap] candidate lists: row; exact cosine (written by the select kernel)
     float *cand_cos;
     uint32_t cap;           // entries per query: n_rows (every pair is tested once, so a list cannot run over)
-    uint32_t arm;           // CX_BATCHQ_ARM: measurement arms (results invalid): 1 workers drop their hits, 4 the service wave drops them
+    uint32_t arm;           // CX_BATCHS_ARM: measurement arms (results invalid): 1 workers drop their hits, 4 the service wave drops them
 };
-bool batchq_supported(uint32_t dim, uint32_t k);
-uint32_t batchq_min_rows();   // fewest rows that take this path (CX_BATCHQ_MIN_ROWS)
-int launch_batchq_pass(const BatchQArgs &a, hipStream_t stream);
-int launch_batchq_select(const BatchQArgs &a, uint32_t *out_rows, float *out_scores, float *out_dists, uint32_t *out_count, hipStream_t stream);
+bool batchs_supported(uint32_t dim, uint32_t k);   // dim % 128 == 0, dim <= 1024, k <= 256
+uint32_t batchs_min_rows();   // fewest rows that take this path (CX_BATCHS_MIN_ROWS)
+int launch_build_nfrag(const float *rows, const uint16_t *rows16, uint16_t *nfrag, uint32_t row_lo, uint32_t row_hi, uint32_t dim, hipStream_t stream);
+int launch_batchs_pass(const BatchSArgs &a, hipStream_t stream);
+int launch_batchs_select(const BatchSArgs &a, uint32_t *out_rows, float *out_scores, float *out_dists, uint32_t *out_count, hipStream_t stream);
 
 // ---- batched search for the other row widths (batchg.hip): dense cosines for <= 64 queries, then top-k ----
 bool batchg_supported(uint32_t dim, uint32_t k);       // dim % 128 == 0, dim <= 4096, k <= 256

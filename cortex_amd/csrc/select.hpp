@@ -1,5 +1,5 @@
 // select.hpp — block-wide exact selection of the k-th largest key over keys held in registers (scan.hip's candidate and
-// bound selections, batchq.hip's list selection).
+// bound selections, batchs.hip's list selection).
 #pragma once
 
 #include "common.hpp"
