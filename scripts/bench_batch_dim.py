@@ -43,7 +43,10 @@ torch.cuda.synchronize()
 el = time.perf_counter() - t0
 ix.profile_enable(False)
 ms, cnt = ix.profile_read(reset=True)
-avg = ms / max(1, cnt); algo = float(n) * d * (2 if a.dtype == "bf16" else 4)
+avg = ms / max(1, cnt); store = float(n) * d * (2 if a.dtype == "bf16" else 4)
+screened = (not a.single) and n >= 131072 and d % 128 == 0 and d <= 1024 and B >= 3   # batchs.hip streams the 2-byte screening copy
+algo = float(n) * d * 2 if screened else store
 print(json.dumps({"rows": n, "dim": d, "dtype": a.dtype, "k": k, "batch": B, "queries_per_s": a.steps * B / el, "ms_per_step": el / a.steps * 1e3,
                   "kernel_ms": avg, "launches": cnt, "hbm_GBs": algo / (avg * 1e-3) / 1e9 if avg else None,
-                  "frac_of_8TBs": algo / (avg * 1e-3) / 8e12 if avg else None}))
+                  "frac_of_8TBs": algo / (avg * 1e-3) / 8e12 if avg else None, "bytes_per_launch": algo,
+                  "frac_step_of_8TBs": algo / (el / a.steps) / 8e12, "store_equivalent_step_GBs": store / (el / a.steps) / 1e9}))

@@ -43,7 +43,7 @@ for src, dst in (("bench.json", f"bench_{rnd}.json"), ("bench_steps20_warmup5.js
                  ("autolink.json", "autolink_100kx768_bench.json"), ("al_mfma_summary.json", "autolink_100kx768_pmc_summary.json"),
                  ("autolink_mfma_utilisation.json", "autolink_100kx768_mfma_utilisation.json"),
                  ("batch_trace_kernel_stats.csv", "batch64_1.25Mx768_kernel_stats.csv"), ("batch.json", "batch64_1.25Mx768_bench.json"),
-                 ("b1024_trace_kernel_stats.csv", "batch64_1Mx1024_kernel_stats.csv"), ("batch64_1Mx1024.json", "batch64_1Mx1024_bench.json"),
+                 ("b1024_trace_kernel_stats.csv", "batch64_6.25Mx1024_bf16_kernel_stats.csv"), ("batch64_6.25Mx1024_bf16.json", "batch64_6.25Mx1024_bf16_bench.json"),
                  ("batch64_other_shapes.jsonl", "batch64_other_shapes.jsonl"), ("autolink_legs.json", "autolink_legs_100kx768.json"), ("single_query_bf16_store.jsonl", "single_query_bf16_store.jsonl"), ("top100_lists_100kx768.log", "top100_lists_100kx768.log"),
                  ("read_shape_probe.log", "read_shape_probe.log"), ("mfma_shape_probe.log", "mfma_shape_probe.log")):
     cp(src, dst)
@@ -52,9 +52,10 @@ if not os.path.exists(os.path.join(S, "cold_start_probe.json")) and os.path.exis
 traffic("knn_1Mx768_pmc_final.json", "scripts/profile_round.sh: rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- "
         "python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-autolink --no-config4", "scan_kernel<768", "knn_fetch_summary.json", "knn_write_summary.json",
         3_072_000_000, "scan_kernel_hbm_bytes_per_launch")
-traffic("batch64_1.25Mx768_pmc_final.json", "scripts/profile_round.sh: rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 scripts/bench_batch.py --steps 5",
-        "batch2_kernel", "batch_fetch_summary.json", None, 1_250_000 * 768 * 4, "batch_kernel_hbm_read_bytes_per_launch")
-traffic("batch64_1Mx1024_pmc_final.json", "scripts/profile_round.sh: rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- "
-        "python3 scripts/bench_batch_dim.py --rows 1000000 --dim 1024 --steps 5", "batchg_kernel<0, true>", "b1024_fetch_summary.json", "b1024_write_summary.json",
-        1_000_000 * 1024 * 4, "batchg_kernel_hbm_bytes_per_launch")
+traffic("batch64_1.25Mx768_pmc_final.json", "scripts/profile_round_b.sh: rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- "
+        "python3 scripts/bench_batch.py --steps 5", "batchs_kernel<768>", "batch_fetch_summary.json", "batch_write_summary.json",
+        1_250_000 * 768 * 2, "batchs_kernel_hbm_bytes_per_launch")
+traffic("batch64_6.25Mx1024_bf16_pmc_final.json", "scripts/profile_round_b.sh: rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- "
+        "python3 scripts/bench_batch_dim.py --rows 6250000 --dim 1024 --dtype bf16 --steps 5", "batchs_kernel<1024>", "b1024_fetch_summary.json", "b1024_write_summary.json",
+        6_250_000 * 1024 * 2, "batchs_kernel_hbm_bytes_per_launch")
 print(sorted(os.listdir(D)))
