@@ -204,7 +204,7 @@ def main() -> None:
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": float(traffic) if traffic else None, "traffic_source": traffic_src,
-            "kernel": "cx::scan_kernel" if B < 3 else f"cx::batchs_kernel<{d}> (streams the 2-byte screening copy: store-equivalent figures)", "avg_kernel_ms": avg_ms, "launches": kern_n,
+            "kernel": "cx::scan_kernel" if B < 3 else f"cx::batchs_kernel<{d}> (streams the 2-byte normalised shadow: store-equivalent figures)", "avg_kernel_ms": avg_ms, "launches": kern_n,
             "algorithmic_bytes_per_launch": algo_bytes,
             "step_achieved": algo_bytes / (elapsed / args.steps) / 1e9, "frac_step": algo_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
         },
@@ -464,7 +464,7 @@ def config1_leg(L, device: int, n: int = 10_000, d: int = 384, k: int = 5, nq: i
 
 def batch_roofline(n: int, d: int, store_elem_bytes: float, avg_kernel_ms: float, step_s: float, kern_n: int, note: str = "") -> dict:
     """HBM roofline object of a batched-search leg.  Stores of >= 131,072 rows go through batchs.hip: one launch streams
-    the index's SCREENING copy of the shard once — rows L2-normalised, bf16, MFMA fragment order: n x d x 2 bytes — and the
+    the index's normalised bf16 shadow of the shard once — the all-pairs filter's tiled copy: n x d x 2 bytes — and the
     survivors (a few hundred per query) are re-scored exactly from the stored rows.  `achieved` / `frac` are those bytes
     over the screening kernel's duration (HIP events around the launch), `frac_step` the same bytes over the whole step
     (re-score, selection, gaps).  The contract's figure (the shard's stored bytes per batch) over the same
@@ -479,7 +479,7 @@ def batch_roofline(n: int, d: int, store_elem_bytes: float, avg_kernel_ms: float
             "step_achieved": algo / step_s / 1e9, "frac_step": algo / step_s / 1e9 / HBM_PEAK_GBS,
             "store_bytes_per_launch": store, "store_equivalent_GBs": store / (avg * 1e-3) / 1e9 if avg else 0.0,
             "store_equivalent_step_GBs": store / step_s / 1e9,
-            "frac_note": "frac: the screening kernel's launches alone over the bytes it streams (the 2-byte screening copy); frac_step: the same "
+            "frac_note": "frac: the screening kernel's launches alone over the bytes it streams (the 2-byte normalised shadow); frac_step: the same "
                          "bytes over the whole step (exact re-score of the survivors, selection, gaps); store_equivalent_*: the stored rows' "
                          "bytes (the contract's per-batch figure) over the same durations" + (("; " + note) if note else "")}
 
@@ -583,7 +583,7 @@ def config4_sharded_leg(L, device: int, dev, rank: int, world: int, total: int =
                         f"({n} rows on this rank), all-gather of partial top-k + merge per batch",
             "scaling": "strong", "n_gpus": world, "queries_per_s": steps * B / el, "ms_per_step": el / steps * 1e3, "steps": steps,
             "roofline": batch_roofline(n, d, 4.0, avg, el / steps, kern_n,
-                                       "rank 0's shard; one launch reads the rank's screening copy once for 64 queries; the step includes the "
+                                       "rank 0's shard; one launch reads the rank's shadow once for 64 queries; the step includes the "
                                        "all-gather and the merge")}
 
 
@@ -619,7 +619,7 @@ def config4_one_process_leg(L, n_dev: int, total: int = 10_000_000, d: int = 768
     p2p = bool(sh.peer_to_peer)
     sh.close()
     torch.cuda.empty_cache()
-    by = float(total) * d * 2.0   # the shards' screening copies (batchs.hip), streamed once per batch
+    by = float(total) * d * 2.0   # the shards' normalised bf16 shadows (batchs.hip), streamed once per batch
     return {"workload": f"cosine kNN k={k}, batches of {B} queries, ONE {total} x {d} f32 corpus behind cx_sharded_search_batch in one process, "
                         f"one shard on each of {len(devs)} visible GPU(s); host queries in, host ids out",
             "scaling": "strong", "n_gpus": len(devs), "peer_to_peer": p2p, "queries_per_s": steps * B / el, "ms_per_step": el / steps * 1e3, "steps": steps,

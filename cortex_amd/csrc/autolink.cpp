@@ -18,10 +18,14 @@ uint32_t cand_cap() {  // candidate slots per scanned row; rows that overflow ar
 // |x^.y^ - cos| <= (2u + u^2) * sum|x_i y_i| <= 2u + u^2 for unit rows; plus f32 accumulation slack.
 constexpr float FILTER_EPS = 2.0f / 256.0f + 1.0f / 65536.0f + 1.0e-4f;
 
+}  // namespace
+
+namespace cx {
 int ensure_shadow(const cx_index *ix, hipStream_t s) {
     std::lock_guard<std::mutex> g(ix->shadow_mu);
     const uint64_t n = ix->n_rows;
     const bool tiled = ix->dim % 32 == 0;
+    bool work = false;
     // ONE copy of the shadow: the tiled layout every filter kernel reads when dim % 32 == 0 (kernels.hpp:
     // tiled_shadow_off), the row-major one otherwise.  (Rounds 1-2 kept both: 12.8 GB more per 6.25M x 1024 shard.)
     if (ix->shadow_cap < n) {
@@ -41,22 +45,29 @@ int ensure_shadow(const cx_index *ix, hipStream_t s) {
         ix->shadow_cap = cap;
         ix->shadow_rows = 0;
         ix->shadow_stale.clear();
+        work = true;
     }
     auto build = [&](uint32_t lo, uint32_t hi) -> int {
         if (tiled) return launch_build_shadow_tiled(ix->dtype == 1 ? nullptr : ix->d_rows, ix->dtype == 1 ? ix->rows16() : nullptr, ix->d_shadow_t, lo, hi, ix->dim, s);
         return ix->dtype == 1 ? launch_build_shadow(ix->rows16(), ix->d_shadow, lo, hi, ix->dim, s) : launch_build_shadow(ix->d_rows, ix->d_shadow, lo, hi, ix->dim, s);
     };
     for (uint32_t r : ix->shadow_stale)
-        if (r < ix->shadow_rows)
+        if (r < ix->shadow_rows) {
             if (int rc = build(r, r + 1)) return rc;
+            work = true;
+        }
     ix->shadow_stale.clear();
     if (ix->shadow_rows < n) {
         if (int rc = build((uint32_t)ix->shadow_rows, (uint32_t)n)) return rc;
         ix->shadow_rows = n;
+        work = true;
     }
-    CX_HIP(hipStreamSynchronize(s));
+    if (work) CX_HIP(hipStreamSynchronize(s));   // (every batched search comes through here: no host wait when nothing changed)
     return CX_OK;
 }
+}  // namespace cx
+
+namespace {
 
 // Scratch of a pass.  It lives in the pooled Ctx (grow-only), so a steady stream of passes does no
 // hipMalloc/hipFree (measured: 1.4 ms of a 11.4 ms pass when allocated per call).

@@ -3,10 +3,13 @@
 // design (allpairs.hip: bf16 filter with a rigorous error bound, then the reference's arithmetic on what is left)
 // applied to up to 64 queries per pass.
 //
-// The operand: the index keeps, for stores this path serves, a copy of the rows L2-normalised and rounded to bf16, laid out
-// as MFMA A fragments (cx_index::d_nfrag: 16-row tile, K-step of 32, one KiB = 64 lanes x 16 bytes; build_nfrag_kernel).
-// Its dot with a normalised bf16 query is the cosine within eps = 2u + u^2 + 1e-4, u = 2^-8 (autolink.cpp: both operands
-// rounded, unit vectors), so
+// The operand is the all-pairs filter's own: the index's tiled shadow (cx_index::d_shadow_t, kernels.hpp: rows L2-normalised,
+// rounded to bf16, one KiB per 16 rows x K-step of 32, a row's four 16-byte pieces XOR-permuted with bits 3-4 of the row).
+// A lane reads ITS piece of the MFMA A fragment out of that KiB — lane (i, kq): row i's piece kq — so a wave-level load is
+// one KiB of contiguous memory in a permuted lane order, which streams exactly as fast as the linear order
+// (scripts/probes/ring_probe.hip: 0.862 against 0.864 of the peak): ONE normalised 2-byte copy of the rows serves the
+// linker passes and the batched search.  Its dot with a normalised bf16 query is the cosine within eps = 2u + u^2 + 1e-4,
+// u = 2^-8 (autolink.cpp: both operands rounded, unit vectors), so
 //   - a row whose approximate cosine is A has an exact cosine >= A - eps;
 //   - if k different rows have approximate cosines >= A_k, the query's exact k-th best is >= A_k - eps, and a row can
 //     only be among the exact k best if its approximate cosine is >= A_k - 2 eps.
@@ -82,42 +85,10 @@ struct BsCfg {
     static constexpr int KS = D / 32;                                   // K-steps per row
     static constexpr int P = KS % 8 == 0 ? 8 : (KS % 6 == 0 ? 6 : 4);   // K-steps a worker keeps in flight (2 KiB each)
     static constexpr uint32_t HB = D > 768 ? 128u : 256u;               // hit-ring entries per worker (a power of two)
-    static constexpr uint32_t T16 = 16u * D * 2u;                       // bytes of a 16-row tile of the fragment store
+    static constexpr uint32_t T16 = 16u * D * 2u;                       // bytes of a 16-row block of the tiled shadow
     static constexpr size_t LDS = (size_t)KS * 4096u + BSL_WORDS * 4 + (size_t)BS_WORK * HB * 12 + BS_WORK * 64 * 4 + 256 * 4 + 64 * 4 + BS_TQ * 4 + 64 * 4;
     static_assert(KS % P == 0 && D % 128 == 0 && LDS <= 160u * 1024u, "unsupported row width");
 };
-
-// rows [row_lo, row_hi) -> the fragment store: L2-normalised (zero and non-finite rows become zero rows: allpairs.hip's
-// rule), rounded to bf16, element j of row r at tile (r / 16) x T16 + K-step (j / 32) x 1 KiB + lane (16 (j % 32 / 8) + r % 16)
-// x 16 bytes + (j % 8) x 2.  One wave per row.
-template <typename S>
-__global__ __launch_bounds__(256) void build_nfrag_kernel(const S *rows, uint16_t *nfrag, uint32_t row_lo, uint32_t row_hi, uint32_t dim) {
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u, n_waves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t r = row_lo + wave; r < row_hi; r += n_waves) {
-        const S *p = rows + (size_t)r * dim;
-        float ss = 0.0f;
-        for (uint32_t j = lane; j < dim; j += 64u) { const float x = ldf(p + j); ss += x * x; }
-#pragma unroll
-        for (int x = 1; x < 64; x <<= 1) ss += __shfl_xor(ss, x, 64);
-        const float inv = ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f;
-        uint16_t *tile = nfrag + (size_t)(r >> 4) * 16u * dim;
-        for (uint32_t j = lane; j < dim; j += 64u) {
-            const float v = ldf(p + j) * inv;
-            const uint16_t b = (v == v && fabsf(v) <= 3.0e38f) ? f32_to_bf16_bits(v) : (uint16_t)0;
-            tile[(j >> 5) * 512u + ((((j >> 3) & 3u) << 4) + (r & 15u)) * 8u + (j & 7u)] = b;
-        }
-    }
-}
-
-int launch_build_nfrag(const float *rows, const uint16_t *rows16, uint16_t *nfrag, uint32_t row_lo, uint32_t row_hi, uint32_t dim, hipStream_t stream) {
-    if (row_hi <= row_lo) return CX_OK;
-    uint32_t grid = (row_hi - row_lo + 3u) / 4u;
-    if (grid > 8192u) grid = 8192u;
-    if (rows16) hipLaunchKernelGGL(build_nfrag_kernel<uint16_t>, dim3(grid), dim3(256), 0, stream, rows16, nfrag, row_lo, row_hi, dim);
-    else hipLaunchKernelGGL(build_nfrag_kernel<float>, dim3(grid), dim3(256), 0, stream, rows, nfrag, row_lo, row_hi, dim);
-    CX_HIP(hipGetLastError());
-    return CX_OK;
-}
 
 template <int D>
 __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
@@ -162,18 +133,19 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
     };
 
     // ---- workers: the ring.  P K-steps x 2 row fragments of 16 bytes per lane.  A 32-row tile is 2 x T16 contiguous bytes
-    // of the fragment store (the store ends with a spare 16-row tile, so the second half of the last tile exists); one
-    // buffer descriptor per tile — SGPR base, the lane's 16 bytes as the only address VGPR
+    // of the tiled shadow (padded to whole 256-row tiles, zero beyond the last row); one buffer descriptor per tile — SGPR
+    // base; the only address VGPRs are the lane's piece inside a KiB for an even and for an odd 16-row block: row i = lane & 15
+    // at 64 i, its piece kq = lane >> 4 at position kq ^ (bits 3-4 of the row) = kq ^ ((i >> 3) | 2 x (block parity))
     s16x8 ring[P][2];
-    const uint32_t voff = lane * 16u;
+    const uint32_t voff[2] = {j * 64u + (((kq ^ (j >> 3)) & 3u) << 4), j * 64u + (((kq ^ ((j >> 3) | 2u)) & 3u) << 4)};
     auto tile_rsrc = [&](uint32_t T) {
         const uint32_t Tc = (uint32_t)__builtin_amdgcn_readfirstlane((int)(T < n32 ? T : n32 - 1u));
-        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(const_cast<uint16_t *>(a.nfrag)) + (size_t)Tc * (2u * T16), 0, (int)(2u * T16), 0x00020000);
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(const_cast<uint16_t *>(a.shadow_t)) + (size_t)Tc * (2u * T16), 0, (int)(2u * T16), 0x00020000);
     };
     auto issue = [&](s16x8 (&slot)[2], __amdgpu_buffer_rsrc_t rs, int ks) {
 #pragma unroll
         for (int f = 0; f < 2; f++)
-            slot[f] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff + (ks & 3) * 1024, (int)(f * T16) + (ks >> 2) * 4096, 2 /* nt */));
+            slot[f] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff[f] + (ks & 3) * 1024, (int)(f * T16) + (ks >> 2) * 4096, 2 /* nt */));
     };
 
     uint32_t T = T_first + wave;

@@ -176,7 +176,6 @@ int upsert_impl(cx_index *ix, uint64_t n, const uint8_t *ids, const float *embs,
         if (it != ix->map.end()) {  // replace in place, row position kept
             if (it->second < ix->shadow_rows) ix->shadow_stale.push_back(it->second);
             if (it->second < ix->norms_rows) ix->norms_stale.push_back(it->second);
-            if (it->second < ix->nfrag_rows) ix->nfrag_stale.push_back(it->second);
             if (int rc = put_rows(it->second, i, 1)) return rc;
             i++;
             continue;
@@ -333,40 +332,6 @@ int ensure_norms(const cx_index *ix, hipStream_t s) {
     return CX_OK;
 }
 
-// The screening copy of the rows (batchs.hip), kept lazily like the norms: whole 16-row tiles plus a spare one (a worker's
-// 32-row tile may start at the last 16-row tile).
-int ensure_nfrag(const cx_index *ix, hipStream_t s) {
-    std::lock_guard<std::mutex> g(ix->nfrag_mu);
-    const uint64_t n = ix->n_rows;
-    bool work = false;
-    if (ix->nfrag_cap < n) {
-        if (ix->d_nfrag) CX_HIP(hipFree(ix->d_nfrag));
-        ix->d_nfrag = nullptr;
-        ix->nfrag_cap = 0;
-        const uint64_t cap = std::max<uint64_t>(n, ix->cap);
-        const size_t bytes = (size_t)((cap + 31) / 16) * 16 * ix->dim * sizeof(uint16_t);
-        CX_HIP(hipMalloc((void **)&ix->d_nfrag, bytes));
-        CX_HIP(hipMemsetAsync(ix->d_nfrag, 0, bytes, s));
-        ix->nfrag_cap = cap;
-        ix->nfrag_rows = 0;
-        ix->nfrag_stale.clear();
-        work = true;
-    }
-    for (uint32_t r : ix->nfrag_stale)
-        if (r < ix->nfrag_rows) {
-            if (int rc = launch_build_nfrag(ix->rows32(), ix->rows16(), ix->d_nfrag, r, r + 1, ix->dim, s)) return rc;
-            work = true;
-        }
-    ix->nfrag_stale.clear();
-    if (ix->nfrag_rows < n) {
-        if (int rc = launch_build_nfrag(ix->rows32(), ix->rows16(), ix->d_nfrag, (uint32_t)ix->nfrag_rows, (uint32_t)n, ix->dim, s)) return rc;
-        ix->nfrag_rows = n;
-        work = true;
-    }
-    if (work) CX_HIP(hipStreamSynchronize(s));
-    return CX_OK;
-}
-
 int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float *tails, uint64_t nq, uint32_t k_eff,
                 const DevFilter &flt, float thr, bool has_thr, uint32_t *d_rows, float *d_scores, float *d_dists,
                 uint32_t *d_counts, hipStream_t s) {
@@ -397,12 +362,12 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
     // peak whatever k is, batch2_kernel's in-kernel wide lists at 0.40-0.49 (1.25M x 384 / 768, k = 100)
     // (1.25M rows, per step: k = 100 at 768 / 384-d 0.82 / 0.51 ms against 1.02 / 0.64; k = 32: 0.78 / 0.46 against 0.81 / 0.58; k = 20
     // at 384-d 0.44 against 0.48; k = 10: 0.77 / 0.45 against 0.65 / 0.43 — batch2's fused lists win while they are short)
-    // Large stores, every width up to 1024 that is a multiple of 128, both store types: batchs.hip — a screening pass over a
-    // normalised bf16 copy of the rows in MFMA fragment order (half the bytes of the f32 rows, one MFMA per pair instead of
-    // three, a rigorous error bound), the survivors re-scored exactly from the stored rows by the select kernel
+    // Large stores, every width up to 1024 that is a multiple of 128, both store types: batchs.hip — a screening pass over the
+    // normalised bf16 shadow the linker passes keep (half the bytes of the f32 rows, one MFMA per pair instead of three, a
+    // rigorous error bound), the survivors re-scored exactly from the stored rows
     static const int bs_ok = getenv("CX_BATCHS") ? atoi(getenv("CX_BATCHS")) : 1;
     if (bs_ok && topk_path && no_tails && nq >= (uint64_t)batch_min && k_eff >= 1 && batchs_supported(ix->dim, k_eff) && n >= batchs_min_rows()) {
-        if (int rc = ensure_nfrag(ix, s)) return rc;
+        if (int rc = ensure_shadow(ix, s)) return rc;
         if (c->bsc_cap < BS_CTL_WORDS) {
             if (int rc = ensure_dev(c->d_bs_ctl, c->bsc_cap, (size_t)BS_CTL_WORDS)) return rc;
             CX_HIP(hipMemsetAsync(c->d_bs_ctl, 0, (size_t)BS_CTL_WORDS * sizeof(uint32_t), s));
@@ -413,7 +378,7 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
             const uint32_t m = (uint32_t)std::min<uint64_t>(64, nq - q0);
             BatchSArgs b;
             memset(&b, 0, sizeof b);
-            b.nfrag = ix->d_nfrag;
+            b.shadow_t = ix->d_shadow_t;
             b.queries = d_queries + q0 * ix->dim;
             b.rows = ix->rows32();
             b.rows16 = ix->rows16();
@@ -796,7 +761,6 @@ void cx_destroy(cx_index *ix) {
     (void)hipFree(ix->d_shadow_t);
     (void)hipFree(ix->d_norms);
     (void)hipFree(ix->d_split);
-    (void)hipFree(ix->d_nfrag);
     (void)hipFree(ix->d_tile_list);
     if (ix->up_stream) (void)hipStreamDestroy(ix->up_stream);
     delete ix;
@@ -961,8 +925,6 @@ int cx_rebuild(cx_index *ix) try {
     ix->shadow_stale.clear();
     ix->norms_rows = 0;   // and so are the row norms
     ix->norms_stale.clear();
-    ix->nfrag_rows = 0;   // and the screening copy
-    ix->nfrag_stale.clear();
     return CX_OK;
 } catch (...) { return cx::on_exception(); }
 

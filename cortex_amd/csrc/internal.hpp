@@ -174,13 +174,6 @@ struct cx_index {
     // bf16 hi/lo split copy of the rows for the batched search (same bytes as the f32 rows, tile-image layout);
     // maintained together with the norms (same validity prefix and stale list)
     mutable char *d_split = nullptr;
-    // rows L2-normalised, rounded to bf16, laid out as MFMA A fragments: the operand of the batched search's screening
-    // pass (batchs.hip); same lazy scheme: rows [0, nfrag_rows) valid, in-place upserts listed in nfrag_stale
-    mutable std::mutex nfrag_mu;
-    mutable uint16_t *d_nfrag = nullptr;
-    mutable uint64_t nfrag_cap = 0;
-    mutable uint64_t nfrag_rows = 0;
-    mutable std::vector<uint32_t> nfrag_stale;
     mutable uint32_t *d_tile_list = nullptr;   // live tiles of the symmetric all-pairs pass, cached per row count
     mutable uint32_t tile_list_rows = 0, tile_list_n = 0, tile_list_big = 0;
     // cx_autolink_filter_profile: the filter GEMM of the last timed all-pairs pass (under shadow_mu)
@@ -255,6 +248,7 @@ int stage_queries(const cx_index *ix, Ctx *c, uint64_t nq, const float *queries,
 bool use_nontemporal(const cx_index *ix);
 // nq single-query scans (query i = d_queries + i*dim) enqueued on s; results at [i*k_eff, ...)
 int ensure_norms(const cx_index *ix, hipStream_t s);   // index.cpp
+int ensure_shadow(const cx_index *ix, hipStream_t s);  // autolink.cpp: the normalised bf16 shadow (linker passes, batched search)
 int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float *tails, uint64_t nq, uint32_t k_eff,
                 const DevFilter &flt, float thr, bool has_thr, uint32_t *d_rows, float *d_scores, float *d_dists,
                 uint32_t *d_counts, hipStream_t s);

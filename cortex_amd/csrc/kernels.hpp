@@ -125,7 +125,7 @@ constexpr uint32_t BS_CTL_CNT = BS_CTL_BOUND + 64;
 constexpr uint32_t BS_CTL_NEXT = BS_CTL_CNT + 64;     // the next unclaimed tile beyond the statically dealt first ones
 constexpr uint32_t BS_CTL_WORDS = BS_CTL_NEXT + 16;
 struct BatchSArgs {
-    const uint16_t *nfrag;  // cx_index::d_nfrag: rows L2-normalised, bf16, as MFMA A fragments (batchs.hip)
+    const uint16_t *shadow_t; // cx_index::d_shadow_t: rows L2-normalised, bf16, the all-pairs filter's tiled layout (tiled_shadow_off below)
     const float *queries;   // [nq][dim] f32 in HBM
     const float *rows;      // the f32 store (the re-score reads it); null for a bf16 store
     const uint16_t *rows16; // the bf16 store
@@ -140,7 +140,6 @@ struct BatchSArgs {
 };
 bool batchs_supported(uint32_t dim, uint32_t k);   // dim % 128 == 0, dim <= 1024, k <= 256
 uint32_t batchs_min_rows();   // fewest rows that take this path (CX_BATCHS_MIN_ROWS)
-int launch_build_nfrag(const float *rows, const uint16_t *rows16, uint16_t *nfrag, uint32_t row_lo, uint32_t row_hi, uint32_t dim, hipStream_t stream);
 int launch_batchs_pass(const BatchSArgs &a, hipStream_t stream);
 int launch_batchs_select(const BatchSArgs &a, uint32_t *out_rows, float *out_scores, float *out_dists, uint32_t *out_count, hipStream_t stream);
 

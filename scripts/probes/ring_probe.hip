@@ -32,17 +32,21 @@ __global__ __launch_bounds__(512, 2) void ring_kernel(const char *src, uint32_t 
         t = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t < n_tiles ? t : n_tiles - 1u));
         return src + (size_t)t * TILE + lane * 16u;
     };
-    const uint32_t r0 = rot ? (gw * 5u) % (uint32_t)KSN : 0u;   // rot: wave-specific starting step (breaks lockstep address patterns)
+    const uint32_t r0 = rot == 1 ? (gw * 5u) % (uint32_t)KSN : 0u;   // rot: wave-specific starting step (breaks lockstep address patterns)
     auto issue = [&](f32x4 (&slot)[NSTR][LPS], const char *b, int ks) {
         uint32_t kk = (uint32_t)ks + r0;
         kk = kk >= (uint32_t)KSN ? kk - KSN : kk;
         if constexpr (BUF) {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(b) - lane * 16u, 0, TILE, 0x00020000);
+            // rot == 2: lane (i = lane & 15, kq = lane >> 4) reads piece kq ^ swizzle of row i: 16 rows x 64 B per KiB (the tiled shadow)
+            const uint32_t i = lane & 15u, kq = lane >> 4;
+            const uint32_t vo[2] = {rot == 2 ? i * 64u + (((kq ^ ((i >> 3) & 1u)) & 3u) << 4) : lane * 16u,
+                                    rot == 2 ? i * 64u + (((kq ^ (((i >> 3) & 1u) | 2u)) & 3u) << 4) : lane * 16u};
 #pragma unroll
             for (int s = 0; s < NSTR; s++)
 #pragma unroll
                 for (int l = 0; l < LPS; l++)
-                    slot[s][l] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane * 16u) + l * 1024, (int)(s * (TILE / NSTR) + kk * STEP), 2));
+                    slot[s][l] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)vo[s & 1] + l * 1024, (int)(s * (TILE / NSTR) + kk * STEP), 2));
         } else {
 #pragma unroll
         for (int s = 0; s < NSTR; s++)
@@ -156,7 +160,7 @@ int main(int argc, char **argv) {
     const int cus = pr.multiProcessorCount;
     printf("CUs %d, %.2f GB per launch, %d reps\n", cus, bytes / 1e9, reps);
 #define RINGB(P, NSTR, STEP, TILE, BUF) \
-    for (int order : {0}) for (int rot : {0, 1}) { \
+    for (int order : {0}) for (int rot : {0, 2}) { \
         CK(hipFuncSetAttribute(reinterpret_cast<const void *>(ring_kernel<P, NSTR, STEP, TILE, BUF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         const uint32_t n_tiles = (uint32_t)(bytes / (TILE)); \
         double g = timed([&] { hipLaunchKernelGGL((ring_kernel<P, NSTR, STEP, TILE, BUF>), dim3(cus), dim3(512), 117 * 1024, 0, buf, n_tiles, sink, order, rot); }, (double)n_tiles * (TILE), reps); \
@@ -174,8 +178,8 @@ int main(int argc, char **argv) {
         hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, (uint32_t *)buf, bytes / 4); CK(hipDeviceSynchronize());
         printf("data: random\n");
     }
-    RING(4, 2, 2048, 49152)
-    RING(6, 2, 2048, 49152)
+    RINGB(8, 2, 1024, 49152, 1)
+    RINGB(4, 2, 2048, 49152, 1)
 #define LIN(U) \
     for (int bpc : {2, 4}) { \
         CK(hipFuncSetAttribute(reinterpret_cast<const void *>(linear_kernel<U>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
