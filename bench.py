@@ -685,7 +685,7 @@ def config5_leg(L, device: int, dev, n: int = 6_250_000, d: int = 1024, thr: flo
         tick_s = best["tick_ms"] * 1e-3
         if b <= 128:
             by = rows_now * d * 2.0
-            roof = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "kernel": "cx::pair_filter_stream_kernel",
+            roof = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "kernel": "cx::batchs_kernel<1024, true> (threshold mode; shards below 131,072 rows: cx::pair_filter_stream_kernel)",
                     "achieved": by / (best["filter_ms"] * 1e-3) / 1e9, "frac": by / (best["filter_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "whole_tick_achieved": by / tick_s / 1e9, "frac_of_whole_tick": by / tick_s / 1e9 / HBM_PEAK_GBS,
                     "algorithmic_bytes_per_tick": by}

@@ -208,6 +208,26 @@ static int launch_stream_d(const PairFilterArgs &a, hipStream_t stream) {
 
 int launch_pair_filter_stream(const PairFilterArgs &a, hipStream_t stream) {
     if (!pair_filter_stream_supported(a)) return set_err(CX_ERR_VALIDATION, "stream pair filter: unsupported shape (n_scan %u, dim %u)", a.n_scan, a.dim);
+    // large shards: the same pass through batchs.hip's worker / service structure (no barrier per tile, tiles claimed
+    // dynamically, hits through LDS rings): the caller lends a word of pair_ctl as the tile counter
+    static const int thr_ok = getenv("CX_PAIR_STREAM_BATCHS") ? atoi(getenv("CX_PAIR_STREAM_BATCHS")) : 1;
+    if (thr_ok && a.shadow_t && a.pair_ctl && batchs_thr_supported(a.n_rows, a.dim, a.n_scan)) {
+        BatchSArgs b;
+        memset(&b, 0, sizeof b);
+        b.shadow_t = a.shadow_t;
+        b.n_rows = a.n_rows;
+        b.nq = a.n_scan;
+        b.dim = a.dim;
+        b.flt.trivial = 1;
+        b.thr_lo = a.thr_lo;
+        b.scan_rows = a.scan_rows;
+        b.shadow_q = a.shadow_q;
+        b.thr_cand_cnt = a.cand_cnt;
+        b.thr_cand = a.cand;
+        b.thr_cap = a.cap;
+        b.thr_next = a.pair_ctl + 24;
+        return launch_batchs_thr(b, stream);
+    }
     if (a.dim == 384) return launch_stream_d<384>(a, stream);
     if (a.dim == 512) return launch_stream_d<512>(a, stream);
     if (a.dim == 768) return launch_stream_d<768>(a, stream);

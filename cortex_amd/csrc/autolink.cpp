@@ -364,6 +364,8 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
                 f.ev_end = ps.ev_k1;
             }
             if (!big && stream_ok && pair_filter_stream_supported(f)) {
+                if (int rc = ensure_dev(ps.d_pair_ctl, ps.c_pair_ctl, (size_t)32)) return rc;   // (a word of it: the tile counter of the pass on large shards)
+                f.pair_ctl = ps.d_pair_ctl;
                 if (int rc = launch_pair_filter_stream(f, s)) return rc;
                 filter_kind = 2;
             } else if (persist) {
@@ -772,6 +774,8 @@ int cx_autolink_lists_dev(const cx_index *ix, uint64_t nq64, const float *d_quer
         static const int big_min = getenv("CX_PAIR_256_MIN") ? atoi(getenv("CX_PAIR_256_MIN")) : 129;
         static const int stream_ok = getenv("CX_PAIR_STREAM") ? atoi(getenv("CX_PAIR_STREAM")) : 1;
         if ((int64_t)nq < big_min && stream_ok && pair_filter_stream_supported(f)) {
+            if (int rc = ensure_dev(ps.d_pair_ctl, ps.c_pair_ctl, (size_t)32)) return rc;
+            f.pair_ctl = ps.d_pair_ctl;
             if (int rc = launch_pair_filter_stream(f, s)) return rc;
         } else if (int rc = ((int64_t)nq >= big_min) ? launch_pair_filter256(f, s) : launch_pair_filter(f, s)) return rc;
         RescoreArgs r;

@@ -90,7 +90,12 @@ struct BsCfg {
     static_assert(KS % P == 0 && D % 128 == 0 && LDS <= 160u * 1024u, "unsupported row width");
 };
 
-template <int D>
+// THR: the same pass as the all-pairs filter of a SMALL scan set (<= 64 scanned rows of the shard, or external vectors:
+// streaming ingest, BASELINE config 5; allpairs_stream.hip's contract): the "queries" are the scanned rows' own shadow
+// pieces, the test is a fixed threshold (thr - eps), there is no bound to establish — no sample, no slots, no wait —, and a
+// hit's row goes into the scanned row's candidate list (cand_cnt / cand, `cap` slots: the exact rescore redoes a row whose
+// count runs over).
+template <int D, bool THR>
 __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
     using C = BsCfg<D>;
     constexpr int KS = C::KS, P = C::P;
@@ -118,7 +123,8 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
     const uint32_t nw = gridDim.x * BS_WORK;                      // worker waves of the grid
     const uint32_t T_first = blockIdx.x * BS_WORK;                // the block's workers start at tiles T_first .. T_first + 6
     const uint32_t in_block = T_first >= n32 ? 0u : (n32 - T_first < BS_WORK ? n32 - T_first : BS_WORK);   // workers with a first tile
-    uint32_t *const g_slots = a.ctl, *const g_bound = a.ctl + BS_CTL_BOUND, *const g_cnt = a.ctl + BS_CTL_CNT, *const g_next = a.ctl + BS_CTL_NEXT;
+    uint32_t *const g_slots = a.ctl, *const g_bound = a.ctl + BS_CTL_BOUND, *const g_cnt = THR ? a.thr_cand_cnt : a.ctl + BS_CTL_CNT;
+    uint32_t *const g_next = THR ? a.thr_next : a.ctl + BS_CTL_NEXT;
     const bool worker = wave < BS_WORK;
     // Tiles: the first nw (one per worker wave: the sample, tile -> slot) are dealt statically; the rest are claimed
     // BS_CLAIM at a time from one grid-wide counter by the service waves and handed over through a queue in LDS
@@ -156,6 +162,23 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         for (int p = 0; p < P; p++) issue(ring[p], crs, p);
     }
 
+    if constexpr (THR) {
+        // ---- prologue (all eight waves): the scanned rows' shadow pieces as B fragments in LDS (they are normalised bf16 already)
+        const uint32_t g = wave & 3u, half = wave >> 2, q = g * 16u + j;
+        const bool live = q < nq;
+        const uint32_t gr = live ? (a.scan_rows ? a.scan_rows[q] : q) : 0u;
+#pragma unroll
+        for (int ks = 0; ks < KS / 2; ks++) {
+            const uint32_t kk = (uint32_t)ks + half * (KS / 2);
+            s16x8 H = a.shadow_q ? reinterpret_cast<const s16x8 *>(a.shadow_q + (size_t)gr * D)[4u * kk + kq]
+                                 : *reinterpret_cast<const s16x8 *>(a.shadow_t + tiled_shadow_off(gr, 4u * kk + kq, KS));
+            if (!live) H = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            *reinterpret_cast<s16x8 *>(qimg + (kk * 4u + g) * 1024u + lane * 16u) = H;
+        }
+        if (tid < BSL_WORDS) s_ctl[tid] = 0u;
+        if (tid < 64u) s_bnd[tid] = 0u;
+        __syncthreads();
+    } else {
     // ---- prologue (all eight waves): |q|, then the queries normalised, rounded to bf16, as B fragments in LDS: wave w
     // takes query group w & 3, K-steps of half w >> 2
     {
@@ -193,6 +216,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
             *reinterpret_cast<s16x8 *>(qimg + (((uint32_t)ks + half * (KS / 2)) * 4u + g) * 1024u + lane * 16u) = H;
         }
     }
+    }
     // the service wave fills the tile queue: tiles n_static + c .. + BS_CLAIM - 1 of a claim c; BS_WORK end marks once
     // the counter has passed the last tile
     bool exhausted = false;
@@ -218,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         // One hit per lane: row filter, candidate list (the exact cosine is the select kernel's), the tile's slot.  Lanes
         // with the same query take their list positions from ONE atomic add.
         auto process_hits = [&](bool active, uint32_t row, uint32_t q, float approx) {
-            active = active && row_passes(a.flt, row);
+            if constexpr (!THR) active = active && row_passes(a.flt, row);   // (the filter pass has no row filter: the rescore and the rules look at the rows)
             row = active ? row : 0u;
             q = active ? q : 0u;
             uint64_t same = __ballot(active);
@@ -232,9 +256,13 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
             if (active && (int)lane == leader) base = atomicAdd(g_cnt + q, (uint32_t)__popcll(same));
             base = (uint32_t)__shfl((int)base, active ? leader : 0, 64);
             const uint32_t pos = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-            if (active && pos < a.cap) a.cand_rows[(size_t)q * a.cap + pos] = row;
-            if (active && approx > 0.0f)
-                __hip_atomic_fetch_max(g_slots + q * BS_SL + ((row >> 5) & (BS_SL - 1u)), __float_as_uint(approx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if constexpr (THR) {
+                if (active && pos < a.thr_cap) a.thr_cand[(size_t)q * a.thr_cap + pos] = row;
+            } else {
+                if (active && pos < a.cap) a.cand_rows[(size_t)q * a.cap + pos] = row;
+                if (active && approx > 0.0f)
+                    __hip_atomic_fetch_max(g_slots + q * BS_SL + ((row >> 5) & (BS_SL - 1u)), __float_as_uint(approx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         };
         // The slots of query q (32 per lane) and the k-th largest of them (a radix walk over four 8-bit digits with a
         // 256-bin histogram in LDS; one wave: its LDS operations stay in order)
@@ -301,10 +329,11 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
             return all_done;
         };
 
+        uint32_t bl = 1u;
+        if constexpr (!THR) {
         // A-C. the warm-up, one polling loop: (A) once the block's workers have left their first tiles' maxima in LDS, write
         // them to the tiles' slots (plain write-through stores); (B) publish this block's queries as soon as a fraction
         // of the grid's sample is in the slots; (C) leave when every live query has a bound or a no-bound mark
-        uint32_t bl = 1u;
         {
             const uint32_t sample = (nw < n32 ? nw : n32) < BS_SL ? (nw < n32 ? nw : n32) : BS_SL;   // slots the first tiles fill
             const uint32_t frac = ((blockIdx.x >> 6) & 3u) + 1u;                                      // 1/8, 2/8, 3/8, 4/8
@@ -325,6 +354,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         }
         bs_lds_st(&s_bnd[lane], bl);
         if (lane == 0u) bs_lds_st_rel(&s_ctl[BSL_READY], 1u);
+        }
         // D. service loop: drain the workers' hit rings, keep the tile queue filled and the block's copy of the bounds
         // fresh (re-read and re-published 2, 4, 8, ... us apart, then every 128 us: see the head of the file)
         uint32_t gap = 200u;           // x10 ns
@@ -366,7 +396,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
             }
             const bool workers_done = bs_lds_ld_acq(&s_ctl[BSL_DONE]) >= BS_WORK;
             const uint64_t t_now = now();
-            if (t_now >= t_next && !workers_done) {
+            if (!THR && t_now >= t_next && !workers_done) {
                 bl = bs_ld_agent(g_bound + lane);
                 if (bl > bs_lds_ld(&s_bnd[lane])) bs_lds_st(&s_bnd[lane], bl);
                 if (gap >= 800u) publish(0u, true);
@@ -445,7 +475,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         }
 
         const uint32_t row0 = T * 32u + 4u * kq;   // this lane's rows: row0 + 16 f + r
-        if (first) {
+        if (!THR && first) {
             // ---- warm-up, once per wave: the tile's best approximate cosine per query into LDS for the service wave,
             // which fills the grid's slots with them and brings the first bounds back
             first = false;
@@ -481,7 +511,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
             }
         }
 #pragma unroll
-        for (int g = 0; g < 4; g++) thr[g] = bs_thr(bs_lds_ld(&s_bnd[16 * g + j]), liveq[g]);
+        for (int g = 0; g < 4; g++) thr[g] = THR ? (liveq[g] ? a.thr_lo : __builtin_inff()) : bs_thr(bs_lds_ld(&s_bnd[16 * g + j]), liveq[g]);
 
         // ---- the test: one compare per pair (a NaN passes); one wave-level branch
         bool any = false;
@@ -698,9 +728,12 @@ uint32_t batchs_min_rows() {
 template <int D>
 static int launch_batchs_d(const BatchSArgs &a, uint32_t grid, hipStream_t stream) {
     static std::atomic<uint64_t> attr_devices{0};
-    if (first_use_on_device(attr_devices))
-        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchs_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL((batchs_kernel<D>), dim3(grid), dim3(512), BsCfg<D>::LDS, stream, a);
+    if (first_use_on_device(attr_devices)) {
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchs_kernel<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchs_kernel<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    if (a.thr_cand) hipLaunchKernelGGL((batchs_kernel<D, true>), dim3(grid), dim3(512), BsCfg<D>::LDS, stream, a);
+    else hipLaunchKernelGGL((batchs_kernel<D, false>), dim3(grid), dim3(512), BsCfg<D>::LDS, stream, a);
     CX_HIP(hipGetLastError());
     return CX_OK;
 }
@@ -725,6 +758,18 @@ int launch_batchs_pass(const BatchSArgs &a_in, hipStream_t stream) {
         case 896: return launch_batchs_d<896>(a, grid, stream);
         default: return launch_batchs_d<1024>(a, grid, stream);
     }
+}
+
+// The all-pairs filter of a small scan set through the same pass (THR): candidate columns out, allpairs_stream.hip's contract.
+bool batchs_thr_supported(uint32_t n_rows, uint32_t dim, uint32_t n_scan) {
+    return n_scan >= 1u && n_scan <= 64u && batchs_supported(dim, 1) && n_rows >= batchs_min_rows();
+}
+int launch_batchs_thr(const BatchSArgs &a_in, hipStream_t stream) {
+    BatchSArgs a = a_in;
+    a.k = 1;
+    if (!a.thr_cand || !a.thr_cand_cnt || !a.thr_next || !a.shadow_t) return set_err(CX_ERR_VALIDATION, "batchs (threshold mode): incomplete arguments");
+    CX_HIP(hipMemsetAsync(a.thr_next, 0, sizeof(uint32_t), stream));
+    return launch_batchs_pass(a, stream);
 }
 
 int launch_batchs_select(const BatchSArgs &a, uint32_t *out_rows, float *out_scores, float *out_dists, uint32_t *out_count, hipStream_t stream) {

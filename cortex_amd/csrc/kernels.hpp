@@ -137,8 +137,18 @@ struct BatchSArgs {
     float *cand_cos;
     uint32_t cap;           // entries per query: n_rows (every pair is tested once, so a list cannot run over)
     uint32_t arm;           // CX_BATCHS_ARM: measurement arms (results invalid): 1 workers drop their hits, 4 the service wave drops them
+    // threshold mode (launch_batchs_thr: the all-pairs filter of <= 64 scanned rows, allpairs_stream.hip's contract); nq = n_scan
+    float thr_lo;               // threshold - eps
+    const uint32_t *scan_rows;  // [n_scan] row of each scanned node, or null = identity
+    const uint16_t *shadow_q;   // scanned vectors that are not rows of this shard ([n_scan][dim] normalised bf16), or null
+    uint32_t *thr_cand_cnt;     // [n_scan], zeroed by the caller
+    uint32_t *thr_cand;         // [n_scan][thr_cap]
+    uint32_t thr_cap;
+    uint32_t *thr_next;         // [1] the pass's tile counter (zeroed by the launcher)
 };
 bool batchs_supported(uint32_t dim, uint32_t k);   // dim % 128 == 0, dim <= 1024, k <= 256
+bool batchs_thr_supported(uint32_t n_rows, uint32_t dim, uint32_t n_scan);
+int launch_batchs_thr(const BatchSArgs &a, hipStream_t stream);
 uint32_t batchs_min_rows();   // fewest rows that take this path (CX_BATCHS_MIN_ROWS)
 int launch_batchs_pass(const BatchSArgs &a, hipStream_t stream);
 int launch_batchs_select(const BatchSArgs &a, uint32_t *out_rows, float *out_scores, float *out_dists, uint32_t *out_count, hipStream_t stream);

@@ -557,3 +557,19 @@ def test_topk_lists_of_many_rows_filter_path(hip, oracle, n, d, topk, monkeypatc
     monkeypatch.setenv("CX_PAIR_CAND_CAP", "16")
     lr3, ls3, lc3 = h.topk_lists_rows(topk, scan)
     assert np.array_equal(lc3, lc2) and np.array_equal(lr3, lr2) and np.array_equal(ls3, ls2)
+
+
+def test_small_scan_sets_through_the_worker_service_pass():
+    """On shards of >= 131,072 rows the filter of a small scan set runs batchs.hip's threshold mode (workers + service wave,
+    tiles claimed dynamically) instead of pair_filter_stream_kernel.  The switch is read once per process: the small-scan-set
+    cases above, the streaming-ingest ticks on a bf16 store and the sharded lists run again in a child process with the row
+    minimum lowered to test sizes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(root, "tests", "test_hip_autolink.py"),
+                        os.path.join(root, "tests", "test_hip_bf16_store.py"), "-k",
+                        "small_scan_sets_take_the_stream_filter or streaming_ingest_tick or pass_sees_upserts"],
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, CX_BATCHS_MIN_ROWS="256"), cwd=root)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
