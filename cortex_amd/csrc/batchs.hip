@@ -346,9 +346,25 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
                         for (uint32_t w = 0; w < in_block; w++)
                             __hip_atomic_store(g_slots + lane * BS_SL + ((T_first + w) & (BS_SL - 1u)), s_wm[w * 64u + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                if (!published) published = publish(want, spin >= 96);
+                // (the fraction waited for halves every few polls: when the grid's blocks are not all resident — another
+                // kernel on the device: a concurrent reader's search — the slots of the missing ones stay empty until the
+                // resident ones are through, and a bound from the k-th largest of what IS there is valid; without it the
+                // query would run without a bound, every pair a hit, at the service wave's pace)
+                if (!published) published = publish((want >> (spin >> 2)) > k ? (want >> (spin >> 2)) : k, spin >= 96);
                 bl = lane < nq ? bs_ld_agent(g_bound + lane) : 1u;
-                if (stored && __ballot(bl == 0u) == 0ull) break;
+                uint64_t missing = __ballot(bl == 0u);
+                if (stored && missing == 0ull) break;
+                // queries nobody has published after ~80 us: their publishers are not resident (see above) — any block may
+                // publish any query (an atomic max: redundancy is harmless)
+                if (spin >= 24 && (spin & 7) == 0) {
+                    while (missing) {
+                        const uint32_t q = (uint32_t)__ffsll((unsigned long long)missing) - 1u;
+                        missing &= missing - 1ull;
+                        const uint32_t nz = slots_load(q);
+                        const uint32_t t = nz >= k ? slots_kth() : 0u;
+                        if (lane == 0u && (t || spin >= 96)) __hip_atomic_fetch_max(g_bound + q, t ? t : BS_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
                 if (published) __builtin_amdgcn_s_sleep(8);
             }
         }
