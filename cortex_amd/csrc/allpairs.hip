@@ -53,9 +53,11 @@ __device__ inline float wave_sum(float v) {
 
 // ---------------------------------------------------------------- 1. shadow
 
+// err_max (optional): the largest rounding error of a row, || bf16(x) - x || for the normalised row x, as the bits of a
+// positive f32 (atomic max): batchs.hip's screening bound uses the error the shadow really has instead of the worst case
 template <typename S>
 __global__ __launch_bounds__(256) void build_shadow_kernel(const S *rows, uint16_t *shadow, uint32_t row_lo,
-                                                           uint32_t row_hi, uint32_t dim, uint32_t tiled) {
+                                                           uint32_t row_hi, uint32_t dim, uint32_t tiled, uint32_t *err_max) {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -66,11 +68,19 @@ __global__ __launch_bounds__(256) void build_shadow_kernel(const S *rows, uint16
         ss = wave_sum(ss);
         const float inv = ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f;  // zero rows -> zero shadow (never a candidate)
         uint16_t *o = shadow + (size_t)r * dim;
+        float es = 0.0f;
         for (uint32_t j = lane; j < dim; j += 64u) {
             const float v = ldf(p + j) * inv;
-            const uint16_t b = (v == v && fabsf(v) <= 3.0e38f) ? f32_to_bf16_rne(v) : (uint16_t)0;
+            const bool fin = v == v && fabsf(v) <= 3.0e38f;
+            const uint16_t b = fin ? f32_to_bf16_rne(v) : (uint16_t)0;
+            const float e = fin ? v - bf16_bits_to_f32(b) : 0.0f;
+            es += e * e;
             if (tiled) shadow[tiled_shadow_off(r, j >> 3, dim / 32u) + (j & 7u)] = b;
             else o[j] = b;
+        }
+        if (err_max) {
+            es = wave_sum(es);
+            if (lane == 0u) __hip_atomic_fetch_max(err_max, __float_as_uint(sqrtf(es) * (1.0f + 1.0e-5f)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -80,7 +90,7 @@ int launch_build_shadow(const float *rows, uint16_t *shadow, uint32_t row_lo, ui
     if (row_hi <= row_lo) return CX_OK;
     uint32_t grid = (row_hi - row_lo + 3u) / 4u;
     if (grid > 8192u) grid = 8192u;
-    hipLaunchKernelGGL(build_shadow_kernel<float>, dim3(grid), dim3(256), 0, stream, rows, shadow, row_lo, row_hi, dim, 0u);
+    hipLaunchKernelGGL(build_shadow_kernel<float>, dim3(grid), dim3(256), 0, stream, rows, shadow, row_lo, row_hi, dim, 0u, nullptr);
     CX_HIP(hipGetLastError());
     return CX_OK;
 }
@@ -89,17 +99,17 @@ int launch_build_shadow(const uint16_t *rows16, uint16_t *shadow, uint32_t row_l
     if (row_hi <= row_lo) return CX_OK;
     uint32_t grid = (row_hi - row_lo + 3u) / 4u;
     if (grid > 8192u) grid = 8192u;
-    hipLaunchKernelGGL(build_shadow_kernel<uint16_t>, dim3(grid), dim3(256), 0, stream, rows16, shadow, row_lo, row_hi, dim, 0u);
+    hipLaunchKernelGGL(build_shadow_kernel<uint16_t>, dim3(grid), dim3(256), 0, stream, rows16, shadow, row_lo, row_hi, dim, 0u, nullptr);
     CX_HIP(hipGetLastError());
     return CX_OK;
 }
-int launch_build_shadow_tiled(const float *rows, const uint16_t *rows16, uint16_t *shadow_t, uint32_t row_lo, uint32_t row_hi, uint32_t dim, hipStream_t stream) {
+int launch_build_shadow_tiled(const float *rows, const uint16_t *rows16, uint16_t *shadow_t, uint32_t row_lo, uint32_t row_hi, uint32_t dim, hipStream_t stream, uint32_t *err_max) {
     if (row_hi <= row_lo) return CX_OK;
     if (dim % 32u) return set_err(CX_ERR_VALIDATION, "tiled shadow needs dim %% 32 == 0 (got %u)", dim);
     uint32_t grid = (row_hi - row_lo + 3u) / 4u;
     if (grid > 8192u) grid = 8192u;
-    if (rows16) hipLaunchKernelGGL(build_shadow_kernel<uint16_t>, dim3(grid), dim3(256), 0, stream, rows16, shadow_t, row_lo, row_hi, dim, 1u);
-    else hipLaunchKernelGGL(build_shadow_kernel<float>, dim3(grid), dim3(256), 0, stream, rows, shadow_t, row_lo, row_hi, dim, 1u);
+    if (rows16) hipLaunchKernelGGL(build_shadow_kernel<uint16_t>, dim3(grid), dim3(256), 0, stream, rows16, shadow_t, row_lo, row_hi, dim, 1u, err_max);
+    else hipLaunchKernelGGL(build_shadow_kernel<float>, dim3(grid), dim3(256), 0, stream, rows, shadow_t, row_lo, row_hi, dim, 1u, err_max);
     CX_HIP(hipGetLastError());
     return CX_OK;
 }

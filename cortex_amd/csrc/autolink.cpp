@@ -47,8 +47,10 @@ int ensure_shadow(const cx_index *ix, hipStream_t s) {
         ix->shadow_stale.clear();
         work = true;
     }
+    if (!ix->d_shadow_err) CX_HIP(hipMalloc((void **)&ix->d_shadow_err, 64));
+    if (ix->shadow_rows == 0) CX_HIP(hipMemsetAsync(ix->d_shadow_err, 0, 64, s));   // built from scratch: the error bound starts over
     auto build = [&](uint32_t lo, uint32_t hi) -> int {
-        if (tiled) return launch_build_shadow_tiled(ix->dtype == 1 ? nullptr : ix->d_rows, ix->dtype == 1 ? ix->rows16() : nullptr, ix->d_shadow_t, lo, hi, ix->dim, s);
+        if (tiled) return launch_build_shadow_tiled(ix->dtype == 1 ? nullptr : ix->d_rows, ix->dtype == 1 ? ix->rows16() : nullptr, ix->d_shadow_t, lo, hi, ix->dim, s, ix->d_shadow_err);
         return ix->dtype == 1 ? launch_build_shadow(ix->rows16(), ix->d_shadow, lo, hi, ix->dim, s) : launch_build_shadow(ix->d_rows, ix->d_shadow, lo, hi, ix->dim, s);
     };
     for (uint32_t r : ix->shadow_stale)

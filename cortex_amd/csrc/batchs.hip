@@ -8,11 +8,14 @@
 // A lane reads ITS piece of the MFMA A fragment out of that KiB — lane (i, kq): row i's piece kq — so a wave-level load is
 // one KiB of contiguous memory in a permuted lane order, which streams exactly as fast as the linear order
 // (scripts/probes/ring_probe.hip: 0.862 against 0.864 of the peak): ONE normalised 2-byte copy of the rows serves the
-// linker passes and the batched search.  Its dot with a normalised bf16 query is the cosine within eps = 2u + u^2 + 1e-4,
-// u = 2^-8 (autolink.cpp: both operands rounded, unit vectors), so
+// linker passes and the batched search.  Its dot x^.y^ with a normalised bf16 query is the cosine x.y within
+//   eps(y) = d_max (1 + u) + d_y (1 + 1e-6) + 1e-4,   d_max = the largest || x^ - x || over the shadow's rows, d_y = || y^ - y ||
+// (|x^.y^ - x.y| <= || x^ - x || || y^ || + || x || || y^ - y ||; u = 2^-8; 1e-4: f32 accumulation and the normalisations) — the
+// errors the rounding really made (the shadow's build keeps d_max, the prologue computes d_y): ~1.6e-3 each on embeddings,
+// against the worst case u || x || = 3.9e-3 each that the all-pairs filter's fixed bound assumes.  So
 //   - a row whose approximate cosine is A has an exact cosine >= A - eps;
 //   - if k different rows have approximate cosines >= A_k, the query's exact k-th best is >= A_k - eps, and a row can
-//     only be among the exact k best if its approximate cosine is >= A_k - 2 eps.
+//     only be among the exact k best if its approximate cosine is >= A_k - 2 eps (the query's margin).
 // The pass therefore streams HALF the bytes of the f32 rows (a quarter of rows + split store), needs ONE
 // v_mfma_f32_16x16x32_bf16 per 16 rows x 16 queries x 32 elements instead of three, tests a pair with one compare,
 // and hands a few hundred survivors per query to the select kernel, which computes their exact cosines from the stored
@@ -52,8 +55,6 @@
 namespace cx {
 
 constexpr uint32_t BS_WORK = 7;        // worker waves per block; the eighth wave is the service wave
-// |approximate - exact cosine| (autolink.cpp: FILTER_EPS)
-constexpr float BS_EPS = 2.0f / 256.0f + 1.0f / 65536.0f + 1.0e-4f;
 
 __device__ inline uint32_t bs_ld_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline uint32_t bs_lds_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -64,11 +65,11 @@ __device__ inline void bs_lds_st_rel(uint32_t *p, uint32_t v) { __hip_atomic_sto
 // A published bound is the bits of an approximate cosine > 0 (the k-th largest slot value A_k); 0 = nothing published
 // yet, BS_NONE = "this query has no bound" (fewer than k slots filled: a zero query, a filter that passes next to nothing).
 constexpr uint32_t BS_NONE = 1u;
-// the test's threshold: a pair is a hit unless its approximate cosine is below A_k - 2 eps.  -inf = every pair passes (no
+// the test's threshold: a pair is a hit unless its approximate cosine is below A_k - margin, margin = 2 eps of the query.  -inf = every pair passes (no
 // bound, or one so low that rows with a non-positive cosine — all tied at the clamped score 0 — could be among the k best);
 // +inf for a query slot beyond nq
-__device__ inline float bs_thr(uint32_t bits, bool live) {
-    const float t = __uint_as_float(bits) - 2.0f * BS_EPS;
+__device__ inline float bs_thr(uint32_t bits, bool live, float margin) {
+    const float t = __uint_as_float(bits) - margin;
     return !live ? __builtin_inff() : ((bits <= BS_NONE || !(t > 0.0f)) ? -__builtin_inff() : t);
 }
 
@@ -203,6 +204,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         }
         __syncthreads();
         const float inv = s_inv[q];
+        float es = 0.0f;   // this lane's share of || y^ - y ||^2
 #pragma unroll
         for (int ks = 0; ks < KS / 2; ks++) {
             const f32x4 v0 = q4[8 * ks + 2 * kq], v1 = q4[8 * ks + 2 * kq + 1];
@@ -211,10 +213,17 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const float v = e[i] * inv;
-                H[i] = (short)((live && v == v && fabsf(v) <= 3.0e38f) ? f32_to_bf16_bits(v) : (uint16_t)0);
+                const bool fin = live && v == v && fabsf(v) <= 3.0e38f;
+                const uint16_t b = fin ? f32_to_bf16_bits(v) : (uint16_t)0;
+                const float d = fin ? v - bf16_bits_to_f32(b) : 0.0f;
+                es += d * d;
+                H[i] = (short)b;
             }
             *reinterpret_cast<s16x8 *>(qimg + (((uint32_t)ks + half * (KS / 2)) * 4u + g) * 1024u + lane * 16u) = H;
         }
+        es += __shfl_xor(es, 16, 64);
+        es += __shfl_xor(es, 32, 64);
+        if (kq == 0u) s_qqp[128u + half * 64u + q] = es;
     }
     }
     // the service wave fills the tile queue: tiles n_static + c .. + BS_CLAIM - 1 of a claim c; BS_WORK end marks once
@@ -447,6 +456,16 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
 #pragma unroll
     for (int g = 0; g < 4; g++) liveq[g] = 16u * g + j < nq;
     float thr[4];                    // the threshold of each of the lane's four queries (bs_thr)
+    float mrg[4];                    // 2 eps of each of them (read here, right behind the prologue's last barrier: the ring that
+                                     // shares this LDS is first written after every worker of the block is past its first tile)
+    {
+        const float dmax = a.shadow_err ? __uint_as_float(*a.shadow_err) : 0.00390625f;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const float dq = THR ? 0.0f : sqrtf(s_qqp[128u + 16u * g + j] + s_qqp[192u + 16u * g + j]);
+            mrg[g] = 2.0f * (dmax * (1.0f + 0.00390625f) + dq * (1.0f + 1.0e-6f) + 1.0e-4f);
+        }
+    }
     auto wait_room = [&](uint32_t n) {   // room for n more entries in the ring (the service wave moves the tail)
         for (int spin = 0; spin < (1 << 20); spin++) {
             if (head + n - bs_lds_ld_acq(&s_ctl[BSL_TAIL + wave]) <= HB) break;
@@ -527,7 +546,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
             }
         }
 #pragma unroll
-        for (int g = 0; g < 4; g++) thr[g] = THR ? (liveq[g] ? a.thr_lo : __builtin_inff()) : bs_thr(bs_lds_ld(&s_bnd[16 * g + j]), liveq[g]);
+        for (int g = 0; g < 4; g++) thr[g] = THR ? (liveq[g] ? a.thr_lo : __builtin_inff()) : bs_thr(bs_lds_ld(&s_bnd[16 * g + j]), liveq[g], mrg[g]);
 
         // ---- the test: one compare per pair (a NaN passes); one wave-level branch
         bool any = false;

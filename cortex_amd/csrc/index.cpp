@@ -379,6 +379,7 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
             BatchSArgs b;
             memset(&b, 0, sizeof b);
             b.shadow_t = ix->d_shadow_t;
+            b.shadow_err = ix->d_shadow_err;
             b.queries = d_queries + q0 * ix->dim;
             b.rows = ix->rows32();
             b.rows16 = ix->rows16();

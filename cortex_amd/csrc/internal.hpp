@@ -161,6 +161,7 @@ struct cx_index {
     // the same shadow cut into the 256-tile filter kernel's LDS-DMA pieces: [16-row block][K-step of 32][16 rows x 64 B,
     // pieces pre-swizzled] — one DMA instruction = 1 KiB of contiguous HBM/L2 (allpairs256.hip); maintained with d_shadow
     mutable uint16_t *d_shadow_t = nullptr;
+    mutable uint32_t *d_shadow_err = nullptr;   // [1] the largest || bf16(x) - x || over the shadow's rows (f32 bits; an upper bound: never lowered by removals)
     mutable uint64_t shadow_cap = 0;
     mutable uint64_t shadow_rows = 0;
     mutable std::vector<uint32_t> shadow_stale;

@@ -126,6 +126,7 @@ constexpr uint32_t BS_CTL_NEXT = BS_CTL_CNT + 64;     // the next unclaimed tile
 constexpr uint32_t BS_CTL_WORDS = BS_CTL_NEXT + 16;
 struct BatchSArgs {
     const uint16_t *shadow_t; // cx_index::d_shadow_t: rows L2-normalised, bf16, the all-pairs filter's tiled layout (tiled_shadow_off below)
+    const uint32_t *shadow_err; // cx_index::d_shadow_err: the largest rounding error of a shadow row (f32 bits); null = the worst case 2^-8
     const float *queries;   // [nq][dim] f32 in HBM
     const float *rows;      // the f32 store (the re-score reads it); null for a bf16 store
     const uint16_t *rows16; // the bf16 store
@@ -193,7 +194,8 @@ int launch_dense_topk(const float *d_dense, uint32_t stride, uint32_t n_rows, ui
 int launch_build_shadow(const float *rows, uint16_t *shadow, uint32_t row_lo, uint32_t row_hi, uint32_t dim,
                         hipStream_t stream);
 // the same rows straight into the tiled layout (dim % 32 == 0)
-int launch_build_shadow_tiled(const float *rows, const uint16_t *rows16, uint16_t *shadow_t, uint32_t row_lo, uint32_t row_hi, uint32_t dim, hipStream_t stream);
+int launch_build_shadow_tiled(const float *rows, const uint16_t *rows16, uint16_t *shadow_t, uint32_t row_lo, uint32_t row_hi, uint32_t dim, hipStream_t stream,
+                              uint32_t *err_max = nullptr);   // err_max: the largest || bf16(x) - x || of a normalised row, f32 bits, atomic max
 int launch_build_shadow(const uint16_t *rows16, uint16_t *shadow, uint32_t row_lo, uint32_t row_hi, uint32_t dim,
                         hipStream_t stream);   // bf16 store
 
