@@ -167,6 +167,8 @@ def main() -> None:
 
     value = args.steps * B * world / elapsed
     algo_bytes = float(n) * d * 4.0  # N*d*sizeof(f32) per query per shard; norms recomputed in-scan
+    if B >= 3:   # (--batch: the batched pass streams the 2-byte normalised shadow once per launch — batch_roofline below)
+        algo_bytes = float(n) * d * 2.0
     avg_ms = kern_ms / max(1, kern_n)
     achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; gfx950 x2 read

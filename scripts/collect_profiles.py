@@ -53,9 +53,9 @@ traffic("knn_1Mx768_pmc_final.json", "scripts/profile_round.sh: rocprofv3 --pmc 
         "python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-autolink --no-config4", "scan_kernel<768", "knn_fetch_summary.json", "knn_write_summary.json",
         3_072_000_000, "scan_kernel_hbm_bytes_per_launch")
 traffic("batch64_1.25Mx768_pmc_final.json", "scripts/profile_round_b.sh: rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- "
-        "python3 scripts/bench_batch.py --steps 5", "batchs_kernel<768>", "batch_fetch_summary.json", "batch_write_summary.json",
+        "python3 scripts/bench_batch.py --steps 5", "batchs_kernel<768, false>", "batch_fetch_summary.json", "batch_write_summary.json",
         1_250_000 * 768 * 2, "batchs_kernel_hbm_bytes_per_launch")
 traffic("batch64_6.25Mx1024_bf16_pmc_final.json", "scripts/profile_round_b.sh: rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- "
-        "python3 scripts/bench_batch_dim.py --rows 6250000 --dim 1024 --dtype bf16 --steps 5", "batchs_kernel<1024>", "b1024_fetch_summary.json", "b1024_write_summary.json",
+        "python3 scripts/bench_batch_dim.py --rows 6250000 --dim 1024 --dtype bf16 --steps 5", "batchs_kernel<1024, false>", "b1024_fetch_summary.json", "b1024_write_summary.json",
         6_250_000 * 1024 * 2, "batchs_kernel_hbm_bytes_per_launch")
 print(sorted(os.listdir(D)))
