@@ -345,8 +345,12 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         // of the grid's sample is in the slots; (C) leave when every live query has a bound or a no-bound mark
         {
             const uint32_t sample = (nw < n32 ? nw : n32) < BS_SL ? (nw < n32 ? nw : n32) : BS_SL;   // slots the first tiles fill
-            const uint32_t frac = ((blockIdx.x >> 6) & 3u) + 1u;                                      // 1/8, 2/8, 3/8, 4/8
-            const uint32_t want = sample * frac / 8u > k ? sample * frac / 8u : k;
+            // the first publisher of a query (blocks 0..63) goes as soon as a.pub_min slots (>= k) are in: a bound from the earliest
+            // finishers' rows lets a couple more pairs per tile through for the few microseconds until the others — at 2/8,
+            // 3/8, 4/8 of the sample — and the service loop tighten it, and everybody starts testing a round trip earlier
+            const uint32_t frac = (blockIdx.x >> 6) & 3u;
+            const uint32_t want0 = frac ? sample * (frac + 1u) / 8u : a.pub_min;
+            const uint32_t want = want0 > k ? want0 : k;
             bool stored = false, published = false;
             for (int spin = 0; spin < 4096; spin++) {   // bounded: a few ms
                 if (!stored && bs_lds_ld_acq(&s_ctl[BSL_ARRIVED]) >= in_block) {
@@ -776,7 +780,9 @@ static int launch_batchs_d(const BatchSArgs &a, uint32_t grid, hipStream_t strea
 int launch_batchs_pass(const BatchSArgs &a_in, hipStream_t stream) {
     BatchSArgs a = a_in;
     static const uint32_t arm_env = getenv("CX_BATCHS_ARM") ? (uint32_t)atoi(getenv("CX_BATCHS_ARM")) : 0u;
+    static const uint32_t pub_env = getenv("CX_BATCHS_PUB_MIN") ? (uint32_t)atoi(getenv("CX_BATCHS_PUB_MIN")) : 64u;
     a.arm = arm_env;
+    a.pub_min = pub_env;
     if (!batchs_supported(a.dim, a.k) || a.nq == 0 || a.nq > 64u || a.n_rows == 0)
         return set_err(CX_ERR_VALIDATION, "batchs: unsupported shape (dim %u, k %u, %u queries, %u rows)", a.dim, a.k, a.nq, a.n_rows);
     const uint32_t cus = device_cus(), n32 = (a.n_rows + 31u) / 32u;
