@@ -17,6 +17,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import Callable, List, Optional, Sequence
 
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -53,6 +55,20 @@ class ShardedKnn:
         self.out_counts = torch.zeros(nq, dtype=torch.int32, device=device)
         self.local_fn = local_fn
         self.merge_fn = merge_fn or _hip_merge
+        # On a GPU submit() runs a stream of batches on `depth` HIP streams in rotation, each with its own exchange and result
+        # buffers: batch i's scan, all-gather and merge are enqueued on stream i % depth, so the fixed costs of one batch's pass
+        # (its prologue, its first bounds, its tail) and its exchange run under the next batches' streaming — measured with
+        # concurrent readers of one shard (profiles/r03/tuning.md 8.7): +24 % batches per second at four in flight.
+        self._streams = None
+        depth = int(os.environ.get("CX_SHARDED_STREAMS", "4")) if device.type == "cuda" else 0
+        if depth >= 2:
+            self._streams = [torch.cuda.Stream(device=device) for _ in range(depth)]
+            self._locals = [torch.zeros(self.words, dtype=torch.int32, device=device) for _ in range(depth)]
+            self._gathered = [torch.zeros(world * self.words, dtype=torch.int32, device=device) for _ in range(depth)]
+            self._outs = [(torch.zeros((nq, k), dtype=torch.int64, device=device), torch.zeros((nq, k), dtype=torch.float32, device=device),
+                           torch.zeros((nq, k), dtype=torch.float32, device=device), torch.zeros(nq, dtype=torch.int32, device=device))
+                          for _ in range(depth)]
+            self.local, self.gathered = self._locals[0], self._gathered[0]
 
     # views into a packed chunk (base = tensor of `words` int32)
     def chunk_views(self, base: torch.Tensor):
@@ -82,6 +98,23 @@ class ShardedKnn:
         and its merge is enqueued by the NEXT submit()/flush(), after that call's local scan — so the
         exchange latency hides under the next scan.  Results of a batch are complete after the following
         submit() or flush(); out_* always hold the most recently merged batch."""
+        if self._streams is not None:
+            i = self._seq % len(self._streams)
+            st = self._streams[i]
+            st.wait_stream(torch.cuda.current_stream(self.device))   # the queries were produced on the caller's stream
+            with torch.cuda.stream(st):
+                self.local, self.gathered = self._locals[i], self._gathered[i]
+                self.out_rows, self.out_scores, self.out_dists, self.out_counts = self._outs[i]
+                self.local_fn(queries, self.nq, self)
+                if self.world > 1:
+                    work = dist.all_gather_into_tensor(self._gathered[i], self._locals[i], group=self.group, async_op=True)
+                    work.wait()   # this stream waits for the collective; the host does not block, the other streams run on
+                    self.merge_fn(self)
+                elif self.merge_fn is not _hip_merge:
+                    self._gathered[i].copy_(self._locals[i])
+                    self.merge_fn(self)
+            self._seq += 1
+            return
         i = self._seq & 1
         self.local, self.gathered = self._locals[i], self._gathered[i]
         self.local_fn(queries, self.nq, self)
@@ -98,6 +131,11 @@ class ShardedKnn:
             self._finish(prev)
 
     def flush(self) -> None:
+        if self._streams is not None:   # the caller's stream waits for every batch in flight
+            cur = torch.cuda.current_stream(self.device)
+            for st in self._streams:
+                cur.wait_stream(st)
+            return
         if self._pending is not None:
             self._finish(self._pending)
             self._pending = None
