@@ -89,6 +89,44 @@ def test_world_one_is_the_local_list(hip, oracle):
         assert_topk_parity(r[qi].cpu().numpy(), sc[qi].cpu().numpy(), e["row"], e["score"], what="world=1")
 
 
+def test_submit_rotates_batches_over_streams(hip, oracle):
+    """submit() on a GPU enqueues a stream of batches on several HIP streams in rotation, each with its own exchange and result
+    buffers; after flush() the caller's stream has every batch: seven different batches (more than there are streams, so
+    buffers are reused), each read back right after its own flush, equal the oracle's answers."""
+    from cortex_amd.sharded import ShardedKnn, hip_local_fn
+    dev = torch.device("cuda", 0)
+    n, d, nq, k = 5000, 768, 8, 10
+    rows = oracle.synth_rows(n, d)
+    ids = ids_for(n)
+    h = hip.HipIndex(d)
+    h.insert_batch(ids, rows)
+    o = oracle.OracleIndex(d)
+    o.insert_batch(ids, rows)
+    s = ShardedKnn(0, 1, [0], nq, k, dev, hip_local_fn(h))
+    assert s._streams is not None and len(s._streams) >= 2
+    all_q = oracle.synth_queries(n, d, 7 * nq)
+    dq = torch.from_numpy(all_q).to(dev)
+    views = []
+    for b in range(7):
+        s.submit(dq.data_ptr() + b * nq * d * 4)
+        views.append(s.chunk_views(s.local))     # world == 1: the local list of the slot this batch used
+        if b % 3 == 2:                            # flush now and then: the batches so far must be complete
+            s.flush()
+            torch.cuda.current_stream().synchronize()
+            for bb in range(b - 2, b + 1):
+                r, sc, di, c = views[bb]
+                for qi in range(nq):
+                    e = o.search(all_q[bb * nq + qi], k)
+                    assert int(c[qi]) == k
+                    assert_topk_parity(r[qi].cpu().numpy(), sc[qi].cpu().numpy(), e["row"], e["score"], what=f"batch {bb} q{qi}")
+    s.flush()
+    torch.cuda.synchronize()
+    r, sc, di, c = views[6]
+    for qi in range(nq):
+        e = o.search(all_q[6 * nq + qi], k)
+        assert_topk_parity(r[qi].cpu().numpy(), sc[qi].cpu().numpy(), e["row"], e["score"], what=f"last batch q{qi}")
+
+
 @pytest.mark.parametrize("n,d,parts,thr,block", [(3000, 768, 3, 0.85, 1024), (2000, 384, 4, 0.75, 512), (900, 100, 2, 0.8, 400)])
 def test_sharded_autolink_equals_single_index_pass(hip, oracle, n, d, parts, thr, block):
     """The all-pairs pass over row-range shards (external-query lists + all-gather layout + merge + rule walk)
