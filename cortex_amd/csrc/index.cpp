@@ -366,7 +366,13 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
     // normalised bf16 shadow the linker passes keep (half the bytes of the f32 rows, one MFMA per pair instead of three, a
     // rigorous error bound), the survivors re-scored exactly from the stored rows
     static const int bs_ok = getenv("CX_BATCHS") ? atoi(getenv("CX_BATCHS")) : 1;
-    if (bs_ok && topk_path && no_tails && nq >= (uint64_t)batch_min && k_eff >= 1 && batchs_supported(ix->dim, k_eff) && n >= batchs_min_rows()) {
+    // (a pass costs ~50 us whatever the store's size and serves 64 queries: from 131,072 rows it wins for any number of queries; from
+    // 32,768 rows for calls of up to 256 queries — 40k x 384, k = 10 / 100: 0.062 / 0.072 ms against 0.082 / 0.157; 100k x 768, k = 100:
+    // 0.133 against 0.387 —, while many queries over a small store are better served by batch.hip's chunk x group launches)
+    static const uint32_t bs_small_rows = getenv("CX_BATCHS_SMALL_ROWS") ? (uint32_t)atoi(getenv("CX_BATCHS_SMALL_ROWS")) : 32768u;
+    static const uint64_t bs_small_nq = getenv("CX_BATCHS_SMALL_NQ") ? (uint64_t)atoll(getenv("CX_BATCHS_SMALL_NQ")) : 256u;
+    const bool bs_rows_ok = n >= batchs_min_rows() || (n >= bs_small_rows && nq <= bs_small_nq);
+    if (bs_ok && topk_path && no_tails && nq >= (uint64_t)batch_min && k_eff >= 1 && batchs_supported(ix->dim, k_eff) && bs_rows_ok) {
         if (int rc = ensure_shadow(ix, s)) return rc;
         if (c->bsc_cap < BS_CTL_WORDS) {
             if (int rc = ensure_dev(c->d_bs_ctl, c->bsc_cap, (size_t)BS_CTL_WORDS)) return rc;
