@@ -661,6 +661,10 @@ __global__ __launch_bounds__(256) void batchs_rescore_kernel(const BatchSArgs a,
     }
 #pragma unroll
     for (int x = 1; x < 64; x <<= 1) qq += __shfl_xor(qq, x, 64);
+    if (!(qq > 0.0f)) {   // a zero (or NaN) query: every cosine is 0 / 0 (or NaN) = NaN whatever the row — no row is read
+        for (uint32_t c = gw * 64u + lane; c < total; c += nwq * 64u) cosv[c] = __builtin_nanf("");
+        return;
+    }
     for (uint32_t c = gw * U; c < total; c += nwq * U) {
         const S *p[U];
 #pragma unroll
@@ -708,6 +712,7 @@ __global__ __launch_bounds__(1024) void batchs_select_kernel(const BatchSArgs a,
     const float *cosv = a.cand_cos + (size_t)q * a.cap;
     constexpr uint32_t CHUNK = (uint32_t)NV * 1024u - 256u;   // room for the survivors so far
     uint32_t n_surv = 0;
+    uint64_t low_so_far = 0ull;   // the k-th best key of the chunks selected so far (1: fewer than k entries yet)
     for (uint32_t c0 = 0; c0 == 0u || c0 < total; c0 += CHUNK) {
         const uint32_t cn = total - c0 < CHUNK ? total - c0 : CHUNK;
         uint64_t key[NV];
@@ -725,10 +730,17 @@ __global__ __launch_bounds__(1024) void batchs_select_kernel(const BatchSArgs a,
                 sim[u] = surv_s[ci - cn];
             }
         }
+        if (c0 != 0u && low_so_far > 1ull) {   // a later chunk of a long list: does any of its entries beat the k best so far?
+            bool beats = false;
+#pragma unroll
+            for (int u = 0; u < NV; u++) beats = beats || (tid + (uint32_t)u * 1024u < cn && key[u] > low_so_far);
+            if (!__syncthreads_or(beats ? 1 : 0)) continue;   // (uniform) no: the survivors stand
+        }
         __syncthreads();
         if (tid == 0) s_n = 0u;
         const uint64_t t = block_select_kth<NV>(key, k, 56, 0, sh);   // 0: fewer than k entries — all of them survive
         const uint64_t low = t ? t : 1ull;
+        low_so_far = low;
 #pragma unroll
         for (int u = 0; u < NV; u++)
             if (key[u] >= low && key[u] != 0ull) {   // keys are unique (the row is part of the key): exactly min(k, live) survivors
