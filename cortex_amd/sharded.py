@@ -60,7 +60,9 @@ class ShardedKnn:
         # (its prologue, its first bounds, its tail) and its exchange run under the next batches' streaming — measured with
         # concurrent readers of one shard (profiles/r03/tuning.md 8.7): +24 % batches per second at four in flight.
         self._streams = None
-        depth = int(os.environ.get("CX_SHARDED_STREAMS", "4")) if device.type == "cuda" else 0
+        # (batches only: single-query scans are one kernel at the stream's rate each — several in flight gain nothing and their
+        # HIP-event durations would span each other)
+        depth = int(os.environ.get("CX_SHARDED_STREAMS", "4" if nq >= 3 else "0")) if device.type == "cuda" else 0
         if depth >= 2:
             self._streams = [torch.cuda.Stream(device=device) for _ in range(depth)]
             self._locals = [torch.zeros(self.words, dtype=torch.int32, device=device) for _ in range(depth)]
