@@ -49,6 +49,8 @@
 
 #include "batch_common.hpp"
 #include "kernels.hpp"
+#include <algorithm>
+#include <vector>
 #include "select.hpp"
 #include "topk.hpp"
 
@@ -130,14 +132,17 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
     // Tiles: the first nw (one per worker wave: the sample, tile -> slot) are dealt statically; the rest are claimed
     // BS_CLAIM at a time from one grid-wide counter by the service waves and handed over through a queue in LDS
     const uint32_t n_static = nw < n32 ? nw : n32;
-    uint32_t claim0 = 0u;
-    if (!worker && lane == 0u) claim0 = atomicAdd(g_next, BS_CLAIM);   // (comes back under the query prologue)
+    // (a block's first claim is dealt, not taken: 256 blocks' atomics on one word at launch are served one after the other,
+    // ~50 ns each, and hipcc waits for the returning atomic where it is issued — the whole block's prologue stood behind it)
+    const uint32_t claim0 = blockIdx.x * BS_CLAIM, claim_base = gridDim.x * BS_CLAIM;
 
     auto now = [&]() -> uint64_t {   // 100 MHz
         uint64_t t;
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
         return t;
     };
+    unsigned long long *const tl = a.tl ? a.tl + (size_t)blockIdx.x * 32u : nullptr;
+    if (tl && tid == 0u) tl[0] = now();
 
     // ---- workers: the ring.  P K-steps x 2 row fragments of 16 bytes per lane.  A 32-row tile is 2 x T16 contiguous bytes
     // of the tiled shadow (padded to whole 256-row tiles, zero beyond the last row); one buffer descriptor per tile — SGPR
@@ -158,12 +163,14 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
     uint32_t T = T_first + wave;
     const bool has_work = worker && T < n32;
     __amdgpu_buffer_rsrc_t crs = tile_rsrc(T);
-    if (has_work) {
+    auto start_ring = [&]() {   // every wave, unconditionally (the service wave's and an idle worker's loads are a clamped tile's first
+                                // K-steps, dropped): a branch here makes hipcc's counted waits behind it assume the shorter queue
 #pragma unroll
         for (int p = 0; p < P; p++) issue(ring[p], crs, p);
-    }
+    };
 
     if constexpr (THR) {
+        start_ring();
         // ---- prologue (all eight waves): the scanned rows' shadow pieces as B fragments in LDS (they are normalised bf16 already)
         const uint32_t g = wave & 3u, half = wave >> 2, q = g * 16u + j;
         const bool live = q < nq;
@@ -181,49 +188,64 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         __syncthreads();
     } else {
     // ---- prologue (all eight waves): |q|, then the queries normalised, rounded to bf16, as B fragments in LDS: wave w
-    // takes query group w & 3, K-steps of half w >> 2
+    // takes query group w & 3, K-steps of half w >> 2.  Lanes 4 r .. 4 r + 3 read 64 contiguous bytes of query 16 g + r
+    // (16 accesses of 64 bytes per load instruction; with the fragment's own lane order — lane 16 kq + j at row j — it was 64
+    // accesses of 16 bytes, and the L1's rate of line accesses made the 196 KiB of a 768-d batch a 9 us read); the lane's
+    // share stays in registers from the norm to the image: read once, every load in flight at once.
     {
-        const uint32_t g = wave & 3u, half = wave >> 2, q = g * 16u + j;
+        const uint32_t g = wave & 3u, half = wave >> 2, r = lane >> 2, c = lane & 3u, q = g * 16u + r;
         const bool live = q < nq;
-        const f32x4 *q4 = reinterpret_cast<const f32x4 *>(a.queries + (size_t)(live ? q : 0u) * D) + half * (KS / 2) * 8;
+        const f32x4 *q4 = reinterpret_cast<const f32x4 *>(a.queries + (size_t)(live ? q : 0u) * D) + half * (KS / 2) * 8 + c;
+        f32x4 v[KS / 2][2];   // K-step ks: elements 4 c .. 4 c + 3 and 16 + 4 c .. 16 + 4 c + 3
+#pragma unroll
+        for (int ks = 0; ks < KS / 2; ks++) { v[ks][0] = q4[8 * ks]; v[ks][1] = q4[8 * ks + 4]; }
+        __builtin_amdgcn_sched_barrier(0);
+        start_ring();   // behind the query loads in the wave's queue: the prologue does not wait for the first rows
+        __builtin_amdgcn_sched_barrier(0);
         float qq = 0.0f;
 #pragma unroll
         for (int ks = 0; ks < KS / 2; ks++) {
-            const f32x4 v0 = q4[8 * ks + 2 * kq], v1 = q4[8 * ks + 2 * kq + 1];
+            const f32x4 v0 = v[ks][0], v1 = v[ks][1];
             qq += v0.x * v0.x + v0.y * v0.y + v0.z * v0.z + v0.w * v0.w + v1.x * v1.x + v1.y * v1.y + v1.z * v1.z + v1.w * v1.w;
         }
-        qq += __shfl_xor(qq, 16, 64);
-        qq += __shfl_xor(qq, 32, 64);
-        if (kq == 0u) s_qqp[half * 64u + q] = live ? qq : 0.0f;
+        qq += __shfl_xor(qq, 1, 64);
+        qq += __shfl_xor(qq, 2, 64);
+        if (c == 0u) s_qqp[half * 64u + q] = live ? qq : 0.0f;
         if (tid < BSL_WORDS) s_ctl[tid] = 0u;
         if (tid < 64u) s_bnd[tid] = 0u;
         __syncthreads();
+        if (tl && tid == 0u) tl[30] = now();
         if (tid < 64u) {
             const float ss = s_qqp[tid] + s_qqp[64u + tid];
             s_inv[tid] = ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f;   // a zero (or non-finite) query: a zero image — it bounds nothing, every row is re-scored
         }
         __syncthreads();
+        if (tl && tid == 0u) tl[31] = now();
         const float inv = s_inv[q];
+        // (inv > 0 <=> |q|^2 is positive and finite <=> every element is finite and so is its scaled value)
+        const bool ok = live && inv > 0.0f;
         float es = 0.0f;   // this lane's share of || y^ - y ||^2
+        // elements 4 p .. 4 p + 3 of a K-step (p = c, 4 + c) are half of fragment lane 16 (p >> 1) + r's 16 bytes
+        char *const dst = qimg + (half * (KS / 2) * 4u + g) * 1024u + (16u * (c >> 1) + r) * 16u + (c & 1u) * 8u;
 #pragma unroll
-        for (int ks = 0; ks < KS / 2; ks++) {
-            const f32x4 v0 = q4[8 * ks + 2 * kq], v1 = q4[8 * ks + 2 * kq + 1];
-            const float e[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            s16x8 H;
+        for (int ks = 0; ks < KS / 2; ks++)
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const float v = e[i] * inv;
-                const bool fin = live && v == v && fabsf(v) <= 3.0e38f;
-                const uint16_t b = fin ? f32_to_bf16_bits(v) : (uint16_t)0;
-                const float d = fin ? v - bf16_bits_to_f32(b) : 0.0f;
-                es += d * d;
-                H[i] = (short)b;
+            for (int i = 0; i < 2; i++) {
+                uint32_t w[2];   // two bf16 pairs (v_cvt_pk_bf16_f32: round to nearest even)
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const f32x2 y = {ok ? v[ks][i][2 * h] * inv : 0.0f, ok ? v[ks][i][2 * h + 1] * inv : 0.0f};
+                    const uint32_t pk = __builtin_bit_cast(uint32_t, __builtin_convertvector(y, bf16x2_t));
+                    const float d0 = y.x - __uint_as_float(pk << 16), d1 = y.y - __uint_as_float(pk & 0xFFFF0000u);
+                    es += d0 * d0 + d1 * d1;
+                    w[h] = pk;
+                }
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<u32x2 *>(dst + ks * 4096 + i * 512) = u32x2{w[0], w[1]};   // (piece 4 + c: fragment lanes 32 further)
             }
-            *reinterpret_cast<s16x8 *>(qimg + (((uint32_t)ks + half * (KS / 2)) * 4u + g) * 1024u + lane * 16u) = H;
-        }
-        es += __shfl_xor(es, 16, 64);
-        es += __shfl_xor(es, 32, 64);
-        if (kq == 0u) s_qqp[128u + half * 64u + q] = es;
+        es += __shfl_xor(es, 1, 64);
+        es += __shfl_xor(es, 2, 64);
+        if (c == 0u) s_qqp[128u + half * 64u + q] = es;
     }
     }
     // the service wave fills the tile queue: tiles n_static + c .. + BS_CLAIM - 1 of a claim c; BS_WORK end marks once
@@ -231,12 +253,13 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
     bool exhausted = false;
     uint32_t q_head = 0u;
     auto push_claim = [&](uint32_t c) {   // service wave, all lanes
+        constexpr uint32_t size = BS_CLAIM;
         c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
         const uint32_t first = n_static + c;
-        const uint32_t have = first >= n32 ? 0u : (n32 - first < BS_CLAIM ? n32 - first : BS_CLAIM);
+        const uint32_t have = first >= n32 ? 0u : (n32 - first < size ? n32 - first : size);
         if (lane < have) bs_lds_st(&s_tq[(q_head + lane) & (BS_TQ - 1u)], first + lane);
         q_head += have;
-        if (have < BS_CLAIM) {
+        if (have < size) {
             if (lane < BS_WORK) bs_lds_st(&s_tq[(q_head + lane) & (BS_TQ - 1u)], BS_NO_TILE);
             q_head += BS_WORK;
             exhausted = true;
@@ -245,6 +268,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
     };
     if (!worker) push_claim(claim0);
     __syncthreads();
+    if (tl && tid == 0u) tl[1] = now();
 
     if (!worker) {
         // =============================================================== the service wave
@@ -354,16 +378,18 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
             bool stored = false, published = false;
             for (int spin = 0; spin < 4096; spin++) {   // bounded: a few ms
                 if (!stored && bs_lds_ld_acq(&s_ctl[BSL_ARRIVED]) >= in_block) {
-                    stored = true;
-                    if (lane < nq)
-                        for (uint32_t w = 0; w < in_block; w++)
-                            __hip_atomic_store(g_slots + lane * BS_SL + ((T_first + w) & (BS_SL - 1u)), s_wm[w * 64u + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    stored = true;   // (every worker of the block has written its first tile's maxima to the slots)
+                    if (tl && lane == 0u) tl[27] = now();
                 }
                 // (the fraction waited for halves every few polls: when the grid's blocks are not all resident — another
                 // kernel on the device: a concurrent reader's search — the slots of the missing ones stay empty until the
                 // resident ones are through, and a bound from the k-th largest of what IS there is valid; without it the
                 // query would run without a bound, every pair a hit, at the service wave's pace)
-                if (!published) published = publish((want >> (spin >> 2)) > k ? (want >> (spin >> 2)) : k, spin >= 96);
+                if (!published) {
+                    published = publish((want >> (spin >> 2)) > k ? (want >> (spin >> 2)) : k, spin >= 96);
+                    if (tl && lane == 0u && published) tl[28] = now();
+                }
+                if (tl && lane == 0u) tl[29] = (unsigned long long)spin + 1ull;
                 bl = lane < nq ? bs_ld_agent(g_bound + lane) : 1u;
                 uint64_t missing = __ballot(bl == 0u);
                 if (stored && missing == 0ull) break;
@@ -383,6 +409,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         }
         bs_lds_st(&s_bnd[lane], bl);
         if (lane == 0u) bs_lds_st_rel(&s_ctl[BSL_READY], 1u);
+        if (tl && lane == 0u) tl[2] = now();
         }
         // D. service loop: drain the workers' hit rings, keep the tile queue filled and the block's copy of the bounds
         // fresh (re-read and re-published 2, 4, 8, ... us apart, then every 128 us: see the head of the file)
@@ -420,7 +447,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
             }
             if (!exhausted && (int32_t)(q_head - bs_lds_ld(&s_ctl[BSL_QTAIL])) < (int32_t)BS_CLAIM) {   // fewer than two tiles per worker queued
                 uint32_t c = 0u;
-                if (lane == 0u) c = atomicAdd(g_next, BS_CLAIM);
+                if (lane == 0u) c = claim_base + atomicAdd(g_next, BS_CLAIM);
                 push_claim(c);
             }
             const bool workers_done = bs_lds_ld_acq(&s_ctl[BSL_DONE]) >= BS_WORK;
@@ -443,6 +470,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
                 }
             }
         }
+        if (tl && lane == 0u) tl[3] = now();
         return;
     }
 
@@ -456,6 +484,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
     float *const hb_dot = s_hdot + wave * HB;
     uint32_t head = 0;               // entries this wave has put into its hit ring (wave-uniform; s_ctl[BSL_HEAD + wave] mirrors it)
     bool first = true;
+    uint32_t n_tiles_done = 0;       // (timeline diagnostic)
     bool liveq[4];
 #pragma unroll
     for (int g = 0; g < 4; g++) liveq[g] = 16u * g + j < nq;
@@ -514,6 +543,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         }
 
         const uint32_t row0 = T * 32u + 4u * kq;   // this lane's rows: row0 + 16 f + r
+        if (tl && lane == 0u) { if (first) tl[4 + wave] = now(); n_tiles_done++; }
         if (!THR && first) {
             // ---- warm-up, once per wave: the tile's best approximate cosine per query into LDS for the service wave,
             // which fills the grid's slots with them and brings the first bounds back
@@ -542,13 +572,16 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                 mine = (kq == (uint32_t)g && 16u * g + j < nq) ? __float_as_uint(mx) : mine;   // lane 16 g + j: query 16 g + j
             }
-            s_wm[wave * 64u + lane] = mine;
+            // (straight to the tile's slots, lane q = query q: a store the wave does not wait for — through the service wave it
+            // waited for the block's slowest worker and for that wave's next poll, ~8 us on every bound of the grid)
+            if (lane < nq) __hip_atomic_store(g_slots + lane * BS_SL + (T & (BS_SL - 1u)), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (lane == 0u) __hip_atomic_fetch_add(&s_ctl[BSL_ARRIVED], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             for (int spin = 0; spin < (1 << 16); spin++) {        // bounded: ~30 ms
                 if (bs_lds_ld_acq(&s_ctl[BSL_READY]) != 0u) break;
                 __builtin_amdgcn_s_sleep(4);
             }
-        }
+            if (tl && lane == 0u && wave == 0u) tl[26] = now();
+        } else if (tl && lane == 0u && wave == 0u && n_tiles_done == 2u) tl[25] = now();
 #pragma unroll
         for (int g = 0; g < 4; g++) thr[g] = THR ? (liveq[g] ? a.thr_lo : __builtin_inff()) : bs_thr(bs_lds_ld(&s_bnd[16 * g + j]), liveq[g], mrg[g]);
 
@@ -630,6 +663,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         T = Tn;
         crs = nrs;
     }
+    if (tl && lane == 0u) { tl[11 + wave] = now(); tl[18 + wave] = n_tiles_done; }
     if (lane == 0u) __hip_atomic_fetch_add(&s_ctl[BSL_DONE], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
@@ -801,6 +835,51 @@ int launch_batchs_pass(const BatchSArgs &a_in, hipStream_t stream) {
     // every worker wave needs a first tile of its own (its warm-up fills a slot); blocks of 7 workers + the service wave
     uint32_t grid = n32 / BS_WORK;
     grid = grid < 1u ? 1u : (grid > cus ? cus : grid);
+    static const bool tl_env = getenv("CX_BATCHS_TL") && atoi(getenv("CX_BATCHS_TL")) != 0;
+    if (tl_env) {   // diagnostic: one pass with stamps, its timeline on stderr
+        static unsigned long long *d_tl = nullptr;
+        if (!d_tl) CX_HIP(hipMalloc(&d_tl, (size_t)1024 * 32 * 8));
+        CX_HIP(hipMemsetAsync(d_tl, 0, (size_t)1024 * 32 * 8, stream));
+        a.tl = d_tl;
+        int rc;
+        switch (a.dim) {
+            case 384: rc = launch_batchs_d<384>(a, grid, stream); break;
+            case 768: rc = launch_batchs_d<768>(a, grid, stream); break;
+            default: rc = launch_batchs_d<1024>(a, grid, stream); break;
+        }
+        if (rc) return rc;
+        CX_HIP(hipStreamSynchronize(stream));
+        std::vector<unsigned long long> h((size_t)grid * 32);
+        CX_HIP(hipMemcpy(h.data(), d_tl, h.size() * 8, hipMemcpyDeviceToHost));
+        static int tl_calls = 0;
+        if (++tl_calls % 8 == 0) {
+            unsigned long long t0 = ~0ull;
+            for (uint32_t b = 0; b < grid; b++) t0 = std::min(t0, h[(size_t)b * 32]);
+            auto stat = [&](const char *name, int lo, int hi) {
+                std::vector<double> v;
+                for (uint32_t b = 0; b < grid; b++)
+                    for (int i = lo; i < hi; i++) if (h[(size_t)b * 32 + i]) v.push_back((double)(h[(size_t)b * 32 + i] - t0) * 0.01);
+                if (v.empty()) return;
+                std::sort(v.begin(), v.end());
+                fprintf(stderr, "  %-28s min %7.1f  p10 %7.1f  med %7.1f  p90 %7.1f  max %7.1f us\n", name, v.front(), v[v.size() / 10], v[v.size() / 2], v[v.size() * 9 / 10], v.back());
+            };
+            fprintf(stderr, "[batchs timeline] %u rows x %u, %u queries, k %u, grid %u\n", a.n_rows, a.dim, a.nq, a.k, grid);
+            stat("block entry", 0, 1); stat("prologue: queries read", 30, 31); stat("prologue: norms", 31, 32); stat("prologue done", 1, 2); stat("worker: first tile done", 4, 11); stat("service: bounds in LDS", 2, 3);
+            stat("service: maxima stored", 27, 28); stat("service: own queries published", 28, 29);
+            stat("worker 0: past the wait", 26, 27); stat("worker 0: second tile done", 25, 26); stat("worker exit", 11, 18); stat("service exit", 3, 4);
+            std::vector<unsigned long long> nt;
+            for (uint32_t b = 0; b < grid; b++) for (int i = 18; i < 25; i++) nt.push_back(h[(size_t)b * 32 + i]);
+            std::sort(nt.begin(), nt.end());
+            fprintf(stderr, "  tiles per worker: min %llu med %llu max %llu\n", nt.front(), nt[nt.size() / 2], nt.back());
+            std::vector<unsigned long long> sp;
+            for (uint32_t b = 0; b < grid; b++) sp.push_back(h[(size_t)b * 32 + 29]);
+            std::sort(sp.begin(), sp.end());
+            fprintf(stderr, "  warm-up polls per block: min %llu med %llu max %llu\n", sp.front(), sp[sp.size() / 2], sp.back());
+            for (uint32_t b : {0u, 1u, 63u, 64u, 128u, 255u}) if (b < grid)
+                fprintf(stderr, "  block %3u: stored %.1f published %.1f ready %.1f polls %llu\n", b, (double)(h[(size_t)b * 32 + 27] - t0) * 0.01, h[(size_t)b * 32 + 28] ? (double)(h[(size_t)b * 32 + 28] - t0) * 0.01 : -1.0, (double)(h[(size_t)b * 32 + 2] - t0) * 0.01, h[(size_t)b * 32 + 29]);
+        }
+        return CX_OK;
+    }
     switch (a.dim) {
         case 128: return launch_batchs_d<128>(a, grid, stream);
         case 256: return launch_batchs_d<256>(a, grid, stream);

@@ -139,6 +139,7 @@ struct BatchSArgs {
     uint32_t cap;           // entries per query: n_rows (every pair is tested once, so a list cannot run over)
     uint32_t arm;           // CX_BATCHS_ARM: measurement arms (results invalid): 1 workers drop their hits, 4 the service wave drops them
     uint32_t pub_min;       // slots a query's first publisher waits for (CX_BATCHS_PUB_MIN, 64; at least k)
+    unsigned long long *tl; // CX_BATCHS_TL=1: [grid][32] s_memrealtime stamps of a pass (diagnostic; null otherwise)
     // threshold mode (launch_batchs_thr: the all-pairs filter of <= 64 scanned rows, allpairs_stream.hip's contract); nq = n_scan
     float thr_lo;               // threshold - eps
     const uint32_t *scan_rows;  // [n_scan] row of each scanned node, or null = identity
