@@ -82,6 +82,7 @@ enum : uint32_t { BSL_HEAD = 0, BSL_TAIL = 8, BSL_ARRIVED = 16, BSL_DONE = 17, B
 constexpr uint32_t BS_TQ = 64;         // entries of the block's tile queue (a power of two)
 constexpr uint32_t BS_CLAIM = 14;      // tiles the service wave claims at a time: two per worker
 constexpr uint32_t BS_NO_TILE = 0xFFFFFFFFu;
+constexpr uint32_t BS_STRUCK = 0xFFFFFFFFu;   // a candidate the re-score struck from its list
 
 template <int D>
 struct BsCfg {
@@ -89,7 +90,7 @@ struct BsCfg {
     static constexpr int P = KS % 8 == 0 ? 8 : (KS % 6 == 0 ? 6 : 4);   // K-steps a worker keeps in flight (2 KiB each)
     static constexpr uint32_t HB = D > 768 ? 128u : 256u;               // hit-ring entries per worker (a power of two)
     static constexpr uint32_t T16 = 16u * D * 2u;                       // bytes of a 16-row block of the tiled shadow
-    static constexpr size_t LDS = (size_t)KS * 4096u + BSL_WORDS * 4 + (size_t)BS_WORK * HB * 12 + BS_WORK * 64 * 4 + 256 * 4 + 64 * 4 + BS_TQ * 4 + 64 * 4;
+    static constexpr size_t LDS = (size_t)KS * 4096u + BSL_WORDS * 4 + (size_t)BS_WORK * HB * 12 + 256 * 4 + 64 * 4 + BS_TQ * 4 + 64 * 4;
     static_assert(KS % P == 0 && D % 128 == 0 && LDS <= 160u * 1024u, "unsupported row width");
 };
 
@@ -105,14 +106,13 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
     constexpr uint32_t HB = C::HB, T16 = C::T16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // LDS: [query fragments: KS x 4 groups x 1 KiB][control words][hit rings: rows | queries | cosines, 7 x HB]
-    //      [warm-up maxima 7 x 64][histogram 256][bounds 64][tile queue][1 / |q|: 64]
+    //      [histogram 256][bounds 64][tile queue][1 / |q|: 64]
     char *qimg = smem;
     uint32_t *s_ctl = reinterpret_cast<uint32_t *>(smem + KS * 4096);
     uint32_t *s_hrow = s_ctl + BSL_WORDS;
     uint32_t *s_hq = s_hrow + BS_WORK * HB;
     float *s_hdot = reinterpret_cast<float *>(s_hq + BS_WORK * HB);
-    uint32_t *s_wm = reinterpret_cast<uint32_t *>(s_hdot + BS_WORK * HB);   // [7 workers][64 queries] warm-up maxima
-    uint32_t *s_hist = s_wm + BS_WORK * 64u;                                // [256] the service wave's digit histogram
+    uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_hdot + BS_WORK * HB); // [256] the service wave's digit histogram
     uint32_t *s_bnd = s_hist + 256u;                                        // [64] the block's copy of the published bounds
     uint32_t *s_tq = s_bnd + 64u;                                           // [BS_TQ] the block's tile queue
     float *s_inv = reinterpret_cast<float *>(s_tq + BS_TQ);                 // [64] 1 / |q| (prologue)
@@ -292,7 +292,10 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
             if constexpr (THR) {
                 if (active && pos < a.thr_cap) a.thr_cand[(size_t)q * a.thr_cap + pos] = row;
             } else {
-                if (active && pos < a.cap) a.cand_rows[(size_t)q * a.cap + pos] = row;
+                if (active && pos < a.cap) {
+                    a.cand_rows[(size_t)q * a.cap + pos] = row;
+                    a.cand_cos[(size_t)q * a.cap + pos] = approx;   // (the re-score looks at it again under the pass's final bound)
+                }
                 if (active && approx > 0.0f)
                     __hip_atomic_fetch_max(g_slots + q * BS_SL + ((row >> 5) & (BS_SL - 1u)), __float_as_uint(approx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -301,10 +304,12 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         // 256-bin histogram in LDS; one wave: its LDS operations stay in order)
         constexpr int NV = (int)(BS_SL / 64u);
         uint32_t v[NV];
-        auto slots_load = [&](uint32_t q) -> uint32_t {   // returns the number of filled slots
+        // (`pre`: the first 256 slots only — the first tiles of the grid's first blocks: an eighth of the round trip's bytes for a
+        // publisher that wants a bound from the earliest finishers; the k-th largest of any subset of the slots is a valid bound)
+        auto slots_load = [&](uint32_t q, bool pre = false) -> uint32_t {   // returns the number of filled slots
             uint32_t nz = 0;
 #pragma unroll
-            for (int i = 0; i < NV; i++) v[i] = bs_ld_agent(g_slots + q * BS_SL + lane + 64u * i);
+            for (int i = 0; i < NV; i++) v[i] = (!pre || i < 4) ? bs_ld_agent(g_slots + q * BS_SL + lane + 64u * i) : 0u;
 #pragma unroll
             for (int i = 0; i < NV; i++) nz += (uint32_t)__popcll(__ballot(v[i] != 0u));
             return nz;
@@ -350,10 +355,10 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         // publisher duty: this block looks after the queries b, b + grid, ... (b = blockIdx mod 64: several blocks per
         // query when the grid is larger); `min_filled`: publish only once that many slots are in; final: a query whose
         // slots have not filled by now is declared to have no bound
-        auto publish = [&](uint32_t min_filled, bool final) -> bool {
+        auto publish = [&](uint32_t min_filled, bool final, bool pre = false) -> bool {
             bool all_done = true;
             for (uint32_t q = blockIdx.x & 63u; q < nq; q += gridDim.x) {
-                const uint32_t nz = slots_load(q);
+                const uint32_t nz = slots_load(q, pre);
                 if (nz < min_filled && !final) { all_done = false; continue; }
                 const uint32_t t = slots_kth();
                 if (lane == 0u && (t || final)) __hip_atomic_fetch_max(g_bound + q, t ? t : BS_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -385,11 +390,16 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
                 // kernel on the device: a concurrent reader's search — the slots of the missing ones stay empty until the
                 // resident ones are through, and a bound from the k-th largest of what IS there is valid; without it the
                 // query would run without a bound, every pair a hit, at the service wave's pace)
-                if (!published) {
-                    published = publish((want >> (spin >> 2)) > k ? (want >> (spin >> 2)) : k, spin >= 96);
+                // One round trip past the L2 per iteration, not two: a first publisher (blocks 0..63) polls its queries' slots until it
+                // has published, then the bounds; the other blocks poll the bounds only — their publications (from 2/8 .. 4/8 of the
+                // sample) are refinements, made here only when the warm-up drags on, otherwise by the service loop's refreshes
+                const bool try_pub = !published && (frac == 0u || spin >= 16);
+                if (try_pub) {
+                    published = publish((want >> (spin >> 2)) > k ? (want >> (spin >> 2)) : k, spin >= 96, frac == 0u && want <= 64u && spin < 16);
                     if (tl && lane == 0u && published) tl[28] = now();
                 }
                 if (tl && lane == 0u) tl[29] = (unsigned long long)spin + 1ull;
+                if (try_pub && !published && spin < 24) continue;
                 bl = lane < nq ? bs_ld_agent(g_bound + lane) : 1u;
                 uint64_t missing = __ballot(bl == 0u);
                 if (stored && missing == 0ull) break;
@@ -410,6 +420,9 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         bs_lds_st(&s_bnd[lane], bl);
         if (lane == 0u) bs_lds_st_rel(&s_ctl[BSL_READY], 1u);
         if (tl && lane == 0u) tl[2] = now();
+        // the first bounds come from the earliest finishers' slots; by now every first tile of the grid is in: one block per query
+        // (the second of its publishers) tightens it from all the slots right away — the others' refreshes pick it up 2 / 6 / 14 us on
+        if (((blockIdx.x >> 6) & 3u) == 1u) publish(0u, true);
         }
         // D. service loop: drain the workers' hit rings, keep the tile queue filled and the block's copy of the bounds
         // fresh (re-read and re-published 2, 4, 8, ... us apart, then every 128 us: see the head of the file)
@@ -497,6 +510,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         for (int g = 0; g < 4; g++) {
             const float dq = THR ? 0.0f : sqrtf(s_qqp[128u + 16u * g + j] + s_qqp[192u + 16u * g + j]);
             mrg[g] = 2.0f * (dmax * (1.0f + 0.00390625f) + dq * (1.0f + 1.0e-6f) + 1.0e-4f);
+            if (!THR && blockIdx.x == 0u && wave == 0u && kq == 0u) a.ctl[BS_CTL_MRG + 16u * g + j] = __float_as_uint(mrg[g]);
         }
     }
     auto wait_room = [&](uint32_t n) {   // room for n more entries in the ring (the service wave moves the tail)
@@ -682,8 +696,11 @@ __global__ __launch_bounds__(256) void batchs_rescore_kernel(const BatchSArgs a,
     uint32_t total = a.ctl[BS_CTL_CNT + q];
     total = total < a.cap ? total : a.cap;
     if (gw * U >= total) return;
-    const uint32_t *cand = a.cand_rows + (size_t)q * a.cap;
-    float *cosv = a.cand_cos + (size_t)q * a.cap;
+    uint32_t *cand = a.cand_rows + (size_t)q * a.cap;
+    float *cosv = a.cand_cos + (size_t)q * a.cap;   // in: the approximate cosine the pass saw; out: the exact one
+    // A candidate came in under the bound of its moment; the pass's last bound is the tightest.  One that fails the same test
+    // against it cannot be among the k best: it is struck from the list (row BS_STRUCK) without its row being read.
+    const float thr = bs_thr(a.ctl[BS_CTL_BOUND + q], true, __uint_as_float(a.ctl[BS_CTL_MRG + q]));
     const uint32_t dim = a.dim, per = dim / 64u;   // dim % 128 == 0: at most 16 elements per lane
     const float *qv = a.queries + (size_t)q * dim;
     float ql[16];
@@ -701,8 +718,17 @@ __global__ __launch_bounds__(256) void batchs_rescore_kernel(const BatchSArgs a,
     }
     for (uint32_t c = gw * U; c < total; c += nwq * U) {
         const S *p[U];
+        bool keep[U];   // (wave-uniform)
 #pragma unroll
-        for (uint32_t u = 0; u < U; u++) p[u] = rows + (size_t)cand[c + u < total ? c + u : c] * dim + lane;
+        for (uint32_t u = 0; u < U; u++) {
+            const uint32_t cu = c + u < total ? c + u : c;
+            keep[u] = !(cosv[cu] < thr);
+            p[u] = rows + (size_t)cand[cu] * dim + lane;
+        }
+        if (!(keep[0] || keep[1] || keep[2] || keep[3])) {
+            if (lane < U && c + lane < total) cand[c + lane] = BS_STRUCK;
+            continue;
+        }
         float dot[U], rr[U];
 #pragma unroll
         for (uint32_t u = 0; u < U; u++) { dot[u] = 0.0f; rr[u] = 0.0f; }
@@ -711,7 +737,7 @@ __global__ __launch_bounds__(256) void batchs_rescore_kernel(const BatchSArgs a,
             if (i < per) {
                 float x[U];
 #pragma unroll
-                for (uint32_t u = 0; u < U; u++) x[u] = ldf(p[u] + 64u * i);
+                for (uint32_t u = 0; u < U; u++) x[u] = keep[u] ? ldf(p[u] + 64u * i) : 0.0f;
 #pragma unroll
                 for (uint32_t u = 0; u < U; u++) { dot[u] += x[u] * ql[i]; rr[u] += x[u] * x[u]; }
             }
@@ -721,7 +747,10 @@ __global__ __launch_bounds__(256) void batchs_rescore_kernel(const BatchSArgs a,
             for (uint32_t u = 0; u < U; u++) { dot[u] += __shfl_xor(dot[u], x, 64); rr[u] += __shfl_xor(rr[u], x, 64); }
 #pragma unroll
         for (uint32_t u = 0; u < U; u++)
-            if (lane == u && c + u < total) cosv[c + u] = cosine_from_sums(dot[u], qq, rr[u]);
+            if (lane == u && c + u < total) {
+                if (keep[u]) cosv[c + u] = cosine_from_sums(dot[u], qq, rr[u]);
+                else cand[c + u] = BS_STRUCK;
+            }
     }
 }
 
@@ -757,8 +786,11 @@ __global__ __launch_bounds__(1024) void batchs_select_kernel(const BatchSArgs a,
             key[u] = 0ull;
             sim[u] = 0.0f;
             if (ci < cn) {
-                sim[u] = cosv[c0 + ci];
-                key[u] = make_key(score_of(distance_of(sim[u])), cand[c0 + ci]);
+                const uint32_t row = cand[c0 + ci];
+                if (row != BS_STRUCK) {   // (struck by the re-score: key 0 = no entry)
+                    sim[u] = cosv[c0 + ci];
+                    key[u] = make_key(score_of(distance_of(sim[u])), row);
+                }
             } else if (ci - cn < n_surv) {
                 key[u] = surv_k[ci - cn];
                 sim[u] = surv_s[ci - cn];

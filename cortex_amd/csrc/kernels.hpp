@@ -123,7 +123,8 @@ constexpr uint32_t BS_SL = 2048;                      // bound slots per query i
 constexpr uint32_t BS_CTL_BOUND = 64 * BS_SL;         // word offsets inside the control block
 constexpr uint32_t BS_CTL_CNT = BS_CTL_BOUND + 64;
 constexpr uint32_t BS_CTL_NEXT = BS_CTL_CNT + 64;     // the next unclaimed tile beyond the statically dealt first ones
-constexpr uint32_t BS_CTL_WORDS = BS_CTL_NEXT + 16;
+constexpr uint32_t BS_CTL_MRG = BS_CTL_NEXT + 16;     // 64 margins (2 eps of each query, f32 bits) of the last pass, for the re-score's second look
+constexpr uint32_t BS_CTL_WORDS = BS_CTL_MRG + 64;
 struct BatchSArgs {
     const uint16_t *shadow_t; // cx_index::d_shadow_t: rows L2-normalised, bf16, the all-pairs filter's tiled layout (tiled_shadow_off below)
     const uint32_t *shadow_err; // cx_index::d_shadow_err: the largest rounding error of a shadow row (f32 bits); null = the worst case 2^-8
