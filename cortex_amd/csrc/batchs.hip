@@ -903,6 +903,16 @@ int launch_batchs_pass(const BatchSArgs &a_in, hipStream_t stream) {
             for (uint32_t b = 0; b < grid; b++) for (int i = 18; i < 25; i++) nt.push_back(h[(size_t)b * 32 + i]);
             std::sort(nt.begin(), nt.end());
             fprintf(stderr, "  tiles per worker: min %llu med %llu max %llu\n", nt.front(), nt[nt.size() / 2], nt.back());
+            for (int w = 0; w < 7; w++) {   // by worker index: tiles done (mean / min / max over the blocks), mean exit time
+                double st = 0, se = 0; unsigned long long mn = ~0ull, mx = 0;
+                for (uint32_t b = 0; b < grid; b++) { const unsigned long long t = h[(size_t)b * 32 + 18 + w]; st += (double)t; mn = std::min(mn, t); mx = std::max(mx, t); se += (double)(h[(size_t)b * 32 + 11 + w] - t0) * 0.01; }
+                fprintf(stderr, "  worker %d: tiles mean %.1f min %llu max %llu, exit mean %.1f us\n", w, st / grid, mn, mx, se / grid);
+            }
+            for (int x = 0; x < 8; x++) {   // by XCD (block index mod 8): tiles per block, exit of the last worker
+                double st = 0, se = 0; int nb = 0;
+                for (uint32_t b = x; b < grid; b += 8) { unsigned long long t = 0, e = 0; for (int w = 0; w < 7; w++) { t += h[(size_t)b * 32 + 18 + w]; e = std::max(e, h[(size_t)b * 32 + 11 + w]); } st += (double)t; se += (double)(e - t0) * 0.01; nb++; }
+                fprintf(stderr, "  blocks = %d mod 8: tiles per block mean %.1f, last worker's exit mean %.1f us\n", x, st / nb, se / nb);
+            }
             std::vector<unsigned long long> sp;
             for (uint32_t b = 0; b < grid; b++) sp.push_back(h[(size_t)b * 32 + 29]);
             std::sort(sp.begin(), sp.end());
