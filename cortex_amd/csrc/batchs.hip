@@ -18,8 +18,10 @@
 //     only be among the exact k best if its approximate cosine is >= A_k - 2 eps (the query's margin).
 // The pass therefore streams HALF the bytes of the f32 rows (a quarter of rows + split store), needs ONE
 // v_mfma_f32_16x16x32_bf16 per 16 rows x 16 queries x 32 elements instead of three, tests a pair with one compare,
-// and hands a few hundred survivors per query to the select kernel, which computes their exact cosines from the stored
-// rows (f32 or bf16 store) with sequential-in-lane f32 sums — the scan path's arithmetic class — before it selects.
+// and hands a few hundred survivors per query to the re-score kernel, which tests each of them once more against the pass's
+// LAST bound (a candidate came in under the bound of its moment; the same inequality, the same proof — what fails is struck
+// without its row being read), computes the exact cosines of the rest from the stored rows (f32 or bf16 store) with
+// sequential-in-lane f32 sums — the scan path's arithmetic class —, and to the select kernel.
 // Results are the exact path's: the screening only ever removes rows that cannot be among the k best.
 //
 // Structure of the pass (every choice below was measured on the way; profiles/r03/tuning.md §8): a block is seven WORKER
@@ -35,10 +37,11 @@
 //    is A_k whatever the timing.  Every worker's first tile fills a slot (1,792 workers x 32 rows: a 57k-row sample without
 //    a pass of its own); the workers test against the block's copy of the bounds in LDS.
 //  - A pair that passes is a HIT: (row, query, approximate cosine) goes into the worker's ring in LDS.
-//  - The service wave owns everything that talks to the rest of the grid: it writes the block's first-tile maxima to the
-//    slots (plain write-through stores — an atomic max per wave and query, 131k at agent scope, took 75 us; one arrival
-//    counter for 2,048 waves 110 us; a release fence per wave ~75 us), publishes the k-th largest slot value of its
-//    queries (radix walk over four 8-bit digits with an LDS histogram: 2 us; a ballot per bit and value: 13), drains the
+//  - The service wave owns everything that WAITS for the rest of the grid (a worker's first-tile maxima go straight to the
+//    slots: plain write-through stores the worker does not wait for — an atomic max per wave and query, 131k at agent scope,
+//    took 75 us; one arrival counter for 2,048 waves 110 us; a release fence per wave ~75 us): it publishes the k-th largest
+//    slot value of its queries (radix walk over four 8-bit digits with an LDS histogram: 2 us; a ballot per bit and value:
+//    13; the first publisher of a query polls a 256-slot prefix, everybody else the bounds: one round trip per poll), drains the
 //    hit rings — row filter, candidate list (room for every row: nothing can overflow, no fallback pass exists), the
 //    tile's slot raised —, re-reads and re-publishes the bounds at growing intervals (256 service waves polling the same
 //    256 bytes every few microseconds keep one HBM channel busy with themselves: -8 %), and deals the tiles: the first
