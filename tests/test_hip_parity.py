@@ -814,6 +814,19 @@ qs = -np.abs(rng.normal(size=(8, d))).astype(np.float32)
 for t in range(6): rows[100 + 37 * t] = -rows[100 + 37 * t]
 h, o, ids, lut = both(rows)
 check(h, o, lut, qs, k, what="six positive", exact_ids=True)
+# rows in ASCENDING order of similarity to the queries (all near one direction): every tile raises the bound, so nearly every
+# candidate came in under a bound far below the pass's last one — the re-score's second look strikes most of the list, and
+# what it keeps must still hold the exact k best (and the reverse order: the first tiles already hold them)
+n = 30000 if d < 1024 else 12000
+rng = np.random.default_rng(21)
+c = rng.normal(size=d).astype(np.float32); c /= np.linalg.norm(c)
+noise = rng.normal(size=(n, d)).astype(np.float32); noise /= np.linalg.norm(noise, axis=1, keepdims=True)
+w = np.linspace(0.0, 1.0, n, dtype=np.float32)[:, None]
+asc = (w * c[None, :] + (1.0 - w) * noise).astype(np.float32)
+qs = (c[None, :] + 0.1 * rng.normal(size=(20, d))).astype(np.float32)
+for name, rows in (("ascending", asc), ("descending", np.ascontiguousarray(asc[::-1]))):
+    h, o, ids, lut = both(rows)
+    for k in (10, 100): check(h, o, lut, qs, k, what="%%s k=%%d" %% (name, k))
 print("ok")
 """ % ((os.path.dirname(os.path.dirname(os.path.abspath(__file__))),) * 2)
     r = subprocess.run([sys.executable, "-c", code, str(d), dtype], capture_output=True, text=True, timeout=900, env=dict(os.environ, CX_BATCHS_MIN_ROWS="256"))
