@@ -144,8 +144,8 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
         return t;
     };
-    unsigned long long *const tl = a.tl ? a.tl + (size_t)blockIdx.x * 32u : nullptr;
-    if (tl && tid == 0u) tl[0] = now();
+    unsigned long long *const stamps = a.tl ? a.tl + (size_t)blockIdx.x * 32u : nullptr;   // (CX_BATCHS_TL)
+    if (stamps && tid == 0u) stamps[0] = now();
 
     // ---- workers: the ring.  P K-steps x 2 row fragments of 16 bytes per lane.  A 32-row tile is 2 x T16 contiguous bytes
     // of the tiled shadow (padded to whole 256-row tiles, zero beyond the last row); one buffer descriptor per tile — SGPR
@@ -217,13 +217,13 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         if (tid < BSL_WORDS) s_ctl[tid] = 0u;
         if (tid < 64u) s_bnd[tid] = 0u;
         __syncthreads();
-        if (tl && tid == 0u) tl[30] = now();
+        if (stamps && tid == 0u) stamps[30] = now();
         if (tid < 64u) {
             const float ss = s_qqp[tid] + s_qqp[64u + tid];
             s_inv[tid] = ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f;   // a zero (or non-finite) query: a zero image — it bounds nothing, every row is re-scored
         }
         __syncthreads();
-        if (tl && tid == 0u) tl[31] = now();
+        if (stamps && tid == 0u) stamps[31] = now();
         const float inv = s_inv[q];
         // (inv > 0 <=> |q|^2 is positive and finite <=> every element is finite and so is its scaled value)
         const bool ok = live && inv > 0.0f;
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
     };
     if (!worker) push_claim(claim0);
     __syncthreads();
-    if (tl && tid == 0u) tl[1] = now();
+    if (stamps && tid == 0u) stamps[1] = now();
 
     if (!worker) {
         // =============================================================== the service wave
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
             for (int spin = 0; spin < 4096; spin++) {   // bounded: a few ms
                 if (!stored && bs_lds_ld_acq(&s_ctl[BSL_ARRIVED]) >= in_block) {
                     stored = true;   // (every worker of the block has written its first tile's maxima to the slots)
-                    if (tl && lane == 0u) tl[27] = now();
+                    if (stamps && lane == 0u) stamps[27] = now();
                 }
                 // (the fraction waited for halves every few polls: when the grid's blocks are not all resident — another
                 // kernel on the device: a concurrent reader's search — the slots of the missing ones stay empty until the
@@ -399,9 +399,9 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
                 const bool try_pub = !published && (frac == 0u || spin >= 16);
                 if (try_pub) {
                     published = publish((want >> (spin >> 2)) > k ? (want >> (spin >> 2)) : k, spin >= 96, frac == 0u && want <= 64u && spin < 16);
-                    if (tl && lane == 0u && published) tl[28] = now();
+                    if (stamps && lane == 0u && published) stamps[28] = now();
                 }
-                if (tl && lane == 0u) tl[29] = (unsigned long long)spin + 1ull;
+                if (stamps && lane == 0u) stamps[29] = (unsigned long long)spin + 1ull;
                 if (try_pub && !published && spin < 24) continue;
                 bl = lane < nq ? bs_ld_agent(g_bound + lane) : 1u;
                 uint64_t missing = __ballot(bl == 0u);
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         }
         bs_lds_st(&s_bnd[lane], bl);
         if (lane == 0u) bs_lds_st_rel(&s_ctl[BSL_READY], 1u);
-        if (tl && lane == 0u) tl[2] = now();
+        if (stamps && lane == 0u) stamps[2] = now();
         // the first bounds come from the earliest finishers' slots; by now every first tile of the grid is in: one block per query
         // (the second of its publishers) tightens it from all the slots right away — the others' refreshes pick it up 2 / 6 / 14 us on
         if (((blockIdx.x >> 6) & 3u) == 1u) publish(0u, true);
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
                 }
             }
         }
-        if (tl && lane == 0u) tl[3] = now();
+        if (stamps && lane == 0u) stamps[3] = now();
         return;
     }
 
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         }
 
         const uint32_t row0 = T * 32u + 4u * kq;   // this lane's rows: row0 + 16 f + r
-        if (tl && lane == 0u) { if (first) tl[4 + wave] = now(); n_tiles_done++; }
+        if (stamps && lane == 0u) { if (first) stamps[4 + wave] = now(); n_tiles_done++; }
         if (!THR && first) {
             // ---- warm-up, once per wave: the tile's best approximate cosine per query into LDS for the service wave,
             // which fills the grid's slots with them and brings the first bounds back
@@ -597,8 +597,8 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
                 if (bs_lds_ld_acq(&s_ctl[BSL_READY]) != 0u) break;
                 __builtin_amdgcn_s_sleep(4);
             }
-            if (tl && lane == 0u && wave == 0u) tl[26] = now();
-        } else if (tl && lane == 0u && wave == 0u && n_tiles_done == 2u) tl[25] = now();
+            if (stamps && lane == 0u && wave == 0u) stamps[26] = now();
+        } else if (stamps && lane == 0u && wave == 0u && n_tiles_done == 2u) stamps[25] = now();
 #pragma unroll
         for (int g = 0; g < 4; g++) thr[g] = THR ? (liveq[g] ? a.thr_lo : __builtin_inff()) : bs_thr(bs_lds_ld(&s_bnd[16 * g + j]), liveq[g], mrg[g]);
 
@@ -680,7 +680,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         T = Tn;
         crs = nrs;
     }
-    if (tl && lane == 0u) { tl[11 + wave] = now(); tl[18 + wave] = n_tiles_done; }
+    if (stamps && lane == 0u) { stamps[11 + wave] = now(); stamps[18 + wave] = n_tiles_done; }
     if (lane == 0u) __hip_atomic_fetch_add(&s_ctl[BSL_DONE], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
