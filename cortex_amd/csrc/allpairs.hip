@@ -39,41 +39,39 @@ __device__ inline uint16_t f32_to_bf16_rne(float x) {  // finite inputs only
     return (uint16_t)(u >> 16);
 }
 
-// sum over the 64 lanes, result in every lane: four DPP steps inside each 16-lane row (VALU rate), then two
-// cross-row exchanges
-__device__ inline float wave_sum(float v) {
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));  // row_half_mirror
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));  // row_mirror
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
-}
-
 // ---------------------------------------------------------------- 1. shadow
 
 // err_max (optional): the largest rounding error of a row, || bf16(x) - x || for the normalised row x, as the bits of a
-// positive f32 (atomic max): batchs.hip's screening bound uses the error the shadow really has instead of the worst case
+// positive f32 (atomic max): batchs.hip's screening bound uses the error the shadow really has instead of the worst case.
+// irr (optional): IRREGULAR rows (kernels.hpp: bs_regular — |x|^2 zero, non-finite or outside [1e-30, 1e30] in the reference's f32
+// arithmetic: it scores such a row 0, 1 or NaN, vector/index.rs:172-177) get a zero shadow row — no screening pass ever lists
+// them — and go on the index's irregular list instead: irr.cnt[0] counts them (it may pass BS_IRR_CAP: the host then switches
+// the screening paths off), irr.rows holds the first BS_IRR_CAP.  A row rebuilt in place (upsert of a known id) is not listed
+// twice: entries [0, irr.n_before) — those of earlier, completed launches — are searched first; rows of one launch are distinct.
+struct IrrList { uint32_t *cnt; uint32_t *rows; uint32_t n_before; };
 template <typename S>
 __global__ __launch_bounds__(256) void build_shadow_kernel(const S *rows, uint16_t *shadow, uint32_t row_lo,
-                                                           uint32_t row_hi, uint32_t dim, uint32_t tiled, uint32_t *err_max) {
+                                                           uint32_t row_hi, uint32_t dim, uint32_t tiled, uint32_t *err_max, const IrrList irr) {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t r = row_lo + wave; r < row_hi; r += n_waves) {
         const S *p = rows + (size_t)r * dim;
         float ss = 0.0f;
-        for (uint32_t j = lane; j < dim; j += 64u) { const float x = ldf(p + j); ss += x * x; }
+        {   // |x|^2 exactly as batchs_rescore_kernel sums it (lane-strided, separately rounded products, wave_sum): the two must
+            // agree on which rows are irregular, to the bit
+#pragma clang fp contract(off)
+            for (uint32_t j = lane; j < dim; j += 64u) { const float x = ldf(p + j); ss += x * x; }
+        }
         ss = wave_sum(ss);
-        const float inv = ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f;  // zero rows -> zero shadow (never a candidate)
+        const bool regular = bs_regular(ss);
+        const float inv = regular ? 1.0f / sqrtf(ss) : 0.0f;  // irregular rows -> zero shadow (never a candidate of a screening pass)
         uint16_t *o = shadow + (size_t)r * dim;
         float es = 0.0f;
         for (uint32_t j = lane; j < dim; j += 64u) {
-            const float v = ldf(p + j) * inv;
-            const bool fin = v == v && fabsf(v) <= 3.0e38f;
-            const uint16_t b = fin ? f32_to_bf16_rne(v) : (uint16_t)0;
-            const float e = fin ? v - bf16_bits_to_f32(b) : 0.0f;
+            const float v = regular ? ldf(p + j) * inv : 0.0f;   // (|v| <= 1: every element of a regular row is finite)
+            const uint16_t b = f32_to_bf16_rne(v);
+            const float e = v - bf16_bits_to_f32(b);
             es += e * e;
             if (tiled) shadow[tiled_shadow_off(r, j >> 3, dim / 32u) + (j & 7u)] = b;
             else o[j] = b;
@@ -81,6 +79,15 @@ __global__ __launch_bounds__(256) void build_shadow_kernel(const S *rows, uint16
         if (err_max) {
             es = wave_sum(es);
             if (lane == 0u) __hip_atomic_fetch_max(err_max, __float_as_uint(sqrtf(es) * (1.0f + 1.0e-5f)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (!regular && irr.cnt) {
+            bool listed = false;
+            const uint32_t nb = irr.n_before < BS_IRR_CAP ? irr.n_before : BS_IRR_CAP;
+            for (uint32_t i = lane; i < nb; i += 64u) listed = listed || irr.rows[i] == r;
+            if (!__ballot(listed) && lane == 0u) {
+                const uint32_t pos = atomicAdd(irr.cnt, 1u);
+                if (pos < BS_IRR_CAP) irr.rows[pos] = r;
+            }
         }
     }
 }
@@ -90,7 +97,7 @@ int launch_build_shadow(const float *rows, uint16_t *shadow, uint32_t row_lo, ui
     if (row_hi <= row_lo) return CX_OK;
     uint32_t grid = (row_hi - row_lo + 3u) / 4u;
     if (grid > 8192u) grid = 8192u;
-    hipLaunchKernelGGL(build_shadow_kernel<float>, dim3(grid), dim3(256), 0, stream, rows, shadow, row_lo, row_hi, dim, 0u, nullptr);
+    hipLaunchKernelGGL(build_shadow_kernel<float>, dim3(grid), dim3(256), 0, stream, rows, shadow, row_lo, row_hi, dim, 0u, nullptr, IrrList{nullptr, nullptr, 0u});
     CX_HIP(hipGetLastError());
     return CX_OK;
 }
@@ -99,17 +106,83 @@ int launch_build_shadow(const uint16_t *rows16, uint16_t *shadow, uint32_t row_l
     if (row_hi <= row_lo) return CX_OK;
     uint32_t grid = (row_hi - row_lo + 3u) / 4u;
     if (grid > 8192u) grid = 8192u;
-    hipLaunchKernelGGL(build_shadow_kernel<uint16_t>, dim3(grid), dim3(256), 0, stream, rows16, shadow, row_lo, row_hi, dim, 0u, nullptr);
+    hipLaunchKernelGGL(build_shadow_kernel<uint16_t>, dim3(grid), dim3(256), 0, stream, rows16, shadow, row_lo, row_hi, dim, 0u, nullptr, IrrList{nullptr, nullptr, 0u});
     CX_HIP(hipGetLastError());
     return CX_OK;
 }
-int launch_build_shadow_tiled(const float *rows, const uint16_t *rows16, uint16_t *shadow_t, uint32_t row_lo, uint32_t row_hi, uint32_t dim, hipStream_t stream, uint32_t *err_max) {
+int launch_build_shadow_index(const float *rows, const uint16_t *rows16, uint16_t *shadow, bool tiled, uint32_t row_lo, uint32_t row_hi, uint32_t dim,
+                              hipStream_t stream, uint32_t *err_max, uint32_t *irr_cnt, uint32_t *irr_rows, uint32_t irr_n_before) {
     if (row_hi <= row_lo) return CX_OK;
-    if (dim % 32u) return set_err(CX_ERR_VALIDATION, "tiled shadow needs dim %% 32 == 0 (got %u)", dim);
+    if (tiled && dim % 32u) return set_err(CX_ERR_VALIDATION, "tiled shadow needs dim %% 32 == 0 (got %u)", dim);
     uint32_t grid = (row_hi - row_lo + 3u) / 4u;
     if (grid > 8192u) grid = 8192u;
-    if (rows16) hipLaunchKernelGGL(build_shadow_kernel<uint16_t>, dim3(grid), dim3(256), 0, stream, rows16, shadow_t, row_lo, row_hi, dim, 1u, err_max);
-    else hipLaunchKernelGGL(build_shadow_kernel<float>, dim3(grid), dim3(256), 0, stream, rows, shadow_t, row_lo, row_hi, dim, 1u, err_max);
+    const IrrList irr{irr_cnt, irr_rows, irr_n_before};
+    if (rows16) hipLaunchKernelGGL(build_shadow_kernel<uint16_t>, dim3(grid), dim3(256), 0, stream, rows16, shadow, row_lo, row_hi, dim, tiled ? 1u : 0u, tiled ? err_max : nullptr, irr);
+    else hipLaunchKernelGGL(build_shadow_kernel<float>, dim3(grid), dim3(256), 0, stream, rows, shadow, row_lo, row_hi, dim, tiled ? 1u : 0u, tiled ? err_max : nullptr, irr);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+
+// ---- irregular rows and the filter (kernels.hpp: bs_regular).  Their shadow rows are zero, so no filter kernel ever returns them — as
+// a neighbour or for their own scan.  The reference computes every pair with them all the same (index.rs:172-177: a row whose
+// squares underflow scores 1.0 against everything it has a positive dot with), so after the filter of a pass
+//  - every scanned row that IS irregular is marked as run over (its list comes from the exact path, like any row the filter
+//    could not serve), and
+//  - the store's irregular rows are appended to the candidates of every other scanned row, to be scored exactly with the rest.
+// irr_now_kernel: which entries of the index's irregular list are irregular NOW (an upsert may have replaced the row: it would
+// be a candidate twice) — the build's own sum, one wave per entry.
+template <typename S>
+__global__ __launch_bounds__(256) void irr_now_kernel(const S *rows, uint32_t dim, uint32_t n_rows, const uint32_t *irr_rows, uint32_t irr_n, uint32_t *irr_ok) {
+    const uint32_t e = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    if (e >= irr_n) return;
+    const uint32_t r = irr_rows[e];
+    float ss = 1.0f;
+    if (r < n_rows) {
+#pragma clang fp contract(off)
+        const S *p = rows + (size_t)r * dim;
+        ss = 0.0f;
+        for (uint32_t j = lane; j < dim; j += 64u) { const float x = ldf(p + j); ss += x * x; }
+    }
+    ss = wave_sum(ss);
+    if (lane == 0u) irr_ok[e] = (r < n_rows && !bs_regular(ss)) ? 1u : 0u;
+}
+// ext_vecs: the scanned vectors are not rows of this shard ([n_scan][dim] f32: the sharded pass's external blocks) — "is the scanned
+// vector itself irregular" is then decided from the vector (its own shadow was built zero just the same)
+__global__ __launch_bounds__(256) void irr_append_kernel(const uint32_t *irr_rows, const uint32_t *irr_ok, uint32_t irr_n, const uint32_t *scan_rows, const float *ext_vecs,
+                                                         uint32_t dim, uint32_t n_scan, uint32_t *cand_cnt, uint32_t *cand, uint32_t cap) {
+    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    if (i >= n_scan) return;
+    const uint32_t me = ext_vecs ? 0xFFFFFFFFu : (scan_rows ? scan_rows[i] : i);
+    const uint32_t cnt = cand_cnt[i];
+    uint32_t n_ok = 0;
+    bool self = false;
+    if (ext_vecs) {
+#pragma clang fp contract(off)
+        float ss = 0.0f;
+        for (uint32_t j = lane; j < dim; j += 64u) { const float x = ext_vecs[(size_t)i * dim + j]; ss += x * x; }
+        self = !bs_regular(wave_sum(ss));
+    }
+    for (uint32_t e0 = 0; e0 < irr_n; e0 += 64u) {
+        const uint32_t e = e0 + lane;
+        const bool ok = e < irr_n && irr_ok[e] != 0u;
+        const uint32_t r = ok ? irr_rows[e] : 0u;
+        self = self || (ok && r == me);
+        const uint64_t m = __ballot(ok);
+        const uint32_t pos = cnt + n_ok + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (ok && pos < cap) cand[(size_t)i * cap + pos] = r;   // (the row itself included: the rescore drops self pairs like any other)
+        n_ok += (uint32_t)__popcll(m);
+    }
+    const bool any_self = __ballot(self) != 0ull;
+    if (lane == 0u) cand_cnt[i] = any_self ? 0x7FFFFFFFu : cnt + n_ok;
+}
+int launch_irr_append(const float *rows, const uint16_t *rows16, uint32_t dim, uint32_t n_rows, const uint32_t *irr_rows, uint32_t irr_n, uint32_t *irr_ok,
+                      const uint32_t *scan_rows, const float *ext_vecs, uint32_t n_scan, uint32_t *cand_cnt, uint32_t *cand, uint32_t cap, hipStream_t stream) {
+    if (!n_scan || (!irr_n && !ext_vecs)) return CX_OK;
+    if (irr_n) {
+        if (rows16) hipLaunchKernelGGL(irr_now_kernel<uint16_t>, dim3((irr_n + 3u) / 4u), dim3(256), 0, stream, rows16, dim, n_rows, irr_rows, irr_n, irr_ok);
+        else hipLaunchKernelGGL(irr_now_kernel<float>, dim3((irr_n + 3u) / 4u), dim3(256), 0, stream, rows, dim, n_rows, irr_rows, irr_n, irr_ok);
+    }
+    hipLaunchKernelGGL(irr_append_kernel, dim3((n_scan + 3u) / 4u), dim3(256), 0, stream, irr_rows, irr_ok, irr_n, scan_rows, ext_vecs, dim, n_scan, cand_cnt, cand, cap);
     CX_HIP(hipGetLastError());
     return CX_OK;
 }

@@ -48,11 +48,18 @@ int ensure_shadow(const cx_index *ix, hipStream_t s) {
         work = true;
     }
     if (!ix->d_shadow_err) CX_HIP(hipMalloc((void **)&ix->d_shadow_err, 64));
-    if (ix->shadow_rows == 0) CX_HIP(hipMemsetAsync(ix->d_shadow_err, 0, 64, s));   // built from scratch: the error bound starts over
+    if (!ix->d_irr_rows) CX_HIP(hipMalloc((void **)&ix->d_irr_rows, BS_IRR_CAP * sizeof(uint32_t)));
+    if (ix->shadow_rows == 0) {   // built from scratch: the error bound and the irregular list start over
+        CX_HIP(hipMemsetAsync(ix->d_shadow_err, 0, 64, s));
+        ix->irr_n = 0;
+        ix->irr_over = false;
+    }
     auto build = [&](uint32_t lo, uint32_t hi) -> int {
-        if (tiled) return launch_build_shadow_tiled(ix->dtype == 1 ? nullptr : ix->d_rows, ix->dtype == 1 ? ix->rows16() : nullptr, ix->d_shadow_t, lo, hi, ix->dim, s, ix->d_shadow_err);
-        return ix->dtype == 1 ? launch_build_shadow(ix->rows16(), ix->d_shadow, lo, hi, ix->dim, s) : launch_build_shadow(ix->d_rows, ix->d_shadow, lo, hi, ix->dim, s);
+        return launch_build_shadow_index(ix->rows32(), ix->rows16(), tiled ? ix->d_shadow_t : ix->d_shadow, tiled, lo, hi, ix->dim, s,
+                                         ix->d_shadow_err, ix->d_shadow_err + 1, ix->d_irr_rows, ix->irr_n);
     };
+    std::sort(ix->shadow_stale.begin(), ix->shadow_stale.end());   // (a row upserted twice is rebuilt once: the irregular list's de-duplication relies on it)
+    ix->shadow_stale.erase(std::unique(ix->shadow_stale.begin(), ix->shadow_stale.end()), ix->shadow_stale.end());
     for (uint32_t r : ix->shadow_stale)
         if (r < ix->shadow_rows) {
             if (int rc = build(r, r + 1)) return rc;
@@ -64,7 +71,13 @@ int ensure_shadow(const cx_index *ix, hipStream_t s) {
         ix->shadow_rows = n;
         work = true;
     }
-    if (work) CX_HIP(hipStreamSynchronize(s));   // (every batched search comes through here: no host wait when nothing changed)
+    if (work) {
+        uint32_t cnt = 0;
+        CX_HIP(hipMemcpyAsync(&cnt, ix->d_shadow_err + 1, sizeof cnt, hipMemcpyDeviceToHost, s));
+        CX_HIP(hipStreamSynchronize(s));   // (every batched search comes through here: no host wait when nothing changed)
+        ix->irr_n = cnt < BS_IRR_CAP ? cnt : BS_IRR_CAP;
+        ix->irr_over = cnt > BS_IRR_CAP;
+    }
     return CX_OK;
 }
 }  // namespace cx
@@ -92,7 +105,8 @@ struct PassScratch {
     hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;   // around the filter GEMM kernel alone (timed passes)
     uint64_t *d_pairs = nullptr;       // persistent filter kernel: hits as (i | j << 32) pairs, before pair_scatter_kernel
     uint32_t *d_pair_ctl = nullptr;    // [16]: pairs written, pairs lost, per-XCD tile tickets
-    size_t c_pairs = 0, c_pair_ctl = 0;
+    uint32_t *d_irr_ok = nullptr;      // [BS_IRR_CAP]: which of the index's irregular rows are irregular now (launch_irr_append)
+    size_t c_pairs = 0, c_pair_ctl = 0, c_irr_ok = 0;
     uint64_t *d_offsets = nullptr, *d_exist_off = nullptr;
     uint32_t *d_exist_to = nullptr;
     size_t c_exist_off = 0, c_exist_to = 0;
@@ -108,7 +122,7 @@ struct PassScratch {
         (void)hipFree(d_list_rows); (void)hipFree(d_list_cnt); (void)hipFree(d_counts); (void)hipFree(d_ident);
         (void)hipFree(d_list_scores); (void)hipFree(d_list_dists); (void)hipFree(d_offsets); (void)hipFree(d_pair_sims);
         (void)hipFree(d_deleted); (void)hipFree(d_temp); (void)hipFree(d_from); (void)hipFree(d_to); (void)hipFree(d_w);
-        (void)hipFree(d_exist_off); (void)hipFree(d_exist_to); (void)hipFree(d_pairs); (void)hipFree(d_pair_ctl);
+        (void)hipFree(d_exist_off); (void)hipFree(d_exist_to); (void)hipFree(d_pairs); (void)hipFree(d_pair_ctl); (void)hipFree(d_irr_ok);
         if (ev_k0) (void)hipEventDestroy(ev_k0);
         if (ev_k1) (void)hipEventDestroy(ev_k1);
     }
@@ -218,7 +232,7 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
     for (uint32_t i = 0; scan_rows && i < n_scan; i++)
         if (scan_rows[i] >= n_rows) return set_err(CX_ERR_VALIDATION, "autolink: scan row %u out of range", scan_rows[i]);
     const uint32_t cap = cyc.cand_cap ? cyc.cand_cap : cand_cap();
-    const bool mfma_path = ix->dim % 64 == 0 && ix->dim > 0;
+    bool mfma_path = ix->dim % 64 == 0 && ix->dim > 0;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (phase_ms) for (auto &e : ev) CX_HIP(hipEventCreate(&e));
 
@@ -272,8 +286,11 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
     int prof_kind = 2;
     uint64_t prof_tiles = 0;
     uint32_t prof_bm = 256;
-    if (mfma_path) {
+    if (mfma_path) {   // (the shadow's build counts the store's irregular rows: more than the passes carry along -> the exact path for every row)
         if (int rc = ensure_shadow(ix, s)) return rc;
+        if (ix->irr_over) mfma_path = false;
+    }
+    if (mfma_path) {
         if (phase_ms) CX_HIP(hipEventRecord(ev[1], s));
         const uint32_t chunk = std::min<uint32_t>(n_scan, CHUNK_ROWS);
         if (int rc = ensure_dev(ps.d_cand_cnt, ps.c_cand_cnt, (size_t)chunk)) return rc;
@@ -399,7 +416,15 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
             r.out_cnt = ps.d_list_cnt + lo;
             r.overflow = ps.d_overflow + lo;
             static const int sym_rescore = getenv("CX_RESCORE_SYMMETRIC") ? atoi(getenv("CX_RESCORE_SYMMETRIC")) : 1;
-            if (f.symmetric && sym_rescore) {   // every list of the store is present: each pair is scored once (allpairs.hip)
+            // irregular rows (zero shadow rows: the filter never returns them): as scanned rows they go down the exact path, as
+            // neighbours they join every other scanned row's candidates (allpairs.hip: launch_irr_append).  A threshold at or below the
+            // filter's eps lets every pair through anyway, zero shadows included.
+            const bool irr = ix->irr_n > 0 && f.thr_lo > 0.0f;
+            if (irr) {
+                if (int rc = ensure_dev(ps.d_irr_ok, ps.c_irr_ok, (size_t)BS_IRR_CAP)) return rc;
+                if (int rc = launch_irr_append(ix->rows32(), ix->rows16(), ix->dim, n_rows, ix->d_irr_rows, ix->irr_n, ps.d_irr_ok, f.scan_rows, nullptr, m, ps.d_cand_cnt, ps.d_cand, cap, s)) return rc;
+            }
+            if (f.symmetric && sym_rescore && !irr) {   // every list of the store is present: each pair is scored once (allpairs.hip)
                 if (int rc = ensure_dev(ps.d_pair_sims, ps.c_pair_sims, (size_t)m * cap)) return rc;
                 r.pair_sims = ps.d_pair_sims;
             }
@@ -751,8 +776,12 @@ int cx_autolink_lists_dev(const cx_index *ix, uint64_t nq64, const float *d_quer
     PassScratch &ps = scratch_of(c);
     const uint32_t cap = cand_cap();
     std::vector<uint32_t> redo;
-    if (ix->dim % 64 == 0 && ix->dim > 0) {
+    bool filtered = ix->dim % 64 == 0 && ix->dim > 0;
+    if (filtered) {
         if (int rc = ensure_shadow(ix, s)) return rc;
+        filtered = !ix->irr_over;   // (more irregular rows than a pass carries along: the exact path for every vector)
+    }
+    if (filtered) {
         // query shadow lives in d_from scratch (uint32 words): nq*dim bf16 = nq*dim/2 words
         if (int rc = ensure_dev(ps.d_from, ps.c_from, (size_t)nq * ix->dim / 2 + 16)) return rc;
         uint16_t *d_qsh = reinterpret_cast<uint16_t *>(ps.d_from);
@@ -780,6 +809,10 @@ int cx_autolink_lists_dev(const cx_index *ix, uint64_t nq64, const float *d_quer
             f.pair_ctl = ps.d_pair_ctl;
             if (int rc = launch_pair_filter_stream(f, s)) return rc;
         } else if (int rc = ((int64_t)nq >= big_min) ? launch_pair_filter256(f, s) : launch_pair_filter(f, s)) return rc;
+        if (f.thr_lo > 0.0f) {   // irregular vectors (zero shadows) go down the exact path, the shard's irregular rows join every other list
+            if (int rc = ensure_dev(ps.d_irr_ok, ps.c_irr_ok, (size_t)BS_IRR_CAP)) return rc;
+            if (int rc = launch_irr_append(ix->rows32(), ix->rows16(), ix->dim, n_rows, ix->d_irr_rows, ix->irr_n, ps.d_irr_ok, nullptr, d_queries, nq, ps.d_cand_cnt, ps.d_cand, cap, s)) return rc;
+        }
         RescoreArgs r;
         memset(&r, 0, sizeof r);
         r.rows = ix->rows32();

@@ -81,7 +81,8 @@ __device__ inline float bs_thr(uint32_t bits, bool live, float margin) {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // LDS control words
-enum : uint32_t { BSL_HEAD = 0, BSL_TAIL = 8, BSL_ARRIVED = 16, BSL_DONE = 17, BSL_READY = 18, BSL_QHEAD = 19, BSL_QTAIL = 20, BSL_WORDS = 24 };
+enum : uint32_t { BSL_HEAD = 0, BSL_TAIL = 8, BSL_ARRIVED = 16, BSL_DONE = 17, BSL_READY = 18, BSL_QHEAD = 19, BSL_QTAIL = 20, BSL_LOC = 21, BSL_WORDS = 24 };
+constexpr uint32_t BS_LOCG = 2u * BS_WORK;   // 16-row groups of a block's first tiles: the values its LOCAL bounds are taken from
 constexpr uint32_t BS_TQ = 64;         // entries of the block's tile queue (a power of two)
 constexpr uint32_t BS_CLAIM = 14;      // tiles the service wave claims at a time: two per worker
 constexpr uint32_t BS_NO_TILE = 0xFFFFFFFFu;
@@ -91,9 +92,11 @@ template <int D>
 struct BsCfg {
     static constexpr int KS = D / 32;                                   // K-steps per row
     static constexpr int P = KS % 8 == 0 ? 8 : (KS % 6 == 0 ? 6 : 4);   // K-steps a worker keeps in flight (2 KiB each)
-    static constexpr uint32_t HB = D > 768 ? 128u : 256u;               // hit-ring entries per worker (a power of two)
+    // hit-ring entries per worker (a power of two), as many as the LDS has room for: while a block runs on its LOCAL bounds (see
+    // the kernel) its service wave holds the hits back, and the rings are the workers' runway until the grid's bounds arrive
+    static constexpr uint32_t HB = D > 896 ? 128u : (D > 768 ? 256u : (D > 384 ? 512u : 1024u));
     static constexpr uint32_t T16 = 16u * D * 2u;                       // bytes of a 16-row block of the tiled shadow
-    static constexpr size_t LDS = (size_t)KS * 4096u + BSL_WORDS * 4 + (size_t)BS_WORK * HB * 12 + 256 * 4 + 64 * 4 + BS_TQ * 4 + 64 * 4;
+    static constexpr size_t LDS = (size_t)KS * 4096u + BSL_WORDS * 4 + (size_t)BS_WORK * HB * 12 + 256 * 4 + 64 * 4 + BS_TQ * 4 + 64 * 4 + 64 * 4 + BS_LOCG * 64 * 4;
     static_assert(KS % P == 0 && D % 128 == 0 && LDS <= 160u * 1024u, "unsupported row width");
 };
 
@@ -118,7 +121,9 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
     uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_hdot + BS_WORK * HB); // [256] the service wave's digit histogram
     uint32_t *s_bnd = s_hist + 256u;                                        // [64] the block's copy of the published bounds
     uint32_t *s_tq = s_bnd + 64u;                                           // [BS_TQ] the block's tile queue
-    float *s_inv = reinterpret_cast<float *>(s_tq + BS_TQ);                 // [64] 1 / |q| (prologue)
+    float *s_inv = reinterpret_cast<float *>(s_tq + BS_TQ);                 // [64] 1 / |q| (prologue); 0 = an irregular query: no image, no hits, redone exactly
+    float *s_mrg = s_inv + 64u;                                             // [64] 2 eps of each query (the service wave's look at a hit)
+    uint32_t *s_loc = reinterpret_cast<uint32_t *>(s_mrg + 64u);            // [BS_LOCG][64] best approximate cosine of each 16-row group of the block's first tiles
     float *s_qqp = s_hdot;                                                  // prologue only: the two halves of every |q|^2
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
             *reinterpret_cast<s16x8 *>(qimg + (kk * 4u + g) * 1024u + lane * 16u) = H;
         }
         if (tid < BSL_WORDS) s_ctl[tid] = 0u;
-        if (tid < 64u) s_bnd[tid] = 0u;
+        if (tid < 64u) { s_bnd[tid] = 0u; s_inv[tid] = tid < nq ? 1.0f : 0.0f; s_mrg[tid] = 0.0f; }
         __syncthreads();
     } else {
     // ---- prologue (all eight waves): |q|, then the queries normalised, rounded to bf16, as B fragments in LDS: wave w
@@ -216,16 +221,21 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         if (c == 0u) s_qqp[half * 64u + q] = live ? qq : 0.0f;
         if (tid < BSL_WORDS) s_ctl[tid] = 0u;
         if (tid < 64u) s_bnd[tid] = 0u;
+        for (uint32_t i = tid; i < BS_LOCG * 64u; i += 512u) s_loc[i] = 0u;
         __syncthreads();
         if (stamps && tid == 0u) stamps[30] = now();
         if (tid < 64u) {
             const float ss = s_qqp[tid] + s_qqp[64u + tid];
-            s_inv[tid] = ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f;   // a zero (or non-finite) query: a zero image — it bounds nothing, every row is re-scored
+            // an IRREGULAR query (kernels.hpp: zero, non-finite, or so large / small that the reference's own sums overflow / underflow):
+            // a zero image, no hits, no bound to wait for — the re-score kernel redoes it with the reference's arithmetic over every row
+            const bool reg = bs_regular(ss);
+            s_inv[tid] = reg ? 1.0f / sqrtf(ss) : 0.0f;
+            if (blockIdx.x == 0u && tid < nq && !reg) a.ctl[BS_CTL_REDO + tid] = 1u;
         }
         __syncthreads();
         if (stamps && tid == 0u) stamps[31] = now();
         const float inv = s_inv[q];
-        // (inv > 0 <=> |q|^2 is positive and finite <=> every element is finite and so is its scaled value)
+        // (inv > 0 <=> the query is regular => every element is finite and so is its scaled value)
         const bool ok = live && inv > 0.0f;
         float es = 0.0f;   // this lane's share of || y^ - y ||^2
         // elements 4 p .. 4 p + 3 of a K-step (p = c, 4 + c) are half of fragment lane 16 (p >> 1) + r's 16 bytes
@@ -278,7 +288,13 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         // One hit per lane: row filter, candidate list (the exact cosine is the select kernel's), the tile's slot.  Lanes
         // with the same query take their list positions from ONE atomic add.
         auto process_hits = [&](bool active, uint32_t row, uint32_t q, float approx) {
-            if constexpr (!THR) active = active && row_passes(a.flt, row);   // (the filter pass has no row filter: the rescore and the rules look at the rows)
+            if constexpr (!THR) {
+                // a hit came in under the bound its worker had at that moment — possibly the block's LOCAL one, with the hits held
+                // back in the rings until the grid's bounds arrived: looked at again under the bound the block has NOW, most of those
+                // leave here, without an atomic or a byte of HBM traffic
+                if (active) active = !(approx < bs_thr(bs_lds_ld(&s_bnd[q]), true, s_mrg[q]));
+                active = active && row_passes(a.flt, row);   // (the filter pass has no row filter: the rescore and the rules look at the rows)
+            }
             row = active ? row : 0u;
             q = active ? q : 0u;
             uint64_t same = __ballot(active);
@@ -361,6 +377,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         auto publish = [&](uint32_t min_filled, bool final, bool pre = false) -> bool {
             bool all_done = true;
             for (uint32_t q = blockIdx.x & 63u; q < nq; q += gridDim.x) {
+                if (!(s_inv[q] > 0.0f)) continue;   // an irregular query has no bound and needs none
                 const uint32_t nz = slots_load(q, pre);
                 if (nz < min_filled && !final) { all_done = false; continue; }
                 const uint32_t t = slots_kth();
@@ -370,6 +387,13 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
             return all_done;
         };
 
+        auto refill = [&]() {   // fewer than two tiles per worker queued: claim the next BS_CLAIM
+            if (!exhausted && (int32_t)(q_head - bs_lds_ld(&s_ctl[BSL_QTAIL])) < (int32_t)BS_CLAIM) {
+                uint32_t c = 0u;
+                if (lane == 0u) c = claim_base + atomicAdd(g_next, BS_CLAIM);
+                push_claim(c);
+            }
+        };
         uint32_t bl = 1u;
         if constexpr (!THR) {
         // A-C. the warm-up, one polling loop: (A) once the block's workers have left their first tiles' maxima in LDS, write
@@ -385,6 +409,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
             const uint32_t want = want0 > k ? want0 : k;
             bool stored = false, published = false;
             for (int spin = 0; spin < 4096; spin++) {   // bounded: a few ms
+                if (bs_lds_ld(&s_ctl[BSL_LOC]) != 0u) refill();   // (the workers are on their way under the block's local bounds)
                 if (!stored && bs_lds_ld_acq(&s_ctl[BSL_ARRIVED]) >= in_block) {
                     stored = true;   // (every worker of the block has written its first tile's maxima to the slots)
                     if (stamps && lane == 0u) stamps[27] = now();
@@ -403,7 +428,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
                 }
                 if (stamps && lane == 0u) stamps[29] = (unsigned long long)spin + 1ull;
                 if (try_pub && !published && spin < 24) continue;
-                bl = lane < nq ? bs_ld_agent(g_bound + lane) : 1u;
+                bl = (lane < nq && s_inv[lane] > 0.0f) ? bs_ld_agent(g_bound + lane) : 1u;
                 uint64_t missing = __ballot(bl == 0u);
                 if (stored && missing == 0ull) break;
                 // queries nobody has published after ~80 us: their publishers are not resident (see above) — any block may
@@ -420,7 +445,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
                 if (published) __builtin_amdgcn_s_sleep(8);
             }
         }
-        bs_lds_st(&s_bnd[lane], bl);
+        __hip_atomic_fetch_max(&s_bnd[lane], bl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (the block's local bound may be there, and may be the higher one)
         if (lane == 0u) bs_lds_st_rel(&s_ctl[BSL_READY], 1u);
         if (stamps && lane == 0u) stamps[2] = now();
         // the first bounds come from the earliest finishers' slots; by now every first tile of the grid is in: one block per query
@@ -461,16 +486,12 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
                     if (took) bs_lds_st_rel(&s_ctl[BSL_TAIL + lane], tl + took);
                 }
             }
-            if (!exhausted && (int32_t)(q_head - bs_lds_ld(&s_ctl[BSL_QTAIL])) < (int32_t)BS_CLAIM) {   // fewer than two tiles per worker queued
-                uint32_t c = 0u;
-                if (lane == 0u) c = claim_base + atomicAdd(g_next, BS_CLAIM);
-                push_claim(c);
-            }
+            refill();
             const bool workers_done = bs_lds_ld_acq(&s_ctl[BSL_DONE]) >= BS_WORK;
             const uint64_t t_now = now();
             if (!THR && t_now >= t_next && !workers_done) {
                 bl = bs_ld_agent(g_bound + lane);
-                if (bl > bs_lds_ld(&s_bnd[lane])) bs_lds_st(&s_bnd[lane], bl);
+                __hip_atomic_fetch_max(&s_bnd[lane], bl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (gap >= 800u) publish(0u, true);
                 gap = gap < 12800u ? gap * 2u : 12800u;
                 t_next = now() + gap;
@@ -503,7 +524,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
     uint32_t n_tiles_done = 0;       // (timeline diagnostic)
     bool liveq[4];
 #pragma unroll
-    for (int g = 0; g < 4; g++) liveq[g] = 16u * g + j < nq;
+    for (int g = 0; g < 4; g++) liveq[g] = 16u * g + j < nq && s_inv[16u * g + j] > 0.0f;   // (an irregular query takes no part in the pass)
     float thr[4];                    // the threshold of each of the lane's four queries (bs_thr)
     float mrg[4];                    // 2 eps of each of them (read here, right behind the prologue's last barrier: the ring that
                                      // shares this LDS is first written after every worker of the block is past its first tile)
@@ -513,14 +534,24 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         for (int g = 0; g < 4; g++) {
             const float dq = THR ? 0.0f : sqrtf(s_qqp[128u + 16u * g + j] + s_qqp[192u + 16u * g + j]);
             mrg[g] = 2.0f * (dmax * (1.0f + 0.00390625f) + dq * (1.0f + 1.0e-6f) + 1.0e-4f);
-            if (!THR && blockIdx.x == 0u && wave == 0u && kq == 0u) a.ctl[BS_CTL_MRG + 16u * g + j] = __float_as_uint(mrg[g]);
+            if (!THR && wave == 0u && kq == 0u) {
+                s_mrg[16u * g + j] = mrg[g];   // (read by the service wave once hits exist: after this wave's first tile)
+                if (blockIdx.x == 0u) a.ctl[BS_CTL_MRG + 16u * g + j] = __float_as_uint(mrg[g]);
+            }
         }
     }
-    auto wait_room = [&](uint32_t n) {   // room for n more entries in the ring (the service wave moves the tail)
-        for (int spin = 0; spin < (1 << 20); spin++) {
-            if (head + n - bs_lds_ld_acq(&s_ctl[BSL_TAIL + wave]) <= HB) break;
+    // room for n more entries in the ring (the service wave moves the tail).  Bounded — half a second —, and a wave that gives up
+    // does NOT write into a ring without room (entries the service wave has not read would be lost without a trace): it drops its
+    // hits and raises the control block's sticky failure word, and the re-score kernel redoes every query of the pass exactly
+    auto wait_room = [&](uint32_t n) -> bool {
+        for (int spin = 0; spin < (1 << 21); spin++) {
+            if (head + n - bs_lds_ld_acq(&s_ctl[BSL_TAIL + wave]) <= HB) return true;
             __builtin_amdgcn_s_sleep(8);
         }
+        if constexpr (THR) {   // (the filter pass: every scanned row's list "runs over" — the caller's exact path redoes them all)
+            if (lane < nq) __hip_atomic_fetch_max(a.thr_cand_cnt + lane, 0x7FFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (lane == 0u) __hip_atomic_store(a.ctl + BS_CTL_FAIL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
     };
     // query fragments: [buffer][group]; the next K-step's are read while this one's MFMAs run
     s16x8 B[2][4];
@@ -577,24 +608,63 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
                     okm |= (row < n_rows && row_passes(a.flt, row)) ? (1u << i) : 0u;
                 }
             }
+            // LOCAL bounds (k <= 14 and a full block): the block's seven first tiles are fourteen 16-row groups; the k-th largest of
+            // their best approximate cosines is an A_k as valid as the grid's (k different rows reach it), known the moment the
+            // block's last worker is through its first tile — no round trip past the L2, where the grid's first bounds take ~14 us
+            // during which the workers of round 3 stood still.  It is weak (the k-th best of 224 rows, not of 57k: some 7 % of the
+            // pairs pass), so until the grid's bounds arrive the service wave — busy polling for them anyway — leaves the hits in
+            // the rings (sized for it: BsCfg::HB), and then drops nearly all of them under the real bound (process_hits).
+            const bool loc = k <= BS_LOCG && in_block == BS_WORK;
             uint32_t mine = 0u;
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 float mx = 0.0f;
 #pragma unroll
-                for (int f = 0; f < 2; f++)
+                for (int f = 0; f < 2; f++) {
+                    float m = 0.0f;
 #pragma unroll
-                    for (int r = 0; r < 4; r++) mx = (((okm >> (4 * f + r)) & 1u) && acc[g][f][r] > mx) ? acc[g][f][r] : mx;
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    for (int r = 0; r < 4; r++) m = (((okm >> (4 * f + r)) & 1u) && acc[g][f][r] > m) ? acc[g][f][r] : m;
+                    m = fmaxf(m, __shfl_xor(m, 16, 64));
+                    m = fmaxf(m, __shfl_xor(m, 32, 64));
+                    if (loc && kq == 0u) s_loc[(2u * wave + (uint32_t)f) * 64u + 16u * g + j] = __float_as_uint(m);
+                    mx = fmaxf(mx, m);
+                }
                 mine = (kq == (uint32_t)g && 16u * g + j < nq) ? __float_as_uint(mx) : mine;   // lane 16 g + j: query 16 g + j
             }
             // (straight to the tile's slots, lane q = query q: a store the wave does not wait for — through the service wave it
             // waited for the block's slowest worker and for that wave's next poll, ~8 us on every bound of the grid)
             if (lane < nq) __hip_atomic_store(g_slots + lane * BS_SL + (T & (BS_SL - 1u)), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (lane == 0u) __hip_atomic_fetch_add(&s_ctl[BSL_ARRIVED], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            uint32_t before = 0u;
+            if (lane == 0u) before = __hip_atomic_fetch_add(&s_ctl[BSL_ARRIVED], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
+            if (loc && before + 1u == in_block) {   // the block's last arrival: lane q sorts query q's fourteen values (a network: ~130 instructions)
+                uint32_t v[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) v[i] = i < (int)BS_LOCG ? bs_lds_ld(&s_loc[(uint32_t)i * 64u + lane]) : 0u;   // (bits of cosines >= 0 order like integers)
+#pragma unroll
+                for (int p2 = 1; p2 < 16; p2 <<= 1)
+#pragma unroll
+                    for (int k2 = p2; k2 >= 1; k2 >>= 1)
+#pragma unroll
+                        for (int j2 = k2 % p2; j2 + k2 < 16; j2 += 2 * k2)
+#pragma unroll
+                            for (int i2 = 0; i2 < k2; i2++)
+                                if ((i2 + j2) / (2 * p2) == (i2 + j2 + k2) / (2 * p2)) {   // Batcher's odd-even merge sort, descending
+                                    const uint32_t x = v[i2 + j2], y = v[i2 + j2 + k2];
+                                    v[i2 + j2] = x > y ? x : y;
+                                    v[i2 + j2 + k2] = x > y ? y : x;
+                                }
+                uint32_t kth = 0u;
+#pragma unroll
+                for (int i = 0; i < (int)BS_LOCG; i++) kth = (uint32_t)i + 1u == k ? v[i] : kth;
+                const bool want = lane < nq && s_inv[lane] > 0.0f;
+                if (!__ballot(want && kth == 0u)) {   // all or nothing: a query without a local bound would flood the rings
+                    if (want) __hip_atomic_fetch_max(&s_bnd[lane], kth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (lane == 0u) bs_lds_st_rel(&s_ctl[BSL_LOC], 1u);
+                }
+            }
             for (int spin = 0; spin < (1 << 16); spin++) {        // bounded: ~30 ms
-                if (bs_lds_ld_acq(&s_ctl[BSL_READY]) != 0u) break;
+                if (bs_lds_ld_acq(&s_ctl[BSL_READY]) != 0u || bs_lds_ld_acq(&s_ctl[BSL_LOC]) != 0u) break;
                 __builtin_amdgcn_s_sleep(4);
             }
             if (stamps && lane == 0u && wave == 0u) stamps[26] = now();
@@ -619,7 +689,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
                 for (int f = 0; f < 2; f++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const bool hit = !(acc[g][f][r] < thr[g]) & (row0 + 16u * f + r < n_rows) & (16u * g + j < nq);
+                        const bool hit = !(acc[g][f][r] < thr[g]) & (row0 + 16u * f + r < n_rows) & liveq[g];
                         hm |= hit ? (1u << ((g * 2 + f) * 4 + r)) : 0u;
                     }
             const uint32_t mine = (uint32_t)__popc(hm);
@@ -630,8 +700,8 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
                 if (lane >= (uint32_t)off) incl += t;
             }
             const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            if (tot <= HB / 2u) {
-                wait_room(tot);
+            if (tot <= HB) {
+                if (!wait_room(tot)) hm = 0u;
                 uint32_t pos = head + incl - mine;
 #pragma unroll
                 for (int g = 0; g < 4; g++)
@@ -646,8 +716,10 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
                                 hb_dot[e] = acc[g][f][r];
                                 pos++;
                             }
-                head += tot;
-                if (lane == 0u) bs_lds_st_rel(&s_ctl[BSL_HEAD + wave], head);
+                if (__ballot(hm != 0u)) {
+                    head += tot;
+                    if (lane == 0u) bs_lds_st_rel(&s_ctl[BSL_HEAD + wave], head);
+                }
             } else {
                 // a tile of a query without a bound: one hit per lane and round
 #pragma unroll 1
@@ -664,7 +736,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
                             for (int r = 0; r < 4; r++) dot = idx == (uint32_t)((g * 2 + f) * 4 + r) ? acc[g][f][r] : dot;
                     const uint64_t om = __ballot(on);
                     const uint32_t n = (uint32_t)__popcll(om);
-                    wait_room(n);
+                    if (!wait_room(n)) break;
                     if (on) {
                         const uint32_t e = (head + (uint32_t)__popcll(om & ((1ull << lane) - 1ull))) & (HB - 1u);
                         hb_row[e] = row0 + 16u * ((idx >> 2) & 1u) + (idx & 3u);
@@ -685,20 +757,100 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Which queries of a pass are REDONE EXACTLY instead of re-scored: the irregular ones (flagged by the pass: no image, no hits), those
+// whose candidate list ran over (more hits than `cap` entries — massive ties at the k-th score, a k-th best cosine that is not
+// positive, a filter that leaves nothing to bound with), every query when a worker gave up on its hit ring.  The same
+// predicate in the re-score and in the select kernel, over words neither of them changes before the last select block is done.
+__device__ inline bool bs_redo(const BatchSArgs &a, uint32_t q) {
+    const uint32_t cnt = a.ctl[BS_CTL_CNT + q];
+    return a.ctl[BS_CTL_REDO + q] != 0u || a.ctl[BS_CTL_FAIL] != 0u || cnt > a.cap || cnt + a.irr_n > a.cap;
+}
+
+// The exact redo of one query by the BS_REDO_WAVES waves of its re-score blocks: the reference's arithmetic over EVERY row (wave w
+// takes rows 4 w .. 4 w + 3 of every BS_REDO_WAVES x 4: the re-score's own inner loop), each wave's k best by (score desc, row asc)
+// in a register list (topk.hpp), written as the query's candidate list: wave w's entries at [w k, (w + 1) k).  Slow — gathered
+// rows, 128 waves: a few ms per million rows — and exact whatever the data; only what the screening cannot decide comes here.
+template <typename S, int KS>
+__device__ inline void bs_exact_redo(const BatchSArgs &a, const S *rows, uint32_t q, uint32_t gw, uint32_t nwq, const float (&ql)[16], float qq,
+                                     uint32_t per, uint32_t lane) {
+#pragma clang fp contract(off)
+    constexpr uint32_t U = 4;
+    const uint32_t n = a.n_rows, k = a.k, dim = a.dim;
+    WaveTopK<KS> top;
+    top.init(k);
+    const DevFilter &f = a.flt;
+    bool nonzero = false;
+#pragma unroll
+    for (uint32_t i = 0; i < 16u; i++) nonzero = nonzero || ql[i] != 0.0f;
+    // every cosine is NaN whatever the row when an element of the query is NaN (every dot is) or all of them are zero (0 / 0; a row
+    // with an infinite element: 0 x inf): the k best are the first k rows that pass the filter — no row is read
+    if (qq != qq || !__ballot(nonzero)) {
+        if (gw == 0u) {
+            uint32_t got = 0;
+            for (uint32_t r0 = 0; r0 < n && got < k; r0 += 64u) {
+                const uint32_t row = r0 + lane;
+                const bool ok = row < n && row_passes(f, row);
+                top.offer_lanes(ok ? make_key(__builtin_nanf(""), row) : 0ull, __builtin_nanf(""), [](uint32_t) { return true; });
+                got += (uint32_t)__popcll(__ballot(ok));
+            }
+        }
+    } else {
+        for (uint32_t c = gw * U; c < n; c += nwq * U) {
+            const S *p[U];
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) p[u] = rows + (size_t)(c + u < n ? c + u : c) * dim + lane;
+            float dot[U], rr[U];
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) { dot[u] = 0.0f; rr[u] = 0.0f; }
+#pragma unroll
+            for (uint32_t i = 0; i < 16u; i++)
+                if (i < per) {
+                    float x[U];
+#pragma unroll
+                    for (uint32_t u = 0; u < U; u++) x[u] = ldf(p[u] + 64u * i);
+#pragma unroll
+                    for (uint32_t u = 0; u < U; u++) { dot[u] += x[u] * ql[i]; rr[u] += x[u] * x[u]; }
+                }
+#pragma unroll
+            for (int x = 1; x < 64; x <<= 1)
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++) { dot[u] += __shfl_xor(dot[u], x, 64); rr[u] += __shfl_xor(rr[u], x, 64); }
+            float sim = 0.0f;
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) sim = lane == u ? cosine_from_sums(dot[u], qq, rr[u]) : sim;
+            const uint64_t kg = (lane < U && c + lane < n) ? make_key(score_of(distance_of(sim)), c + lane) : 0ull;
+            top.offer_lanes(kg, sim, [&f](uint32_t rw) { return row_passes(f, rw); });
+        }
+    }
+    uint32_t *o_r = a.cand_rows + (size_t)q * a.cap + (size_t)gw * k;
+    float *o_c = a.cand_cos + (size_t)q * a.cap + (size_t)gw * k;
+#pragma unroll
+    for (int sl = 0; sl < KS; sl++) {
+        const uint32_t i = (uint32_t)sl * 64u + lane;
+        if (i < k) { o_r[i] = top.key[sl] ? key_row(top.key[sl]) : BS_STRUCK; o_c[i] = top.sim[sl]; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // The exact cosine of every candidate from the stored rows: grid = (slices, queries); a wave takes four candidates at a time
 // (their row reads in flight together: a gathered 3 KiB row per candidate is a latency, not a bandwidth, problem); each
 // lane sums its strided share of dot and |row|^2 in f32 with separately rounded products — the query's share and |q|^2
 // are in registers, computed once per wave —, lanes folded by a butterfly, the reference's epilogue (cosine_from_sums).
 // The value depends on the row and the query only, not on where the candidate sits in the list.
-template <typename S>
+// Behind the listed candidates come the store's IRREGULAR rows (kernels.hpp; the shadow's build lists them, their shadow rows are
+// zero): entry e of that list is candidate cnt + e of every query — kept if the row passes the filter and IS irregular (an upsert
+// may have replaced it since), while a LISTED candidate that is irregular (a query without a bound takes every row) is struck: each
+// row is in the list once.  Both sides decide by the sum the shadow's build took (same order, same rounding: wave_sum).
+template <typename S, int KS>
 __global__ __launch_bounds__(256) void batchs_rescore_kernel(const BatchSArgs a, const S *rows) {
 #pragma clang fp contract(off)
     constexpr uint32_t U = 4;
     const uint32_t q = blockIdx.y, lane = threadIdx.x & 63u;
     const uint32_t gw = blockIdx.x * 4u + (threadIdx.x >> 6), nwq = gridDim.x * 4u;
-    uint32_t total = a.ctl[BS_CTL_CNT + q];
-    total = total < a.cap ? total : a.cap;
-    if (gw * U >= total) return;
+    const uint32_t total = a.ctl[BS_CTL_CNT + q];
+    const bool redo = bs_redo(a, q);
+    const uint32_t n_all = total + a.irr_n;
+    if (!redo && gw * U >= n_all) return;
     uint32_t *cand = a.cand_rows + (size_t)q * a.cap;
     float *cosv = a.cand_cos + (size_t)q * a.cap;   // in: the approximate cosine the pass saw; out: the exact one
     // A candidate came in under the bound of its moment; the pass's last bound is the tightest.  One that fails the same test
@@ -715,21 +867,24 @@ __global__ __launch_bounds__(256) void batchs_rescore_kernel(const BatchSArgs a,
     }
 #pragma unroll
     for (int x = 1; x < 64; x <<= 1) qq += __shfl_xor(qq, x, 64);
-    if (!(qq > 0.0f)) {   // a zero (or NaN) query: every cosine is 0 / 0 (or NaN) = NaN whatever the row — no row is read
-        for (uint32_t c = gw * 64u + lane; c < total; c += nwq * 64u) cosv[c] = __builtin_nanf("");
+    if (redo) {
+        bs_exact_redo<S, KS>(a, rows, q, gw, nwq, ql, qq, per, lane);
         return;
     }
-    for (uint32_t c = gw * U; c < total; c += nwq * U) {
+    for (uint32_t c = gw * U; c < n_all; c += nwq * U) {
         const S *p[U];
-        bool keep[U];   // (wave-uniform)
+        uint32_t row[U];
+        bool keep[U], listed[U];   // (wave-uniform)
 #pragma unroll
         for (uint32_t u = 0; u < U; u++) {
-            const uint32_t cu = c + u < total ? c + u : c;
-            keep[u] = !(cosv[cu] < thr);
-            p[u] = rows + (size_t)cand[cu] * dim + lane;
+            const uint32_t cu = c + u < n_all ? c + u : c;
+            listed[u] = cu < total;
+            row[u] = listed[u] ? cand[cu] : a.irr_rows[cu - total];
+            keep[u] = listed[u] ? !(cosv[cu] < thr) : (row[u] < a.n_rows && row_passes(a.flt, row[u]));
+            p[u] = rows + (size_t)(keep[u] ? row[u] : 0u) * dim + lane;
         }
         if (!(keep[0] || keep[1] || keep[2] || keep[3])) {
-            if (lane < U && c + lane < total) cand[c + lane] = BS_STRUCK;
+            if (lane < U && c + lane < n_all) cand[c + lane] = BS_STRUCK;
             continue;
         }
         float dot[U], rr[U];
@@ -744,15 +899,19 @@ __global__ __launch_bounds__(256) void batchs_rescore_kernel(const BatchSArgs a,
 #pragma unroll
                 for (uint32_t u = 0; u < U; u++) { dot[u] += x[u] * ql[i]; rr[u] += x[u] * x[u]; }
             }
+        bool regular[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) regular[u] = bs_regular(wave_sum(rr[u]));   // (the build's own sum: see above)
 #pragma unroll
         for (int x = 1; x < 64; x <<= 1)
 #pragma unroll
             for (uint32_t u = 0; u < U; u++) { dot[u] += __shfl_xor(dot[u], x, 64); rr[u] += __shfl_xor(rr[u], x, 64); }
 #pragma unroll
         for (uint32_t u = 0; u < U; u++)
-            if (lane == u && c + u < total) {
-                if (keep[u]) cosv[c + u] = cosine_from_sums(dot[u], qq, rr[u]);
-                else cand[c + u] = BS_STRUCK;
+            if (lane == u && c + u < n_all) {
+                const bool ok = keep[u] && regular[u] == listed[u];
+                cand[c + u] = ok ? row[u] : BS_STRUCK;
+                if (ok) cosv[c + u] = cosine_from_sums(dot[u], qq, rr[u]);
             }
     }
 }
@@ -772,8 +931,10 @@ __global__ __launch_bounds__(1024) void batchs_select_kernel(const BatchSArgs a,
     const uint32_t tid = threadIdx.x, q = blockIdx.x, k = a.k;
     uint32_t *const g_slots = a.ctl, *const g_bound = a.ctl + BS_CTL_BOUND, *const g_cnt = a.ctl + BS_CTL_CNT;
     if (q == 0u && tid == 0u) a.ctl[BS_CTL_NEXT] = 0u;
-    uint32_t total = g_cnt[q];
-    total = total < a.cap ? total : a.cap;
+    // a query that was redone exactly: its list is the redo waves' k best each (already exact); otherwise the listed candidates
+    // and, behind them, the store's irregular rows (batchs_rescore_kernel)
+    const uint32_t total = bs_redo(a, q) ? BS_REDO_WAVES * k : g_cnt[q] + a.irr_n;
+    __syncthreads();   // (every thread has read the control words this block is about to clear)
     const uint32_t *cand = a.cand_rows + (size_t)q * a.cap;
     const float *cosv = a.cand_cos + (size_t)q * a.cap;
     constexpr uint32_t CHUNK = (uint32_t)NV * 1024u - 256u;   // room for the survivors so far
@@ -833,7 +994,14 @@ __global__ __launch_bounds__(1024) void batchs_select_kernel(const BatchSArgs a,
             o_scores[rank] = score_of(dist);
         }
     }
-    if (tid == 0) { out_count[q] = Sn < k ? Sn : k; g_cnt[q] = 0u; g_bound[q] = 0u; }
+    if (tid == 0) {
+        out_count[q] = Sn < k ? Sn : k;
+        g_cnt[q] = 0u;
+        g_bound[q] = 0u;
+        a.ctl[BS_CTL_REDO + q] = 0u;
+        // the failure word is every block's to read (they have, above): the last block through clears it and the counter that says who is last
+        if (atomicAdd(a.ctl + BS_CTL_FAIL + 1, 1u) == gridDim.x - 1u) { a.ctl[BS_CTL_FAIL] = 0u; a.ctl[BS_CTL_FAIL + 1] = 0u; }
+    }
     for (uint32_t s = tid; s < BS_SL; s += 1024u) g_slots[q * BS_SL + s] = 0u;
 }
 
@@ -870,18 +1038,29 @@ int launch_batchs_pass(const BatchSArgs &a_in, hipStream_t stream) {
     // every worker wave needs a first tile of its own (its warm-up fills a slot); blocks of 7 workers + the service wave
     uint32_t grid = n32 / BS_WORK;
     grid = grid < 1u ? 1u : (grid > cus ? cus : grid);
+    auto dispatch = [](const BatchSArgs &b, uint32_t g, hipStream_t st) -> int {
+        switch (b.dim) {
+            case 128: return launch_batchs_d<128>(b, g, st);
+            case 256: return launch_batchs_d<256>(b, g, st);
+            case 384: return launch_batchs_d<384>(b, g, st);
+            case 512: return launch_batchs_d<512>(b, g, st);
+            case 640: return launch_batchs_d<640>(b, g, st);
+            case 768: return launch_batchs_d<768>(b, g, st);
+            case 896: return launch_batchs_d<896>(b, g, st);
+            default: return launch_batchs_d<1024>(b, g, st);   // (batchs_supported: 1024)
+        }
+    };
     static const bool tl_env = getenv("CX_BATCHS_TL") && atoi(getenv("CX_BATCHS_TL")) != 0;
-    if (tl_env) {   // diagnostic: one pass with stamps, its timeline on stderr
-        static unsigned long long *d_tl = nullptr;
+    if (tl_env) {   // diagnostic: one pass with stamps, its timeline on stderr (one stamp buffer per device)
+        static unsigned long long *d_tls[64] = {nullptr};
+        int dev = 0;
+        CX_HIP(hipGetDevice(&dev));
+        if (dev < 0 || dev > 63) return set_err(CX_ERR_DEVICE, "batchs timeline: device %d", dev);
+        unsigned long long *&d_tl = d_tls[dev];
         if (!d_tl) CX_HIP(hipMalloc(&d_tl, (size_t)1024 * 32 * 8));
         CX_HIP(hipMemsetAsync(d_tl, 0, (size_t)1024 * 32 * 8, stream));
         a.tl = d_tl;
-        int rc;
-        switch (a.dim) {
-            case 384: rc = launch_batchs_d<384>(a, grid, stream); break;
-            case 768: rc = launch_batchs_d<768>(a, grid, stream); break;
-            default: rc = launch_batchs_d<1024>(a, grid, stream); break;
-        }
+        int rc = dispatch(a, grid, stream);
         if (rc) return rc;
         CX_HIP(hipStreamSynchronize(stream));
         std::vector<unsigned long long> h((size_t)grid * 32);
@@ -925,16 +1104,7 @@ int launch_batchs_pass(const BatchSArgs &a_in, hipStream_t stream) {
         }
         return CX_OK;
     }
-    switch (a.dim) {
-        case 128: return launch_batchs_d<128>(a, grid, stream);
-        case 256: return launch_batchs_d<256>(a, grid, stream);
-        case 384: return launch_batchs_d<384>(a, grid, stream);
-        case 512: return launch_batchs_d<512>(a, grid, stream);
-        case 640: return launch_batchs_d<640>(a, grid, stream);
-        case 768: return launch_batchs_d<768>(a, grid, stream);
-        case 896: return launch_batchs_d<896>(a, grid, stream);
-        default: return launch_batchs_d<1024>(a, grid, stream);
-    }
+    return dispatch(a, grid, stream);
 }
 
 // The all-pairs filter of a small scan set through the same pass (THR): candidate columns out, allpairs_stream.hip's contract.
@@ -949,14 +1119,32 @@ int launch_batchs_thr(const BatchSArgs &a_in, hipStream_t stream) {
     return launch_batchs_pass(a, stream);
 }
 
+template <typename S>
+static void launch_rescore_s(const BatchSArgs &a, const S *rows, hipStream_t stream) {
+    // 128 waves per query (those past the list's end leave at once): a few hundred to a few thousand candidates; BS_REDO_WAVES
+    // when a query is redone exactly
+    const dim3 grid(BS_REDO_WAVES / 4u, a.nq), block(256);
+    if (a.k <= 64u) hipLaunchKernelGGL((batchs_rescore_kernel<S, 1>), grid, block, 0, stream, a, rows);
+    else if (a.k <= 128u) hipLaunchKernelGGL((batchs_rescore_kernel<S, 2>), grid, block, 0, stream, a, rows);
+    else hipLaunchKernelGGL((batchs_rescore_kernel<S, 4>), grid, block, 0, stream, a, rows);
+}
+
 int launch_batchs_select(const BatchSArgs &a, uint32_t *out_rows, float *out_scores, float *out_dists, uint32_t *out_count, hipStream_t stream) {
-    const uint32_t slices = 32u;   // 128 waves per query (those past the list's end leave at once): a few hundred to a few thousand candidates
-    if (a.rows16) hipLaunchKernelGGL(batchs_rescore_kernel<uint16_t>, dim3(slices, a.nq), dim3(256), 0, stream, a, a.rows16);
-    else hipLaunchKernelGGL(batchs_rescore_kernel<float>, dim3(slices, a.nq), dim3(256), 0, stream, a, a.rows);
+    if ((uint64_t)BS_REDO_WAVES * a.k > a.cap) return set_err(CX_ERR_VALIDATION, "batchs: candidate lists of %u entries cannot hold an exact redo (k %u)", a.cap, a.k);
+    if (a.rows16) launch_rescore_s(a, a.rows16, stream);
+    else launch_rescore_s(a, a.rows, stream);
     if (a.k <= 32u) hipLaunchKernelGGL(batchs_select_kernel<4>, dim3(a.nq), dim3(1024), 0, stream, a, out_rows, out_scores, out_dists, out_count);
     else hipLaunchKernelGGL(batchs_select_kernel<8>, dim3(a.nq), dim3(1024), 0, stream, a, out_rows, out_scores, out_dists, out_count);
     CX_HIP(hipGetLastError());
     return CX_OK;
+}
+
+// entries per query of the candidate lists (index.cpp sizes the scratch with it): every row of a small store, CX_BATCHS_CAND_CAP
+// (65,536) of a large one — 33.5 MB per context for 64 queries, where round 3 held 512 bytes per ROW —, never fewer than an
+// exact redo writes
+uint32_t batchs_cand_cap(uint32_t n_rows, uint32_t k) {
+    static const uint32_t cap_env = getenv("CX_BATCHS_CAND_CAP") ? (uint32_t)std::max(1, atoi(getenv("CX_BATCHS_CAND_CAP"))) : 65536u;
+    return std::max<uint32_t>(std::min<uint32_t>(n_rows, cap_env), BS_REDO_WAVES * k);
 }
 
 }  // namespace cx

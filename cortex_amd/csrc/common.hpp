@@ -140,6 +140,17 @@ __host__ __device__ inline uint16_t f32_to_bf16_bits(float x) {
     return (uint16_t)(u >> 16);
 }
 #ifdef __HIPCC__
+// sum over the 64 lanes, result in every lane: four DPP steps inside each 16-lane row (VALU rate), then two
+// cross-row exchanges
+__device__ inline float wave_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));  // row_mirror
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
 // row elements of either store type
 __device__ inline float ldf(const float *p) { return *p; }
 __device__ inline float ldf(const uint16_t *p) { return bf16_bits_to_f32(*p); }

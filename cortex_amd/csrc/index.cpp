@@ -372,14 +372,31 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
     static const uint32_t bs_small_rows = getenv("CX_BATCHS_SMALL_ROWS") ? (uint32_t)atoi(getenv("CX_BATCHS_SMALL_ROWS")) : 32768u;
     static const uint64_t bs_small_nq = getenv("CX_BATCHS_SMALL_NQ") ? (uint64_t)atoll(getenv("CX_BATCHS_SMALL_NQ")) : 256u;
     const bool bs_rows_ok = n >= batchs_min_rows() || (n >= bs_small_rows && nq <= bs_small_nq);
-    if (bs_ok && topk_path && no_tails && nq >= (uint64_t)batch_min && k_eff >= 1 && batchs_supported(ix->dim, k_eff) && bs_rows_ok) {
-        if (int rc = ensure_shadow(ix, s)) return rc;
-        if (c->bsc_cap < BS_CTL_WORDS) {
-            if (int rc = ensure_dev(c->d_bs_ctl, c->bsc_cap, (size_t)BS_CTL_WORDS)) return rc;
-            CX_HIP(hipMemsetAsync(c->d_bs_ctl, 0, (size_t)BS_CTL_WORDS * sizeof(uint32_t), s));
+    // The screening pass needs the shadow (0.5 x an f32 store, built on the first batched search — inside a `&self` call) and its
+    // candidate scratch: when either cannot be had (out of device memory), or the store holds more irregular rows than the pass
+    // carries along (kernels.hpp: BS_IRR_CAP), the search goes on below with the kernels that read the stored rows themselves.
+    // CX_SINGLE_SCREENED=1 (read per call: a routed option, off by default — the single-query scan stays the contract's path):
+    // one or two queries take the screening pass as well — half the bytes of an f32 store per query (1.536 GB instead of 3.072 at
+    // 1M x 768), the same exact results; for callers that search node by node (the linker's per-node loop, the HTTP handler)
+    const char *ss_env = getenv("CX_SINGLE_SCREENED");
+    const bool single_screened = ss_env && atoi(ss_env) != 0 && ix->dtype == 0;
+    bool bs_go = bs_ok && topk_path && no_tails && (nq >= (uint64_t)batch_min || (single_screened && nq >= 1)) && k_eff >= 1 && batchs_supported(ix->dim, k_eff) && bs_rows_ok;
+    const uint32_t bs_cap = bs_go ? batchs_cand_cap(n, k_eff) : 0u;
+    if (bs_go) {
+        int rc = ensure_shadow(ix, s);
+        if (!rc && ix->irr_over) bs_go = false;
+        if (!rc && bs_go && c->bsc_cap < BS_CTL_WORDS) {
+            rc = ensure_dev(c->d_bs_ctl, c->bsc_cap, (size_t)BS_CTL_WORDS);
+            if (!rc && hipMemsetAsync(c->d_bs_ctl, 0, (size_t)BS_CTL_WORDS * sizeof(uint32_t), s) != hipSuccess) rc = CX_ERR_DEVICE;
         }
-        if (int rc = ensure_dev(c->d_bs_rows, c->bsr_cap, (size_t)64 * n)) return rc;
-        if (int rc = ensure_dev(c->d_bs_cos, c->bss_cap, (size_t)64 * n)) return rc;
+        if (!rc && bs_go) rc = ensure_dev(c->d_bs_rows, c->bsr_cap, (size_t)64 * bs_cap);
+        if (!rc && bs_go) rc = ensure_dev(c->d_bs_cos, c->bss_cap, (size_t)64 * bs_cap);
+        if (rc) {
+            (void)hipGetLastError();   // (a failed hipMalloc is sticky until read)
+            bs_go = false;
+        }
+    }
+    if (bs_go) {
         for (uint64_t q0 = 0; q0 < nq; q0 += 64) {
             const uint32_t m = (uint32_t)std::min<uint64_t>(64, nq - q0);
             BatchSArgs b;
@@ -397,7 +414,9 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
             b.ctl = c->d_bs_ctl;
             b.cand_rows = c->d_bs_rows;
             b.cand_cos = c->d_bs_cos;
-            b.cap = n;
+            b.cap = bs_cap;
+            b.irr_rows = ix->d_irr_rows;
+            b.irr_n = ix->irr_n;
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (ix->profiling) {
                 CX_HIP(hipEventCreate(&e0));
@@ -407,12 +426,12 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
                 CX_HIP(hipEventRecord(e0, s));
             }
             int rc = launch_batchs_pass(b, s);
-            if (e1) CX_HIP(hipEventRecord(e1, s));
+            if (e1 && !rc && hipEventRecord(e1, s) != hipSuccess) rc = set_err(CX_ERR_DEVICE, "hipEventRecord failed");   // (no early return between a pass and its select: see below)
             static const int bs_diag = getenv("CX_BATCHS_DIAG") ? atoi(getenv("CX_BATCHS_DIAG")) : 0;
             if (bs_diag && !rc) {   // candidates per query and published bounds of this pass, on stderr
                 std::vector<uint32_t> dg(128);
-                CX_HIP(hipStreamSynchronize(s));
-                CX_HIP(hipMemcpy(dg.data(), c->d_bs_ctl + BS_CTL_BOUND, 128 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                (void)hipStreamSynchronize(s);
+                (void)hipMemcpy(dg.data(), c->d_bs_ctl + BS_CTL_BOUND, 128 * sizeof(uint32_t), hipMemcpyDeviceToHost);
                 uint64_t tot = 0; uint32_t mx = 0, nob = 0;
                 for (uint32_t q = 0; q < m; q++) { tot += dg[64 + q]; mx = std::max(mx, dg[64 + q]); nob += dg[q] <= 1u; }
                 float b0; memcpy(&b0, &dg[0], 4);
@@ -766,6 +785,8 @@ void cx_destroy(cx_index *ix) {
     (void)hipFree(ix->d_agent);
     (void)hipFree(ix->d_shadow);
     (void)hipFree(ix->d_shadow_t);
+    (void)hipFree(ix->d_shadow_err);
+    (void)hipFree(ix->d_irr_rows);
     (void)hipFree(ix->d_norms);
     (void)hipFree(ix->d_split);
     (void)hipFree(ix->d_tile_list);

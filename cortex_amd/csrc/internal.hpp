@@ -161,7 +161,13 @@ struct cx_index {
     // the same shadow cut into the 256-tile filter kernel's LDS-DMA pieces: [16-row block][K-step of 32][16 rows x 64 B,
     // pieces pre-swizzled] — one DMA instruction = 1 KiB of contiguous HBM/L2 (allpairs256.hip); maintained with d_shadow
     mutable uint16_t *d_shadow_t = nullptr;
-    mutable uint32_t *d_shadow_err = nullptr;   // [1] the largest || bf16(x) - x || over the shadow's rows (f32 bits; an upper bound: never lowered by removals)
+    mutable uint32_t *d_shadow_err = nullptr;   // [0] the largest || bf16(x) - x || over the shadow's rows (f32 bits; an upper bound: never lowered by removals); [1] irregular rows counted so far
+    // IRREGULAR rows (kernels.hpp: bs_regular): zero shadow rows, listed here by the shadow's build; every screening path adds them
+    // to its candidates and computes them with the reference's arithmetic.  irr_n = the count as of the last build (read back
+    // at the sync the build ends with); more than BS_IRR_CAP of them switch the screening paths off (irr_over) until a rebuild.
+    mutable uint32_t *d_irr_rows = nullptr;     // [BS_IRR_CAP]
+    mutable uint32_t irr_n = 0;
+    mutable bool irr_over = false;
     mutable uint64_t shadow_cap = 0;
     mutable uint64_t shadow_rows = 0;
     mutable std::vector<uint32_t> shadow_stale;

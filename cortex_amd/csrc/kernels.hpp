@@ -124,7 +124,19 @@ constexpr uint32_t BS_CTL_BOUND = 64 * BS_SL;         // word offsets inside the
 constexpr uint32_t BS_CTL_CNT = BS_CTL_BOUND + 64;
 constexpr uint32_t BS_CTL_NEXT = BS_CTL_CNT + 64;     // the next unclaimed tile beyond the statically dealt first ones
 constexpr uint32_t BS_CTL_MRG = BS_CTL_NEXT + 16;     // 64 margins (2 eps of each query, f32 bits) of the last pass, for the re-score's second look
-constexpr uint32_t BS_CTL_WORDS = BS_CTL_MRG + 64;
+constexpr uint32_t BS_CTL_REDO = BS_CTL_MRG + 64;     // 64 flags: the query is irregular (|q|^2 is zero, non-finite or outside [BS_REG_LO, BS_REG_HI]) — screened not at all, redone exactly
+constexpr uint32_t BS_CTL_FAIL = BS_CTL_REDO + 64;    // sticky: a worker gave up waiting for room in its hit ring (hits dropped): every query of the pass is redone exactly
+constexpr uint32_t BS_CTL_WORDS = BS_CTL_FAIL + 16;
+// A vector is REGULAR when its sum of squares, as the reference's f32 arithmetic computes it (vector/index.rs:174-175), is a
+// number in [BS_REG_LO, BS_REG_HI]: then no product or partial sum of a pair of regular vectors overflows, what underflows is
+// below 1e-8 of |x||y|, and the screening bound's 1e-4 of f32 slack holds.  Anything else — a zero vector, elements scaled by
+// 1e+-20 (x^2 overflows to infinity / underflows to 0: the reference divides by infinity or by zero and scores 0, 1 or NaN), an
+// Inf or NaN element — is IRREGULAR: it gets a zero shadow row, is never screened, and every pair it is part of is computed with
+// the reference's arithmetic (irregular rows: a short list re-scored for every query; irregular queries: the exact redo).
+constexpr float BS_REG_LO = 1.0e-30f, BS_REG_HI = 1.0e30f;
+__host__ __device__ inline bool bs_regular(float sumsq) { return sumsq >= BS_REG_LO && sumsq <= BS_REG_HI; }   // (a NaN fails both)
+constexpr uint32_t BS_IRR_CAP = 1024;                 // irregular rows a store may hold before its screening paths are switched off
+constexpr uint32_t BS_REDO_WAVES = 128;               // waves that redo one query exactly (the re-score kernel's 32 slices x 4)
 struct BatchSArgs {
     const uint16_t *shadow_t; // cx_index::d_shadow_t: rows L2-normalised, bf16, the all-pairs filter's tiled layout (tiled_shadow_off below)
     const uint32_t *shadow_err; // cx_index::d_shadow_err: the largest rounding error of a shadow row (f32 bits); null = the worst case 2^-8
@@ -137,7 +149,9 @@ struct BatchSArgs {
                             // passes (the select kernel clears what a pass used)
     uint32_t *cand_rows;    // [64][cap] candidate lists: row; exact cosine (written by the select kernel)
     float *cand_cos;
-    uint32_t cap;           // entries per query: n_rows (every pair is tested once, so a list cannot run over)
+    uint32_t cap;           // entries per query (>= BS_REDO_WAVES x k): a query whose list runs over is redone exactly by the re-score kernel
+    const uint32_t *irr_rows; // [irr_n] the store's irregular rows (zero shadow rows: never hits), re-scored for every query
+    uint32_t irr_n;
     uint32_t arm;           // CX_BATCHS_ARM: measurement arms (results invalid): 1 workers drop their hits, 4 the service wave drops them
     uint32_t pub_min;       // slots a query's first publisher waits for (CX_BATCHS_PUB_MIN, 64; at least k)
     unsigned long long *tl; // CX_BATCHS_TL=1: [grid][32] s_memrealtime stamps of a pass (diagnostic; null otherwise)
@@ -154,6 +168,7 @@ bool batchs_supported(uint32_t dim, uint32_t k);   // dim % 128 == 0, dim <= 102
 bool batchs_thr_supported(uint32_t n_rows, uint32_t dim, uint32_t n_scan);
 int launch_batchs_thr(const BatchSArgs &a, hipStream_t stream);
 uint32_t batchs_min_rows();   // fewest rows that take this path (CX_BATCHS_MIN_ROWS)
+uint32_t batchs_cand_cap(uint32_t n_rows, uint32_t k);   // entries per query of the candidate lists (CX_BATCHS_CAND_CAP, 65,536; never fewer than an exact redo writes)
 int launch_batchs_pass(const BatchSArgs &a, hipStream_t stream);
 int launch_batchs_select(const BatchSArgs &a, uint32_t *out_rows, float *out_scores, float *out_dists, uint32_t *out_count, hipStream_t stream);
 
@@ -196,11 +211,18 @@ int launch_dense_topk(const float *d_dense, uint32_t stride, uint32_t n_rows, ui
 // ---- all-pairs auto-link pass (allpairs.hip) ----
 int launch_build_shadow(const float *rows, uint16_t *shadow, uint32_t row_lo, uint32_t row_hi, uint32_t dim,
                         hipStream_t stream);
-// the same rows straight into the tiled layout (dim % 32 == 0)
-int launch_build_shadow_tiled(const float *rows, const uint16_t *rows16, uint16_t *shadow_t, uint32_t row_lo, uint32_t row_hi, uint32_t dim, hipStream_t stream,
-                              uint32_t *err_max = nullptr);   // err_max: the largest || bf16(x) - x || of a normalised row, f32 bits, atomic max
+// the index's own shadow (autolink.cpp: ensure_shadow), tiled (dim % 32 == 0) or row-major: err_max = the largest || bf16(x) - x ||
+// of a normalised row (f32 bits, atomic max; tiled only); irregular rows (bs_regular above) get zero shadow rows and are
+// counted in *irr_cnt / listed in irr_rows[BS_IRR_CAP] unless entries [0, irr_n_before) already hold them
+int launch_build_shadow_index(const float *rows, const uint16_t *rows16, uint16_t *shadow, bool tiled, uint32_t row_lo, uint32_t row_hi, uint32_t dim,
+                              hipStream_t stream, uint32_t *err_max, uint32_t *irr_cnt, uint32_t *irr_rows, uint32_t irr_n_before);
 int launch_build_shadow(const uint16_t *rows16, uint16_t *shadow, uint32_t row_lo, uint32_t row_hi, uint32_t dim,
                         hipStream_t stream);   // bf16 store
+// after the filter of a pass over a store with irregular rows: scanned rows that are irregular are marked as run over
+// (cand_cnt > cap: the exact path lists them), the irregular rows become candidates of every other scanned row; irr_ok: [irr_n] scratch;
+// ext_vecs: the scanned vectors themselves when they are not rows of this shard (f32 [n_scan][dim]), else null
+int launch_irr_append(const float *rows, const uint16_t *rows16, uint32_t dim, uint32_t n_rows, const uint32_t *irr_rows, uint32_t irr_n, uint32_t *irr_ok,
+                      const uint32_t *scan_rows, const float *ext_vecs, uint32_t n_scan, uint32_t *cand_cnt, uint32_t *cand, uint32_t cap, hipStream_t stream);
 
 
 // Tiled shadow (dim % 32 == 0): [16-row block][K-step of 32 elements][16 rows x 64 B], the four 16-byte pieces of a row's

@@ -46,3 +46,41 @@ def test_no_device_memory_growth_under_mixed_calls(hip, oracle):
     free1, _ = torch.cuda.mem_get_info()
     # rows added since the baseline account for < 4000 x 384 x 4 x (rows + split + shadow) ~ 15 MB; allow 64 MB in all
     assert free0 - free1 < 64 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 60 rounds"
+
+
+def test_batched_search_scratch_does_not_scale_with_the_store(hip):
+    """Round 3's screening pass kept candidate lists with room for every row: 512 bytes per ROW and context (5 GB per context at
+    10M rows, times the rotating streams, times the pooled readers).  The lists are bounded now (CX_BATCHS_CAND_CAP, 65,536
+    entries per query = 33.5 MB per context whatever the store's size; a list that runs over is redone exactly): the first
+    batched search of a 2M-row store may take the shadow (rows x dim x 2) plus well under 0.1 GB — round 3 took 1 GB on top —,
+    and four more contexts (four host threads at once) under 0.3 GB."""
+    import threading
+    import torch
+    from cortex_amd import _lib
+    L = _lib.load()
+    n, d = 2_000_000, 128
+    gen = torch.empty((n, d), dtype=torch.float32, device="cuda:0")
+    assert L.cx_synth_fill_dev(0, gen.data_ptr(), 20260313, 20260313, 20260315, n // 50, 0, n, d, 1) == 0
+    ids = np.zeros((n, 16), np.uint8)
+    ids[:, 8:] = np.arange(n, dtype=np.uint64).astype(">u8").view(np.uint8).reshape(n, 8)
+    h = hip.HipIndex(d)
+    h.insert_batch_dev(ids, gen.data_ptr(), n, d)
+    qs_t = torch.empty((64, d), dtype=torch.float32, device="cuda:0")
+    assert L.cx_synth_fill_dev(0, qs_t.data_ptr(), 20260313, 20260314, 20260315, n // 50, 0, 64, d, 0) == 0
+    qs = qs_t.cpu().numpy()
+    h.search_arrays(qs[0], 10)                       # the scan's own scratch
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    h.search_batch_arrays(qs, 10)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    shadow = ((n + 255) // 256) * 256 * d * 2
+    assert free0 - free1 < shadow + (100 << 20), f"first batched search took {(free0 - free1) >> 20} MiB, shadow {(shadow) >> 20} MiB"
+    th = [threading.Thread(target=lambda: [h.search_batch_arrays(qs, 100) for _ in range(3)]) for _ in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    free2, _ = torch.cuda.mem_get_info()
+    assert free1 - free2 < 300 << 20, f"four concurrent readers took {(free1 - free2) >> 20} MiB of scratch"
