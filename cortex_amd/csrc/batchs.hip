@@ -83,8 +83,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // LDS control words
 enum : uint32_t { BSL_HEAD = 0, BSL_TAIL = 8, BSL_ARRIVED = 16, BSL_DONE = 17, BSL_READY = 18, BSL_QHEAD = 19, BSL_QTAIL = 20, BSL_LOC = 21, BSL_WORDS = 24 };
 constexpr uint32_t BS_LOCG = 2u * BS_WORK;   // 16-row groups of a block's first tiles: the values its LOCAL bounds are taken from
-constexpr uint32_t BS_TQ = 64;         // entries of the block's tile queue (a power of two)
-constexpr uint32_t BS_CLAIM = 14;      // tiles the service wave claims at a time: two per worker
+constexpr uint32_t BS_TQ = 128;        // entries of the block's tile queue (a power of two)
+constexpr uint32_t BS_CLAIM = 21;      // tiles the service wave claims at a time: three per worker (14 / 21 / 28 measured: round 4 tuning notes)
 constexpr uint32_t BS_NO_TILE = 0xFFFFFFFFu;
 constexpr uint32_t BS_STRUCK = 0xFFFFFFFFu;   // a candidate the re-score struck from its list
 
@@ -96,7 +96,7 @@ struct BsCfg {
     // the kernel) its service wave holds the hits back, and the rings are the workers' runway until the grid's bounds arrive
     static constexpr uint32_t HB = D > 896 ? 128u : (D > 768 ? 256u : (D > 384 ? 512u : 1024u));
     static constexpr uint32_t T16 = 16u * D * 2u;                       // bytes of a 16-row block of the tiled shadow
-    static constexpr size_t LDS = (size_t)KS * 4096u + BSL_WORDS * 4 + (size_t)BS_WORK * HB * 12 + 256 * 4 + 64 * 4 + BS_TQ * 4 + 64 * 4 + 64 * 4 + BS_LOCG * 64 * 4;
+    static constexpr size_t LDS = (size_t)KS * 4096u + BSL_WORDS * 4 + (size_t)BS_WORK * HB * 12 + 256 * 4 + 64 * 4 + BS_TQ * 4 + 64 * 4 + 64 * 4 + BS_LOCG * 64 * 4 + 128 * 12;
     static_assert(KS % P == 0 && D % 128 == 0 && LDS <= 160u * 1024u, "unsupported row width");
 };
 
@@ -124,6 +124,9 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
     float *s_inv = reinterpret_cast<float *>(s_tq + BS_TQ);                 // [64] 1 / |q| (prologue); 0 = an irregular query: no image, no hits, redone exactly
     float *s_mrg = s_inv + 64u;                                             // [64] 2 eps of each query (the service wave's look at a hit)
     uint32_t *s_loc = reinterpret_cast<uint32_t *>(s_mrg + 64u);            // [BS_LOCG][64] best approximate cosine of each 16-row group of the block's first tiles
+    uint32_t *s_stg_row = s_loc + BS_LOCG * 64u;                            // [128] the service wave's staging area: hits that passed its look under the bounds of the moment
+    uint32_t *s_stg_q = s_stg_row + 128u;
+    float *s_stg_dot = reinterpret_cast<float *>(s_stg_q + 128u);
     float *s_qqp = s_hdot;                                                  // prologue only: the two halves of every |q|^2
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -142,14 +145,15 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
     const uint32_t n_static = nw < n32 ? nw : n32;
     // (a block's first claim is dealt, not taken: 256 blocks' atomics on one word at launch are served one after the other,
     // ~50 ns each, and hipcc waits for the returning atomic where it is issued — the whole block's prologue stood behind it)
-    const uint32_t claim0 = blockIdx.x * BS_CLAIM, claim_base = gridDim.x * BS_CLAIM;
+    const uint32_t CLAIM = a.claim;   // tiles the service wave claims at a time (BS_CLAIM; CX_BATCHS_CLAIM)
+    const uint32_t claim0 = blockIdx.x * CLAIM, claim_base = gridDim.x * CLAIM;
 
     auto now = [&]() -> uint64_t {   // 100 MHz
         uint64_t t;
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
         return t;
     };
-    unsigned long long *const stamps = a.tl ? a.tl + (size_t)blockIdx.x * 32u : nullptr;   // (CX_BATCHS_TL)
+    unsigned long long *const stamps = a.tl ? a.tl + (size_t)blockIdx.x * 48u : nullptr;   // (CX_BATCHS_TL)
     if (stamps && tid == 0u) stamps[0] = now();
 
     // ---- workers: the ring.  P K-steps x 2 row fragments of 16 bytes per lane.  A 32-row tile is 2 x T16 contiguous bytes
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
     bool exhausted = false;
     uint32_t q_head = 0u;
     auto push_claim = [&](uint32_t c) {   // service wave, all lanes
-        constexpr uint32_t size = BS_CLAIM;
+        const uint32_t size = CLAIM;
         c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
         const uint32_t first = n_static + c;
         const uint32_t have = first >= n32 ? 0u : (n32 - first < size ? n32 - first : size);
@@ -288,13 +292,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         // One hit per lane: row filter, candidate list (the exact cosine is the select kernel's), the tile's slot.  Lanes
         // with the same query take their list positions from ONE atomic add.
         auto process_hits = [&](bool active, uint32_t row, uint32_t q, float approx) {
-            if constexpr (!THR) {
-                // a hit came in under the bound its worker had at that moment — possibly the block's LOCAL one, with the hits held
-                // back in the rings until the grid's bounds arrived: looked at again under the bound the block has NOW, most of those
-                // leave here, without an atomic or a byte of HBM traffic
-                if (active) active = !(approx < bs_thr(bs_lds_ld(&s_bnd[q]), true, s_mrg[q]));
-                active = active && row_passes(a.flt, row);   // (the filter pass has no row filter: the rescore and the rules look at the rows)
-            }
+            if constexpr (!THR) active = active && row_passes(a.flt, row);   // (the filter pass has no row filter: the rescore and the rules look at the rows)
             row = active ? row : 0u;
             q = active ? q : 0u;
             uint64_t same = __ballot(active);
@@ -390,7 +388,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         auto refill = [&]() {   // fewer than two tiles per worker queued: claim the next BS_CLAIM
             if (!exhausted && (int32_t)(q_head - bs_lds_ld(&s_ctl[BSL_QTAIL])) < (int32_t)BS_CLAIM) {
                 uint32_t c = 0u;
-                if (lane == 0u) c = claim_base + atomicAdd(g_next, BS_CLAIM);
+                if (lane == 0u) c = claim_base + atomicAdd(g_next, CLAIM);
                 push_claim(c);
             }
         };
@@ -454,8 +452,16 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         }
         // D. service loop: drain the workers' hit rings, keep the tile queue filled and the block's copy of the bounds
         // fresh (re-read and re-published 2, 4, 8, ... us apart, then every 128 us: see the head of the file)
+        // A round takes up to 64 pending entries from the rings, in worker order, and looks at each under the block's bounds of the
+        // moment (one compare: most hits of a block that ran ahead on its local bounds leave here); what is left goes to a staging
+        // area in LDS and is handed to process_hits 64 at a time — ONE returning atomic per 64 survivors: its round trip past the L2
+        // takes 2-3 us under the row stream, and paid per round (a survivor or two in nearly every round) it made the service wave
+        // the last to leave by 30-60 us.  The housekeeping (tile queue, clock, bound refresh) runs every eighth busy round.
         uint32_t gap = 200u;           // x10 ns
         uint64_t t_next = now() + gap;
+        unsigned long long n_rounds = 0, n_hits = 0, n_kept = 0, max_pend = 0;   // (timeline diagnostics)
+        bool drained = false, seen_done = false, workers_done = false;
+        uint32_t n_stage = 0u, it = 0u;
         for (;;) {
             uint32_t hd = 0u, tl = 0u;
             if (lane < BS_WORK) { hd = bs_lds_ld_acq(&s_ctl[BSL_HEAD + lane]); tl = bs_lds_ld(&s_ctl[BSL_TAIL + lane]); }   // (the tails are this wave's own)
@@ -468,7 +474,13 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
             }
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)BS_WORK - 1);
             const bool busy = total != 0u;
-            if (busy) {   // up to 64 pending entries, taken from the rings in worker order, in one round
+            if (stamps) {
+                n_rounds++;
+                n_hits += total < 64u ? total : 64u;
+                max_pend = total > max_pend ? total : max_pend;
+                if (!busy && !drained) { drained = true; if (lane == 0u) stamps[32] = now(); }
+            }
+            if (busy) {
                 uint32_t w_of = 0u, first_of = 0u, tail_of = 0u;
 #pragma unroll
                 for (uint32_t w = 0; w < BS_WORK; w++) {
@@ -479,24 +491,52 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
                 }
                 const bool on = lane < total;
                 const uint32_t e = w_of * HB + ((tail_of + lane - first_of) & (HB - 1u));
-                if (!(a.arm & 4u)) process_hits(on, on ? s_hrow[e] : 0u, on ? s_hq[e] : 0u, on ? s_hdot[e] : 0.0f);
+                const uint32_t h_row = on ? s_hrow[e] : 0u, h_q = on ? s_hq[e] : 0u;
+                const float h_dot = on ? s_hdot[e] : 0.0f;
+                bool keep = on && !(a.arm & 4u);
+                if constexpr (!THR) keep = keep && !(h_dot < bs_thr(bs_lds_ld(&s_bnd[h_q]), true, s_mrg[h_q]));
+                const uint64_t km = __ballot(keep);
+                if (keep) {
+                    const uint32_t sp = n_stage + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
+                    s_stg_row[sp] = h_row; s_stg_q[sp] = h_q; s_stg_dot[sp] = h_dot;
+                }
+                n_stage += (uint32_t)__popcll(km);
+                if (stamps) n_kept += (uint32_t)__popcll(km);
                 if (lane < BS_WORK) {
                     const uint32_t beg = incl - pend;
                     const uint32_t took = beg >= 64u ? 0u : (incl <= 64u ? pend : 64u - beg);
                     if (took) bs_lds_st_rel(&s_ctl[BSL_TAIL + lane], tl + took);
                 }
             }
-            refill();
-            const bool workers_done = bs_lds_ld_acq(&s_ctl[BSL_DONE]) >= BS_WORK;
-            const uint64_t t_now = now();
-            if (!THR && t_now >= t_next && !workers_done) {
-                bl = bs_ld_agent(g_bound + lane);
-                __hip_atomic_fetch_max(&s_bnd[lane], bl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (gap >= 800u) publish(0u, true);
-                gap = gap < 12800u ? gap * 2u : 12800u;
-                t_next = now() + gap;
+            if (n_stage >= 64u || (n_stage != 0u && !busy)) {   // 64 survivors (or the last few): row filter, list positions, slots
+                const uint32_t take = n_stage < 64u ? n_stage : 64u;
+                const bool on = lane < take;
+                const uint32_t r0 = on ? s_stg_row[lane] : 0u, q0 = on ? s_stg_q[lane] : 0u;
+                const float d0 = on ? s_stg_dot[lane] : 0.0f;
+                const bool more = lane + 64u < n_stage;
+                const uint32_t r1 = more ? s_stg_row[64u + lane] : 0u, q1 = more ? s_stg_q[64u + lane] : 0u;
+                const float d1 = more ? s_stg_dot[64u + lane] : 0.0f;
+                if (more) { s_stg_row[lane] = r1; s_stg_q[lane] = q1; s_stg_dot[lane] = d1; }   // (one wave: its LDS operations stay in order)
+                n_stage -= take;
+                process_hits(on, r0, q0, d0);
             }
-            if (!busy) {
+            refill();   // (an LDS read unless the queue runs low: the workers of a 384-d pass empty fourteen entries in 11 us)
+            const bool house = !busy || (++it & 7u) == 0u;
+            if (house) {
+                workers_done = bs_lds_ld_acq(&s_ctl[BSL_DONE]) >= BS_WORK;
+                const uint64_t t_now = now();
+                if (stamps && workers_done && !seen_done) { seen_done = true; if (lane == 0u) stamps[37] = t_now; }
+                if (!THR && t_now >= t_next && !workers_done) {
+                    bl = bs_ld_agent(g_bound + lane);
+                    __hip_atomic_fetch_max(&s_bnd[lane], bl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (stamps && lane == 0u) stamps[35] = now();
+                    if (gap >= 800u && !(a.arm & 16u)) publish(0u, true);
+                    if (stamps && lane == 0u) stamps[36] = now();
+                    gap = gap < 12800u ? gap * 2u : 12800u;
+                    t_next = now() + gap;
+                }
+            }
+            if (!busy && n_stage == 0u) {
                 if (workers_done) {   // every worker is through; one more look at the rings, then out
                     bool left = false;
 #pragma unroll 1
@@ -507,7 +547,8 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
                 }
             }
         }
-        if (stamps && lane == 0u) stamps[3] = now();
+        if (stamps && lane == 0u) stamps[34] = n_kept;
+        if (stamps && lane == 0u) { stamps[3] = now(); stamps[33] = n_hits; stamps[38] = n_rounds; stamps[39] = max_pend; }
         return;
     }
 
@@ -614,7 +655,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
             // during which the workers of round 3 stood still.  It is weak (the k-th best of 224 rows, not of 57k: some 7 % of the
             // pairs pass), so until the grid's bounds arrive the service wave — busy polling for them anyway — leaves the hits in
             // the rings (sized for it: BsCfg::HB), and then drops nearly all of them under the real bound (process_hits).
-            const bool loc = k <= BS_LOCG && in_block == BS_WORK;
+            const bool loc = k <= BS_LOCG && in_block == BS_WORK && !(a.arm & 8u);
             uint32_t mine = 0u;
 #pragma unroll
             for (int g = 0; g < 4; g++) {
@@ -842,15 +883,14 @@ __device__ inline void bs_exact_redo(const BatchSArgs &a, const S *rows, uint32_
 // may have replaced it since), while a LISTED candidate that is irregular (a query without a bound takes every row) is struck: each
 // row is in the list once.  Both sides decide by the sum the shadow's build took (same order, same rounding: wave_sum).
 template <typename S, int KS>
-__global__ __launch_bounds__(256) void batchs_rescore_kernel(const BatchSArgs a, const S *rows) {
+__device__ inline void bs_rescore_body(const BatchSArgs &a, const S *rows, uint32_t q, uint32_t gw, uint32_t nwq, bool redo) {
 #pragma clang fp contract(off)
     constexpr uint32_t U = 4;
-    const uint32_t q = blockIdx.y, lane = threadIdx.x & 63u;
-    const uint32_t gw = blockIdx.x * 4u + (threadIdx.x >> 6), nwq = gridDim.x * 4u;
+    const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total = a.ctl[BS_CTL_CNT + q];
-    const bool redo = bs_redo(a, q);
     const uint32_t n_all = total + a.irr_n;
-    if (!redo && gw * U >= n_all) return;
+    const uint32_t n_it = n_all;
+    if (!redo && gw * U >= n_it) return;
     uint32_t *cand = a.cand_rows + (size_t)q * a.cap;
     float *cosv = a.cand_cos + (size_t)q * a.cap;   // in: the approximate cosine the pass saw; out: the exact one
     // A candidate came in under the bound of its moment; the pass's last bound is the tightest.  One that fails the same test
@@ -871,20 +911,23 @@ __global__ __launch_bounds__(256) void batchs_rescore_kernel(const BatchSArgs a,
         bs_exact_redo<S, KS>(a, rows, q, gw, nwq, ql, qq, per, lane);
         return;
     }
-    for (uint32_t c = gw * U; c < n_all; c += nwq * U) {
+    for (uint32_t c = gw * U; c < n_it; c += nwq * U) {
         const S *p[U];
-        uint32_t row[U];
+        uint32_t row[U], cu[U];
         bool keep[U], listed[U];   // (wave-uniform)
 #pragma unroll
         for (uint32_t u = 0; u < U; u++) {
-            const uint32_t cu = c + u < n_all ? c + u : c;
-            listed[u] = cu < total;
-            row[u] = listed[u] ? cand[cu] : a.irr_rows[cu - total];
-            keep[u] = listed[u] ? !(cosv[cu] < thr) : (row[u] < a.n_rows && row_passes(a.flt, row[u]));
+            const uint32_t ci = c + u < n_it ? c + u : c;
+            cu[u] = ci;
+            listed[u] = cu[u] < total;
+            row[u] = listed[u] ? cand[cu[u]] : a.irr_rows[cu[u] - total];
+            keep[u] = listed[u] ? !(cosv[cu[u]] < thr) : (row[u] < a.n_rows && row_passes(a.flt, row[u]));
             p[u] = rows + (size_t)(keep[u] ? row[u] : 0u) * dim + lane;
         }
         if (!(keep[0] || keep[1] || keep[2] || keep[3])) {
-            if (lane < U && c + lane < n_all) cand[c + lane] = BS_STRUCK;
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++)
+                if (lane == u && c + u < n_it) cand[cu[u]] = BS_STRUCK;
             continue;
         }
         float dot[U], rr[U];
@@ -908,12 +951,17 @@ __global__ __launch_bounds__(256) void batchs_rescore_kernel(const BatchSArgs a,
             for (uint32_t u = 0; u < U; u++) { dot[u] += __shfl_xor(dot[u], x, 64); rr[u] += __shfl_xor(rr[u], x, 64); }
 #pragma unroll
         for (uint32_t u = 0; u < U; u++)
-            if (lane == u && c + u < n_all) {
+            if (lane == u && c + u < n_it) {
                 const bool ok = keep[u] && regular[u] == listed[u];
-                cand[c + u] = ok ? row[u] : BS_STRUCK;
-                if (ok) cosv[c + u] = cosine_from_sums(dot[u], qq, rr[u]);
+                cand[cu[u]] = ok ? row[u] : BS_STRUCK;
+                if (ok) cosv[cu[u]] = cosine_from_sums(dot[u], qq, rr[u]);
             }
     }
+}
+
+template <typename S, int KS>
+__global__ __launch_bounds__(256) void batchs_rescore_kernel(const BatchSArgs a, const S *rows) {
+    bs_rescore_body<S, KS>(a, rows, blockIdx.y, blockIdx.x * 4u + (threadIdx.x >> 6), gridDim.x * 4u, bs_redo(a, blockIdx.y));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -922,13 +970,13 @@ __global__ __launch_bounds__(256) void batchs_rescore_kernel(const BatchSArgs a,
 // entries is held in registers and selected once; a longer one (weak bounds: massive ties, a selective row filter, a
 // zero query) is folded chunk by chunk, the survivors so far riding along — exact whatever the length.
 template <int NV>
-__global__ __launch_bounds__(1024) void batchs_select_kernel(const BatchSArgs a, uint32_t *out_rows, float *out_scores, float *out_dists,
-                                                             uint32_t *out_count) {
+__device__ inline void bs_select_body(const BatchSArgs &a, uint32_t q, uint32_t n_query_blocks, uint32_t *out_rows, float *out_scores, float *out_dists,
+                                      uint32_t *out_count) {
     __shared__ uint32_t sh[264];
     __shared__ uint64_t surv_k[256 + 64];
     __shared__ float surv_s[256 + 64];
     __shared__ uint32_t s_n;
-    const uint32_t tid = threadIdx.x, q = blockIdx.x, k = a.k;
+    const uint32_t tid = threadIdx.x, k = a.k;
     uint32_t *const g_slots = a.ctl, *const g_bound = a.ctl + BS_CTL_BOUND, *const g_cnt = a.ctl + BS_CTL_CNT;
     if (q == 0u && tid == 0u) a.ctl[BS_CTL_NEXT] = 0u;
     // a query that was redone exactly: its list is the redo waves' k best each (already exact); otherwise the listed candidates
@@ -1000,9 +1048,15 @@ __global__ __launch_bounds__(1024) void batchs_select_kernel(const BatchSArgs a,
         g_bound[q] = 0u;
         a.ctl[BS_CTL_REDO + q] = 0u;
         // the failure word is every block's to read (they have, above): the last block through clears it and the counter that says who is last
-        if (atomicAdd(a.ctl + BS_CTL_FAIL + 1, 1u) == gridDim.x - 1u) { a.ctl[BS_CTL_FAIL] = 0u; a.ctl[BS_CTL_FAIL + 1] = 0u; }
+        if (atomicAdd(a.ctl + BS_CTL_FAIL + 1, 1u) == n_query_blocks - 1u) { a.ctl[BS_CTL_FAIL] = 0u; a.ctl[BS_CTL_FAIL + 1] = 0u; }
     }
     for (uint32_t s = tid; s < BS_SL; s += 1024u) g_slots[q * BS_SL + s] = 0u;
+}
+
+template <int NV>
+__global__ __launch_bounds__(1024) void batchs_select_kernel(const BatchSArgs a, uint32_t *out_rows, float *out_scores, float *out_dists,
+                                                             uint32_t *out_count) {
+    bs_select_body<NV>(a, blockIdx.x, gridDim.x, out_rows, out_scores, out_dists, out_count);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1030,8 +1084,10 @@ int launch_batchs_pass(const BatchSArgs &a_in, hipStream_t stream) {
     BatchSArgs a = a_in;
     static const uint32_t arm_env = getenv("CX_BATCHS_ARM") ? (uint32_t)atoi(getenv("CX_BATCHS_ARM")) : 0u;
     static const uint32_t pub_env = getenv("CX_BATCHS_PUB_MIN") ? (uint32_t)atoi(getenv("CX_BATCHS_PUB_MIN")) : 64u;
+    static const uint32_t claim_env = getenv("CX_BATCHS_CLAIM") ? (uint32_t)std::min(32, std::max(1, atoi(getenv("CX_BATCHS_CLAIM")))) : BS_CLAIM;
     a.arm = arm_env;
     a.pub_min = pub_env;
+    a.claim = claim_env;
     if (!batchs_supported(a.dim, a.k) || a.nq == 0 || a.nq > 64u || a.n_rows == 0)
         return set_err(CX_ERR_VALIDATION, "batchs: unsupported shape (dim %u, k %u, %u queries, %u rows)", a.dim, a.k, a.nq, a.n_rows);
     const uint32_t cus = device_cus(), n32 = (a.n_rows + 31u) / 32u;
@@ -1057,22 +1113,22 @@ int launch_batchs_pass(const BatchSArgs &a_in, hipStream_t stream) {
         CX_HIP(hipGetDevice(&dev));
         if (dev < 0 || dev > 63) return set_err(CX_ERR_DEVICE, "batchs timeline: device %d", dev);
         unsigned long long *&d_tl = d_tls[dev];
-        if (!d_tl) CX_HIP(hipMalloc(&d_tl, (size_t)1024 * 32 * 8));
-        CX_HIP(hipMemsetAsync(d_tl, 0, (size_t)1024 * 32 * 8, stream));
+        if (!d_tl) CX_HIP(hipMalloc(&d_tl, (size_t)1024 * 48 * 8));
+        CX_HIP(hipMemsetAsync(d_tl, 0, (size_t)1024 * 48 * 8, stream));
         a.tl = d_tl;
         int rc = dispatch(a, grid, stream);
         if (rc) return rc;
         CX_HIP(hipStreamSynchronize(stream));
-        std::vector<unsigned long long> h((size_t)grid * 32);
+        std::vector<unsigned long long> h((size_t)grid * 48);
         CX_HIP(hipMemcpy(h.data(), d_tl, h.size() * 8, hipMemcpyDeviceToHost));
         static int tl_calls = 0;
         if (++tl_calls % 8 == 0) {
             unsigned long long t0 = ~0ull;
-            for (uint32_t b = 0; b < grid; b++) t0 = std::min(t0, h[(size_t)b * 32]);
+            for (uint32_t b = 0; b < grid; b++) t0 = std::min(t0, h[(size_t)b * 48]);
             auto stat = [&](const char *name, int lo, int hi) {
                 std::vector<double> v;
                 for (uint32_t b = 0; b < grid; b++)
-                    for (int i = lo; i < hi; i++) if (h[(size_t)b * 32 + i]) v.push_back((double)(h[(size_t)b * 32 + i] - t0) * 0.01);
+                    for (int i = lo; i < hi; i++) if (h[(size_t)b * 48 + i]) v.push_back((double)(h[(size_t)b * 48 + i] - t0) * 0.01);
                 if (v.empty()) return;
                 std::sort(v.begin(), v.end());
                 fprintf(stderr, "  %-28s min %7.1f  p10 %7.1f  med %7.1f  p90 %7.1f  max %7.1f us\n", name, v.front(), v[v.size() / 10], v[v.size() / 2], v[v.size() * 9 / 10], v.back());
@@ -1080,27 +1136,35 @@ int launch_batchs_pass(const BatchSArgs &a_in, hipStream_t stream) {
             fprintf(stderr, "[batchs timeline] %u rows x %u, %u queries, k %u, grid %u\n", a.n_rows, a.dim, a.nq, a.k, grid);
             stat("block entry", 0, 1); stat("prologue: queries read", 30, 31); stat("prologue: norms", 31, 32); stat("prologue done", 1, 2); stat("worker: first tile done", 4, 11); stat("service: bounds in LDS", 2, 3);
             stat("service: maxima stored", 27, 28); stat("service: own queries published", 28, 29);
+            stat("service: backlog drained", 32, 33); stat("service: last refresh begins", 35, 36); stat("service: last refresh ends", 36, 37); stat("service: sees workers done", 37, 38);
+            {
+                unsigned long long hits = 0, rounds = 0, mp = 0;
+                for (uint32_t b = 0; b < grid; b++) { hits += h[(size_t)b * 48 + 33]; rounds += h[(size_t)b * 48 + 38]; mp = std::max(mp, h[(size_t)b * 48 + 39]); }
+                unsigned long long kept = 0;
+                for (uint32_t b = 0; b < grid; b++) kept += h[(size_t)b * 48 + 34];
+                fprintf(stderr, "  service waves: %llu hits taken from the rings (%.0f per block), %llu kept under the bounds of the moment, %.0f loop rounds per block, largest backlog %llu\n", hits, (double)hits / grid, kept, (double)rounds / grid, mp);
+            }
             stat("worker 0: past the wait", 26, 27); stat("worker 0: second tile done", 25, 26); stat("worker exit", 11, 18); stat("service exit", 3, 4);
             std::vector<unsigned long long> nt;
-            for (uint32_t b = 0; b < grid; b++) for (int i = 18; i < 25; i++) nt.push_back(h[(size_t)b * 32 + i]);
+            for (uint32_t b = 0; b < grid; b++) for (int i = 18; i < 25; i++) nt.push_back(h[(size_t)b * 48 + i]);
             std::sort(nt.begin(), nt.end());
             fprintf(stderr, "  tiles per worker: min %llu med %llu max %llu\n", nt.front(), nt[nt.size() / 2], nt.back());
             for (int w = 0; w < 7; w++) {   // by worker index: tiles done (mean / min / max over the blocks), mean exit time
                 double st = 0, se = 0; unsigned long long mn = ~0ull, mx = 0;
-                for (uint32_t b = 0; b < grid; b++) { const unsigned long long t = h[(size_t)b * 32 + 18 + w]; st += (double)t; mn = std::min(mn, t); mx = std::max(mx, t); se += (double)(h[(size_t)b * 32 + 11 + w] - t0) * 0.01; }
+                for (uint32_t b = 0; b < grid; b++) { const unsigned long long t = h[(size_t)b * 48 + 18 + w]; st += (double)t; mn = std::min(mn, t); mx = std::max(mx, t); se += (double)(h[(size_t)b * 48 + 11 + w] - t0) * 0.01; }
                 fprintf(stderr, "  worker %d: tiles mean %.1f min %llu max %llu, exit mean %.1f us\n", w, st / grid, mn, mx, se / grid);
             }
             for (int x = 0; x < 8; x++) {   // by XCD (block index mod 8): tiles per block, exit of the last worker
                 double st = 0, se = 0; int nb = 0;
-                for (uint32_t b = x; b < grid; b += 8) { unsigned long long t = 0, e = 0; for (int w = 0; w < 7; w++) { t += h[(size_t)b * 32 + 18 + w]; e = std::max(e, h[(size_t)b * 32 + 11 + w]); } st += (double)t; se += (double)(e - t0) * 0.01; nb++; }
+                for (uint32_t b = x; b < grid; b += 8) { unsigned long long t = 0, e = 0; for (int w = 0; w < 7; w++) { t += h[(size_t)b * 48 + 18 + w]; e = std::max(e, h[(size_t)b * 48 + 11 + w]); } st += (double)t; se += (double)(e - t0) * 0.01; nb++; }
                 fprintf(stderr, "  blocks = %d mod 8: tiles per block mean %.1f, last worker's exit mean %.1f us\n", x, st / nb, se / nb);
             }
             std::vector<unsigned long long> sp;
-            for (uint32_t b = 0; b < grid; b++) sp.push_back(h[(size_t)b * 32 + 29]);
+            for (uint32_t b = 0; b < grid; b++) sp.push_back(h[(size_t)b * 48 + 29]);
             std::sort(sp.begin(), sp.end());
             fprintf(stderr, "  warm-up polls per block: min %llu med %llu max %llu\n", sp.front(), sp[sp.size() / 2], sp.back());
             for (uint32_t b : {0u, 1u, 63u, 64u, 128u, 255u}) if (b < grid)
-                fprintf(stderr, "  block %3u: stored %.1f published %.1f ready %.1f polls %llu\n", b, (double)(h[(size_t)b * 32 + 27] - t0) * 0.01, h[(size_t)b * 32 + 28] ? (double)(h[(size_t)b * 32 + 28] - t0) * 0.01 : -1.0, (double)(h[(size_t)b * 32 + 2] - t0) * 0.01, h[(size_t)b * 32 + 29]);
+                fprintf(stderr, "  block %3u: stored %.1f published %.1f ready %.1f polls %llu\n", b, (double)(h[(size_t)b * 48 + 27] - t0) * 0.01, h[(size_t)b * 48 + 28] ? (double)(h[(size_t)b * 48 + 28] - t0) * 0.01 : -1.0, (double)(h[(size_t)b * 48 + 2] - t0) * 0.01, h[(size_t)b * 48 + 29]);
         }
         return CX_OK;
     }
