@@ -599,11 +599,31 @@ def config4_leg(L, device: int, dev, n: int = 1_250_000, d: int = 768, k: int = 
     el = time.perf_counter() - t0
     ix.profile_enable(False)
     kern_ms, kern_n = ix.profile_read(reset=True)
+    # the same shard the way a rank of the sharded search runs it (ShardedKnn.submit, world = 1 here: no all-gather): a stream of
+    # batches on rotating HIP streams, each batch's re-score / selection and the next one's pass free to overlap — `frac_step`
+    # above is ONE stream, every kernel of a step behind the previous one
+    from cortex_amd.sharded import ShardedKnn, hip_local_fn
+    knn = ShardedKnn(0, 1, [0], B, k, dev, hip_local_fn(ix))
+    for i in range(8):
+        knn.submit(qs.data_ptr() + ((i * B) % (256 - B + 1)) * d * 4)
+    knn.flush()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        knn.submit(qs.data_ptr() + ((i * B) % (256 - B + 1)) * d * 4)
+    knn.flush()
+    torch.cuda.synchronize()
+    el_s = time.perf_counter() - t0
     ix.close()
     avg = kern_ms / max(1, kern_n)
+    roof = batch_roofline(n, d, 2.0 if dtype == "bf16" else 4.0, avg, el / steps, kern_n)
+    roof["frac_step_stream_of_batches"] = roof["algorithmic_bytes_per_launch"] / (el_s / steps) / 1e9 / HBM_PEAK_GBS
+    roof["frac_note"] += ("; frac_step_stream_of_batches: the same bytes over a step of a STREAM of batches on rotating HIP streams "
+                          "(ShardedKnn.submit: what a rank of the sharded search runs)")
     return {"workload": f"cosine kNN k={k}, batch of {B} queries per step, {n} x {d} {dtype} rows ({shard_note})",
             "queries_per_s": steps * B / el, "ms_per_step": el / steps * 1e3,
-            "roofline": batch_roofline(n, d, 2.0 if dtype == "bf16" else 4.0, avg, el / steps, kern_n)}
+            "stream_of_batches": {"queries_per_s": steps * B / el_s, "ms_per_step": el_s / steps * 1e3},
+            "roofline": roof}
 
 
 def config4_sharded_leg(L, device: int, dev, rank: int, world: int, total: int = 10_000_000, d: int = 768, k: int = 10,
@@ -942,6 +962,24 @@ def autolink_leg(L, device: int, d: int, skip_cpu: bool, n: int = 100_000, thr: 
         "roofline": mfma_roofline(flops, prof2, ph2[1]),
     }
     del fr, to, w
+    # the same pass with the scanned nodes given as a LIST (a cycle's batch in the order the storage returns it; the sharded pass's
+    # external-query blocks take the same route): the rows' shadow pieces are gathered into a staged panel and the persistent kernel
+    # runs on it (round 3: pair_filter256_kernel for every list).  No symmetry credit here: every ordered pair's tile is computed.
+    perm = np.random.default_rng(9).permutation(n).astype(np.uint32)
+    best3 = None
+    for rep in range(4):
+        t0 = time.perf_counter()
+        ne3, ph3 = ix.autolink_pass_timed(100, thr32, 50, perm)
+        wall3 = time.perf_counter() - t0
+        if rep and (best3 is None or wall3 < best3[0]):
+            best3 = (wall3, ph3, ne3, ix.autolink_filter_profile())
+    wall3, ph3, ne3, prof3 = best3
+    res["row_list_scan"] = {
+        "mode": f"all {n} rows scanned as a shuffled LIST (staged I panel + cx::pair_filter_p_kernel; no symmetry: 2 N^2 d flops executed)",
+        "pairs_per_s": n * float(n) / wall3, "wall_ms": wall3 * 1e3, "edges": int(ne3),
+        "phase_ms": {"shadow_refresh": ph3[0], "mfma_filter_gemm": ph3[1], "exact_rescore": ph3[2], "link_rules": ph3[3]},
+        "roofline": mfma_roofline(flops, prof3, ph3[1]),
+    }
     # the ordered top-100 neighbour lists of every row (SURVEY a14': what the linker needs when the reference's legacy
     # structural rules are on — its default): the batched search in its wide mode over the same corpus, host API
     ix.topk_lists_rows(100, np.arange(2048, dtype=np.uint32))

@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcortex_hip.so")
 
 
 def build(force: bool = False, jobs: int = 8) -> str:
-    cmd = ["make", "-C", CSRC, f"-j{jobs}"]
+    cmd = ["make", "-C", CSRC, f"-j{jobs}", "all"]   # the product library + the tests' fault-injection build of it
     if force:
         cmd.append("-B")
     subprocess.check_call(cmd)

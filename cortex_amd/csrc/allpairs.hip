@@ -146,43 +146,58 @@ __global__ __launch_bounds__(256) void irr_now_kernel(const S *rows, uint32_t di
     ss = wave_sum(ss);
     if (lane == 0u) irr_ok[e] = (r < n_rows && !bs_regular(ss)) ? 1u : 0u;
 }
-// ext_vecs: the scanned vectors are not rows of this shard ([n_scan][dim] f32: the sharded pass's external blocks) — "is the scanned
-// vector itself irregular" is then decided from the vector (its own shadow was built zero just the same)
-__global__ __launch_bounds__(256) void irr_append_kernel(const uint32_t *irr_rows, const uint32_t *irr_ok, uint32_t irr_n, const uint32_t *scan_rows, const float *ext_vecs,
-                                                         uint32_t dim, uint32_t n_scan, uint32_t *cand_cnt, uint32_t *cand, uint32_t cap) {
+// irr_append_kernel: the irregular rows behind every scanned row's candidates (a list that runs over its cap with them is redone on
+// the exact path like any other).  irr_mark_kernel, AFTER the rescore (which writes every row's overflow flag itself): the scanned
+// vectors that are irregular THEMSELVES are flagged as run over — a flag, not a count: the entries of a list are only ever the ones a
+// kernel wrote.  ext_vecs: the scanned vectors are not rows of this shard ([n_scan][dim] f32: the sharded pass's external blocks) —
+// "is the scanned vector irregular" is then decided from the vector (its own shadow was built zero just the same).
+__global__ __launch_bounds__(256) void irr_append_kernel(const uint32_t *irr_rows, const uint32_t *irr_ok, uint32_t irr_n, uint32_t n_scan,
+                                                         uint32_t *cand_cnt, uint32_t *cand, uint32_t cap) {
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
     if (i >= n_scan) return;
-    const uint32_t me = ext_vecs ? 0xFFFFFFFFu : (scan_rows ? scan_rows[i] : i);
     const uint32_t cnt = cand_cnt[i];
     uint32_t n_ok = 0;
+    for (uint32_t e0 = 0; e0 < irr_n; e0 += 64u) {
+        const uint32_t e = e0 + lane;
+        const bool ok = e < irr_n && irr_ok[e] != 0u;
+        const uint32_t r = ok ? irr_rows[e] : 0u;
+        const uint64_t m = __ballot(ok);
+        const uint32_t pos = cnt + n_ok + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (ok && pos < cap) cand[(size_t)i * cap + pos] = r;   // (the row itself included: the rules drop self pairs like any other)
+        n_ok += (uint32_t)__popcll(m);
+    }
+    if (lane == 0u && n_ok) cand_cnt[i] = cnt + n_ok;
+}
+__global__ __launch_bounds__(256) void irr_mark_kernel(const uint32_t *irr_rows, const uint32_t *irr_ok, uint32_t irr_n, const uint32_t *scan_rows, const float *ext_vecs,
+                                                       uint32_t dim, uint32_t n_scan, uint32_t *overflow) {
+    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    if (i >= n_scan) return;
     bool self = false;
     if (ext_vecs) {
 #pragma clang fp contract(off)
         float ss = 0.0f;
         for (uint32_t j = lane; j < dim; j += 64u) { const float x = ext_vecs[(size_t)i * dim + j]; ss += x * x; }
         self = !bs_regular(wave_sum(ss));
-    }
-    for (uint32_t e0 = 0; e0 < irr_n; e0 += 64u) {
-        const uint32_t e = e0 + lane;
-        const bool ok = e < irr_n && irr_ok[e] != 0u;
-        const uint32_t r = ok ? irr_rows[e] : 0u;
-        self = self || (ok && r == me);
-        const uint64_t m = __ballot(ok);
-        const uint32_t pos = cnt + n_ok + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (ok && pos < cap) cand[(size_t)i * cap + pos] = r;   // (the row itself included: the rescore drops self pairs like any other)
-        n_ok += (uint32_t)__popcll(m);
+    } else {
+        const uint32_t me = scan_rows ? scan_rows[i] : i;
+        for (uint32_t e = lane; e < irr_n; e += 64u) self = self || (irr_ok[e] != 0u && irr_rows[e] == me);
     }
     const bool any_self = __ballot(self) != 0ull;
-    if (lane == 0u) cand_cnt[i] = any_self ? 0x7FFFFFFFu : cnt + n_ok;
+    if (lane == 0u && any_self) overflow[i] = 1u;
 }
 int launch_irr_append(const float *rows, const uint16_t *rows16, uint32_t dim, uint32_t n_rows, const uint32_t *irr_rows, uint32_t irr_n, uint32_t *irr_ok,
-                      const uint32_t *scan_rows, const float *ext_vecs, uint32_t n_scan, uint32_t *cand_cnt, uint32_t *cand, uint32_t cap, hipStream_t stream) {
+                      uint32_t n_scan, uint32_t *cand_cnt, uint32_t *cand, uint32_t cap, hipStream_t stream) {
+    if (!n_scan || !irr_n) return CX_OK;
+    if (rows16) hipLaunchKernelGGL(irr_now_kernel<uint16_t>, dim3((irr_n + 3u) / 4u), dim3(256), 0, stream, rows16, dim, n_rows, irr_rows, irr_n, irr_ok);
+    else hipLaunchKernelGGL(irr_now_kernel<float>, dim3((irr_n + 3u) / 4u), dim3(256), 0, stream, rows, dim, n_rows, irr_rows, irr_n, irr_ok);
+    hipLaunchKernelGGL(irr_append_kernel, dim3((n_scan + 3u) / 4u), dim3(256), 0, stream, irr_rows, irr_ok, irr_n, n_scan, cand_cnt, cand, cap);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+}
+int launch_irr_mark(const uint32_t *irr_rows, const uint32_t *irr_ok, uint32_t irr_n, const uint32_t *scan_rows, const float *ext_vecs, uint32_t dim, uint32_t n_scan,
+                    uint32_t *overflow, hipStream_t stream) {
     if (!n_scan || (!irr_n && !ext_vecs)) return CX_OK;
-    if (irr_n) {
-        if (rows16) hipLaunchKernelGGL(irr_now_kernel<uint16_t>, dim3((irr_n + 3u) / 4u), dim3(256), 0, stream, rows16, dim, n_rows, irr_rows, irr_n, irr_ok);
-        else hipLaunchKernelGGL(irr_now_kernel<float>, dim3((irr_n + 3u) / 4u), dim3(256), 0, stream, rows, dim, n_rows, irr_rows, irr_n, irr_ok);
-    }
-    hipLaunchKernelGGL(irr_append_kernel, dim3((n_scan + 3u) / 4u), dim3(256), 0, stream, irr_rows, irr_ok, irr_n, scan_rows, ext_vecs, dim, n_scan, cand_cnt, cand, cap);
+    hipLaunchKernelGGL(irr_mark_kernel, dim3((n_scan + 3u) / 4u), dim3(256), 0, stream, irr_rows, irr_ok, irr_n, scan_rows, ext_vecs, dim, n_scan, overflow);
     CX_HIP(hipGetLastError());
     return CX_OK;
 }

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(pp::Cfg<BM>::WAVES * 64, 2) void pair_filter_p_kern
         d.i0 = ti * BM;
         d.j0 = tj * BN;
         // the tiled shadow is padded to whole 256-row tiles (ensure_shadow): no clamping of the last panel
-        d.A = reinterpret_cast<const char *>(a.shadow_t) + (size_t)(scan_blk0 + d.i0 / 16u + wave * NDA) * KT * 1024u;
+        d.A = reinterpret_cast<const char *>(a.shadow_i ? a.shadow_i : a.shadow_t) + (size_t)(scan_blk0 + d.i0 / 16u + wave * NDA) * KT * 1024u;
         d.B = reinterpret_cast<const char *>(a.shadow_t) + (size_t)(d.j0 / 16u + wave * NDB) * KT * 1024u;
         return d;
     };
@@ -548,10 +548,37 @@ __global__ __launch_bounds__(256) void pair_scatter_kernel(const uint64_t *pairs
 }
 
 bool pair_filter_p_supported(const PairFilterArgs &a) {
-    // a contiguous range of the shard's rows scanned in order from the tiled shadow; >= 12 K-steps (the hooks of a tile sit
-    // behind its steps 1, 3, 5 and 7)
-    return a.shadow_t && !a.shadow_q && (!a.scan_rows || a.scan_contig) && (uint64_t)a.scan_lo + a.n_scan <= a.n_rows && a.dim % 64u == 0 &&
-           a.dim >= 384u && a.pairs && a.pair_ctl && a.pair_cap;
+    // the scanned vectors as tiled shadow rows in order — a run of the shard's own rows, or a staged panel (shadow_i) —; >= 12 K-steps
+    // (the hooks of a tile sit behind its steps 1, 3, 5 and 7)
+    const bool own = !a.shadow_i && (!a.scan_rows || a.scan_contig) && (uint64_t)a.scan_lo + a.n_scan <= a.n_rows;
+    const bool staged = a.shadow_i && a.scan_lo == 0u && a.scan_contig && !a.symmetric;
+    return a.shadow_t && !a.shadow_q && (own || staged) && a.dim % 64u == 0 && a.dim >= 384u && a.pairs && a.pair_ctl && a.pair_cap;
+}
+
+// A list of scanned rows as a staged I panel: one 16-byte piece per thread, copied from the row's place in the tiled shadow to
+// position i's; the pieces of a K-step are XOR-permuted with bits 3-4 of the row they sit at, so a piece changes its slot when
+// (row >> 3) & 3 differs between source and destination — tiled_shadow_off on both sides.  Rows n_scan .. n_pad are zero.
+__global__ __launch_bounds__(256) void stage_scan_rows_kernel(const uint16_t *shadow_t, const uint32_t *scan_rows, uint32_t n_scan, uint32_t n_pad, uint32_t dim,
+                                                              uint16_t *out) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t pieces = dim / 8u, kt32 = dim / 32u;
+    const uint64_t total = (uint64_t)n_pad * pieces;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t i = (uint32_t)(t / pieces), p = (uint32_t)(t % pieces);
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (i < n_scan) v = *reinterpret_cast<const u32x4 *>(shadow_t + tiled_shadow_off(scan_rows[i], p, kt32));
+        *reinterpret_cast<u32x4 *>(out + tiled_shadow_off(i, p, kt32)) = v;
+    }
+}
+int launch_stage_scan_rows(const uint16_t *shadow_t, const uint32_t *d_scan_rows, uint32_t n_scan, uint32_t dim, uint16_t *out, hipStream_t stream) {
+    if (!n_scan) return CX_OK;
+    if (dim % 32u) return set_err(CX_ERR_VALIDATION, "staged scan rows need dim %% 32 == 0 (got %u)", dim);
+    const uint32_t n_pad = (n_scan + 255u) / 256u * 256u;
+    const uint64_t total = (uint64_t)n_pad * (dim / 8u);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255u) / 256u, 16384u);
+    hipLaunchKernelGGL(stage_scan_rows_kernel, dim3(grid), dim3(256), 0, stream, shadow_t, d_scan_rows, n_scan, n_pad, dim, out);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
 }
 
 template <int BM, bool DYN, bool DIAG = false, int ARM = 0>

@@ -89,10 +89,15 @@ namespace {
 struct RedoScratch {   // exact-path redo of a pass: gathered vectors and their contiguous lists
     float *d_vec = nullptr, *d_scores = nullptr, *d_dists = nullptr;
     uint32_t *d_src = nullptr, *d_pos = nullptr, *d_rows = nullptr, *d_cnt = nullptr, *d_rows2 = nullptr, *d_cnt2 = nullptr, *d_of = nullptr;
+    uint64_t *d_src_off = nullptr;                                     // the dedup pass's dense rows: their pairs staged for the splice
+    uint32_t *d_from_row = nullptr, *d_to_h = nullptr;
+    float *d_w_h = nullptr;
     size_t c_vec = 0, c_scores = 0, c_dists = 0, c_src = 0, c_pos = 0, c_rows = 0, c_cnt = 0, c_rows2 = 0, c_cnt2 = 0, c_of = 0;
+    size_t c_src_off = 0, c_from_row = 0, c_to_h = 0, c_w_h = 0;
     ~RedoScratch() {
         (void)hipFree(d_vec); (void)hipFree(d_scores); (void)hipFree(d_dists); (void)hipFree(d_src); (void)hipFree(d_pos);
         (void)hipFree(d_rows); (void)hipFree(d_cnt); (void)hipFree(d_rows2); (void)hipFree(d_cnt2); (void)hipFree(d_of);
+        (void)hipFree(d_src_off); (void)hipFree(d_from_row); (void)hipFree(d_to_h); (void)hipFree(d_w_h);
     }
 };
 
@@ -106,7 +111,8 @@ struct PassScratch {
     uint64_t *d_pairs = nullptr;       // persistent filter kernel: hits as (i | j << 32) pairs, before pair_scatter_kernel
     uint32_t *d_pair_ctl = nullptr;    // [16]: pairs written, pairs lost, per-XCD tile tickets
     uint32_t *d_irr_ok = nullptr;      // [BS_IRR_CAP]: which of the index's irregular rows are irregular now (launch_irr_append)
-    size_t c_pairs = 0, c_pair_ctl = 0, c_irr_ok = 0;
+    uint16_t *d_stage_t = nullptr;     // persistent filter kernel: the scanned vectors of a row LIST / an external block as a staged I panel (tiled layout)
+    size_t c_pairs = 0, c_pair_ctl = 0, c_irr_ok = 0, c_stage_t = 0;
     uint64_t *d_offsets = nullptr, *d_exist_off = nullptr;
     uint32_t *d_exist_to = nullptr;
     size_t c_exist_off = 0, c_exist_to = 0;
@@ -122,7 +128,7 @@ struct PassScratch {
         (void)hipFree(d_list_rows); (void)hipFree(d_list_cnt); (void)hipFree(d_counts); (void)hipFree(d_ident);
         (void)hipFree(d_list_scores); (void)hipFree(d_list_dists); (void)hipFree(d_offsets); (void)hipFree(d_pair_sims);
         (void)hipFree(d_deleted); (void)hipFree(d_temp); (void)hipFree(d_from); (void)hipFree(d_to); (void)hipFree(d_w);
-        (void)hipFree(d_exist_off); (void)hipFree(d_exist_to); (void)hipFree(d_pairs); (void)hipFree(d_pair_ctl); (void)hipFree(d_irr_ok);
+        (void)hipFree(d_exist_off); (void)hipFree(d_exist_to); (void)hipFree(d_pairs); (void)hipFree(d_pair_ctl); (void)hipFree(d_irr_ok); (void)hipFree(d_stage_t);
         if (ev_k0) (void)hipEventDestroy(ev_k0);
         if (ev_k1) (void)hipEventDestroy(ev_k1);
     }
@@ -297,7 +303,7 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
         if (int rc = ensure_dev(ps.d_cand, ps.c_cand, (size_t)chunk * cap)) return rc;
         // phases are timed over all chunks: filter launches first would need all scratch at once, so
         // filter+rescore alternate per chunk and the two event pairs bracket their sums approximately
-        bool used_persist = false;
+        bool used_persist = false, used_stream = false;
         uint32_t pairs_lost = 0;
         int filter_kind = 2;
         uint64_t filter_tiles = 0;
@@ -341,7 +347,24 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
                 if (scan_rows) {
                     bool run = true;
                     for (uint32_t i = 1; i < m && run; i++) run = scan_rows[lo + i] == scan_rows[lo] + i;
-                    if (run) { f.scan_lo = scan_rows[lo]; f.scan_contig = 1; }
+                    static const int stage_ok = getenv("CX_PAIR_P_STAGE") ? atoi(getenv("CX_PAIR_P_STAGE")) : 1;
+                    // (a run that starts k rows past a 32-row boundary is tiled from that boundary: 500 rows + k > 512 take a THIRD
+                    // 256-row panel — config 5's 500-row ticks alternated between 5.5 and 7.5 ms with their start row; staged, a
+                    // run always starts at row 0 of its panel)
+                    const bool run_spills = run && (m + scan_rows[lo] % 32u + 255u) / 256u > (m + 255u) / 256u;
+                    if (run && !(run_spills && stage_ok && ix->d_shadow_t)) {
+                        f.scan_lo = scan_rows[lo];
+                        f.scan_contig = 1;
+                    } else if (stage_ok && ix->d_shadow_t) {
+                        // a LIST of rows (a cycle's batch of nodes, a subset dedup): their shadow pieces gathered into a staged I panel
+                        // (m x dim x 2 bytes copied once: 0.05 ms at 100k x 768 against a 6 ms GEMM) — the same kernel as a range
+                        const size_t words = (size_t)((m + 255u) / 256u) * 256u * ix->dim;
+                        if (int rc = ensure_dev(ps.d_stage_t, ps.c_stage_t, words)) return rc;
+                        if (int rc = launch_stage_scan_rows(ix->d_shadow_t, f.scan_rows, m, ix->dim, ps.d_stage_t, s)) return rc;
+                        f.shadow_i = ps.d_stage_t;
+                        f.scan_lo = 0;
+                        f.scan_contig = 1;
+                    }
                 } else {
                     f.scan_lo = lo;
                     f.scan_contig = 1;   // (a later chunk's materialised identity rows are exactly this range)
@@ -383,9 +406,11 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
                 f.ev_end = ps.ev_k1;
             }
             if (!big && stream_ok && pair_filter_stream_supported(f)) {
-                if (int rc = ensure_dev(ps.d_pair_ctl, ps.c_pair_ctl, (size_t)32)) return rc;   // (a word of it: the tile counter of the pass on large shards)
+                if (int rc = ensure_dev(ps.d_pair_ctl, ps.c_pair_ctl, (size_t)32)) return rc;   // (two words of it: the tile counter and the give-up flag of the pass on large shards)
+                CX_HIP(hipMemsetAsync(ps.d_pair_ctl + 24, 0, 8, s));
                 f.pair_ctl = ps.d_pair_ctl;
                 if (int rc = launch_pair_filter_stream(f, s)) return rc;
+                used_stream = true;
                 filter_kind = 2;
             } else if (persist) {
                 if (int rc = launch_pair_filter_p(f, s)) return rc;
@@ -422,13 +447,15 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
             const bool irr = ix->irr_n > 0 && f.thr_lo > 0.0f;
             if (irr) {
                 if (int rc = ensure_dev(ps.d_irr_ok, ps.c_irr_ok, (size_t)BS_IRR_CAP)) return rc;
-                if (int rc = launch_irr_append(ix->rows32(), ix->rows16(), ix->dim, n_rows, ix->d_irr_rows, ix->irr_n, ps.d_irr_ok, f.scan_rows, nullptr, m, ps.d_cand_cnt, ps.d_cand, cap, s)) return rc;
+                if (int rc = launch_irr_append(ix->rows32(), ix->rows16(), ix->dim, n_rows, ix->d_irr_rows, ix->irr_n, ps.d_irr_ok, m, ps.d_cand_cnt, ps.d_cand, cap, s)) return rc;
             }
             if (f.symmetric && sym_rescore && !irr) {   // every list of the store is present: each pair is scored once (allpairs.hip)
                 if (int rc = ensure_dev(ps.d_pair_sims, ps.c_pair_sims, (size_t)m * cap)) return rc;
                 r.pair_sims = ps.d_pair_sims;
             }
             if (int rc = launch_rescore(r, s)) return rc;
+            if (irr)
+                if (int rc = launch_irr_mark(ix->d_irr_rows, ps.d_irr_ok, ix->irr_n, f.scan_rows, nullptr, ix->dim, m, ps.d_overflow + lo, s)) return rc;
             if (used_persist && n_scan > chunk) {   // the control words are reused by the next chunk
                 uint32_t lost = 0;
                 CX_HIP(hipMemcpyAsync(&lost, ps.d_pair_ctl + 1, 4, hipMemcpyDeviceToHost, s));
@@ -446,7 +473,10 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
         std::vector<uint32_t> of(n_scan);
         CX_HIP(hipMemcpyAsync(of.data(), ps.d_overflow, (size_t)n_scan * 4, hipMemcpyDeviceToHost, s));
         if (used_persist && n_scan <= chunk) CX_HIP(hipMemcpyAsync(&pairs_lost, ps.d_pair_ctl + 1, 4, hipMemcpyDeviceToHost, s));
+        uint32_t stream_gave_up = 0;   // (batchs.hip's threshold mode: a worker dropped hits — every scanned row goes down the exact path)
+        if (used_stream) CX_HIP(hipMemcpyAsync(&stream_gave_up, ps.d_pair_ctl + 25, 4, hipMemcpyDeviceToHost, s));
         CX_HIP(hipStreamSynchronize(s));
+        if (stream_gave_up) std::fill(of.begin(), of.end(), 1u);
         if (pairs_lost) {   // more hits than the pair buffer holds (a threshold far below the data's): the per-row path has no such limit
             if (phase_ms) for (auto &e : ev) (void)hipEventDestroy(e);
             CycleInputs again = cyc;
@@ -605,23 +635,20 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
             RedoScratch &rs = ps.redo;
             std::vector<uint32_t> from_row(dense.size());
             for (size_t t = 0; t < dense.size(); t++) from_row[t] = scan_rows ? scan_rows[dense[t]] : dense[t];
-            uint64_t *d_src_off = nullptr;
-            uint32_t *d_to_h = nullptr, *d_from_row = nullptr;
-            float *d_w_h = nullptr;
-            CX_HIP(hipMalloc((void **)&d_src_off, (dense.size() + 1) * 8));
-            CX_HIP(hipMalloc((void **)&d_from_row, dense.size() * 4));
-            CX_HIP(hipMalloc((void **)&d_to_h, dense_to.size() * 4));
-            CX_HIP(hipMalloc((void **)&d_w_h, dense_w.size() * 4));
-            hipError_t e1 = hipMemcpyAsync(d_src_off, dense_src_off.data(), (dense.size() + 1) * 8, hipMemcpyHostToDevice, s);
-            hipError_t e2 = hipMemcpyAsync(d_from_row, from_row.data(), dense.size() * 4, hipMemcpyHostToDevice, s);
-            hipError_t e3 = hipMemcpyAsync(d_to_h, dense_to.data(), dense_to.size() * 4, hipMemcpyHostToDevice, s);
-            hipError_t e4 = hipMemcpyAsync(d_w_h, dense_w.data(), dense_w.size() * 4, hipMemcpyHostToDevice, s);
+            // (grow-only scratch of the pooled context: nothing to leak on an early return, no allocation per dense pass)
+            if (int rc = ensure_dev(rs.d_src_off, rs.c_src_off, dense.size() + 1)) return rc;
+            if (int rc = ensure_dev(rs.d_from_row, rs.c_from_row, dense.size())) return rc;
+            if (int rc = ensure_dev(rs.d_to_h, rs.c_to_h, dense_to.size())) return rc;
+            if (int rc = ensure_dev(rs.d_w_h, rs.c_w_h, dense_w.size())) return rc;
+            hipError_t e1 = hipMemcpyAsync(rs.d_src_off, dense_src_off.data(), (dense.size() + 1) * 8, hipMemcpyHostToDevice, s);
+            hipError_t e2 = hipMemcpyAsync(rs.d_from_row, from_row.data(), dense.size() * 4, hipMemcpyHostToDevice, s);
+            hipError_t e3 = hipMemcpyAsync(rs.d_to_h, dense_to.data(), dense_to.size() * 4, hipMemcpyHostToDevice, s);
+            hipError_t e4 = hipMemcpyAsync(rs.d_w_h, dense_w.data(), dense_w.size() * 4, hipMemcpyHostToDevice, s);
             int rc = (e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess && e4 == hipSuccess)
-                         ? launch_copy_edge_segments(ps.d_offsets, rs.d_pos, d_src_off, d_from_row, d_to_h, d_w_h, (uint32_t)dense.size(), ps.d_from,
+                         ? launch_copy_edge_segments(ps.d_offsets, rs.d_pos, rs.d_src_off, rs.d_from_row, rs.d_to_h, rs.d_w_h, (uint32_t)dense.size(), ps.d_from,
                                                      ps.d_to, ps.d_w, s)
                          : set_err(CX_ERR_DEVICE, "dedup: staging the dense rows' pairs failed");
-            (void)hipStreamSynchronize(s);
-            (void)hipFree(d_src_off); (void)hipFree(d_from_row); (void)hipFree(d_to_h); (void)hipFree(d_w_h);
+            (void)hipStreamSynchronize(s);   // (the host vectors staged above go out of scope)
             if (rc) return rc;
         }
     }
@@ -804,14 +831,48 @@ int cx_autolink_lists_dev(const cx_index *ix, uint64_t nq64, const float *d_quer
         f.cap = cap;
         static const int big_min = getenv("CX_PAIR_256_MIN") ? atoi(getenv("CX_PAIR_256_MIN")) : 129;
         static const int stream_ok = getenv("CX_PAIR_STREAM") ? atoi(getenv("CX_PAIR_STREAM")) : 1;
-        if ((int64_t)nq < big_min && stream_ok && pair_filter_stream_supported(f)) {
+        static const int stage_ok = getenv("CX_PAIR_P_STAGE") ? atoi(getenv("CX_PAIR_P_STAGE")) : 1;
+        const int persist_ok = getenv("CX_PAIR_PERSIST") ? atoi(getenv("CX_PAIR_PERSIST")) : 1;
+        bool done = false, used_stream = false;
+        if ((int64_t)nq >= big_min && stage_ok && persist_ok && ix->d_shadow_t) {
+            // a block of external vectors (the sharded pass's Q blocks): their shadow built straight into a staged I panel in the
+            // tiled layout, then the persistent kernel — the single-GPU pass's own (round 3: pair_filter256_kernel, 15 % slower)
+            PairFilterArgs g = f;
+            const uint32_t n_pad = (nq + 255u) / 256u * 256u;
+            if (int rc = ensure_dev(ps.d_stage_t, ps.c_stage_t, (size_t)n_pad * ix->dim)) return rc;
+            CX_HIP(hipMemsetAsync(ps.d_stage_t, 0, (size_t)n_pad * ix->dim * sizeof(uint16_t), s));
+            if (int rc = launch_build_shadow_index(d_queries, nullptr, ps.d_stage_t, true, 0, nq, ix->dim, s, nullptr, nullptr, nullptr, 0)) return rc;
+            const size_t pair_cap = (size_t)std::min<uint64_t>((uint64_t)nq * cap / 2u, 128ull << 20);
+            if (int rc = ensure_dev(ps.d_pairs, ps.c_pairs, pair_cap)) return rc;
             if (int rc = ensure_dev(ps.d_pair_ctl, ps.c_pair_ctl, (size_t)32)) return rc;
+            g.shadow_q = nullptr;
+            g.shadow_i = ps.d_stage_t;
+            g.scan_lo = 0;
+            g.scan_contig = 1;
+            g.pairs = ps.d_pairs;
+            g.pair_ctl = ps.d_pair_ctl;
+            g.pair_cap = (uint32_t)pair_cap;
+            g.block_rows = pair_filter_p_block_rows();
+            if (pair_filter_p_supported(g)) {
+                if (int rc = launch_pair_filter_p(g, s)) return rc;
+                uint32_t lost = 0;
+                CX_HIP(hipMemcpyAsync(&lost, ps.d_pair_ctl + 1, 4, hipMemcpyDeviceToHost, s));
+                CX_HIP(hipStreamSynchronize(s));
+                if (lost) CX_HIP(hipMemsetAsync(ps.d_cand_cnt, 0, (size_t)nq * 4, s));   // more hits than the pair buffer holds: the per-row kernel below has no such limit
+                else done = true;
+            }
+        }
+        if (done) {
+        } else if ((int64_t)nq < big_min && stream_ok && pair_filter_stream_supported(f)) {
+            if (int rc = ensure_dev(ps.d_pair_ctl, ps.c_pair_ctl, (size_t)32)) return rc;
+            CX_HIP(hipMemsetAsync(ps.d_pair_ctl + 24, 0, 8, s));
             f.pair_ctl = ps.d_pair_ctl;
             if (int rc = launch_pair_filter_stream(f, s)) return rc;
+            used_stream = true;
         } else if (int rc = ((int64_t)nq >= big_min) ? launch_pair_filter256(f, s) : launch_pair_filter(f, s)) return rc;
         if (f.thr_lo > 0.0f) {   // irregular vectors (zero shadows) go down the exact path, the shard's irregular rows join every other list
             if (int rc = ensure_dev(ps.d_irr_ok, ps.c_irr_ok, (size_t)BS_IRR_CAP)) return rc;
-            if (int rc = launch_irr_append(ix->rows32(), ix->rows16(), ix->dim, n_rows, ix->d_irr_rows, ix->irr_n, ps.d_irr_ok, nullptr, d_queries, nq, ps.d_cand_cnt, ps.d_cand, cap, s)) return rc;
+            if (int rc = launch_irr_append(ix->rows32(), ix->rows16(), ix->dim, n_rows, ix->d_irr_rows, ix->irr_n, ps.d_irr_ok, nq, ps.d_cand_cnt, ps.d_cand, cap, s)) return rc;
         }
         RescoreArgs r;
         memset(&r, 0, sizeof r);
@@ -832,11 +893,15 @@ int cx_autolink_lists_dev(const cx_index *ix, uint64_t nq64, const float *d_quer
         r.out_cnt = d_out_counts;
         r.overflow = ps.d_overflow;
         if (int rc = launch_rescore(r, s)) return rc;
+        if (f.thr_lo > 0.0f)
+            if (int rc = launch_irr_mark(ix->d_irr_rows, ps.d_irr_ok, ix->irr_n, nullptr, d_queries, ix->dim, nq, ps.d_overflow, s)) return rc;
         std::vector<uint32_t> of(nq);
         CX_HIP(hipMemcpyAsync(of.data(), ps.d_overflow, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+        uint32_t stream_gave_up = 0;
+        if (used_stream) CX_HIP(hipMemcpyAsync(&stream_gave_up, ps.d_pair_ctl + 25, 4, hipMemcpyDeviceToHost, s));
         CX_HIP(hipStreamSynchronize(s));
         for (uint32_t i = 0; i < nq; i++)
-            if (of[i]) redo.push_back(i);
+            if (of[i] || stream_gave_up) redo.push_back(i);
     } else {
         redo.resize(nq);
         for (uint32_t i = 0; i < nq; i++) redo[i] = i;

@@ -589,9 +589,9 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
             if (head + n - bs_lds_ld_acq(&s_ctl[BSL_TAIL + wave]) <= HB) return true;
             __builtin_amdgcn_s_sleep(8);
         }
-        if constexpr (THR) {   // (the filter pass: every scanned row's list "runs over" — the caller's exact path redoes them all)
-            if (lane < nq) __hip_atomic_fetch_max(a.thr_cand_cnt + lane, 0x7FFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (lane == 0u) __hip_atomic_store(a.ctl + BS_CTL_FAIL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (the filter pass: the word behind its tile counter — the caller reads it with the pass's other flags and sends every scanned
+        // row down the exact path; the lists' counts are left alone: a count only ever covers entries that were written)
+        if (lane == 0u) __hip_atomic_store(THR ? a.thr_next + 1 : a.ctl + BS_CTL_FAIL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return false;
     };
     // query fragments: [buffer][group]; the next K-step's are read while this one's MFMAs run
@@ -1179,7 +1179,7 @@ int launch_batchs_thr(const BatchSArgs &a_in, hipStream_t stream) {
     BatchSArgs a = a_in;
     a.k = 1;
     if (!a.thr_cand || !a.thr_cand_cnt || !a.thr_next || !a.shadow_t) return set_err(CX_ERR_VALIDATION, "batchs (threshold mode): incomplete arguments");
-    CX_HIP(hipMemsetAsync(a.thr_next, 0, sizeof(uint32_t), stream));
+    CX_HIP(hipMemsetAsync(a.thr_next, 0, 2 * sizeof(uint32_t), stream));   // the tile counter and the give-up flag behind it
     return launch_batchs_pass(a, stream);
 }
 

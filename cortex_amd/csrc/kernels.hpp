@@ -163,7 +163,8 @@ struct BatchSArgs {
     uint32_t *thr_cand_cnt;     // [n_scan], zeroed by the caller
     uint32_t *thr_cand;         // [n_scan][thr_cap]
     uint32_t thr_cap;
-    uint32_t *thr_next;         // [1] the pass's tile counter (zeroed by the launcher)
+    uint32_t *thr_next;         // [2] the pass's tile counter, and a flag a worker raises when it gave up on its hit ring (hits dropped: the caller
+                                // redoes every scanned row exactly); both zeroed by the launcher
 };
 bool batchs_supported(uint32_t dim, uint32_t k);   // dim % 128 == 0, dim <= 1024, k <= 256
 bool batchs_thr_supported(uint32_t n_rows, uint32_t dim, uint32_t n_scan);
@@ -219,11 +220,13 @@ int launch_build_shadow_index(const float *rows, const uint16_t *rows16, uint16_
                               hipStream_t stream, uint32_t *err_max, uint32_t *irr_cnt, uint32_t *irr_rows, uint32_t irr_n_before);
 int launch_build_shadow(const uint16_t *rows16, uint16_t *shadow, uint32_t row_lo, uint32_t row_hi, uint32_t dim,
                         hipStream_t stream);   // bf16 store
-// after the filter of a pass over a store with irregular rows: scanned rows that are irregular are marked as run over
-// (cand_cnt > cap: the exact path lists them), the irregular rows become candidates of every other scanned row; irr_ok: [irr_n] scratch;
-// ext_vecs: the scanned vectors themselves when they are not rows of this shard (f32 [n_scan][dim]), else null
+// a pass over a store with irregular rows.  After the filter: the irregular rows (those that still are: irr_ok, [irr_n] scratch,
+// filled here) become candidates of every scanned row.  After the rescore: scanned vectors that are irregular themselves are flagged
+// in `overflow` (the exact path lists them); ext_vecs = the scanned vectors when they are not rows of this shard (f32 [n_scan][dim])
 int launch_irr_append(const float *rows, const uint16_t *rows16, uint32_t dim, uint32_t n_rows, const uint32_t *irr_rows, uint32_t irr_n, uint32_t *irr_ok,
-                      const uint32_t *scan_rows, const float *ext_vecs, uint32_t n_scan, uint32_t *cand_cnt, uint32_t *cand, uint32_t cap, hipStream_t stream);
+                      uint32_t n_scan, uint32_t *cand_cnt, uint32_t *cand, uint32_t cap, hipStream_t stream);
+int launch_irr_mark(const uint32_t *irr_rows, const uint32_t *irr_ok, uint32_t irr_n, const uint32_t *scan_rows, const float *ext_vecs, uint32_t dim, uint32_t n_scan,
+                    uint32_t *overflow, hipStream_t stream);
 
 
 // Tiled shadow (dim % 32 == 0): [16-row block][K-step of 32 elements][16 rows x 64 B], the four 16-byte pieces of a row's
@@ -254,6 +257,9 @@ struct PairFilterArgs {
     uint32_t scan_lo;           // persistent kernel: the scanned rows are the shard's rows scan_lo .. scan_lo + n_scan in order (0 with
                                 // scan_rows == null; with scan_contig set, scan_rows[i] == scan_lo + i and the kernel ignores the array)
     uint32_t scan_contig;
+    const uint16_t *shadow_i;   // persistent kernel: the I operand when the scanned vectors are NOT a run of the shard's rows — a staged panel in the
+                                // tiled layout (scanned vector i at tiled row i, whole 256-row tiles, zero beyond n_scan: launch_stage_scan_rows /
+                                // launch_build_shadow_index); scan_lo = 0, scan_contig = 1 then.  null = the shard's own shadow_t
     uint32_t block_rows;        // persistent kernel: scanned rows per tile, 256 (default) or 128 (pair_filter_p_block_rows)
     void *ev_begin, *ev_end;    // optional hipEvent_t pair recorded around the GEMM kernel alone (256-tile and persistent kernels)
 };
@@ -265,6 +271,9 @@ int launch_pair_filter256(const PairFilterArgs &a, hipStream_t stream);
 // persistent blocks, LDS ring running through the tile boundaries, hits handed over as pairs (allpairs_p.hip); scanned
 // rows = the shard's rows in order (tiled shadow both sides), dim % 64 == 0, dim >= 384
 bool pair_filter_p_supported(const PairFilterArgs &a);
+// the scanned rows of a LIST (arbitrary rows of the shard) as a staged I panel: their shadow pieces copied out of the tiled shadow into
+// `out` (tiled layout, scanned row i at row i, n_pad = n_scan rounded up to 256 rows, zero beyond n_scan); bytes = n_pad x dim x 2
+int launch_stage_scan_rows(const uint16_t *shadow_t, const uint32_t *d_scan_rows, uint32_t n_scan, uint32_t dim, uint16_t *out, hipStream_t stream);
 uint32_t pair_filter_p_block_rows();
 void pair_filter_p_tile_list(uint32_t n_rows, uint32_t bm, std::vector<uint32_t> &out);
 int launch_pair_filter_p(const PairFilterArgs &a, hipStream_t stream);

@@ -261,10 +261,12 @@ int upsert_impl(cx_sharded *h, uint64_t n, const uint8_t *ids, const float *embs
             i++;
         }
         const uint64_t m = i - run_start;
-        static const long fail_at = getenv("CX_SHARD_FAIL_UPSERT") ? atol(getenv("CX_SHARD_FAIL_UPSERT")) : -1;   // fault injection (tests): the N-th shard append fails
+#ifdef CX_TEST_HOOKS   // fault injection, compiled into libcortex_hip_testhooks.so only (csrc/Makefile): the N-th shard append fails
+        static const long fail_at = getenv("CX_SHARD_FAIL_UPSERT") ? atol(getenv("CX_SHARD_FAIL_UPSERT")) : -1;
         static std::atomic<long> appends{0};
         if (fail_at >= 0 && appends.fetch_add(1) == fail_at) rc = set_err(CX_ERR_DEVICE, "injected failure of a shard append (CX_SHARD_FAIL_UPSERT)");
         else
+#endif
             rc = on_device ? cx_upsert_batch_dev(h->shards[s], m, ids + 16 * run_start, embs + run_start * len, len)
                            : cx_upsert_batch(h->shards[s], m, ids + 16 * run_start, embs + run_start * len, len);
         const uint64_t now = cx_row_count(h->shards[s]);

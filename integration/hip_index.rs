@@ -27,6 +27,7 @@ struct CxFilter {
 #[link(name = "cortex_hip")]
 extern "C" {
     fn cx_last_error() -> *const c_char;
+    fn cx_device_count() -> c_int;
     fn cx_create(dimension: u32, device: c_int) -> *mut c_void;
     fn cx_create_ex(dimension: u32, device: c_int, dtype: c_int) -> *mut c_void;
     fn cx_dtype(h: *const c_void) -> c_int;
@@ -515,11 +516,23 @@ impl VectorIndex for ShardedHipIndex {
         let p = std::ffi::CString::new(path.to_string_lossy().as_bytes()).map_err(|e| CortexError::Validation(e.to_string()))?;
         check(unsafe { cx_sharded_save(self.h, p.as_ptr()) })
     }
-    /// vector/index.rs:447-473 — over the GPUs named in CORTEX_HIP_DEVICES ("0,1,2,3,4,5,6,7"; default: device 0 only)
+    /// vector/index.rs:447-473 — over the GPUs named in CORTEX_HIP_DEVICES ("0,1,2,3,4,5,6,7"); unset or empty: every device
+    /// cx_device_count() reports.  An entry that is not a device number is an error — a typo must not shrink the shard set silently.
     fn load(path: &Path) -> Result<Self> {
         let p = std::ffi::CString::new(path.to_string_lossy().as_bytes()).map_err(|e| CortexError::Validation(e.to_string()))?;
-        let devs: Vec<c_int> = std::env::var("CORTEX_HIP_DEVICES").ok()
-            .map(|v| v.split(',').filter_map(|x| x.trim().parse().ok()).collect()).filter(|v: &Vec<c_int>| !v.is_empty()).unwrap_or_else(|| vec![0]);
+        let n_dev = unsafe { cx_device_count() };
+        let devs: Vec<c_int> = match std::env::var("CORTEX_HIP_DEVICES").ok().filter(|v| !v.trim().is_empty()) {
+            Some(v) => {
+                let mut out = Vec::new();
+                for x in v.split(',') {
+                    let d: c_int = x.trim().parse().map_err(|_| CortexError::Validation(format!("CORTEX_HIP_DEVICES: '{}' is not a device number", x.trim())))?;
+                    if d < 0 || d >= n_dev { return Err(CortexError::Validation(format!("CORTEX_HIP_DEVICES: device {} of {} visible", d, n_dev))); }
+                    out.push(d);
+                }
+                out
+            }
+            None => (0..n_dev.max(1)).collect(),
+        };
         let bf16 = std::env::var("CORTEX_HIP_DTYPE").map(|v| v == "bf16").unwrap_or(false);
         let h = unsafe { cx_sharded_load_ex(p.as_ptr(), devs.len() as u32, devs.as_ptr(), if bf16 { 1 } else { 0 }) };
         if h.is_null() { return Err(last_error()); }

@@ -11,5 +11,5 @@ def brief(x):
     return {"wall_ms": round(x["wall_ms"], 3), "edges": x["edges"], "phase_ms": {k: round(v, 3) for k, v in x["phase_ms"].items()},
             "kernel": x["roofline"]["kernel"], "kernel_ms": round(x["roofline"]["avg_kernel_ms"], 3), "frac": round(x["roofline"]["frac"], 4),
             "frac_of_phase": round(x["roofline"]["frac_of_phase"], 4), "clock": round(x["roofline"]["shader_clock_ghz_in_kernel"], 3)}
-print(json.dumps({"first": brief(r), "rescan": brief(r["rescan_with_existing_edges"]), "lists_s": round(r["top100_lists_all_rows"]["seconds"], 4),
+print(json.dumps({"first": brief(r), "rescan": brief(r["rescan_with_existing_edges"]), "row_list": brief(r["row_list_scan"]), "lists_s": round(r["top100_lists_all_rows"]["seconds"], 4),
                   "full_lists": r["top100_lists_all_rows"]["full_lists"]}))

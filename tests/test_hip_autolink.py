@@ -484,6 +484,27 @@ def test_persistent_filter_kernel_equals_the_per_tile_kernel(hip, oracle, monkey
             assert len(ref[0]) > 100
             for a, b in zip(got, ref):
                 assert np.array_equal(a, b), f"range scan [{lo_s}, {lo_s + m_s}) n={n} d={d} thr={thr} env={env}"
+        # round 4: a LIST of rows (a cycle's batch in arbitrary order, with a repeated row and rows from the store's last 16-row
+        # block) is gathered into a staged I panel and runs through the same persistent kernel — same bytes as the per-tile kernel
+        rng = np.random.default_rng(n)
+        for m_s in (700, 257, 130):
+            scan = rng.permutation(n)[:m_s].astype(np.uint32)
+            scan[5] = scan[9]
+            scan[0], scan[1] = n - 1, n - 3
+            monkeypatch.setenv("CX_PAIR_PERSIST", "0")
+            ref = h.autolink_pass_rows(scan, 100, thr32, 50)
+            monkeypatch.setenv("CX_PAIR_PERSIST", "1")
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            got = h.autolink_pass_rows(scan, 100, thr32, 50)
+            for k in env:
+                monkeypatch.delenv(k)
+            assert len(ref[0]) > 50
+            for a, b in zip(got, ref):
+                assert np.array_equal(a, b), f"list scan of {m_s} rows n={n} d={d} thr={thr} env={env}"
+            if d == 768 and m_s == 700:
+                e = o.autolink_pass(scan, 100, thr32, 50, n_threads=8)
+                compare_edges(per_node(*got), per_node(e["from_row"], e["to_row"], e["weight"]), thr32, oracle_scores(o, rows), "list scan vs oracle")
 
 
 def test_removed_rows_are_not_scanned(hip, oracle):

@@ -240,7 +240,7 @@ def test_sharded_save_and_load_are_the_single_index_file(hip, oracle, tmp_path):
 
 def test_failed_shard_append_leaves_the_handle_consistent(hip):
     """Round-2 ADVICE: a shard append that fails (a hipMalloc in grow_rows is enough; here injected with
-    CX_SHARD_FAIL_UPSERT) must not leave ids live in the handle but absent from the shard.  The failed call reports the
+    CX_SHARD_FAIL_UPSERT in the test-hooks build of the library) must not leave ids live in the handle but absent from the shard.  The failed call reports the
     error, the rows placed before it stay, a retry of the SAME batch places the rest, and the index then answers like a
     single index over the same rows.  The switch is read once per process: a child process."""
     import os
@@ -274,7 +274,10 @@ fo = one.autolink_pass_rows(None, 100, float(np.float32(0.85)), 50)
 assert len(fo[0]) > 100 and np.array_equal(fr[0], fo[0]) and np.array_equal(fr[1], fo[1])
 print("OK")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CX_SHARD_FAIL_UPSERT="2", CX_SHARD_PLACEMENT_BLOCK="512")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hooks = os.path.join(root, "cortex_amd", "lib", "libcortex_hip_testhooks.so")   # the fault injection is not compiled into the product
+    assert os.path.exists(hooks), "build() makes libcortex_hip_testhooks.so beside the product library"
+    env = dict(os.environ, CX_SHARD_FAIL_UPSERT="2", CX_SHARD_PLACEMENT_BLOCK="512", CORTEX_HIP_LIB=hooks)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == "OK", (r.stdout[-500:], r.stderr[-2000:])
 
