@@ -987,7 +987,7 @@ def autolink_leg(L, device: int, d: int, skip_cpu: bool, n: int = 100_000, thr: 
     lr, ls, lc = ix.topk_lists_rows(100, None)
     t_lists = time.perf_counter() - t0
     res["top100_lists_all_rows"] = {"seconds": t_lists, "lists_per_s": n / t_lists, "full_lists": int((lc == 100).sum()),
-                                    "kernel": "cx::pair_filter256_kernel at a sampled k-th-best threshold + exact rescore; short / "
+                                    "kernel": "cx::pair_filter_p_kernel at a sampled k-th-best threshold + exact rescore; short / "
                                               "overflowed lists redone by cx::batch2_kernel (wide lists) — autolink.cpp: lists_by_filter",
                                     "round1_seconds_same_call": 0.196}
     del lr, ls, lc

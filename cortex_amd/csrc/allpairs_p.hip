@@ -1,10 +1,31 @@
 // allpairs_p.hip — the filter GEMM of the all-pairs pass as PERSISTENT blocks (round 3).
 //
-// Same contract as pair_filter256_kernel (allpairs256.hip): bf16 shadow rows in, candidate columns out, no score
-// matrix; replaces the per-node search loop of AutoLinker::run_cycle (linker/auto_linker.rs:215-264) and of
-// DedupScanner::scan (linker/dedup.rs:65-127).  Same 256x256x32 K-step on the same 4-slot LDS ring, 8 waves as
-// 2 (M) x 4 (N) of 128 x 64.  What changes is everything AROUND the K loop, which at dim 768 (24 K-steps per tile)
-// was a quarter of every tile (profiles/r03/tuning.md §1):
+// Same contract as pair_filter_kernel (allpairs.hip): bf16 shadow rows in, candidate columns out, no score matrix; replaces
+// the per-node search loop of AutoLinker::run_cycle (linker/auto_linker.rs:215-264) and of DedupScanner::scan
+// (linker/dedup.rs:65-127).
+//
+// The K loop (rounds 1-2 built it as a kernel launched per tile, allpairs256.hip, retired in round 4 when row lists and
+// external blocks moved here too):
+//  - 256x256 block tile, BK = 32, 8 waves as 2 (M) x 4 (N), each wave a 128x64 sub-tile = 4x2 tiles of
+//    mfma_f32_32x32x16_bf16 (128 accumulator registers), two waves per SIMD;
+//  - per K-step a wave issues 4 LDS-DMA instructions (2 A + 2 B, 1 KiB each: one instruction = one contiguous,
+//    pre-swizzled KiB of the tiled shadow, SGPR base + lane * 16), 12 ds_read_b128 and 16 MFMAs, interleaved one-for-one;
+//  - LDS = ring of 4 slots x (A 16 KiB + B 16 KiB) = 128 KiB.  In step t a wave issues the DMA of step t+3 and the fragment
+//    reads of step t+1 (double-buffered registers), then the MFMAs of step t; the wait at the end of a step is
+//    `s_waitcnt vmcnt(4)` — this wave's part of step t+2 has landed, step t+3 stays in flight — followed by a raw
+//    s_barrier (a __syncthreads() would drain vmcnt(0)).  All LDS is one array and there are no ordinary global loads in
+//    the loop, so hipcc adds no vmcnt(0) of its own (checked in the ISA);
+//  - RAW: slot t+2 is read (in step t+1) one barrier after the wait that retired it.  WAR: slot (t+3) % 4 was last read in
+//    step t-2; those ds_reads retired before the MFMAs of step t-1 that consumed them;
+//  - 16-byte pieces of a 64-byte row are stored at piece ^ (row >> 3 & 3): with rows at a 64-byte stride every
+//    ds_read_b128 lane group of the 32-row x 2-piece operand pattern hits 16 different 16-byte bank groups
+//    (SQ_LDS_BANK_CONFLICT stays 0);
+//  - measured on the way (100k x 768, symmetric): loads only 2.88 ms, MFMAs only 3.87 ms, the per-tile kernel 6.75 ms = their
+//    SUM — an in-order wave that is issuing an LDS-DMA feeds the matrix pipe nothing, and its SIMD partner is in the same
+//    place; ping-pong between SIMD partners, priorities, staggered DMA slots and a 5-slot ring were all slower
+//    (profiles/r02/tuning.md §2).
+// What round 3 changed is everything AROUND the K loop, which at dim 768 (24 K-steps per tile) was a quarter of every tile
+// (profiles/r03/tuning.md §1):
 //
 //  - one block per CU for the whole launch; a block walks its tiles and the LDS ring runs THROUGH the tile
 //    boundaries: the last three K-steps of a tile issue the LDS-DMAs of the next tile's first three, the last one
@@ -73,7 +94,7 @@ struct Cfg {
     static constexpr int LDS_BYTES = CTL_OFF + 64;
     static_assert(BM_ == 256 && LDS_BYTES <= 160 * 1024, "one block per CU");
 };
-// same LDS image as allpairs256.hip: 16-byte piece p of a 64-byte row at p ^ (row >> 3 & 3)
+// the LDS image: 16-byte piece p of a 64-byte row at p ^ (row >> 3 & 3)
 __device__ inline uint32_t off(uint32_t row, uint32_t piece) { return row * 64u + ((piece ^ ((row >> 3) & 3u)) << 4); }
 // LDS control words, records and the pair list are touched through inline assembly: hipcc tracks every in-flight LDS-DMA
 // as a pending LDS write and puts `s_waitcnt vmcnt(0)` in front of any LDS access it cannot tell apart from the ring —
@@ -146,7 +167,7 @@ __global__ __launch_bounds__(pp::Cfg<BM>::WAVES * 64, 2) void pair_filter_p_kern
             const uint32_t t = scalar_load_u32(a.tile_list + idx);
             ti = t >> 16;
             tj = t & 0xFFFFu;
-        } else {   // 1,024 scanned rows of I-panels per J-panel, as pair_filter256_kernel
+        } else {   // 1,024 scanned rows of I-panels per J-panel
             const uint32_t GS = 1024u / BM, per_group = GS * tiles_j;
             const uint32_t group = idx / per_group, first_i = group * GS;
             const uint32_t gsz = (tiles_i - first_i) < GS ? (tiles_i - first_i) : GS;
@@ -295,7 +316,7 @@ __global__ __launch_bounds__(pp::Cfg<BM>::WAVES * 64, 2) void pair_filter_p_kern
     // One K-step (g = steps since the block started: ring slot g & 3; kt = step inside the tile): the MFMAs of step kt
     // on the fragments read during the step before, and after each MFMA one other instruction of the step — the
     // LDS-DMAs of step kt + 3 (the NEXT tile's when kt + 3 >= KT) and the fragment reads of step kt + 1 (the next tile's
-    // step 0 when kt is the last) — then the counted wait and the raw barrier (allpairs256.hip: RAW / WAR argument).
+    // step 0 when kt is the last) — then the counted wait and the raw barrier (the RAW / WAR argument: head of the file).
     // KIND 1 = first step of a tile (accumulators start from the inline 0), 2 = last (tile by tile, screening under the MFMAs).
     auto step = [&](auto kind_tag, uint32_t g, uint32_t kt, const Desc &cur, const Desc &nxt, const bf16x8 *fa, const bf16x8 *fb,
                     bf16x8 *na, bf16x8 *nb) {
@@ -618,7 +639,7 @@ static int launch_p_diag(const PairFilterArgs &a, uint32_t grid, bool dyn, hipSt
 uint32_t pair_filter_p_block_rows() { return 256u; }   // scanned rows per tile
 
 // live tiles of the symmetric pass for tiles of bm scanned rows x 256 rows: (ti << 16) | tj with the tile's last column
-// at or beyond its first row, GS I-panels (1,024 scanned rows) per J-panel as pair_filter256_tile_list
+// at or beyond its first row, GS I-panels (1,024 scanned rows) per J-panel
 void pair_filter_p_tile_list(uint32_t n_rows, uint32_t bm, std::vector<uint32_t> &out) {
     const uint32_t tiles_i = (n_rows + bm - 1) / bm, tiles_j = (n_rows + 255u) / 256u, GS = 1024u / bm;
     out.clear();

@@ -223,7 +223,7 @@ struct CycleInputs {
     bool lists_only = false;
     uint32_t min_count = 0;
     uint32_t cand_cap = 0;      // candidate slots per scanned row; 0 = cand_cap()
-    bool no_persist = false;    // the retry of a pass whose pair buffer ran over: pair_filter256_kernel instead
+    bool no_persist = false;    // the retry of a pass whose pair buffer ran over: the per-tile kernel (pair_filter_kernel) instead
 };
 
 int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, const uint32_t *scan_rows,
@@ -323,7 +323,7 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
             f.cand_cnt = ps.d_cand_cnt;
             f.cand = ps.d_cand;
             f.cap = cap;
-            // large scan sets: 256x256 tiles on the 4-slot ring (allpairs256.hip); small ones (streaming ingest) keep
+            // large scan sets: 256x256 tiles on the 4-slot ring (allpairs_p.hip); small ones (streaming ingest) keep
             // the 128x128 kernel, where a mostly empty 256-row tile would waste MFMAs
             static const int big_min = getenv("CX_PAIR_256_MIN") ? atoi(getenv("CX_PAIR_256_MIN")) : 129;
             const bool big = ix->dim % 32 == 0 && (int64_t)m >= big_min;
@@ -371,12 +371,12 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
                 }
                 persist = pair_filter_p_supported(f);
             }
-            const uint32_t tile_kind = !big ? 0u : (persist ? f.block_rows : 256u);   // which tile list: 128^2 kernel, or bm x 256 tiles
+            const uint32_t tile_kind = persist ? f.block_rows : 0u;   // which tile list: the 128^2 kernel's, or the persistent kernel's bm x 256 tiles
             if (f.symmetric) {
                 std::lock_guard<std::mutex> g(ix->shadow_mu);
                 if (ix->tile_list_rows != n_rows || !ix->d_tile_list || ix->tile_list_big != tile_kind) {
                     std::vector<uint32_t> tl;
-                    if (big) pair_filter_p_tile_list(n_rows, tile_kind, tl);   // bm = 256: the order of pair_filter256_tile_list
+                    if (persist) pair_filter_p_tile_list(n_rows, tile_kind, tl);
                     else pair_filter_tile_list(n_rows, tl);
                     ix->tile_list_big = tile_kind;
                     if (ix->d_tile_list) CX_HIP(hipFree(ix->d_tile_list));
@@ -417,8 +417,8 @@ int pass_core(const cx_index *ix, Ctx *c, PassScratch &ps, uint64_t n_scan64, co
                 used_persist = true;
                 filter_kind = 1;
             } else {
-                if (int rc = big ? launch_pair_filter256(f, s) : launch_pair_filter(f, s)) return rc;
-                filter_kind = big ? 0 : 2;
+                if (int rc = launch_pair_filter(f, s)) return rc;   // (round 4: the 256-tile per-launch kernel is gone — what the persistent kernel
+                filter_kind = 2;                                    // does not take — dims below 384, a pair buffer that ran over — runs on 128 x 128 tiles)
             }
             filter_bm = persist ? f.block_rows : 256u;
             if (lo == 0) filter_tiles = f.symmetric ? f.n_tiles : (uint64_t)((m + (persist ? f.scan_lo % 32u : 0u) + filter_bm - 1u) / filter_bm) * ((n_rows + 255u) / 256u);
@@ -836,7 +836,7 @@ int cx_autolink_lists_dev(const cx_index *ix, uint64_t nq64, const float *d_quer
         bool done = false, used_stream = false;
         if ((int64_t)nq >= big_min && stage_ok && persist_ok && ix->d_shadow_t) {
             // a block of external vectors (the sharded pass's Q blocks): their shadow built straight into a staged I panel in the
-            // tiled layout, then the persistent kernel — the single-GPU pass's own (round 3: pair_filter256_kernel, 15 % slower)
+            // tiled layout, then the persistent kernel — the single-GPU pass's own (round 3: the 256-tile per-launch kernel, 15 % slower, retired in round 4)
             PairFilterArgs g = f;
             const uint32_t n_pad = (nq + 255u) / 256u * 256u;
             if (int rc = ensure_dev(ps.d_stage_t, ps.c_stage_t, (size_t)n_pad * ix->dim)) return rc;
@@ -869,7 +869,7 @@ int cx_autolink_lists_dev(const cx_index *ix, uint64_t nq64, const float *d_quer
             f.pair_ctl = ps.d_pair_ctl;
             if (int rc = launch_pair_filter_stream(f, s)) return rc;
             used_stream = true;
-        } else if (int rc = ((int64_t)nq >= big_min) ? launch_pair_filter256(f, s) : launch_pair_filter(f, s)) return rc;
+        } else if (int rc = launch_pair_filter(f, s)) return rc;
         if (f.thr_lo > 0.0f) {   // irregular vectors (zero shadows) go down the exact path, the shard's irregular rows join every other list
             if (int rc = ensure_dev(ps.d_irr_ok, ps.c_irr_ok, (size_t)BS_IRR_CAP)) return rc;
             if (int rc = launch_irr_append(ix->rows32(), ix->rows16(), ix->dim, n_rows, ix->d_irr_rows, ix->irr_n, ps.d_irr_ok, nq, ps.d_cand_cnt, ps.d_cand, cap, s)) return rc;

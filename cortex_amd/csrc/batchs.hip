@@ -654,8 +654,12 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
             // block's last worker is through its first tile — no round trip past the L2, where the grid's first bounds take ~14 us
             // during which the workers of round 3 stood still.  It is weak (the k-th best of 224 rows, not of 57k: some 7 % of the
             // pairs pass), so until the grid's bounds arrive the service wave — busy polling for them anyway — leaves the hits in
-            // the rings (sized for it: BsCfg::HB), and then drops nearly all of them under the real bound (process_hits).
-            const bool loc = k <= BS_LOCG && in_block == BS_WORK && !(a.arm & 8u);
+            // the rings (sized for it: BsCfg::HB), and then drops nearly all of them under the real bound (the staging step of its
+            // loop).  Those hits are work: a pass pays ~3,500 ring entries per block for the 14 us it does not stand still, and the
+            // narrower the rows the more tiles go by meanwhile — measured (profiles/r04/tuning.md): a gain from 400k rows at 768-d
+            // (0.164 against 0.173 ms) and from ~1M rows at 384-d (1.25M: 0.202 against 0.208), a loss below (100k x 384: 0.115
+            // against 0.074) — so only passes of at least a.loc_min_rows rows do it (launch_batchs_pass).
+            const bool loc = k <= BS_LOCG && in_block == BS_WORK && n_rows >= a.loc_min_rows && !(a.arm & 8u);
             uint32_t mine = 0u;
 #pragma unroll
             for (int g = 0; g < 4; g++) {
@@ -1088,6 +1092,8 @@ int launch_batchs_pass(const BatchSArgs &a_in, hipStream_t stream) {
     a.arm = arm_env;
     a.pub_min = pub_env;
     a.claim = claim_env;
+    static const long loc_env = getenv("CX_BATCHS_LOC_MIN") ? atol(getenv("CX_BATCHS_LOC_MIN")) : -1;
+    a.loc_min_rows = loc_env >= 0 ? (uint32_t)loc_env : (a.dim >= 640u ? 393216u : 1048576u);   // (block-local first bounds: see the kernel)
     if (!batchs_supported(a.dim, a.k) || a.nq == 0 || a.nq > 64u || a.n_rows == 0)
         return set_err(CX_ERR_VALIDATION, "batchs: unsupported shape (dim %u, k %u, %u queries, %u rows)", a.dim, a.k, a.nq, a.n_rows);
     const uint32_t cus = device_cus(), n32 = (a.n_rows + 31u) / 32u;

@@ -159,7 +159,7 @@ struct cx_index {
     mutable std::mutex shadow_mu;
     mutable uint16_t *d_shadow = nullptr;
     // the same shadow cut into the 256-tile filter kernel's LDS-DMA pieces: [16-row block][K-step of 32][16 rows x 64 B,
-    // pieces pre-swizzled] — one DMA instruction = 1 KiB of contiguous HBM/L2 (allpairs256.hip); maintained with d_shadow
+    // pieces pre-swizzled] — one DMA instruction = 1 KiB of contiguous HBM/L2 (allpairs_p.hip); maintained with d_shadow
     mutable uint16_t *d_shadow_t = nullptr;
     mutable uint32_t *d_shadow_err = nullptr;   // [0] the largest || bf16(x) - x || over the shadow's rows (f32 bits; an upper bound: never lowered by removals); [1] irregular rows counted so far
     // IRREGULAR rows (kernels.hpp: bs_regular): zero shadow rows, listed here by the shadow's build; every screening path adds them

@@ -154,7 +154,8 @@ struct BatchSArgs {
     uint32_t irr_n;
     uint32_t arm;           // CX_BATCHS_ARM: measurement arms (results invalid): 1 workers drop their hits, 4 the service wave drops them
     uint32_t pub_min;       // slots a query's first publisher waits for (CX_BATCHS_PUB_MIN, 64; at least k)
-    uint32_t claim;         // tiles a service wave claims at a time (set by the launcher: 14, CX_BATCHS_CLAIM)
+    uint32_t claim;         // tiles a service wave claims at a time (set by the launcher: 21, CX_BATCHS_CLAIM)
+    uint32_t loc_min_rows;  // fewest rows of a pass whose blocks run ahead on block-local first bounds (set by the launcher; CX_BATCHS_LOC_MIN)
     unsigned long long *tl; // CX_BATCHS_TL=1: [grid][32] s_memrealtime stamps of a pass (diagnostic; null otherwise)
     // threshold mode (launch_batchs_thr: the all-pairs filter of <= 64 scanned rows, allpairs_stream.hip's contract); nq = n_scan
     float thr_lo;               // threshold - eps
@@ -265,9 +266,6 @@ struct PairFilterArgs {
 };
 // live tiles of the symmetric pass in L2-friendly order (host side); tile = 128 rows
 void pair_filter_tile_list(uint32_t n_rows, std::vector<uint32_t> &out);
-// 256x256-tile variant for large scan sets (allpairs256.hip); tile list with 256-row tiles
-void pair_filter256_tile_list(uint32_t n_rows, std::vector<uint32_t> &out);
-int launch_pair_filter256(const PairFilterArgs &a, hipStream_t stream);
 // persistent blocks, LDS ring running through the tile boundaries, hits handed over as pairs (allpairs_p.hip); scanned
 // rows = the shard's rows in order (tiled shadow both sides), dim % 64 == 0, dim >= 384
 bool pair_filter_p_supported(const PairFilterArgs &a);

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void probe_mfma_kernel(uint32_t iters, float *
 }
 
 // The filter GEMM's inner step without its global traffic: per step a wave reads 12 fragments from LDS (ds_read_b128,
-// conflict-free: the pair_filter256 operand pattern) and issues 16 v_mfma_f32_32x32x16_bf16 on them, 2 waves per SIMD.
+// conflict-free: the filter GEMM's operand pattern) and issues 16 v_mfma_f32_32x32x16_bf16 on them, 2 waves per SIMD.
 // What the matrix pipe sustains when it is fed from LDS at the GEMM's ratio — the ceiling of that kernel's main loop.
 template <int DMA>   // 0 none, 1 LDS-DMA, 2 register-staged (global_load_dwordx4 -> ds_write_b128, three steps in flight)
 __global__ __launch_bounds__(512) void probe_mfma_lds_kernel(uint32_t iters, float *sink, const char *src) {

@@ -468,7 +468,7 @@ class HipIndex:
         """cx_autolink_filter_profile: the MFMA filter GEMM of the last timed pass (kernel ms, executed flops, tiles, kernel, clock)."""
         out = (C.c_double * 5)()
         self._check(self._L.cx_autolink_filter_profile(self._h, out))
-        kern = {0: "cx::pair_filter256_kernel", 1: "cx::pair_filter_p_kernel", 2: "cx::pair_filter_kernel / pair_filter_stream_kernel"}[int(out[3])]
+        kern = {0: "cx::pair_filter256_kernel (retired in round 4)", 1: "cx::pair_filter_p_kernel", 2: "cx::pair_filter_kernel / pair_filter_stream_kernel"}[int(out[3])]
         return {"kernel_ms": out[0], "executed_flops": out[1], "tiles": int(out[2]), "kernel": kern, "shader_clock_ghz": out[4]}
 
     def autolink_lists_dev(self, d_queries: int, nq: int, topk: int, threshold: float, d_rows: int, d_scores: int,

@@ -1,5 +1,5 @@
 import sys, json, os
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 import bench
 from cortex_amd import _lib

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds the library of a git revision (default HEAD) beside the working tree's, as cortex_amd/lib/libcortex_hip_base.so, for
-# same-box A/B runs (CORTEX_HIP_LIB=... selects it; scripts/r3_batch_arms.sh).  Not part of the product.
+# same-box A/B runs (CORTEX_HIP_LIB=... selects it).  Not part of the product.
 set -e
 REV=${1:-HEAD}; W=/tmp/cx_base_build; rm -rf $W; mkdir -p $W
 cd "$(dirname "$0")/.."

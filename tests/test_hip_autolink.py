@@ -449,7 +449,7 @@ def test_persistent_filter_kernel_equals_the_per_tile_kernel(hip, oracle, monkey
     """allpairs_p.hip: persistent blocks whose LDS ring runs through the tile boundaries and whose hits leave the GEMM as
     records -> pairs.  With few blocks every block walks many tiles (the boundary code), at threshold 0.3 a tile holds
     more hit lanes than records and more hits than the LDS list (in-place walk, flush, direct appends).  Both filters feed the same exact rescore, so the edges must be the
-    same bytes as pair_filter256_kernel's, and equal to the oracle's (auto_linker.rs:215-264)."""
+    same bytes as the per-tile kernel's (pair_filter_kernel, 128 x 128 tiles), and equal to the oracle's (auto_linker.rs:215-264)."""
     for n, d, thr in ((5000, 768, 0.85), (4000, 384, 0.3), (2100, 1024, 0.75)):
         rows = oracle.synth_rows(n, d)
         h, o, ids = build(hip, oracle, rows)
