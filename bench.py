@@ -204,7 +204,7 @@ def main() -> None:
     # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; gfx950 x2 read
     # correction) whose summary is committed under profiles/; reported only for the shape it was taken on
     traffic, traffic_src = None, None
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         pmc = os.path.join(ROOT, "profiles", rnd, "knn_1Mx768_pmc_final.json")
         if B == 1 and n == 1_000_000 and d == 768 and os.path.exists(pmc):
             traffic = json.load(open(pmc)).get("scan_kernel_hbm_bytes_per_launch")

@@ -456,12 +456,12 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         // moment (one compare: most hits of a block that ran ahead on its local bounds leave here); what is left goes to a staging
         // area in LDS and is handed to process_hits 64 at a time — ONE returning atomic per 64 survivors: its round trip past the L2
         // takes 2-3 us under the row stream, and paid per round (a survivor or two in nearly every round) it made the service wave
-        // the last to leave by 30-60 us.  The housekeeping (tile queue, clock, bound refresh) runs every eighth busy round.
+        // the last to leave by 30-60 us.
         uint32_t gap = 200u;           // x10 ns
         uint64_t t_next = now() + gap;
         unsigned long long n_rounds = 0, n_hits = 0, n_kept = 0, max_pend = 0;   // (timeline diagnostics)
         bool drained = false, seen_done = false, workers_done = false;
-        uint32_t n_stage = 0u, it = 0u;
+        uint32_t n_stage = 0u;
         for (;;) {
             uint32_t hd = 0u, tl = 0u;
             if (lane < BS_WORK) { hd = bs_lds_ld_acq(&s_ctl[BSL_HEAD + lane]); tl = bs_lds_ld(&s_ctl[BSL_TAIL + lane]); }   // (the tails are this wave's own)
@@ -521,8 +521,9 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
                 process_hits(on, r0, q0, d0);
             }
             refill();   // (an LDS read unless the queue runs low: the workers of a 384-d pass empty fourteen entries in 11 us)
-            const bool house = !busy || (++it & 7u) == 0u;
-            if (house) {
+            // (the clock and the bound refresh in EVERY round: looked at every eighth busy round only, the refreshes of a pass with many
+            // survivors — k = 100 — came late, its workers tested against stale bounds and let 40 % more candidates through)
+            {
                 workers_done = bs_lds_ld_acq(&s_ctl[BSL_DONE]) >= BS_WORK;
                 const uint64_t t_now = now();
                 if (stamps && workers_done && !seen_done) { seen_done = true; if (lane == 0u) stamps[37] = t_now; }

@@ -5,6 +5,6 @@ set -e
 REV=${1:-HEAD}; W=/tmp/cx_base_build; rm -rf $W; mkdir -p $W
 cd "$(dirname "$0")/.."
 git archive $REV cortex_amd/csrc include | tar -x -C $W
-make -C $W/cortex_amd/csrc -j4 > $W/build.log 2>&1 || { tail -20 $W/build.log; exit 1; }
+make -C $W/cortex_amd/csrc -j8 > $W/build.log 2>&1 || { tail -20 $W/build.log; exit 1; }
 cp $W/cortex_amd/lib/libcortex_hip.so cortex_amd/lib/libcortex_hip_base.so
 ls -la cortex_amd/lib/

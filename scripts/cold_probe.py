@@ -93,5 +93,6 @@ tiny = torch.empty(1024, dtype=torch.float32, device=dev)
 for _ in range(8):
     tiny.add_(1.0)
 res["idle1s_then_8_dummy_launches"] = burst(40, "dummies  ")
-os.makedirs("gpurun_out", exist_ok=True)
-json.dump(res, open("gpurun_out/cold_probe.json", "w"))
+_out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+os.makedirs(_out, exist_ok=True)
+json.dump(res, open(os.path.join(_out, "cold_probe.json"), "w"))

@@ -1,6 +1,6 @@
 #!/bin/bash
-# The batched-search artifacts of a round (batchs.hip), run through gpurun from the repo root; the other workloads' steps
-# are scripts/profile_round.sh's.  Output: gpurun_out/prof_round/ ; scripts/collect_profiles.py copies the judged
+# The batched-search artifacts of a round (batchs.hip), run through gpurun from the repo root; bench.py itself and the other
+# workloads' steps are scripts/profile_round.sh's.  Output: gpurun_out/prof_round/ ; scripts/collect_profiles.py copies the judged
 # summaries into profiles/rNN/.  Counters are collected in their own passes (FETCH_SIZE, WRITE_SIZE), program directly
 # after `--`.
 set -o pipefail
@@ -10,8 +10,6 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 step() { echo "== $1"; }
 if [ "${1:-all}" != "pmc" ]; then
-step bench; timeout -k 10 600 python3 $R/bench.py > $O/bench.json 2> $O/bench.err || { tail -5 $O/bench.err; exit 1; }
-step bench-driver-cmdline; timeout -k 10 300 python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-autolink --no-config4 > $O/bench_steps20_warmup5.json 2> $O/bench_steps20.err || { tail -5 $O/bench_steps20.err; exit 1; }
 step batch-shapes; for a in "1250000 768 10 f32" "1250000 768 100 f32" "1250000 384 10 f32" "1250000 384 100 f32" "5000000 768 10 f32" "5000000 384 10 f32" "4000000 1024 10 f32" "1000000 1024 100 f32" "1000000 1024 256 f32" "2000000 512 10 f32" "1000000 1024 10 bf16" "6250000 1024 10 bf16" "6250000 1024 100 bf16" "1250000 768 100 bf16" "150000 384 10 f32" "300000 768 10 f32"; do set -- $a; timeout -k 10 200 python3 $R/scripts/bench_batch_dim.py --rows $1 --dim $2 --k $3 --dtype $4 --steps 40 2>/dev/null; done > $O/batch64_other_shapes.jsonl
 fi
 if [ "${1:-all}" != "bench" ]; then
