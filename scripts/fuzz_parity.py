@@ -15,7 +15,23 @@ ap.add_argument("--seconds", type=float, default=120.0)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--big", action="store_true", help="corpora of 50k-300k rows at 384/768-d: many compactions per list, several query groups")
 ap.add_argument("--dtype", default="f32", help="bf16: the index is a bf16 row store (cx_create_ex) and the oracle is fed the rounded rows")
+ap.add_argument("--irregular", type=float, default=0.25, help="share of the cases that hold vectors scaled by 1e+-20 / 1e-25, Inf or NaN elements (rows and queries)")
 a = ap.parse_args()
+
+
+def spoil(v, rng, count):
+    """`count` vectors of v made irregular in place: |x|^2 overflows / underflows in f32, or an element is not finite"""
+    v = v.copy()
+    with np.errstate(over="ignore", under="ignore", invalid="ignore"):
+        for r in rng.integers(0, len(v), count):
+            kind = int(rng.integers(0, 6))
+            if kind == 0: v[r] = v[r] * np.float32(1e20)
+            elif kind == 1: v[r] = v[r] * np.float32(1e-25)
+            elif kind == 2: v[r, int(rng.integers(0, v.shape[1]))] = np.inf
+            elif kind == 3: v[r, int(rng.integers(0, v.shape[1]))] = np.nan
+            elif kind == 4: v[r] = v[r] * np.float32(-1e-16)
+            else: v[r] = 0.0
+    return v
 
 
 def stored(x):   # what the index keeps of a row
@@ -37,6 +53,9 @@ while time.time() < t_end:
         rows = rows.copy(); rows[rng.integers(0, n, 3)] = 0.0                  # zero-norm rows (NaN scores)
     if rng.random() < 0.2 and n > 10:
         rows = rows.copy(); rows[n // 2:] = rows[: n - n // 2]                # every row twice: ties everywhere
+    irregular = rng.random() < a.irregular
+    if irregular:
+        rows = spoil(rows, rng, int(rng.integers(1, 5)))
     ids = ids_for(n)
     h = hip.HipIndex(d, dtype=a.dtype); h.insert_batch(ids, rows)
     o = O.OracleIndex(d); o.insert_batch(ids, stored(rows))
@@ -54,6 +73,8 @@ while time.time() < t_end:
         k = int(rng.choice([1, 10, 32, 33, 100, 104]))
         nq = int(rng.choice([33, 64, 65, 130]))
         rows = O.synth_rows(n, d, seed_rows=int(rng.integers(1, 1 << 30)))
+        if irregular:
+            rows = spoil(rows, rng, int(rng.integers(1, 5)))
         ids = ids_for(n)
         h = hip.HipIndex(d, dtype=a.dtype); h.insert_batch(ids, rows)
         o = O.OracleIndex(d); o.insert_batch(ids, stored(rows))
@@ -61,8 +82,10 @@ while time.time() < t_end:
             h.remove(ids[r].tobytes()); o.remove(ids[r].tobytes())
         hf = of = None
     qs = O.synth_queries(max(n, 64), d, nq, seed_centres=int(rng.integers(1, 1 << 30)))
+    if irregular and rng.random() < 0.7:
+        qs = spoil(qs, rng, int(rng.integers(1, 3)))
     lut = {ids[i].tobytes(): i for i in range(n)}
-    what = f"case n={n} d={d} k={k} nq={nq} filter={hf is not None} dtype={a.dtype}"
+    what = f"case n={n} d={d} k={k} nq={nq} filter={hf is not None} dtype={a.dtype} irregular={irregular}"
     try:
         bi, bs, bd, bc = h.search_batch_arrays(qs, k, hf)
         exp_all = o.search_batch(qs, k, of, n_threads=16) if a.big else None
