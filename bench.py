@@ -306,6 +306,8 @@ def main() -> None:
         # the same shard at the reference's default embedding width (384-d, embedding.rs:43-50) and with the linker's lists
         out["extra"]["batch64_1.25Mx384_k10"] = config4_leg(L, local_rank, dev, d=384, steps=100,
                                                             shard_note="the reference's default width; one of 8 shards of 10M rows")
+        out["extra"]["batch128_1.25Mx384_k10"] = config4_leg(L, local_rank, dev, d=384, B=128, steps=100,
+                                                             shard_note="the reference's default width; 128 queries per call = ONE pass of two 64-query banks (row widths up to 512)")
         out["extra"]["batch64_1.25Mx384_k100"] = config4_leg(L, local_rank, dev, d=384, k=100, steps=100,
                                                              shard_note="the reference's default width, the linker's list length")
         out["extra"]["batch64_1.25Mx768_k100"] = config4_leg(L, local_rank, dev, k=100, steps=60,

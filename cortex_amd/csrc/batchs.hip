@@ -88,16 +88,22 @@ constexpr uint32_t BS_CLAIM = 21;      // tiles the service wave claims at a tim
 constexpr uint32_t BS_NO_TILE = 0xFFFFFFFFu;
 constexpr uint32_t BS_STRUCK = 0xFFFFFFFFu;   // a candidate the re-score struck from its list
 
-template <int D>
+// NB: 64-query BANKS of a pass.  One bank is the pass of round 3; two (row widths up to 512: the fragments of 128 queries are 96 KiB
+// at 384-d, 128 KiB at 512-d) let a call of more than 64 queries stream the shadow once per 128 of them — index.rs:397-403 is one
+// par_iter over any number of queries.  A worker then holds eight query groups' accumulators (64 registers) and issues 16 MFMAs per
+// K-step on the same two row fragments; everything per query (slots, bounds, lists) is indexed by query 0..127.
+template <int D, int NB = 1>
 struct BsCfg {
     static constexpr int KS = D / 32;                                   // K-steps per row
     static constexpr int P = KS % 8 == 0 ? 8 : (KS % 6 == 0 ? 6 : 4);   // K-steps a worker keeps in flight (2 KiB each)
+    static constexpr int NG = 4 * NB;                                   // query groups of 16
+    static constexpr uint32_t QN = 64u * NB;                            // queries of a pass
     // hit-ring entries per worker (a power of two), as many as the LDS has room for: while a block runs on its LOCAL bounds (see
     // the kernel) its service wave holds the hits back, and the rings are the workers' runway until the grid's bounds arrive
-    static constexpr uint32_t HB = D > 896 ? 128u : (D > 768 ? 256u : (D > 384 ? 512u : 1024u));
+    static constexpr uint32_t HB = NB == 2 ? (D > 384 ? 128u : 512u) : (D > 896 ? 128u : (D > 768 ? 256u : (D > 384 ? 512u : 1024u)));
     static constexpr uint32_t T16 = 16u * D * 2u;                       // bytes of a 16-row block of the tiled shadow
-    static constexpr size_t LDS = (size_t)KS * 4096u + BSL_WORDS * 4 + (size_t)BS_WORK * HB * 12 + 256 * 4 + 64 * 4 + BS_TQ * 4 + 64 * 4 + 64 * 4 + BS_LOCG * 64 * 4 + 128 * 12;
-    static_assert(KS % P == 0 && D % 128 == 0 && LDS <= 160u * 1024u, "unsupported row width");
+    static constexpr size_t LDS = (size_t)KS * 1024u * NG + BSL_WORDS * 4 + (size_t)BS_WORK * HB * 12 + 256 * 4 + QN * 4 + BS_TQ * 4 + QN * 4 + QN * 4 + BS_LOCG * QN * 4 + 128 * 12;
+    static_assert(KS % P == 0 && D % 128 == 0 && LDS <= 160u * 1024u && (NB == 1 || (NB == 2 && D <= 512)), "unsupported row width");
 };
 
 // THR: the same pass as the all-pairs filter of a SMALL scan set (<= 64 scanned rows of the shard, or external vectors:
@@ -105,29 +111,30 @@ struct BsCfg {
 // pieces, the test is a fixed threshold (thr - eps), there is no bound to establish — no sample, no slots, no wait —, and a
 // hit's row goes into the scanned row's candidate list (cand_cnt / cand, `cap` slots: the exact rescore redoes a row whose
 // count runs over).
-template <int D, bool THR>
+template <int D, bool THR, int NB>
 __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
-    using C = BsCfg<D>;
-    constexpr int KS = C::KS, P = C::P;
-    constexpr uint32_t HB = C::HB, T16 = C::T16;
+    using C = BsCfg<D, NB>;
+    static_assert(!(THR && NB != 1), "the filter pass scans at most 64 rows");
+    constexpr int KS = C::KS, P = C::P, NG = C::NG;
+    constexpr uint32_t HB = C::HB, T16 = C::T16, QN = C::QN;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // LDS: [query fragments: KS x 4 groups x 1 KiB][control words][hit rings: rows | queries | cosines, 7 x HB]
     //      [histogram 256][bounds 64][tile queue][1 / |q|: 64]
     char *qimg = smem;
-    uint32_t *s_ctl = reinterpret_cast<uint32_t *>(smem + KS * 4096);
+    uint32_t *s_ctl = reinterpret_cast<uint32_t *>(smem + KS * 1024 * NG);
     uint32_t *s_hrow = s_ctl + BSL_WORDS;
     uint32_t *s_hq = s_hrow + BS_WORK * HB;
     float *s_hdot = reinterpret_cast<float *>(s_hq + BS_WORK * HB);
     uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_hdot + BS_WORK * HB); // [256] the service wave's digit histogram
     uint32_t *s_bnd = s_hist + 256u;                                        // [64] the block's copy of the published bounds
-    uint32_t *s_tq = s_bnd + 64u;                                           // [BS_TQ] the block's tile queue
+    uint32_t *s_tq = s_bnd + QN;                                            // [BS_TQ] the block's tile queue
     float *s_inv = reinterpret_cast<float *>(s_tq + BS_TQ);                 // [64] 1 / |q| (prologue); 0 = an irregular query: no image, no hits, redone exactly
-    float *s_mrg = s_inv + 64u;                                             // [64] 2 eps of each query (the service wave's look at a hit)
-    uint32_t *s_loc = reinterpret_cast<uint32_t *>(s_mrg + 64u);            // [BS_LOCG][64] best approximate cosine of each 16-row group of the block's first tiles
-    uint32_t *s_stg_row = s_loc + BS_LOCG * 64u;                            // [128] the service wave's staging area: hits that passed its look under the bounds of the moment
+    float *s_mrg = s_inv + QN;                                              // [QN] 2 eps of each query (the service wave's look at a hit)
+    uint32_t *s_loc = reinterpret_cast<uint32_t *>(s_mrg + QN);             // [BS_LOCG][QN] best approximate cosine of each 16-row group of the block's first tiles
+    uint32_t *s_stg_row = s_loc + BS_LOCG * QN;                            // [128] the service wave's staging area: hits that passed its look under the bounds of the moment
     uint32_t *s_stg_q = s_stg_row + 128u;
     float *s_stg_dot = reinterpret_cast<float *>(s_stg_q + 128u);
-    float *s_qqp = s_hdot;                                                  // prologue only: the two halves of every |q|^2
+    float *s_qqp = s_hdot;                                                  // prologue only: [2][QN] the two halves of every |q|^2, [2][QN] of every || y^ - y ||^2
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
             s16x8 H = a.shadow_q ? reinterpret_cast<const s16x8 *>(a.shadow_q + (size_t)gr * D)[4u * kk + kq]
                                  : *reinterpret_cast<const s16x8 *>(a.shadow_t + tiled_shadow_off(gr, 4u * kk + kq, KS));
             if (!live) H = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            *reinterpret_cast<s16x8 *>(qimg + (kk * 4u + g) * 1024u + lane * 16u) = H;
+            *reinterpret_cast<s16x8 *>(qimg + (kk * NG + g) * 1024u + lane * 16u) = H;
         }
         if (tid < BSL_WORDS) s_ctl[tid] = 0u;
         if (tid < 64u) { s_bnd[tid] = 0u; s_inv[tid] = tid < nq ? 1.0f : 0.0f; s_mrg[tid] = 0.0f; }
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
     // (16 accesses of 64 bytes per load instruction; with the fragment's own lane order — lane 16 kq + j at row j — it was 64
     // accesses of 16 bytes, and the L1's rate of line accesses made the 196 KiB of a 768-d batch a 9 us read); the lane's
     // share stays in registers from the norm to the image: read once, every load in flight at once.
-    {
+    if constexpr (NB == 1) {
         const uint32_t g = wave & 3u, half = wave >> 2, r = lane >> 2, c = lane & 3u, q = g * 16u + r;
         const bool live = q < nq;
         const f32x4 *q4 = reinterpret_cast<const f32x4 *>(a.queries + (size_t)(live ? q : 0u) * D) + half * (KS / 2) * 8 + c;
@@ -222,10 +229,10 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         }
         qq += __shfl_xor(qq, 1, 64);
         qq += __shfl_xor(qq, 2, 64);
-        if (c == 0u) s_qqp[half * 64u + q] = live ? qq : 0.0f;
+        if (c == 0u) s_qqp[half * QN + q] = live ? qq : 0.0f;
         if (tid < BSL_WORDS) s_ctl[tid] = 0u;
         if (tid < 64u) s_bnd[tid] = 0u;
-        for (uint32_t i = tid; i < BS_LOCG * 64u; i += 512u) s_loc[i] = 0u;
+        for (uint32_t i = tid; i < BS_LOCG * QN; i += 512u) s_loc[i] = 0u;
         __syncthreads();
         if (stamps && tid == 0u) stamps[30] = now();
         if (tid < 64u) {
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         const bool ok = live && inv > 0.0f;
         float es = 0.0f;   // this lane's share of || y^ - y ||^2
         // elements 4 p .. 4 p + 3 of a K-step (p = c, 4 + c) are half of fragment lane 16 (p >> 1) + r's 16 bytes
-        char *const dst = qimg + (half * (KS / 2) * 4u + g) * 1024u + (16u * (c >> 1) + r) * 16u + (c & 1u) * 8u;
+        char *const dst = qimg + (half * (KS / 2) * NG + g) * 1024u + (16u * (c >> 1) + r) * 16u + (c & 1u) * 8u;
 #pragma unroll
         for (int ks = 0; ks < KS / 2; ks++)
 #pragma unroll
@@ -258,11 +265,80 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
                     w[h] = pk;
                 }
                 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                *reinterpret_cast<u32x2 *>(dst + ks * 4096 + i * 512) = u32x2{w[0], w[1]};   // (piece 4 + c: fragment lanes 32 further)
+                *reinterpret_cast<u32x2 *>(dst + ks * (NG * 1024) + i * 512) = u32x2{w[0], w[1]};   // (piece 4 + c: fragment lanes 32 further)
             }
         es += __shfl_xor(es, 1, 64);
         es += __shfl_xor(es, 2, 64);
-        if (c == 0u) s_qqp[128u + half * 64u + q] = es;
+        if (c == 0u) s_qqp[2u * QN + half * QN + q] = es;
+    } else {
+        // two banks: wave w takes query group w (eight groups), both halves of the K-steps one after the other — the lane's share of
+        // a whole row does not fit the registers next to the ring, so the queries are read twice (from the L2): once for |q|, once
+        // for the image
+        const uint32_t g = wave, r = lane >> 2, c = lane & 3u, q = g * 16u + r;
+        const bool live = q < nq;
+        const f32x4 *q4 = reinterpret_cast<const f32x4 *>(a.queries + (size_t)(live ? q : 0u) * D) + c;
+        float qq = 0.0f;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            f32x4 v[KS / 2][2];
+#pragma unroll
+            for (int ks = 0; ks < KS / 2; ks++) { v[ks][0] = q4[8 * (half * (KS / 2) + ks)]; v[ks][1] = q4[8 * (half * (KS / 2) + ks) + 4]; }
+            if (half == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                start_ring();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS / 2; ks++) {
+                const f32x4 v0 = v[ks][0], v1 = v[ks][1];
+                qq += v0.x * v0.x + v0.y * v0.y + v0.z * v0.z + v0.w * v0.w + v1.x * v1.x + v1.y * v1.y + v1.z * v1.z + v1.w * v1.w;
+            }
+        }
+        qq += __shfl_xor(qq, 1, 64);
+        qq += __shfl_xor(qq, 2, 64);
+        if (c == 0u) { s_qqp[q] = live ? qq : 0.0f; s_qqp[QN + q] = 0.0f; }
+        if (tid < BSL_WORDS) s_ctl[tid] = 0u;
+        if (tid < QN) s_bnd[tid] = 0u;
+        for (uint32_t i = tid; i < BS_LOCG * QN; i += 512u) s_loc[i] = 0u;
+        __syncthreads();
+        if (stamps && tid == 0u) stamps[30] = now();
+        if (tid < QN) {
+            const float ss = s_qqp[tid] + s_qqp[QN + tid];
+            const bool reg = bs_regular(ss);
+            s_inv[tid] = reg ? 1.0f / sqrtf(ss) : 0.0f;
+            if (blockIdx.x == 0u && tid < nq && !reg) a.ctl[BS_CTL_REDO + tid] = 1u;
+        }
+        __syncthreads();
+        if (stamps && tid == 0u) stamps[31] = now();
+        const float inv = s_inv[q];
+        const bool ok = live && inv > 0.0f;
+        float es = 0.0f;
+        char *const dst = qimg + g * 1024u + (16u * (c >> 1) + r) * 16u + (c & 1u) * 8u;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            f32x4 v[KS / 2][2];
+#pragma unroll
+            for (int ks = 0; ks < KS / 2; ks++) { v[ks][0] = q4[8 * (half * (KS / 2) + ks)]; v[ks][1] = q4[8 * (half * (KS / 2) + ks) + 4]; }
+#pragma unroll
+            for (int ks = 0; ks < KS / 2; ks++)
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    uint32_t w[2];
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const f32x2 y = {ok ? v[ks][i][2 * h] * inv : 0.0f, ok ? v[ks][i][2 * h + 1] * inv : 0.0f};
+                        const uint32_t pk = __builtin_bit_cast(uint32_t, __builtin_convertvector(y, bf16x2_t));
+                        const float d0 = y.x - __uint_as_float(pk << 16), d1 = y.y - __uint_as_float(pk & 0xFFFF0000u);
+                        es += d0 * d0 + d1 * d1;
+                        w[h] = pk;
+                    }
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    *reinterpret_cast<u32x2 *>(dst + (half * (KS / 2) + ks) * (NG * 1024) + i * 512) = u32x2{w[0], w[1]};
+                }
+        }
+        es += __shfl_xor(es, 1, 64);
+        es += __shfl_xor(es, 2, 64);
+        if (c == 0u) { s_qqp[2u * QN + q] = es; s_qqp[3u * QN + q] = 0.0f; }
     }
     }
     // the service wave fills the tile queue: tiles n_static + c .. + BS_CLAIM - 1 of a claim c; BS_WORK end marks once
@@ -297,7 +373,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
             q = active ? q : 0u;
             uint64_t same = __ballot(active);
 #pragma unroll
-            for (int b = 0; b < 6; b++) {
+            for (int b = 0; b < (NB == 1 ? 6 : 7); b++) {
                 const uint64_t m = __ballot((q >> b) & 1u);
                 same &= ((q >> b) & 1u) ? m : ~m;
             }
@@ -374,7 +450,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         // slots have not filled by now is declared to have no bound
         auto publish = [&](uint32_t min_filled, bool final, bool pre = false) -> bool {
             bool all_done = true;
-            for (uint32_t q = blockIdx.x & 63u; q < nq; q += gridDim.x) {
+            for (uint32_t q = blockIdx.x % QN; q < nq; q += gridDim.x) {
                 if (!(s_inv[q] > 0.0f)) continue;   // an irregular query has no bound and needs none
                 const uint32_t nz = slots_load(q, pre);
                 if (nz < min_filled && !final) { all_done = false; continue; }
@@ -392,7 +468,10 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
                 push_claim(c);
             }
         };
-        uint32_t bl = 1u;
+        uint32_t bl[NB];   // (lane, bank): the published bound of query 64 bank + lane
+#pragma unroll
+        for (int bk = 0; bk < NB; bk++) bl[bk] = 1u;
+        constexpr uint32_t FRAC_MASK = NB == 1 ? 3u : 1u;   // publishers per query in a grid of 256 blocks: four (one bank) or two
         if constexpr (!THR) {
         // A-C. the warm-up, one polling loop: (A) once the block's workers have left their first tiles' maxima in LDS, write
         // them to the tiles' slots (plain write-through stores); (B) publish this block's queries as soon as a fraction
@@ -402,7 +481,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
             // the first publisher of a query (blocks 0..63) goes as soon as a.pub_min slots (>= k) are in: a bound from the earliest
             // finishers' rows lets a couple more pairs per tile through for the few microseconds until the others — at 2/8,
             // 3/8, 4/8 of the sample — and the service loop tighten it, and everybody starts testing a round trip earlier
-            const uint32_t frac = (blockIdx.x >> 6) & 3u;
+            const uint32_t frac = (blockIdx.x / QN) & FRAC_MASK;
             const uint32_t want0 = frac ? sample * (frac + 1u) / 8u : a.pub_min;
             const uint32_t want = want0 > k ? want0 : k;
             bool stored = false, published = false;
@@ -426,29 +505,40 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
                 }
                 if (stamps && lane == 0u) stamps[29] = (unsigned long long)spin + 1ull;
                 if (try_pub && !published && spin < 24) continue;
-                bl = (lane < nq && s_inv[lane] > 0.0f) ? bs_ld_agent(g_bound + lane) : 1u;
-                uint64_t missing = __ballot(bl == 0u);
-                if (stored && missing == 0ull) break;
+                uint64_t missing[NB];
+                bool any_missing = false;
+#pragma unroll
+                for (int bk = 0; bk < NB; bk++) {
+                    const uint32_t ql = 64u * bk + lane;
+                    bl[bk] = (ql < nq && s_inv[ql] > 0.0f) ? bs_ld_agent(g_bound + ql) : 1u;
+                    missing[bk] = __ballot(bl[bk] == 0u);
+                    any_missing = any_missing || missing[bk] != 0ull;
+                }
+                if (stored && !any_missing) break;
                 // queries nobody has published after ~80 us: their publishers are not resident (see above) — any block may
                 // publish any query (an atomic max: redundancy is harmless)
                 if (spin >= 24 && (spin & 7) == 0) {
-                    while (missing) {
-                        const uint32_t q = (uint32_t)__ffsll((unsigned long long)missing) - 1u;
-                        missing &= missing - 1ull;
-                        const uint32_t nz = slots_load(q);
-                        const uint32_t t = nz >= k ? slots_kth() : 0u;
-                        if (lane == 0u && (t || spin >= 96)) __hip_atomic_fetch_max(g_bound + q, t ? t : BS_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
+#pragma unroll
+                    for (int bk = 0; bk < NB; bk++)
+                        while (missing[bk]) {
+                            const uint32_t q = 64u * bk + (uint32_t)__ffsll((unsigned long long)missing[bk]) - 1u;
+                            missing[bk] &= missing[bk] - 1ull;
+                            const uint32_t nz = slots_load(q);
+                            const uint32_t t = nz >= k ? slots_kth() : 0u;
+                            if (lane == 0u && (t || spin >= 96)) __hip_atomic_fetch_max(g_bound + q, t ? t : BS_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                 }
                 if (published) __builtin_amdgcn_s_sleep(8);
             }
         }
-        __hip_atomic_fetch_max(&s_bnd[lane], bl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (the block's local bound may be there, and may be the higher one)
+#pragma unroll
+        for (int bk = 0; bk < NB; bk++)   // (the block's local bound may be there, and may be the higher one)
+            __hip_atomic_fetch_max(&s_bnd[64u * bk + lane], bl[bk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (lane == 0u) bs_lds_st_rel(&s_ctl[BSL_READY], 1u);
         if (stamps && lane == 0u) stamps[2] = now();
         // the first bounds come from the earliest finishers' slots; by now every first tile of the grid is in: one block per query
         // (the second of its publishers) tightens it from all the slots right away — the others' refreshes pick it up 2 / 6 / 14 us on
-        if (((blockIdx.x >> 6) & 3u) == 1u) publish(0u, true);
+        if (((blockIdx.x / QN) & FRAC_MASK) == 1u) publish(0u, true);
         }
         // D. service loop: drain the workers' hit rings, keep the tile queue filled and the block's copy of the bounds
         // fresh (re-read and re-published 2, 4, 8, ... us apart, then every 128 us: see the head of the file)
@@ -528,8 +618,11 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
                 const uint64_t t_now = now();
                 if (stamps && workers_done && !seen_done) { seen_done = true; if (lane == 0u) stamps[37] = t_now; }
                 if (!THR && t_now >= t_next && !workers_done) {
-                    bl = bs_ld_agent(g_bound + lane);
-                    __hip_atomic_fetch_max(&s_bnd[lane], bl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+                    for (int bk = 0; bk < NB; bk++) {
+                        bl[bk] = bs_ld_agent(g_bound + 64u * bk + lane);
+                        __hip_atomic_fetch_max(&s_bnd[64u * bk + lane], bl[bk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                     if (stamps && lane == 0u) stamps[35] = now();
                     if (gap >= 800u && !(a.arm & 16u)) publish(0u, true);
                     if (stamps && lane == 0u) stamps[36] = now();
@@ -564,17 +657,17 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
     uint32_t head = 0;               // entries this wave has put into its hit ring (wave-uniform; s_ctl[BSL_HEAD + wave] mirrors it)
     bool first = true;
     uint32_t n_tiles_done = 0;       // (timeline diagnostic)
-    bool liveq[4];
+    bool liveq[NG];
 #pragma unroll
-    for (int g = 0; g < 4; g++) liveq[g] = 16u * g + j < nq && s_inv[16u * g + j] > 0.0f;   // (an irregular query takes no part in the pass)
-    float thr[4];                    // the threshold of each of the lane's four queries (bs_thr)
-    float mrg[4];                    // 2 eps of each of them (read here, right behind the prologue's last barrier: the ring that
+    for (int g = 0; g < NG; g++) liveq[g] = 16u * g + j < nq && s_inv[16u * g + j] > 0.0f;   // (an irregular query takes no part in the pass)
+    float thr[NG];                   // the threshold of each of the lane's four (eight) queries (bs_thr)
+    float mrg[NG];                   // 2 eps of each of them (read here, right behind the prologue's last barrier: the ring that
                                      // shares this LDS is first written after every worker of the block is past its first tile)
     {
         const float dmax = a.shadow_err ? __uint_as_float(*a.shadow_err) : 0.00390625f;
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const float dq = THR ? 0.0f : sqrtf(s_qqp[128u + 16u * g + j] + s_qqp[192u + 16u * g + j]);
+        for (int g = 0; g < NG; g++) {
+            const float dq = THR ? 0.0f : sqrtf(s_qqp[2u * QN + 16u * g + j] + s_qqp[3u * QN + 16u * g + j]);
             mrg[g] = 2.0f * (dmax * (1.0f + 0.00390625f) + dq * (1.0f + 1.0e-6f) + 1.0e-4f);
             if (!THR && wave == 0u && kq == 0u) {
                 s_mrg[16u * g + j] = mrg[g];   // (read by the service wave once hits exist: after this wave's first tile)
@@ -595,10 +688,13 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         if (lane == 0u) __hip_atomic_store(THR ? a.thr_next + 1 : a.ctl + BS_CTL_FAIL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return false;
     };
-    // query fragments: [buffer][group]; the next K-step's are read while this one's MFMAs run
-    s16x8 B[2][4];
+    // query fragments: [buffer][group]; one bank: the next K-step's are read while this one's MFMAs run; two banks: a K-step's eight
+    // are read at its head (their waits fall behind the first MFMAs; the SIMD's other wave covers the rest)
+    s16x8 B[NB == 1 ? 2 : 1][NG];
+    if constexpr (NB == 1) {
 #pragma unroll
-    for (int g = 0; g < 4; g++) B[0][g] = *reinterpret_cast<const s16x8 *>(my_q + g * 1024);
+        for (int g = 0; g < NG; g++) B[0][g] = *reinterpret_cast<const s16x8 *>(my_q + g * 1024);
+    }
     auto claim = [&]() -> uint32_t {   // the next tile of this wave: an entry of the block's queue
         uint32_t idx = 0u;
         if (lane == 0u) idx = __hip_atomic_fetch_add(&s_ctl[BSL_QTAIL], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -610,19 +706,24 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
     while (T != BS_NO_TILE) {
         const uint32_t Tn = claim();
         const __amdgpu_buffer_rsrc_t nrs = tile_rsrc(Tn != BS_NO_TILE ? Tn : T);
-        f32x4 acc[4][2];
+        f32x4 acc[NG][2];
 #pragma unroll
-        for (int g = 0; g < 4; g++) { acc[g][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; acc[g][1] = acc[g][0]; }
+        for (int g = 0; g < NG; g++) { acc[g][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; acc[g][1] = acc[g][0]; }
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
-            const int p = ks % P, cur = ks & 1, nxt = cur ^ 1;
-            const int nks = ks + 1 < KS ? ks + 1 : 0;   // the last step reads the next tile's first query fragments
+            const int p = ks % P, cur = NB == 1 ? (ks & 1) : 0, nxt = cur ^ 1;
+            if constexpr (NB == 1) {
+                const int nks = ks + 1 < KS ? ks + 1 : 0;   // the last step reads the next tile's first query fragments
 #pragma unroll
-            for (int g = 0; g < 4; g++) B[nxt][g] = *reinterpret_cast<const s16x8 *>(my_q + (nks * 4 + g) * 1024);
+                for (int g = 0; g < NG; g++) B[nxt][g] = *reinterpret_cast<const s16x8 *>(my_q + (nks * NG + g) * 1024);
+            } else {
+#pragma unroll
+                for (int g = 0; g < NG; g++) B[0][g] = *reinterpret_cast<const s16x8 *>(my_q + (ks * NG + g) * 1024);
+            }
             __builtin_amdgcn_sched_barrier(0);
             const s16x8 h0 = ring[p][0], h1 = ring[p][1];
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
+            for (int g = 0; g < NG; g++) {
                 acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h0, B[cur][g], acc[g][0], 0, 0, 0);
                 acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1, B[cur][g], acc[g][1], 0, 0, 0);
             }
@@ -661,9 +762,11 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
             // (0.164 against 0.173 ms) and from ~1M rows at 384-d (1.25M: 0.202 against 0.208), a loss below (100k x 384: 0.115
             // against 0.074) — so only passes of at least a.loc_min_rows rows do it (launch_batchs_pass).
             const bool loc = k <= BS_LOCG && in_block == BS_WORK && n_rows >= a.loc_min_rows && !(a.arm & 8u);
-            uint32_t mine = 0u;
+            uint32_t mine[NB];   // (lane, bank): the tile's best approximate cosine of query 64 bank + lane
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
+            for (int bk = 0; bk < NB; bk++) mine[bk] = 0u;
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
                 float mx = 0.0f;
 #pragma unroll
                 for (int f = 0; f < 2; f++) {
@@ -672,40 +775,52 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
                     for (int r = 0; r < 4; r++) m = (((okm >> (4 * f + r)) & 1u) && acc[g][f][r] > m) ? acc[g][f][r] : m;
                     m = fmaxf(m, __shfl_xor(m, 16, 64));
                     m = fmaxf(m, __shfl_xor(m, 32, 64));
-                    if (loc && kq == 0u) s_loc[(2u * wave + (uint32_t)f) * 64u + 16u * g + j] = __float_as_uint(m);
+                    if (loc && kq == 0u) s_loc[(2u * wave + (uint32_t)f) * QN + 16u * g + j] = __float_as_uint(m);
                     mx = fmaxf(mx, m);
                 }
-                mine = (kq == (uint32_t)g && 16u * g + j < nq) ? __float_as_uint(mx) : mine;   // lane 16 g + j: query 16 g + j
+                mine[g >> 2] = (kq == (uint32_t)(g & 3) && 16u * g + j < nq) ? __float_as_uint(mx) : mine[g >> 2];   // lane 16 (g mod 4) + j, bank g / 4: query 16 g + j
             }
             // (straight to the tile's slots, lane q = query q: a store the wave does not wait for — through the service wave it
             // waited for the block's slowest worker and for that wave's next poll, ~8 us on every bound of the grid)
-            if (lane < nq) __hip_atomic_store(g_slots + lane * BS_SL + (T & (BS_SL - 1u)), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int bk = 0; bk < NB; bk++)
+                if (64u * bk + lane < nq) __hip_atomic_store(g_slots + (64u * bk + lane) * BS_SL + (T & (BS_SL - 1u)), mine[bk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             uint32_t before = 0u;
             if (lane == 0u) before = __hip_atomic_fetch_add(&s_ctl[BSL_ARRIVED], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
             before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
-            if (loc && before + 1u == in_block) {   // the block's last arrival: lane q sorts query q's fourteen values (a network: ~130 instructions)
-                uint32_t v[16];
+            if (loc && before + 1u == in_block) {   // the block's last arrival: lane q sorts query q's fourteen values (a network: ~130 instructions), bank by bank
+                uint32_t kth[NB];
+                bool none = false;
 #pragma unroll
-                for (int i = 0; i < 16; i++) v[i] = i < (int)BS_LOCG ? bs_lds_ld(&s_loc[(uint32_t)i * 64u + lane]) : 0u;   // (bits of cosines >= 0 order like integers)
+                for (int bk = 0; bk < NB; bk++) {
+                    const uint32_t ql = 64u * bk + lane;
+                    uint32_t v[16];
 #pragma unroll
-                for (int p2 = 1; p2 < 16; p2 <<= 1)
+                    for (int i = 0; i < 16; i++) v[i] = i < (int)BS_LOCG ? bs_lds_ld(&s_loc[(uint32_t)i * QN + ql]) : 0u;   // (bits of cosines >= 0 order like integers)
 #pragma unroll
-                    for (int k2 = p2; k2 >= 1; k2 >>= 1)
+                    for (int p2 = 1; p2 < 16; p2 <<= 1)
 #pragma unroll
-                        for (int j2 = k2 % p2; j2 + k2 < 16; j2 += 2 * k2)
+                        for (int k2 = p2; k2 >= 1; k2 >>= 1)
 #pragma unroll
-                            for (int i2 = 0; i2 < k2; i2++)
-                                if ((i2 + j2) / (2 * p2) == (i2 + j2 + k2) / (2 * p2)) {   // Batcher's odd-even merge sort, descending
-                                    const uint32_t x = v[i2 + j2], y = v[i2 + j2 + k2];
-                                    v[i2 + j2] = x > y ? x : y;
-                                    v[i2 + j2 + k2] = x > y ? y : x;
-                                }
-                uint32_t kth = 0u;
+                            for (int j2 = k2 % p2; j2 + k2 < 16; j2 += 2 * k2)
 #pragma unroll
-                for (int i = 0; i < (int)BS_LOCG; i++) kth = (uint32_t)i + 1u == k ? v[i] : kth;
-                const bool want = lane < nq && s_inv[lane] > 0.0f;
-                if (!__ballot(want && kth == 0u)) {   // all or nothing: a query without a local bound would flood the rings
-                    if (want) __hip_atomic_fetch_max(&s_bnd[lane], kth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                for (int i2 = 0; i2 < k2; i2++)
+                                    if ((i2 + j2) / (2 * p2) == (i2 + j2 + k2) / (2 * p2)) {   // Batcher's odd-even merge sort, descending
+                                        const uint32_t x = v[i2 + j2], y = v[i2 + j2 + k2];
+                                        v[i2 + j2] = x > y ? x : y;
+                                        v[i2 + j2 + k2] = x > y ? y : x;
+                                    }
+                    kth[bk] = 0u;
+#pragma unroll
+                    for (int i = 0; i < (int)BS_LOCG; i++) kth[bk] = (uint32_t)i + 1u == k ? v[i] : kth[bk];
+                    const bool want = ql < nq && s_inv[ql] > 0.0f;
+                    none = none || __ballot(want && kth[bk] == 0u) != 0ull;
+                    kth[bk] = want ? kth[bk] : 0u;
+                }
+                if (!none) {   // all or nothing: a query without a local bound would flood the rings
+#pragma unroll
+                    for (int bk = 0; bk < NB; bk++)
+                        if (kth[bk]) __hip_atomic_fetch_max(&s_bnd[64u * bk + lane], kth[bk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (lane == 0u) bs_lds_st_rel(&s_ctl[BSL_LOC], 1u);
                 }
             }
@@ -716,29 +831,29 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
             if (stamps && lane == 0u && wave == 0u) stamps[26] = now();
         } else if (stamps && lane == 0u && wave == 0u && n_tiles_done == 2u) stamps[25] = now();
 #pragma unroll
-        for (int g = 0; g < 4; g++) thr[g] = THR ? (liveq[g] ? a.thr_lo : __builtin_inff()) : bs_thr(bs_lds_ld(&s_bnd[16 * g + j]), liveq[g], mrg[g]);
+        for (int g = 0; g < NG; g++) thr[g] = THR ? (liveq[g] ? a.thr_lo : __builtin_inff()) : bs_thr(bs_lds_ld(&s_bnd[16 * g + j]), liveq[g], mrg[g]);
 
         // ---- the test: one compare per pair (a NaN passes); one wave-level branch
         bool any = false;
 #pragma unroll
-        for (int g = 0; g < 4; g++)
+        for (int g = 0; g < NG; g++)
 #pragma unroll
             for (int f = 0; f < 2; f++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) any |= !(acc[g][f][r] < thr[g]);
         if (a.arm & 1u) any = false;
         if (__ballot(any)) {
-            uint32_t hm = 0;             // hit mask (bit (g * 2 + f) * 4 + r)
+            uint64_t hm = 0;             // hit mask (bit (g * 2 + f) * 4 + r)
 #pragma unroll
-            for (int g = 0; g < 4; g++)
+            for (int g = 0; g < NG; g++)
 #pragma unroll
                 for (int f = 0; f < 2; f++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const bool hit = !(acc[g][f][r] < thr[g]) & (row0 + 16u * f + r < n_rows) & liveq[g];
-                        hm |= hit ? (1u << ((g * 2 + f) * 4 + r)) : 0u;
+                        hm |= hit ? (1ull << ((g * 2 + f) * 4 + r)) : 0ull;
                     }
-            const uint32_t mine = (uint32_t)__popc(hm);
+            const uint32_t mine = (uint32_t)__popcll(hm);
             uint32_t incl = mine;        // inclusive prefix sum over the lanes
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
@@ -747,10 +862,10 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
             }
             const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             if (tot <= HB) {
-                if (!wait_room(tot)) hm = 0u;
+                if (!wait_room(tot)) hm = 0ull;
                 uint32_t pos = head + incl - mine;
 #pragma unroll
-                for (int g = 0; g < 4; g++)
+                for (int g = 0; g < NG; g++)
 #pragma unroll
                     for (int f = 0; f < 2; f++)
 #pragma unroll
@@ -762,20 +877,20 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
                                 hb_dot[e] = acc[g][f][r];
                                 pos++;
                             }
-                if (__ballot(hm != 0u)) {
+                if (__ballot(hm != 0ull)) {
                     head += tot;
                     if (lane == 0u) bs_lds_st_rel(&s_ctl[BSL_HEAD + wave], head);
                 }
             } else {
                 // a tile of a query without a bound: one hit per lane and round
 #pragma unroll 1
-                while (__ballot(hm != 0u)) {
-                    const bool on = hm != 0u;
-                    const uint32_t idx = on ? (uint32_t)__ffs((int)hm) - 1u : 0u;
-                    hm &= hm - 1u;
+                while (__ballot(hm != 0ull)) {
+                    const bool on = hm != 0ull;
+                    const uint32_t idx = on ? (uint32_t)__ffsll((unsigned long long)hm) - 1u : 0u;
+                    hm &= hm - 1ull;
                     float dot = 0.0f;
 #pragma unroll
-                    for (int g = 0; g < 4; g++)
+                    for (int g = 0; g < NG; g++)
 #pragma unroll
                         for (int f = 0; f < 2; f++)
 #pragma unroll
@@ -1067,6 +1182,13 @@ __global__ __launch_bounds__(1024) void batchs_select_kernel(const BatchSArgs a,
 // ---------------------------------------------------------------------------------------------------
 bool batchs_supported(uint32_t dim, uint32_t k) { return dim >= 128u && dim <= 1024u && dim % 128u == 0u && k >= 1u && k <= 256u; }
 
+// queries one pass serves: 128 (two banks) for calls of more than 64 queries at row widths up to 512 over at least 128 blocks' worth
+// of rows (every query needs a publisher block: batchs_kernel), 64 otherwise; CX_BATCHS_QPP=64 switches the second bank off
+uint32_t batchs_queries_per_pass(uint32_t dim, uint32_t n_rows, uint64_t nq) {
+    static const uint32_t qpp_env = getenv("CX_BATCHS_QPP") ? (uint32_t)atoi(getenv("CX_BATCHS_QPP")) : 128u;
+    return (qpp_env >= 128u && dim <= 512u && nq > 64u && n_rows >= 128u * BS_WORK * 32u) ? 128u : 64u;
+}
+
 uint32_t batchs_min_rows() {
     static const uint32_t v = getenv("CX_BATCHS_MIN_ROWS") ? (uint32_t)atoi(getenv("CX_BATCHS_MIN_ROWS")) : 131072u;
     return v;
@@ -1076,11 +1198,19 @@ template <int D>
 static int launch_batchs_d(const BatchSArgs &a, uint32_t grid, hipStream_t stream) {
     static std::atomic<uint64_t> attr_devices{0};
     if (first_use_on_device(attr_devices)) {
-        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchs_kernel<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchs_kernel<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchs_kernel<D, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchs_kernel<D, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if constexpr (D <= 512)
+            CX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(batchs_kernel<D, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
-    if (a.thr_cand) hipLaunchKernelGGL((batchs_kernel<D, true>), dim3(grid), dim3(512), BsCfg<D>::LDS, stream, a);
-    else hipLaunchKernelGGL((batchs_kernel<D, false>), dim3(grid), dim3(512), BsCfg<D>::LDS, stream, a);
+    if (a.thr_cand) {
+        hipLaunchKernelGGL((batchs_kernel<D, true, 1>), dim3(grid), dim3(512), BsCfg<D>::LDS, stream, a);
+    } else if (a.nq > 64u) {   // two banks of 64 queries (launch_batchs_pass has checked the width)
+        if constexpr (D <= 512) hipLaunchKernelGGL((batchs_kernel<D, false, 2>), dim3(grid), dim3(512), (BsCfg<D, 2>::LDS), stream, a);
+        else return set_err(CX_ERR_VALIDATION, "batchs: %u queries in one pass need a row width of at most 512 (got %u)", a.nq, a.dim);
+    } else {
+        hipLaunchKernelGGL((batchs_kernel<D, false, 1>), dim3(grid), dim3(512), BsCfg<D>::LDS, stream, a);
+    }
     CX_HIP(hipGetLastError());
     return CX_OK;
 }
@@ -1095,7 +1225,7 @@ int launch_batchs_pass(const BatchSArgs &a_in, hipStream_t stream) {
     a.claim = claim_env;
     static const long loc_env = getenv("CX_BATCHS_LOC_MIN") ? atol(getenv("CX_BATCHS_LOC_MIN")) : -1;
     a.loc_min_rows = loc_env >= 0 ? (uint32_t)loc_env : (a.dim >= 640u ? 393216u : 1048576u);   // (block-local first bounds: see the kernel)
-    if (!batchs_supported(a.dim, a.k) || a.nq == 0 || a.nq > 64u || a.n_rows == 0)
+    if (!batchs_supported(a.dim, a.k) || a.nq == 0 || a.nq > batchs_queries_per_pass(a.dim, a.n_rows, a.nq) || a.n_rows == 0 || (a.thr_cand && a.nq > 64u))
         return set_err(CX_ERR_VALIDATION, "batchs: unsupported shape (dim %u, k %u, %u queries, %u rows)", a.dim, a.k, a.nq, a.n_rows);
     const uint32_t cus = device_cus(), n32 = (a.n_rows + 31u) / 32u;
     // every worker wave needs a first tile of its own (its warm-up fills a slot); blocks of 7 workers + the service wave

@@ -389,16 +389,18 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
             rc = ensure_dev(c->d_bs_ctl, c->bsc_cap, (size_t)BS_CTL_WORDS);
             if (!rc && hipMemsetAsync(c->d_bs_ctl, 0, (size_t)BS_CTL_WORDS * sizeof(uint32_t), s) != hipSuccess) rc = CX_ERR_DEVICE;
         }
-        if (!rc && bs_go) rc = ensure_dev(c->d_bs_rows, c->bsr_cap, (size_t)64 * bs_cap);
-        if (!rc && bs_go) rc = ensure_dev(c->d_bs_cos, c->bss_cap, (size_t)64 * bs_cap);
+        // (calls of more than 64 queries at row widths up to 512 run 128 queries per pass: batchs.hip's two banks)
+        const size_t bs_q = batchs_queries_per_pass(ix->dim, n, nq);
+        if (!rc && bs_go) rc = ensure_dev(c->d_bs_rows, c->bsr_cap, bs_q * bs_cap);
+        if (!rc && bs_go) rc = ensure_dev(c->d_bs_cos, c->bss_cap, bs_q * bs_cap);
         if (rc) {
             (void)hipGetLastError();   // (a failed hipMalloc is sticky until read)
             bs_go = false;
         }
     }
     if (bs_go) {
-        for (uint64_t q0 = 0; q0 < nq; q0 += 64) {
-            const uint32_t m = (uint32_t)std::min<uint64_t>(64, nq - q0);
+        for (uint64_t q0 = 0; q0 < nq;) {
+            const uint32_t m = (uint32_t)std::min<uint64_t>(batchs_queries_per_pass(ix->dim, n, nq - q0), nq - q0);
             BatchSArgs b;
             memset(&b, 0, sizeof b);
             b.shadow_t = ix->d_shadow_t;
@@ -429,11 +431,11 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
             if (e1 && !rc && hipEventRecord(e1, s) != hipSuccess) rc = set_err(CX_ERR_DEVICE, "hipEventRecord failed");   // (no early return between a pass and its select: see below)
             static const int bs_diag = getenv("CX_BATCHS_DIAG") ? atoi(getenv("CX_BATCHS_DIAG")) : 0;
             if (bs_diag && !rc) {   // candidates per query and published bounds of this pass, on stderr
-                std::vector<uint32_t> dg(128);
+                std::vector<uint32_t> dg(2 * BS_MAXQ);   // bounds | list lengths
                 (void)hipStreamSynchronize(s);
-                (void)hipMemcpy(dg.data(), c->d_bs_ctl + BS_CTL_BOUND, 128 * sizeof(uint32_t), hipMemcpyDeviceToHost);
+                (void)hipMemcpy(dg.data(), c->d_bs_ctl + BS_CTL_BOUND, 2 * BS_MAXQ * sizeof(uint32_t), hipMemcpyDeviceToHost);
                 uint64_t tot = 0; uint32_t mx = 0, nob = 0;
-                for (uint32_t q = 0; q < m; q++) { tot += dg[64 + q]; mx = std::max(mx, dg[64 + q]); nob += dg[q] <= 1u; }
+                for (uint32_t q = 0; q < m; q++) { tot += dg[BS_MAXQ + q]; mx = std::max(mx, dg[BS_MAXQ + q]); nob += dg[q] <= 1u; }
                 float b0; memcpy(&b0, &dg[0], 4);
                 fprintf(stderr, "[batchs diag] %u queries: %llu candidates (max %u per query), %u without a bound, bound[0] = %.4f\n", m, (unsigned long long)tot, mx, nob, b0);
             }
@@ -442,6 +444,7 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
                 (void)hipMemsetAsync(c->d_bs_ctl, 0, (size_t)BS_CTL_WORDS * sizeof(uint32_t), s);
                 return rc;
             }
+            q0 += m;
         }
         return CX_OK;
     }

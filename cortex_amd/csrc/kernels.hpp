@@ -120,12 +120,13 @@ int launch_cand_select(const MergeArgs &m, uint32_t nq, uint32_t *d_redo, hipStr
 
 // ---- batched search as a bf16 screening pass + exact re-score of the survivors (batchs.hip) ----
 constexpr uint32_t BS_SL = 2048;                      // bound slots per query in the control block (tile t -> slot t mod BS_SL)
-constexpr uint32_t BS_CTL_BOUND = 64 * BS_SL;         // word offsets inside the control block
-constexpr uint32_t BS_CTL_CNT = BS_CTL_BOUND + 64;
-constexpr uint32_t BS_CTL_NEXT = BS_CTL_CNT + 64;     // the next unclaimed tile beyond the statically dealt first ones
+constexpr uint32_t BS_MAXQ = 128;                     // queries of one pass: two banks of 64 at row widths up to 512 (batchs.hip: NB), one bank above
+constexpr uint32_t BS_CTL_BOUND = BS_MAXQ * BS_SL;    // word offsets inside the control block
+constexpr uint32_t BS_CTL_CNT = BS_CTL_BOUND + BS_MAXQ;
+constexpr uint32_t BS_CTL_NEXT = BS_CTL_CNT + BS_MAXQ; // the next unclaimed tile beyond the statically dealt first ones
 constexpr uint32_t BS_CTL_MRG = BS_CTL_NEXT + 16;     // 64 margins (2 eps of each query, f32 bits) of the last pass, for the re-score's second look
-constexpr uint32_t BS_CTL_REDO = BS_CTL_MRG + 64;     // 64 flags: the query is irregular (|q|^2 is zero, non-finite or outside [BS_REG_LO, BS_REG_HI]) — screened not at all, redone exactly
-constexpr uint32_t BS_CTL_FAIL = BS_CTL_REDO + 64;    // sticky: a worker gave up waiting for room in its hit ring (hits dropped): every query of the pass is redone exactly
+constexpr uint32_t BS_CTL_REDO = BS_CTL_MRG + BS_MAXQ;     // 64 flags: the query is irregular (|q|^2 is zero, non-finite or outside [BS_REG_LO, BS_REG_HI]) — screened not at all, redone exactly
+constexpr uint32_t BS_CTL_FAIL = BS_CTL_REDO + BS_MAXQ;    // sticky: a worker gave up waiting for room in its hit ring (hits dropped): every query of the pass is redone exactly
 constexpr uint32_t BS_CTL_WORDS = BS_CTL_FAIL + 16;
 // A vector is REGULAR when its sum of squares, as the reference's f32 arithmetic computes it (vector/index.rs:174-175), is a
 // number in [BS_REG_LO, BS_REG_HI]: then no product or partial sum of a pair of regular vectors overflows, what underflows is
@@ -145,9 +146,9 @@ struct BatchSArgs {
     const uint16_t *rows16; // the bf16 store
     uint32_t n_rows, nq, dim, k;
     DevFilter flt;
-    uint32_t *ctl;          // [BS_CTL_WORDS]: 64 x BS_SL bound slots | 64 published bounds | 64 list lengths | tile counter; zero between
+    uint32_t *ctl;          // [BS_CTL_WORDS]: BS_MAXQ x BS_SL bound slots | published bounds | list lengths | tile counter | margins | flags; zero between
                             // passes (the select kernel clears what a pass used)
-    uint32_t *cand_rows;    // [64][cap] candidate lists: row; exact cosine (written by the select kernel)
+    uint32_t *cand_rows;    // [nq][cap] candidate lists: row; approximate, then exact cosine (written by the re-score kernel)
     float *cand_cos;
     uint32_t cap;           // entries per query (>= BS_REDO_WAVES x k): a query whose list runs over is redone exactly by the re-score kernel
     const uint32_t *irr_rows; // [irr_n] the store's irregular rows (zero shadow rows: never hits), re-scored for every query
@@ -171,6 +172,7 @@ bool batchs_supported(uint32_t dim, uint32_t k);   // dim % 128 == 0, dim <= 102
 bool batchs_thr_supported(uint32_t n_rows, uint32_t dim, uint32_t n_scan);
 int launch_batchs_thr(const BatchSArgs &a, hipStream_t stream);
 uint32_t batchs_min_rows();   // fewest rows that take this path (CX_BATCHS_MIN_ROWS)
+uint32_t batchs_queries_per_pass(uint32_t dim, uint32_t n_rows, uint64_t nq);   // 128 for calls of more than 64 queries at widths up to 512 (CX_BATCHS_QPP), else 64
 uint32_t batchs_cand_cap(uint32_t n_rows, uint32_t k);   // entries per query of the candidate lists (CX_BATCHS_CAND_CAP, 65,536; never fewer than an exact redo writes)
 int launch_batchs_pass(const BatchSArgs &a, hipStream_t stream);
 int launch_batchs_select(const BatchSArgs &a, uint32_t *out_rows, float *out_scores, float *out_dists, uint32_t *out_count, hipStream_t stream);

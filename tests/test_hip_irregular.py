@@ -86,6 +86,13 @@ for k in (10, 100):
     for i in range(len(qs)):
         m = int(bc[i])
         check_list(bi[i, :m], bs[i, :m], bd[i, :m], o.search(qs[i], k), "batch k=%%d q%%d" %% (k, i))
+# more than 64 queries in one call (row widths up to 512 on stores of >= 28,672 rows: 128 queries per pass, two banks of the
+# screening kernel — irregular queries in both banks)
+qs_many = np.ascontiguousarray(np.concatenate([qs, qs[::-1], oracle.synth_queries(n, d, 70), qs[5:]], axis=0))
+bi, bs, bd, bc = h.search_batch_arrays(qs_many, 10)
+for i in range(0, len(qs_many), 3):
+    m = int(bc[i])
+    check_list(bi[i, :m], bs[i, :m], bd[i, :m], o.search(qs_many[i], 10), "many queries q%%d" %% i)
 # ... again after an irregular row was replaced by a regular one and a regular one by an irregular one (in-place upserts:
 # the screening copy and the irregular list follow), and with a filter + tombstones
 with np.errstate(over="ignore", under="ignore"):

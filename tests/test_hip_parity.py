@@ -772,7 +772,8 @@ def check(h, o, lut, qs, k, hf=None, of=None, what="", exact_ids=False):
             assert list(map(int, got)) == list(map(int, e["row"])), (what, i, got[:8], e["row"][:8])
         else:
             assert_topk_parity(got, bs[i, :m], e["row"], e["score"], what="%%s q%%d" %% (what, i))
-for n, k, nq in [(3001, 10, 100), (40000, 100, 70), (20000, 256, 5), (777, 32, 7), (300, 100, 64), (257, 1, 3), (60000, 10, 64)]:
+# (45000 rows, 128 / 97 / 130 queries: at row widths up to 512 a call of more than 64 queries runs 128 per pass — two banks)
+for n, k, nq in [(3001, 10, 100), (40000, 100, 70), (20000, 256, 5), (777, 32, 7), (300, 100, 64), (257, 1, 3), (60000, 10, 64), (45000, 10, 128), (45000, 32, 97), (45000, 100, 130)]:
     if d >= 1024 and n > 20000: n = 20000
     rows = oracle.synth_rows(n, d); qs = oracle.synth_queries(n, d, nq)
     h, o, ids, lut = both(rows)
