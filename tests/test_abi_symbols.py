@@ -102,3 +102,16 @@ def test_storage_dtype_codes_match_the_header():
         assert _dtype_code(name) == code
     with pytest.raises(Exception):
         _dtype_code("fp8")
+
+
+def test_fault_injection_is_not_in_the_product_library():
+    """Round-3 ADVICE: CX_SHARD_FAIL_UPSERT was compiled into the production upsert path.  It now exists only in
+    libcortex_hip_testhooks.so (csrc/Makefile: -DCX_TEST_HOOKS), which exports the same ABI; the product does not know the switch."""
+    lib = os.path.join(ROOT, "cortex_amd", "lib", "libcortex_hip.so")
+    hooks = os.path.join(ROOT, "cortex_amd", "lib", "libcortex_hip_testhooks.so")
+    assert os.path.exists(lib) and os.path.exists(hooks), "__graft_entry__.build() makes both"
+    assert b"CX_SHARD_FAIL_UPSERT" not in open(lib, "rb").read()
+    assert b"CX_SHARD_FAIL_UPSERT" in open(hooks, "rb").read()
+    H = ctypes.CDLL(hooks)
+    for n in declared_symbols():
+        assert hasattr(H, n), f"{n} missing from the test-hooks build"
