@@ -345,9 +345,10 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
     // the counter has passed the last tile
     bool exhausted = false;
     uint32_t q_head = 0u;
-    auto push_claim = [&](uint32_t c) {   // service wave, all lanes
-        const uint32_t size = CLAIM;
+    uint32_t seen = claim_base;   // the highest claim start this block has seen (how far the grid is: stale is fine)
+    auto push_claim = [&](uint32_t c, uint32_t size) {   // service wave, all lanes
         c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+        seen = c + size > seen ? c + size : seen;
         const uint32_t first = n_static + c;
         const uint32_t have = first >= n32 ? 0u : (n32 - first < size ? n32 - first : size);
         if (lane < have) bs_lds_st(&s_tq[(q_head + lane) & (BS_TQ - 1u)], first + lane);
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         }
         if (lane == 0u) bs_lds_st_rel(&s_ctl[BSL_QHEAD], q_head);
     };
-    if (!worker) push_claim(claim0);
+    if (!worker) push_claim(claim0, CLAIM);
     __syncthreads();
     if (stamps && tid == 0u) stamps[1] = now();
 
@@ -463,9 +464,13 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
 
         auto refill = [&]() {   // fewer than two tiles per worker queued: claim the next BS_CLAIM
             if (!exhausted && (int32_t)(q_head - bs_lds_ld(&s_ctl[BSL_QTAIL])) < (int32_t)BS_CLAIM) {
+                // the last claims of a pass are small ones (a.claim_tail tiles once fewer than a full claim per block are left): a slow XCD's
+                // block takes 50 us over 21 tiles, and the pass ends with its slowest block
+                const uint32_t n_dyn = n32 - n_static;
+                const uint32_t size = (a.claim_tail && seen + gridDim.x * CLAIM >= n_dyn) ? a.claim_tail : CLAIM;
                 uint32_t c = 0u;
-                if (lane == 0u) c = claim_base + atomicAdd(g_next, CLAIM);
-                push_claim(c);
+                if (lane == 0u) c = claim_base + atomicAdd(g_next, size);
+                push_claim(c, size);
             }
         };
         uint32_t bl[NB];   // (lane, bank): the published bound of query 64 bank + lane
@@ -1223,6 +1228,8 @@ int launch_batchs_pass(const BatchSArgs &a_in, hipStream_t stream) {
     a.arm = arm_env;
     a.pub_min = pub_env;
     a.claim = claim_env;
+    static const uint32_t tail_env = getenv("CX_BATCHS_CLAIM_TAIL") ? (uint32_t)std::min(32, std::max(0, atoi(getenv("CX_BATCHS_CLAIM_TAIL")))) : BS_WORK;
+    a.claim_tail = tail_env;
     static const long loc_env = getenv("CX_BATCHS_LOC_MIN") ? atol(getenv("CX_BATCHS_LOC_MIN")) : -1;
     a.loc_min_rows = loc_env >= 0 ? (uint32_t)loc_env : (a.dim >= 640u ? 393216u : 1048576u);   // (block-local first bounds: see the kernel)
     if (!batchs_supported(a.dim, a.k) || a.nq == 0 || a.nq > batchs_queries_per_pass(a.dim, a.n_rows, a.nq) || a.n_rows == 0 || (a.thr_cand && a.nq > 64u))

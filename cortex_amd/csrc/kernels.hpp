@@ -156,6 +156,7 @@ struct BatchSArgs {
     uint32_t arm;           // CX_BATCHS_ARM: measurement arms (results invalid): 1 workers drop their hits, 4 the service wave drops them
     uint32_t pub_min;       // slots a query's first publisher waits for (CX_BATCHS_PUB_MIN, 64; at least k)
     uint32_t claim;         // tiles a service wave claims at a time (set by the launcher: 21, CX_BATCHS_CLAIM)
+    uint32_t claim_tail;    // tiles per claim once fewer than a full claim per block are left (7; 0 = the same size to the end; CX_BATCHS_CLAIM_TAIL)
     uint32_t loc_min_rows;  // fewest rows of a pass whose blocks run ahead on block-local first bounds (set by the launcher; CX_BATCHS_LOC_MIN)
     unsigned long long *tl; // CX_BATCHS_TL=1: [grid][32] s_memrealtime stamps of a pass (diagnostic; null otherwise)
     // threshold mode (launch_batchs_thr: the all-pairs filter of <= 64 scanned rows, allpairs_stream.hip's contract); nq = n_scan
