@@ -399,8 +399,41 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
         }
     }
     if (bs_go) {
-        for (uint64_t q0 = 0; q0 < nq;) {
+        // Several passes of one call (more queries than a pass serves): on two side streams in turn, each with its own control block
+        // and candidate lists, joined back into s at the end — consecutive passes overlap like the batches of a stream do
+        // (profiles/r04/tuning.md: +12-14 %).  One pass, or the diagnostics that stop the stream: everything on s.
+        static const int pipe_env = getenv("CX_BATCHS_PIPE") ? atoi(getenv("CX_BATCHS_PIPE")) : 1;
+        static const int bs_diag = getenv("CX_BATCHS_DIAG") ? atoi(getenv("CX_BATCHS_DIAG")) : 0;
+        static const bool tl_env = getenv("CX_BATCHS_TL") && atoi(getenv("CX_BATCHS_TL")) != 0;
+        const uint32_t qpp0 = batchs_queries_per_pass(ix->dim, n, nq);
+        bool piped = pipe_env && !bs_diag && !tl_env && nq > qpp0;
+        if (piped) {
+            int rc = CX_OK;
+            for (int i = 0; i < 2 && !rc; i++) {
+                if (!c->bs_aux[i] && hipStreamCreateWithFlags(&c->bs_aux[i], hipStreamNonBlocking) != hipSuccess) rc = CX_ERR_DEVICE;
+                if (!rc && !c->bs_ev_done[i] && hipEventCreateWithFlags(&c->bs_ev_done[i], hipEventDisableTiming) != hipSuccess) rc = CX_ERR_DEVICE;
+            }
+            if (!rc && !c->bs_ev_in && hipEventCreateWithFlags(&c->bs_ev_in, hipEventDisableTiming) != hipSuccess) rc = CX_ERR_DEVICE;
+            if (!rc && c->bsc2_cap < BS_CTL_WORDS) {
+                rc = ensure_dev(c->d_bs_ctl2, c->bsc2_cap, (size_t)BS_CTL_WORDS);
+                if (!rc && hipMemsetAsync(c->d_bs_ctl2, 0, (size_t)BS_CTL_WORDS * sizeof(uint32_t), s) != hipSuccess) rc = CX_ERR_DEVICE;
+            }
+            if (!rc) rc = ensure_dev(c->d_bs_rows2, c->bsr2_cap, (size_t)qpp0 * bs_cap);
+            if (!rc) rc = ensure_dev(c->d_bs_cos2, c->bss2_cap, (size_t)qpp0 * bs_cap);
+            if (!rc && hipEventRecord(c->bs_ev_in, s) != hipSuccess) rc = CX_ERR_DEVICE;   // (queries, filter, everything queued on s so far)
+            for (int i = 0; i < 2 && !rc; i++)
+                if (hipStreamWaitEvent(c->bs_aux[i], c->bs_ev_in, 0) != hipSuccess) rc = CX_ERR_DEVICE;
+            if (rc) {   // (no second scratch set, no streams: the passes run one after the other on s)
+                (void)hipGetLastError();
+                piped = false;
+            }
+        }
+        int rc_all = CX_OK;
+        uint32_t pass_i = 0;
+        for (uint64_t q0 = 0; q0 < nq && !rc_all; pass_i++) {
             const uint32_t m = (uint32_t)std::min<uint64_t>(batchs_queries_per_pass(ix->dim, n, nq - q0), nq - q0);
+            const bool second = piped && (pass_i & 1u);
+            hipStream_t st = piped ? c->bs_aux[pass_i & 1u] : s;
             BatchSArgs b;
             memset(&b, 0, sizeof b);
             b.shadow_t = ix->d_shadow_t;
@@ -413,40 +446,49 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
             b.dim = ix->dim;
             b.k = k_eff;
             b.flt = flt;
-            b.ctl = c->d_bs_ctl;
-            b.cand_rows = c->d_bs_rows;
-            b.cand_cos = c->d_bs_cos;
+            b.ctl = second ? c->d_bs_ctl2 : c->d_bs_ctl;
+            b.cand_rows = second ? c->d_bs_rows2 : c->d_bs_rows;
+            b.cand_cos = second ? c->d_bs_cos2 : c->d_bs_cos;
             b.cap = bs_cap;
             b.irr_rows = ix->d_irr_rows;
             b.irr_n = ix->irr_n;
             hipEvent_t e0 = nullptr, e1 = nullptr;
+            int rc = CX_OK;
             if (ix->profiling) {
-                CX_HIP(hipEventCreate(&e0));
-                CX_HIP(hipEventCreate(&e1));
-                std::lock_guard<std::mutex> g(ix->mu);
-                ix->prof_events.emplace_back(e0, e1);
-                CX_HIP(hipEventRecord(e0, s));
+                if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) rc = set_err(CX_ERR_DEVICE, "hipEventCreate failed");
+                if (!rc) {
+                    std::lock_guard<std::mutex> g(ix->mu);
+                    ix->prof_events.emplace_back(e0, e1);
+                }
+                if (!rc && hipEventRecord(e0, st) != hipSuccess) rc = set_err(CX_ERR_DEVICE, "hipEventRecord failed");
             }
-            int rc = launch_batchs_pass(b, s);
-            if (e1 && !rc && hipEventRecord(e1, s) != hipSuccess) rc = set_err(CX_ERR_DEVICE, "hipEventRecord failed");   // (no early return between a pass and its select: see below)
-            static const int bs_diag = getenv("CX_BATCHS_DIAG") ? atoi(getenv("CX_BATCHS_DIAG")) : 0;
+            if (!rc) rc = launch_batchs_pass(b, st);
+            if (e1 && !rc && hipEventRecord(e1, st) != hipSuccess) rc = set_err(CX_ERR_DEVICE, "hipEventRecord failed");   // (no early return between a pass and its select: see below)
             if (bs_diag && !rc) {   // candidates per query and published bounds of this pass, on stderr
                 std::vector<uint32_t> dg(2 * BS_MAXQ);   // bounds | list lengths
-                (void)hipStreamSynchronize(s);
-                (void)hipMemcpy(dg.data(), c->d_bs_ctl + BS_CTL_BOUND, 2 * BS_MAXQ * sizeof(uint32_t), hipMemcpyDeviceToHost);
+                (void)hipStreamSynchronize(st);
+                (void)hipMemcpy(dg.data(), b.ctl + BS_CTL_BOUND, 2 * BS_MAXQ * sizeof(uint32_t), hipMemcpyDeviceToHost);
                 uint64_t tot = 0; uint32_t mx = 0, nob = 0;
                 for (uint32_t q = 0; q < m; q++) { tot += dg[BS_MAXQ + q]; mx = std::max(mx, dg[BS_MAXQ + q]); nob += dg[q] <= 1u; }
                 float b0; memcpy(&b0, &dg[0], 4);
                 fprintf(stderr, "[batchs diag] %u queries: %llu candidates (max %u per query), %u without a bound, bound[0] = %.4f\n", m, (unsigned long long)tot, mx, nob, b0);
             }
-            if (!rc) rc = launch_batchs_select(b, d_rows + q0 * k_eff, d_scores + q0 * k_eff, d_dists + q0 * k_eff, d_counts + q0, s);
+            if (!rc) rc = launch_batchs_select(b, d_rows + q0 * k_eff, d_scores + q0 * k_eff, d_dists + q0 * k_eff, d_counts + q0, st);
             if (rc) {   // a pass that did not run to its select leaves the control block in an unknown state
-                (void)hipMemsetAsync(c->d_bs_ctl, 0, (size_t)BS_CTL_WORDS * sizeof(uint32_t), s);
-                return rc;
+                (void)hipMemsetAsync(b.ctl, 0, (size_t)BS_CTL_WORDS * sizeof(uint32_t), st);
+                rc_all = rc;
             }
             q0 += m;
         }
-        return CX_OK;
+        if (piped) {   // s goes on behind both side streams (also after an error: nothing of this call may still be running behind the caller's back)
+            for (int i = 0; i < 2; i++) {
+                if (hipEventRecord(c->bs_ev_done[i], c->bs_aux[i]) != hipSuccess || hipStreamWaitEvent(s, c->bs_ev_done[i], 0) != hipSuccess) {
+                    (void)hipStreamSynchronize(c->bs_aux[i]);
+                    if (!rc_all) rc_all = set_err(CX_ERR_DEVICE, "joining the passes' side streams failed");
+                }
+            }
+        }
+        return rc_all;
     }
     const bool wide_to_bg = (k_eff > 32 || (ix->dim <= 384 && k_eff >= 20)) && bg_ok && filter_ok && n >= filter_min && batchg_supported(ix->dim, k_eff);
     if (b2_ok && ix->dtype == 0 && !wide_to_bg && topk_path && no_tails && nq >= (uint64_t)batch_min && k_eff >= 1 && batch_supported(ix->dim, k_eff)) {

@@ -71,8 +71,15 @@ struct Ctx {
     float *d_cand_sims = nullptr; size_t cs_cap = 0;
     uint32_t *d_bg_ctl = nullptr; size_t bc_cap = 0;   // [64] bounds + [1] overflow flag
     uint32_t *d_bs_ctl = nullptr; size_t bsc_cap = 0;  // batchs: bound slots, published bounds, list lengths, tile counter (BS_CTL_WORDS; zero between passes)
-    uint32_t *d_bs_rows = nullptr; size_t bsr_cap = 0; // batchs: candidate lists [64][rows]: row, exact cosine
+    uint32_t *d_bs_rows = nullptr; size_t bsr_cap = 0; // batchs: candidate lists [queries of a pass][cap]: row, approximate then exact cosine
     float *d_bs_cos = nullptr; size_t bss_cap = 0;
+    // a call of several passes runs them on two side streams in turn, each with its own control block and lists: pass i + 1's
+    // prologue and first tiles under pass i's tail, re-score and selection (what a stream of batches gains, inside one call)
+    hipStream_t bs_aux[2] = {nullptr, nullptr};
+    hipEvent_t bs_ev_in = nullptr, bs_ev_done[2] = {nullptr, nullptr};
+    uint32_t *d_bs_ctl2 = nullptr; size_t bsc2_cap = 0;
+    uint32_t *d_bs_rows2 = nullptr; size_t bsr2_cap = 0;
+    float *d_bs_cos2 = nullptr; size_t bss2_cap = 0;
     uint32_t *d_out_rows = nullptr; size_t or_cap = 0;
     float *d_out_scores = nullptr; size_t os_cap = 0;
     float *d_out_dists = nullptr; size_t od_cap = 0;
@@ -96,6 +103,12 @@ struct Ctx {
         if (pass_scratch && pass_scratch_free) pass_scratch_free(pass_scratch);
         (void)hipFree(d_dense); (void)hipFree(d_qimg); (void)hipFree(d_cand_keys); (void)hipFree(d_cand_sims); (void)hipFree(d_bg_ctl);
         (void)hipFree(d_bs_ctl); (void)hipFree(d_bs_rows); (void)hipFree(d_bs_cos);
+        (void)hipFree(d_bs_ctl2); (void)hipFree(d_bs_rows2); (void)hipFree(d_bs_cos2);
+        for (int i = 0; i < 2; i++) {
+            if (bs_aux[i]) (void)hipStreamDestroy(bs_aux[i]);
+            if (bs_ev_done[i]) (void)hipEventDestroy(bs_ev_done[i]);
+        }
+        if (bs_ev_in) (void)hipEventDestroy(bs_ev_in);
         (void)hipFree(d_query); (void)hipFree(d_gslots); (void)hipFree(d_part_keys); (void)hipFree(d_part_sims); (void)hipFree(d_out_rows);
         (void)hipFree(d_out_scores); (void)hipFree(d_out_dists); (void)hipFree(d_out_counts); (void)hipFree(d_excl);
         (void)hipFree(d_kinds); (void)hipFree(d_keys); (void)hipFree(d_keys2); (void)hipFree(d_sims); (void)hipFree(d_sims2);
