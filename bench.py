@@ -620,6 +620,11 @@ def config4_leg(L, device: int, dev, n: int = 1_250_000, d: int = 768, k: int = 
     avg = kern_ms / max(1, kern_n)
     roof = batch_roofline(n, d, 2.0 if dtype == "bf16" else 4.0, avg, el / steps, kern_n)
     roof["frac_step_stream_of_batches"] = roof["algorithmic_bytes_per_launch"] / (el_s / steps) / 1e9 / HBM_PEAK_GBS
+    if B > 64:
+        roof["frac_note"] += ("; a pass of 128 queries (two 64-query banks, row widths up to 512) streams the same bytes as a pass of 64 and takes "
+                              "~1.3x as long (16 MFMAs per K-step and wave instead of 8): the fractions are per launch — compare queries_per_s "
+                              "with the 64-query leg of the same shard (two one-bank passes for 128 queries: 0.427 ms against 0.263, "
+                              "profiles/r04/tuning.md 1.7)")
     roof["frac_note"] += ("; frac_step_stream_of_batches: the same bytes over a step of a STREAM of batches on rotating HIP streams "
                           "(ShardedKnn.submit: what a rank of the sharded search runs)")
     return {"workload": f"cosine kNN k={k}, batch of {B} queries per step, {n} x {d} {dtype} rows ({shard_note})",
