@@ -1,7 +1,7 @@
 // batchs.hip — batched exact search (search_batch, vector/index.rs:390-410; BASELINE config 4's inner loop) as a SCREENING
 // pass over a 2-byte copy of the rows followed by an exact f32 re-score of the survivors — the all-pairs pass's own
 // design (allpairs.hip: bf16 filter with a rigorous error bound, then the reference's arithmetic on what is left)
-// applied to up to 64 queries per pass.
+// applied to up to 64 queries per pass (128 at row widths up to 512: the kernel's NB parameter).
 //
 // The operand is the all-pairs filter's own: the index's tiled shadow (cx_index::d_shadow_t, kernels.hpp: rows L2-normalised,
 // rounded to bf16, one KiB per 16 rows x K-step of 32, a row's four 16-byte pieces XOR-permuted with bits 3-4 of the row).
@@ -45,9 +45,21 @@
 //    hit rings — row filter, candidate list (room for every row: nothing can overflow, no fallback pass exists), the
 //    tile's slot raised —, re-reads and re-publishes the bounds at growing intervals (256 service waves polling the same
 //    256 bytes every few microseconds keep one HBM channel busy with themselves: -8 %), and deals the tiles: the first
-//    one of every worker is static (the sample), the rest are claimed 14 at a time from one grid-wide counter and handed
-//    over through a queue in LDS (blocks do not get equal shares of the HBM: at 5M rows the fastest block took 38 % more
-//    tiles than the slowest; statically dealt tiles left a quarter of the chip idle at the end).
+//    one of every worker is static (the sample), the rest are claimed 21 at a time (7 near the end) from one grid-wide counter
+//    and handed over through a queue in LDS (blocks do not get equal shares of the HBM: at 5M rows the fastest block took 38 %
+//    more tiles than the slowest; statically dealt tiles left a quarter of the chip idle at the end).
+//
+// Round 4 (profiles/r04/tuning.md):
+//  - candidate lists are BOUNDED (BatchSArgs::cap entries per query; round 3: room for every row).  A query whose list runs
+//    over, an IRREGULAR query (kernels.hpp: bs_regular — zero, non-finite, |q|^2 outside [1e-30, 1e30]) and every query of a pass
+//    in which a worker gave up on its ring are redone by the re-score kernel with the reference's arithmetic over every row
+//    (bs_exact_redo); the store's irregular rows (zero shadow rows: never hits) ride behind every query's list;
+//  - large passes do not stand still for the grid's first bounds: the k-th largest of the fourteen 16-row-group maxima of a
+//    block's own first tiles is a valid bound at once (k <= 14), the hits it lets through wait in the rings until the service wave
+//    can drop them under the grid's bounds — which it does without an atomic: survivors are staged in LDS and handed to
+//    process_hits 64 at a time;
+//  - NB = 2: two banks of 64 queries in one pass at row widths up to 512 (128 queries' fragments fit the LDS): a call of more than
+//    64 queries streams the shadow once per 128.
 #include <vector>
 
 #include "batch_common.hpp"
