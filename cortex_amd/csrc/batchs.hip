@@ -568,65 +568,68 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         uint64_t t_next = now() + gap;
         unsigned long long n_rounds = 0, n_hits = 0, n_kept = 0, max_pend = 0;   // (timeline diagnostics)
         bool drained = false, seen_done = false, workers_done = false;
-        uint32_t n_stage = 0u;
+        uint32_t n_stage = 0u, w_start = 0u;
+        // survivors of the staging area, 64 at a time: row filter, list positions, slots
+        auto flush_stage = [&]() {
+            const uint32_t take = n_stage < 64u ? n_stage : 64u;
+            const bool on = lane < take;
+            const uint32_t r0 = on ? s_stg_row[lane] : 0u, q0 = on ? s_stg_q[lane] : 0u;
+            const float d0 = on ? s_stg_dot[lane] : 0.0f;
+            const bool more = lane + 64u < n_stage;
+            const uint32_t r1 = more ? s_stg_row[64u + lane] : 0u, q1 = more ? s_stg_q[64u + lane] : 0u;
+            const float d1 = more ? s_stg_dot[64u + lane] : 0.0f;
+            if (more) { s_stg_row[lane] = r1; s_stg_q[lane] = q1; s_stg_dot[lane] = d1; }   // (one wave: its LDS operations stay in order)
+            n_stage -= take;
+            process_hits(on, r0, q0, d0);
+        };
         for (;;) {
             uint32_t hd = 0u, tl = 0u;
             if (lane < BS_WORK) { hd = bs_lds_ld_acq(&s_ctl[BSL_HEAD + lane]); tl = bs_lds_ld(&s_ctl[BSL_TAIL + lane]); }   // (the tails are this wave's own)
             const uint32_t pend = hd - tl;
-            uint32_t incl = pend;        // inclusive prefix sum over the first lanes
-#pragma unroll
-            for (int off = 1; off < 8; off <<= 1) {
-                const uint32_t t = (uint32_t)__shfl_up((int)incl, off, 64);
-                if (lane >= (uint32_t)off) incl += t;
-            }
-            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)BS_WORK - 1);
-            const bool busy = total != 0u;
-            if (stamps) {
-                n_rounds++;
-                n_hits += total < 64u ? total : 64u;
-                max_pend = total > max_pend ? total : max_pend;
-                if (!busy && !drained) { drained = true; if (lane == 0u) stamps[32] = now(); }
-            }
+            const bool busy = __ballot(pend != 0u) != 0ull;
+            if (stamps && !busy && !drained) { drained = true; if (lane == 0u) stamps[32] = now(); }
             if (busy) {
-                uint32_t w_of = 0u, first_of = 0u, tail_of = 0u;
-#pragma unroll
-                for (uint32_t w = 0; w < BS_WORK; w++) {
-                    const uint32_t end_w = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)w);
-                    const uint32_t beg_w = end_w - (uint32_t)__builtin_amdgcn_readlane((int)pend, (int)w);
-                    const uint32_t tl_w = (uint32_t)__builtin_amdgcn_readlane((int)tl, (int)w);
-                    if (lane >= beg_w && lane < end_w) { w_of = w; first_of = beg_w; tail_of = tl_w; }
+                // ring by ring (starting where the last iteration stopped), chunks of 64 entries, one read of the heads for all of it; the
+                // first form packed 64 entries across the rings per iteration — a chain of prefix sums and lane reads of ~2 us per 64
+                // entries, and at 384-d the service wave drained a block's ~3,500 held hits until after its workers had left.  An
+                // iteration ends after eight chunks or after a flush (a returning atomic: 2-3 us): the bounds' refresh below must
+                // stay on time — late refreshes let 40 % more candidates through at k = 100.
+                uint32_t budget = 8u, next_start = w_start;
+                bool flushed = false;
+#pragma unroll 1
+                for (uint32_t wi = 0; wi < BS_WORK && budget && !flushed; wi++) {
+                    const uint32_t w = (w_start + wi) % BS_WORK;
+                    uint32_t pw = (uint32_t)__builtin_amdgcn_readlane((int)pend, (int)w);
+                    if (!pw) continue;
+                    const uint32_t tlw = (uint32_t)__builtin_amdgcn_readlane((int)tl, (int)w);
+                    uint32_t taken = 0u;
+                    if (stamps) max_pend = pw > max_pend ? pw : max_pend;
+#pragma unroll 1
+                    for (; budget && pw && !flushed; budget--) {
+                        const uint32_t take = pw < 64u ? pw : 64u;
+                        const bool on = lane < take;
+                        const uint32_t e = w * HB + ((tlw + taken + lane) & (HB - 1u));
+                        const uint32_t h_row = on ? s_hrow[e] : 0u, h_q = on ? s_hq[e] : 0u;
+                        const float h_dot = on ? s_hdot[e] : 0.0f;
+                        bool keep = on && !(a.arm & 4u);
+                        if constexpr (!THR) keep = keep && !(h_dot < bs_thr(bs_lds_ld(&s_bnd[h_q]), true, s_mrg[h_q]));
+                        const uint64_t km = __ballot(keep);
+                        if (keep) {
+                            const uint32_t sp = n_stage + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
+                            s_stg_row[sp] = h_row; s_stg_q[sp] = h_q; s_stg_dot[sp] = h_dot;
+                        }
+                        n_stage += (uint32_t)__popcll(km);
+                        if (stamps) { n_rounds++; n_hits += take; n_kept += (uint32_t)__popcll(km); }
+                        if (n_stage >= 64u) { flush_stage(); flushed = true; }
+                        taken += take;
+                        pw -= take;
+                    }
+                    if (lane == 0u) bs_lds_st_rel(&s_ctl[BSL_TAIL + w], tlw + taken);
+                    next_start = pw ? w : (w + 1u) % BS_WORK;   // (a ring that still holds entries goes first next time)
                 }
-                const bool on = lane < total;
-                const uint32_t e = w_of * HB + ((tail_of + lane - first_of) & (HB - 1u));
-                const uint32_t h_row = on ? s_hrow[e] : 0u, h_q = on ? s_hq[e] : 0u;
-                const float h_dot = on ? s_hdot[e] : 0.0f;
-                bool keep = on && !(a.arm & 4u);
-                if constexpr (!THR) keep = keep && !(h_dot < bs_thr(bs_lds_ld(&s_bnd[h_q]), true, s_mrg[h_q]));
-                const uint64_t km = __ballot(keep);
-                if (keep) {
-                    const uint32_t sp = n_stage + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
-                    s_stg_row[sp] = h_row; s_stg_q[sp] = h_q; s_stg_dot[sp] = h_dot;
-                }
-                n_stage += (uint32_t)__popcll(km);
-                if (stamps) n_kept += (uint32_t)__popcll(km);
-                if (lane < BS_WORK) {
-                    const uint32_t beg = incl - pend;
-                    const uint32_t took = beg >= 64u ? 0u : (incl <= 64u ? pend : 64u - beg);
-                    if (took) bs_lds_st_rel(&s_ctl[BSL_TAIL + lane], tl + took);
-                }
+                w_start = next_start;
             }
-            if (n_stage >= 64u || (n_stage != 0u && !busy)) {   // 64 survivors (or the last few): row filter, list positions, slots
-                const uint32_t take = n_stage < 64u ? n_stage : 64u;
-                const bool on = lane < take;
-                const uint32_t r0 = on ? s_stg_row[lane] : 0u, q0 = on ? s_stg_q[lane] : 0u;
-                const float d0 = on ? s_stg_dot[lane] : 0.0f;
-                const bool more = lane + 64u < n_stage;
-                const uint32_t r1 = more ? s_stg_row[64u + lane] : 0u, q1 = more ? s_stg_q[64u + lane] : 0u;
-                const float d1 = more ? s_stg_dot[64u + lane] : 0.0f;
-                if (more) { s_stg_row[lane] = r1; s_stg_q[lane] = q1; s_stg_dot[lane] = d1; }   // (one wave: its LDS operations stay in order)
-                n_stage -= take;
-                process_hits(on, r0, q0, d0);
-            }
+            if (n_stage != 0u && !busy) flush_stage();
             refill();   // (an LDS read unless the queue runs low: the workers of a 384-d pass empty fourteen entries in 11 us)
             // (the clock and the bound refresh in EVERY round: looked at every eighth busy round only, the refreshes of a pass with many
             // survivors — k = 100 — came late, its workers tested against stale bounds and let 40 % more candidates through)
@@ -1079,25 +1082,38 @@ __device__ inline void bs_rescore_body(const BatchSArgs &a, const S *rows, uint3
 #pragma unroll
                 for (uint32_t u = 0; u < U; u++) { dot[u] += x[u] * ql[i]; rr[u] += x[u] * x[u]; }
             }
-        bool regular[U];
-#pragma unroll
-        for (uint32_t u = 0; u < U; u++) regular[u] = bs_regular(wave_sum(rr[u]));   // (the build's own sum: see above)
 #pragma unroll
         for (int x = 1; x < 64; x <<= 1)
 #pragma unroll
             for (uint32_t u = 0; u < U; u++) { dot[u] += __shfl_xor(dot[u], x, 64); rr[u] += __shfl_xor(rr[u], x, 64); }
+        // regular or not: as the shadow's build decided.  Its sum (wave_sum's order) and this one (a butterfly) differ in the last
+        // bits only, so the butterfly's value decides unless it lies within a factor of two of a limit — only then is the build's own
+        // sum taken again from the row (wave-uniform, next to never)
+        bool regular[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            const float t = rr[u];
+            const bool inside = t >= 2.0f * BS_REG_LO && t <= 0.5f * BS_REG_HI, outside = !(t >= 0.5f * BS_REG_LO && t <= 2.0f * BS_REG_HI);
+            regular[u] = inside;
+            if (!inside && !outside && keep[u]) {
+                float ss = 0.0f;
+                for (uint32_t i = 0; i < per; i++) { const float x = ldf(p[u] + 64u * i); ss += x * x; }
+                regular[u] = bs_regular(wave_sum(ss));
+            }
+        }
 #pragma unroll
         for (uint32_t u = 0; u < U; u++)
             if (lane == u && c + u < n_it) {
                 const bool ok = keep[u] && regular[u] == listed[u];
-                cand[cu[u]] = ok ? row[u] : BS_STRUCK;
+                if (!ok || !listed[u]) cand[cu[u]] = ok ? row[u] : BS_STRUCK;   // (a listed candidate that stays keeps its entry)
                 if (ok) cosv[cu[u]] = cosine_from_sums(dot[u], qq, rr[u]);
             }
     }
 }
 
+// (four waves per SIMD: the exact redo — a cold path — must not cost the re-score its occupancy; at 129 registers it ran three)
 template <typename S, int KS>
-__global__ __launch_bounds__(256) void batchs_rescore_kernel(const BatchSArgs a, const S *rows) {
+__global__ __launch_bounds__(256, 4) void batchs_rescore_kernel(const BatchSArgs a, const S *rows) {
     bs_rescore_body<S, KS>(a, rows, blockIdx.y, blockIdx.x * 4u + (threadIdx.x >> 6), gridDim.x * 4u, bs_redo(a, blockIdx.y));
 }
 
