@@ -708,13 +708,12 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         if (lane == 0u) __hip_atomic_store(THR ? a.thr_next + 1 : a.ctl + BS_CTL_FAIL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return false;
     };
-    // query fragments: [buffer][group]; one bank: the next K-step's are read while this one's MFMAs run; two banks: a K-step's eight
-    // are read at its head (their waits fall behind the first MFMAs; the SIMD's other wave covers the rest)
-    s16x8 B[NB == 1 ? 2 : 1][NG];
-    if constexpr (NB == 1) {
+    // query fragments: [buffer][group of four]; one bank: the next K-step's four are read while this one's MFMAs run; two banks: a
+    // K-step's eight in two halves — the second half while the first half's MFMAs run, the next step's first half while the second
+    // half's do (the same 32 registers; read all eight at the step's head, every step began with the LDS latency in the open)
+    s16x8 B[2][4];
 #pragma unroll
-        for (int g = 0; g < NG; g++) B[0][g] = *reinterpret_cast<const s16x8 *>(my_q + g * 1024);
-    }
+    for (int g = 0; g < 4; g++) B[0][g] = *reinterpret_cast<const s16x8 *>(my_q + g * 1024);
     auto claim = [&]() -> uint32_t {   // the next tile of this wave: an entry of the block's queue
         uint32_t idx = 0u;
         if (lane == 0u) idx = __hip_atomic_fetch_add(&s_ctl[BSL_QTAIL], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -731,21 +730,37 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
         for (int g = 0; g < NG; g++) { acc[g][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; acc[g][1] = acc[g][0]; }
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
-            const int p = ks % P, cur = NB == 1 ? (ks & 1) : 0, nxt = cur ^ 1;
+            const int p = ks % P;
+            const int nks = ks + 1 < KS ? ks + 1 : 0;   // the last step reads the next tile's first query fragments
+            const s16x8 h0 = ring[p][0], h1 = ring[p][1];
             if constexpr (NB == 1) {
-                const int nks = ks + 1 < KS ? ks + 1 : 0;   // the last step reads the next tile's first query fragments
+                const int cur = ks & 1, nxt = cur ^ 1;
 #pragma unroll
-                for (int g = 0; g < NG; g++) B[nxt][g] = *reinterpret_cast<const s16x8 *>(my_q + (nks * NG + g) * 1024);
+                for (int g = 0; g < 4; g++) B[nxt][g] = *reinterpret_cast<const s16x8 *>(my_q + (nks * NG + g) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h0, B[cur][g], acc[g][0], 0, 0, 0);
+                    acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1, B[cur][g], acc[g][1], 0, 0, 0);
+                }
             } else {
 #pragma unroll
-                for (int g = 0; g < NG; g++) B[0][g] = *reinterpret_cast<const s16x8 *>(my_q + (ks * NG + g) * 1024);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            const s16x8 h0 = ring[p][0], h1 = ring[p][1];
+                for (int g = 0; g < 4; g++) B[1][g] = *reinterpret_cast<const s16x8 *>(my_q + (ks * NG + 4 + g) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int g = 0; g < NG; g++) {
-                acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h0, B[cur][g], acc[g][0], 0, 0, 0);
-                acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1, B[cur][g], acc[g][1], 0, 0, 0);
+                for (int g = 0; g < 4; g++) {
+                    acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h0, B[0][g], acc[g][0], 0, 0, 0);
+                    acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1, B[0][g], acc[g][1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 4; g++) B[0][g] = *reinterpret_cast<const s16x8 *>(my_q + (nks * NG + g) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    acc[4 + g][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h0, B[1][g], acc[4 + g][0], 0, 0, 0);
+                    acc[4 + g][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1, B[1][g], acc[4 + g][1], 0, 0, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             // the slot is free: K-step ks + P of this tile, or of the next one

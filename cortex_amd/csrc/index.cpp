@@ -406,7 +406,9 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
         static const int bs_diag = getenv("CX_BATCHS_DIAG") ? atoi(getenv("CX_BATCHS_DIAG")) : 0;
         static const bool tl_env = getenv("CX_BATCHS_TL") && atoi(getenv("CX_BATCHS_TL")) != 0;
         const uint32_t qpp0 = batchs_queries_per_pass(ix->dim, n, nq);
-        bool piped = pipe_env && !bs_diag && !tl_env && nq > qpp0;
+        // (one-bank passes only: two two-bank passes in each other's way lose — 256 queries k = 100 x 1.25M x 384: 0.694 ms piped
+        // against 0.625; 768-d, 1024-d and small stores gain 4-7 %)
+        bool piped = pipe_env && !bs_diag && !tl_env && nq > qpp0 && qpp0 == 64u;
         if (piped) {
             int rc = CX_OK;
             for (int i = 0; i < 2 && !rc; i++) {
