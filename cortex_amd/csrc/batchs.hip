@@ -42,7 +42,7 @@
 //    took 75 us; one arrival counter for 2,048 waves 110 us; a release fence per wave ~75 us): it publishes the k-th largest
 //    slot value of its queries (radix walk over four 8-bit digits with an LDS histogram: 2 us; a ballot per bit and value:
 //    13; the first publisher of a query polls a 256-slot prefix, everybody else the bounds: one round trip per poll), drains the
-//    hit rings — row filter, candidate list (room for every row: nothing can overflow, no fallback pass exists), the
+//    hit rings — row filter, candidate list (bounded since round 4: a list that runs over is redone exactly, below), the
 //    tile's slot raised —, re-reads and re-publishes the bounds at growing intervals (256 service waves polling the same
 //    256 bytes every few microseconds keep one HBM channel busy with themselves: -8 %), and deals the tiles: the first
 //    one of every worker is static (the sample), the rest are claimed 21 at a time (7 near the end) from one grid-wide counter
