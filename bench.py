@@ -160,7 +160,7 @@ def main() -> None:
     # Two timed regions of the same W warm-up + K steps (round-2 ADVICE: both figures, always):
     #  (1) exactly as asked, nothing in front — `value`, `ms_per_step`, `roofline`.  After ANY idle gap of the device (0.2 s is
     #      enough) a stream of identical scans starts at the steady 0.437 ms, climbs to ~0.50 ms around the 10th launch and is
-    #      back by the 40th (scripts/cold_probe.py, profiles/r03/cold_start_probe.json): the board's power management settling
+    #      back by the 40th (scripts/cold_probe.py, profiles/r04/cold_start_probe.json): the board's power management settling
     #      under a memory-bound load, not first touch; a trickle of work during the gap or dummy launches in front do not
     #      remove it.  `--steps 20 --warmup 5` sits on that hump, and that is what a server sees on the first scans of a burst.
     #  (2) the same again behind `--preroll` untimed scans — `extra.steady_state`: the rate of a stream that keeps coming.
@@ -245,7 +245,7 @@ def main() -> None:
     avg_ss = kern_ms_ss / max(1, kern_n_ss)
     out.setdefault("extra", {})["steady_state"] = {
         "what": f"the same {args.warmup} warm-up + {args.steps} timed steps again, behind {args.preroll} untimed scans run back to back with them "
-                "(the post-idle transient of the board has passed: profiles/r03/cold_start_probe.json)",
+                "(the post-idle transient of the board has passed: profiles/r04/cold_start_probe.json)",
         "value": args.steps * B * world / elapsed_ss, "ms_per_step": elapsed_ss / args.steps * 1e3, "preroll_untimed": args.preroll,
         "roofline": {"bound": "hbm", "achieved": algo_bytes / (avg_ss * 1e-3) / 1e9 if avg_ss > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": (algo_bytes / (avg_ss * 1e-3) / 1e9 / HBM_PEAK_GBS) if avg_ss > 0 else 0.0, "avg_kernel_ms": avg_ss, "launches": kern_n_ss},
