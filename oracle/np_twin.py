@@ -26,7 +26,7 @@ def distance(a: np.ndarray, b: np.ndarray) -> np.float32:
     """EmbeddingPoint::distance, vector/index.rs:169-179."""
     a = a.astype(F)
     b = b.astype(F)
-    with np.errstate(invalid="ignore", divide="ignore"):
+    with np.errstate(invalid="ignore", divide="ignore", over="ignore", under="ignore"):
         dot = _seq_sum(a * b)
         na = np.sqrt(_seq_sum(a * a), dtype=F)
         nb = np.sqrt(_seq_sum(b * b), dtype=F)
@@ -38,7 +38,7 @@ def distances(q: np.ndarray, rows: np.ndarray) -> np.ndarray:
     """distance(q, row) for every row, sequential sums along the feature axis."""
     q = q.astype(F)
     rows = rows.astype(F)
-    with np.errstate(invalid="ignore", divide="ignore"):
+    with np.errstate(invalid="ignore", divide="ignore", over="ignore", under="ignore"):
         dot = np.cumsum(rows * q[None, :], axis=1, dtype=F)[:, -1] if rows.shape[1] else np.zeros(len(rows), F)
         nr = np.sqrt(np.cumsum(rows * rows, axis=1, dtype=F)[:, -1], dtype=F) if rows.shape[1] else np.zeros(len(rows), F)
         nq = np.sqrt(_seq_sum(q * q), dtype=F)
