@@ -474,12 +474,16 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
             return all_done;
         };
 
-        auto refill = [&]() {   // fewer than two tiles per worker queued: claim the next BS_CLAIM
-            if (!exhausted && (int32_t)(q_head - bs_lds_ld(&s_ctl[BSL_QTAIL])) < (int32_t)BS_CLAIM) {
-                // the last claims of a pass are small ones (a.claim_tail tiles once fewer than a full claim per block are left): a slow XCD's
-                // block takes 50 us over 21 tiles, and the pass ends with its slowest block
-                const uint32_t n_dyn = n32 - n_static;
-                const uint32_t size = (a.claim_tail && seen + gridDim.x * CLAIM >= n_dyn) ? a.claim_tail : CLAIM;
+        auto refill = [&]() {   // fewer than a claim's worth of tiles queued: claim the next
+            if (exhausted) return;
+            // Near the end of a pass (fewer than a full claim per block left, as far as this block has seen the counter) the claims
+            // are small (a.claim_tail tiles): within the boards' noise at 1.25M rows, 0.6 % at 6.25M.  (Keeping the QUEUE short there as
+            // well — tiles in a block's queue are that block's for good, 21 to 41 of them when the counter runs dry — was measured
+            // too: the workers then wait for claims, +2-3 % at 384-d.)
+            const uint32_t n_dyn = n32 - n_static;
+            const bool tail = a.claim_tail && seen + gridDim.x * CLAIM >= n_dyn;
+            const uint32_t size = tail ? a.claim_tail : CLAIM, low = CLAIM;
+            if ((int32_t)(q_head - bs_lds_ld(&s_ctl[BSL_QTAIL])) < (int32_t)low) {
                 uint32_t c = 0u;
                 if (lane == 0u) c = claim_base + atomicAdd(g_next, size);
                 push_claim(c, size);
@@ -638,6 +642,10 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
                 const uint64_t t_now = now();
                 if (stamps && workers_done && !seen_done) { seen_done = true; if (lane == 0u) stamps[37] = t_now; }
                 if (!THR && t_now >= t_next && !workers_done) {
+                    {   // (how far the grid's tile counter is: the same round trip as the bounds')
+                        const uint32_t far = claim_base + bs_ld_agent(g_next);
+                        seen = far > seen ? far : seen;
+                    }
 #pragma unroll
                     for (int bk = 0; bk < NB; bk++) {
                         bl[bk] = bs_ld_agent(g_bound + 64u * bk + lane);
