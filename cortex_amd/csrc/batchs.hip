@@ -505,11 +505,14 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
             const uint32_t frac = (blockIdx.x / QN) & FRAC_MASK;
             const uint32_t want0 = frac ? sample * (frac + 1u) / 8u : a.pub_min;
             const uint32_t want = want0 > k ? want0 : k;
-            bool stored = false, published = false;
+            // (all_in: every block of the grid has its first tiles in the slots — a query that has fewer than k filled slots THEN has no
+            // bound to wait for: a row filter that passes next to nothing.  Round 3 found that out after 96 polls, ~1 ms into a 0.4 ms pass.)
+            bool stored = false, published = false, all_in = false;
             for (int spin = 0; spin < 4096; spin++) {   // bounded: a few ms
                 if (bs_lds_ld(&s_ctl[BSL_LOC]) != 0u) refill();   // (the workers are on their way under the block's local bounds)
                 if (!stored && bs_lds_ld_acq(&s_ctl[BSL_ARRIVED]) >= in_block) {
                     stored = true;   // (every worker of the block has written its first tile's maxima to the slots)
+                    if (lane == 0u) __hip_atomic_fetch_add(a.ctl + BS_CTL_ARR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (stamps && lane == 0u) stamps[27] = now();
                 }
                 // (the fraction waited for halves every few polls: when the grid's blocks are not all resident — another
@@ -521,7 +524,8 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
                 // sample) are refinements, made here only when the warm-up drags on, otherwise by the service loop's refreshes
                 const bool try_pub = !published && (frac == 0u || spin >= 16);
                 if (try_pub) {
-                    published = publish((want >> (spin >> 2)) > k ? (want >> (spin >> 2)) : k, spin >= 96, frac == 0u && want <= 64u && spin < 16);
+                    if (!all_in && spin >= 8) all_in = bs_ld_agent(a.ctl + BS_CTL_ARR) >= gridDim.x;   // (only a publisher that is still waiting asks)
+                    published = publish((want >> (spin >> 2)) > k ? (want >> (spin >> 2)) : k, spin >= 96 || all_in, frac == 0u && want <= 64u && spin < 16 && !all_in);
                     if (stamps && lane == 0u && published) stamps[28] = now();
                 }
                 if (stamps && lane == 0u) stamps[29] = (unsigned long long)spin + 1ull;
@@ -546,7 +550,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
                             missing[bk] &= missing[bk] - 1ull;
                             const uint32_t nz = slots_load(q);
                             const uint32_t t = nz >= k ? slots_kth() : 0u;
-                            if (lane == 0u && (t || spin >= 96)) __hip_atomic_fetch_max(g_bound + q, t ? t : BS_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (lane == 0u && (t || spin >= 96 || all_in)) __hip_atomic_fetch_max(g_bound + q, t ? t : BS_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
                 }
                 if (published) __builtin_amdgcn_s_sleep(8);
@@ -886,6 +890,29 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
                 for (int r = 0; r < 4; r++) any |= !(acc[g][f][r] < thr[g]);
         if (a.arm & 1u) any = false;
         if (__ballot(any)) {
+            // A query WITHOUT a bound (a row filter that passes next to nothing leaves fewer than k slots filled; a k-th best cosine
+            // that is not positive) takes every pair of the tile.  With a row filter the rows are looked at HERE then, before 2,048
+            // hits per tile go through the ring for the service wave to drop all but a handful (125 of 1.25M rows passing: 3.7 ms
+            // per batch instead of 0.4): the one case besides its first tile in which a worker reads row metadata.
+            uint32_t okt = 0xFFu;        // bit 4 f + r: row row0 + 16 f + r passes the filter
+            if constexpr (!THR) {
+                if (!a.flt.trivial) {
+                    bool unbounded = false;
+#pragma unroll
+                    for (int g = 0; g < NG; g++) unbounded = unbounded || (liveq[g] && thr[g] == -__builtin_inff());
+                    if (__ballot(unbounded)) {
+                        okt = 0u;
+                        uint32_t mm[8];   // (the eight rows' metadata in flight together: one after the other they cost the tile 8 round trips)
+#pragma unroll
+                        for (uint32_t i = 0; i < 8u; i++) {
+                            const uint32_t row = row0 + 16u * (i >> 2) + (i & 3u);
+                            mm[i] = row < n_rows ? a.flt.meta[row] : META_REMOVED;
+                        }
+#pragma unroll
+                        for (uint32_t i = 0; i < 8u; i++) okt |= row_passes_meta(a.flt, row0 + 16u * (i >> 2) + (i & 3u), mm[i]) ? (1u << i) : 0u;
+                    }
+                }
+            }
             uint64_t hm = 0;             // hit mask (bit (g * 2 + f) * 4 + r)
 #pragma unroll
             for (int g = 0; g < NG; g++)
@@ -893,7 +920,7 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
                 for (int f = 0; f < 2; f++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const bool hit = !(acc[g][f][r] < thr[g]) & (row0 + 16u * f + r < n_rows) & liveq[g];
+                        const bool hit = !(acc[g][f][r] < thr[g]) & (row0 + 16u * f + r < n_rows) & liveq[g] & (((okt >> (4 * f + r)) & 1u) != 0u);
                         hm |= hit ? (1ull << ((g * 2 + f) * 4 + r)) : 0ull;
                     }
             const uint32_t mine = (uint32_t)__popcll(hm);
@@ -1154,7 +1181,7 @@ __device__ inline void bs_select_body(const BatchSArgs &a, uint32_t q, uint32_t 
     __shared__ uint32_t s_n;
     const uint32_t tid = threadIdx.x, k = a.k;
     uint32_t *const g_slots = a.ctl, *const g_bound = a.ctl + BS_CTL_BOUND, *const g_cnt = a.ctl + BS_CTL_CNT;
-    if (q == 0u && tid == 0u) a.ctl[BS_CTL_NEXT] = 0u;
+    if (q == 0u && tid == 0u) { a.ctl[BS_CTL_NEXT] = 0u; a.ctl[BS_CTL_ARR] = 0u; }
     // a query that was redone exactly: its list is the redo waves' k best each (already exact); otherwise the listed candidates
     // and, behind them, the store's irregular rows (batchs_rescore_kernel)
     const uint32_t total = bs_redo(a, q) ? BS_REDO_WAVES * k : g_cnt[q] + a.irr_n;

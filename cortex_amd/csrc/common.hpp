@@ -87,9 +87,13 @@ struct DevFilter {
 constexpr uint32_t META_REMOVED = 1u;
 constexpr uint32_t META_HAS = 2u;
 
+// (m = f.meta[row], already loaded: callers that look at several rows issue their metadata loads together)
+__device__ inline bool row_passes_meta(const DevFilter &f, uint32_t row, uint32_t m);
 __device__ inline bool row_passes(const DevFilter &f, uint32_t row) {
     if (f.trivial) return true;
-    const uint32_t m = f.meta[row];
+    return row_passes_meta(f, row, f.meta[row]);
+}
+__device__ inline bool row_passes_meta(const DevFilter &f, uint32_t row, uint32_t m) {
     if (m & META_REMOVED) return false;
     for (uint32_t i = 0; i < f.n_exclude; i++)
         if (f.exclude_rows[i] == row) return false;

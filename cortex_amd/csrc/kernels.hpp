@@ -124,9 +124,11 @@ constexpr uint32_t BS_MAXQ = 128;                     // queries of one pass: tw
 constexpr uint32_t BS_CTL_BOUND = BS_MAXQ * BS_SL;    // word offsets inside the control block
 constexpr uint32_t BS_CTL_CNT = BS_CTL_BOUND + BS_MAXQ;
 constexpr uint32_t BS_CTL_NEXT = BS_CTL_CNT + BS_MAXQ; // the next unclaimed tile beyond the statically dealt first ones
+
 constexpr uint32_t BS_CTL_MRG = BS_CTL_NEXT + 16;     // 64 margins (2 eps of each query, f32 bits) of the last pass, for the re-score's second look
 constexpr uint32_t BS_CTL_REDO = BS_CTL_MRG + BS_MAXQ;     // 64 flags: the query is irregular (|q|^2 is zero, non-finite or outside [BS_REG_LO, BS_REG_HI]) — screened not at all, redone exactly
 constexpr uint32_t BS_CTL_FAIL = BS_CTL_REDO + BS_MAXQ;    // sticky: a worker gave up waiting for room in its hit ring (hits dropped): every query of the pass is redone exactly
+constexpr uint32_t BS_CTL_ARR = BS_CTL_FAIL + 2;   // blocks whose workers are through their first tiles (one add per block): when all are, what the slots hold is all the sample there is (a line of its own kind: not the tile counter's)
 constexpr uint32_t BS_CTL_WORDS = BS_CTL_FAIL + 16;
 // A vector is REGULAR when its sum of squares, as the reference's f32 arithmetic computes it (vector/index.rs:174-175), is a
 // number in [BS_REG_LO, BS_REG_HI]: then no product or partial sum of a pair of regular vectors overflows, what underflows is

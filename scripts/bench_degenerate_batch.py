@@ -1,5 +1,5 @@
 import sys, os, time, json
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import cortex_amd
 from cortex_amd import _lib
@@ -33,3 +33,20 @@ print("zero query ids", ids0, "scores", r1[1][7, :3])
 assert all(np.array_equal(r0[0][i], r1[0][i]) for i in range(64) if i != 7)
 g = ix.search_arrays(q2[7], k)
 print("negated query batch vs single ids equal:", np.array_equal(r2[0][7, :k], g[0]), r2[1][7, :3], g[1][:3])
+
+# a filter that passes next to nothing (125 of 1.25M rows): no query gets a bound from rows that pass
+all_ids = np.zeros((n, 16), np.uint8); all_ids[:, 8:] = np.arange(n, dtype=np.uint64).astype(">u8").view(np.uint8).reshape(n, 8)
+kinds = ["common"] * n
+for r in range(0, n, 10000): kinds[r] = "rare"
+ix.set_metadata_batch(all_ids, kinds, ["kai"] * n)
+flt = cortex_amd.VectorFilter(kinds=["rare"])
+ix.search_batch_arrays(qs, k, flt)
+t0 = time.perf_counter()
+for _ in range(5): rf = ix.search_batch_arrays(qs, k, flt)
+print("selective filter (125 rows pass):", round((time.perf_counter() - t0) / 5 * 1e3, 3), "ms per batch")
+g = ix.search_arrays(qs[3], k, flt)
+print("filtered batch vs single ids equal:", np.array_equal(rf[0][3, :k], g[0]), "rows", [int.from_bytes(bytes(x[8:]), "big") for x in g[0][:4]])
+flt2 = cortex_amd.VectorFilter(kinds=["common"])
+t0 = time.perf_counter()
+for _ in range(5): ix.search_batch_arrays(qs, k, flt2)
+print("unselective filter (all but 125 pass):", round((time.perf_counter() - t0) / 5 * 1e3, 3), "ms per batch")
