@@ -890,29 +890,6 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
                 for (int r = 0; r < 4; r++) any |= !(acc[g][f][r] < thr[g]);
         if (a.arm & 1u) any = false;
         if (__ballot(any)) {
-            // A query WITHOUT a bound (a row filter that passes next to nothing leaves fewer than k slots filled; a k-th best cosine
-            // that is not positive) takes every pair of the tile.  With a row filter the rows are looked at HERE then, before 2,048
-            // hits per tile go through the ring for the service wave to drop all but a handful (125 of 1.25M rows passing: 3.7 ms
-            // per batch instead of 0.4): the one case besides its first tile in which a worker reads row metadata.
-            uint32_t okt = 0xFFu;        // bit 4 f + r: row row0 + 16 f + r passes the filter
-            if constexpr (!THR) {
-                if (!a.flt.trivial) {
-                    bool unbounded = false;
-#pragma unroll
-                    for (int g = 0; g < NG; g++) unbounded = unbounded || (liveq[g] && thr[g] == -__builtin_inff());
-                    if (__ballot(unbounded)) {
-                        okt = 0u;
-                        uint32_t mm[8];   // (the eight rows' metadata in flight together: one after the other they cost the tile 8 round trips)
-#pragma unroll
-                        for (uint32_t i = 0; i < 8u; i++) {
-                            const uint32_t row = row0 + 16u * (i >> 2) + (i & 3u);
-                            mm[i] = row < n_rows ? a.flt.meta[row] : META_REMOVED;
-                        }
-#pragma unroll
-                        for (uint32_t i = 0; i < 8u; i++) okt |= row_passes_meta(a.flt, row0 + 16u * (i >> 2) + (i & 3u), mm[i]) ? (1u << i) : 0u;
-                    }
-                }
-            }
             uint64_t hm = 0;             // hit mask (bit (g * 2 + f) * 4 + r)
 #pragma unroll
             for (int g = 0; g < NG; g++)
@@ -920,9 +897,24 @@ __global__ __launch_bounds__(512, 2) void batchs_kernel(const BatchSArgs a) {
                 for (int f = 0; f < 2; f++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const bool hit = !(acc[g][f][r] < thr[g]) & (row0 + 16u * f + r < n_rows) & liveq[g] & (((okt >> (4 * f + r)) & 1u) != 0u);
+                        const bool hit = !(acc[g][f][r] < thr[g]) & (row0 + 16u * f + r < n_rows) & liveq[g];
                         hm |= hit ? (1ull << ((g * 2 + f) * 4 + r)) : 0ull;
                     }
+            // A tile FULL of hits under a row filter: queries without a bound (a filter that passes next to nothing leaves fewer than k
+            // slots filled) or with a bound that says little (the k-th best of the handful of rows that pass: below most rows' cosines).
+            // The rows are looked at HERE then, before a thousand hits per tile go through the ring for the service wave to drop all but
+            // a handful (125 of 1.25M rows passing: 3.7 ms per batch instead of 0.4) — the one case besides its first tile in which a
+            // worker reads row metadata.  (Under bounds that do their work a tile has hits in a few lanes: nothing changes for those.)
+            if constexpr (!THR) {
+                if (!a.flt.trivial && __popcll(__ballot(hm != 0ull)) > 16) {
+                    // (lane l < 32 looks at row 32 T + l: one metadata load per lane, the tile's 32 verdicts by ballot)
+                    const uint32_t rl = T * 32u + (lane & 31u);
+                    const uint32_t m = rl < n_rows ? a.flt.meta[rl] : META_REMOVED;
+                    const uint32_t pass32 = (uint32_t)__ballot(lane < 32u && row_passes_meta(a.flt, rl, m));
+                    const uint32_t okt = ((pass32 >> (4u * kq)) & 0xFu) | (((pass32 >> (16u + 4u * kq)) & 0xFu) << 4);   // bit 4 f + r: row row0 + 16 f + r passes
+                    hm &= (uint64_t)okt * 0x0101010101010101ull;
+                }
+            }
             const uint32_t mine = (uint32_t)__popcll(hm);
             uint32_t incl = mine;        // inclusive prefix sum over the lanes
 #pragma unroll

@@ -789,6 +789,15 @@ for n, k, nq in [(3001, 10, 100), (40000, 100, 70), (20000, 256, 5), (777, 32, 7
         check(h, o, lut, qs, k, cortex_amd.VectorFilter(kinds=["fact"], exclude=excl), oracle.Filter(kinds=["fact"], exclude=excl), what="filtered")
         for r in range(0, 40): h.set_metadata(ids[7 * r + 1].tobytes(), "rare", "zed"); o.set_metadata(ids[7 * r + 1].tobytes(), "rare", "zed")
         check(h, o, lut, qs, 50, cortex_amd.VectorFilter(kinds=["rare"]), oracle.Filter(kinds=["rare"]), what="rare kind")
+        # every row with metadata: a filter passing 1 row in 500 (bounds from a handful of rows say little or never form: the workers
+        # look at the rows' metadata themselves then) and one passing 1 in 10
+        kinds_all = ["sparse" if r %% 500 == 7 else ("tenth" if r %% 10 == 3 else "common") for r in range(n)]
+        h.set_metadata_batch(ids, kinds_all, ["kai"] * n)
+        for r in range(n): o.set_metadata(ids[r].tobytes(), kinds_all[r], "kai")
+        for kk in (10, 50):
+            check(h, o, lut, qs, kk, cortex_amd.VectorFilter(kinds=["sparse"]), oracle.Filter(kinds=["sparse"]), what="1 in 500 passes k=%%d" %% kk)
+            check(h, o, lut, qs, kk, cortex_amd.VectorFilter(kinds=["tenth"]), oracle.Filter(kinds=["tenth"]), what="1 in 10 passes k=%%d" %% kk)
+        check(h, o, lut, qs, 10, cortex_amd.VectorFilter(kinds=["sparse", "tenth"], exclude=excl), oracle.Filter(kinds=["sparse", "tenth"], exclude=excl), what="two kinds")
         # in-place upserts and appends after the screening copy exists
         for r, src, sc in ((5, 100, 2.0), (4000, 7, 0.5)):
             v = (rows[src] * sc).astype(np.float32)
