@@ -1080,76 +1080,106 @@ __device__ inline void bs_rescore_body(const BatchSArgs &a, const S *rows, uint3
     const float thr = bs_thr(a.ctl[BS_CTL_BOUND + q], true, __uint_as_float(a.ctl[BS_CTL_MRG + q]));
     const uint32_t dim = a.dim, per = dim / 64u;   // dim % 128 == 0: at most 16 elements per lane
     const float *qv = a.queries + (size_t)q * dim;
+    if (redo) {   // (cold: the exact scan sums in the scan kernels' order, element lane + 64 i)
+        float qs[16];
+        float qq = 0.0f;
+#pragma unroll
+        for (uint32_t i = 0; i < 16u; i++) {
+            qs[i] = i < per ? qv[lane + 64u * i] : 0.0f;
+            qq += qs[i] * qs[i];
+        }
+#pragma unroll
+        for (int x = 1; x < 64; x <<= 1) qq += __shfl_xor(qq, x, 64);
+        bs_exact_redo<S, KS>(a, rows, q, gw, nwq, qs, qq, per, lane);
+        return;
+    }
+    // a lane's share of a row: the groups of four elements lane, lane + 64, ... (16 bytes per load from an f32 store, 8 from a bf16
+    // one: a gathered row in 3 wave-loads at 768-d, not 12)
+    const uint32_t per4 = dim / 4u;
     float ql[16];
     float qq = 0.0f;
 #pragma unroll
-    for (uint32_t i = 0; i < 16u; i++) {
-        ql[i] = i < per ? qv[lane + 64u * i] : 0.0f;
-        qq += ql[i] * ql[i];
+    for (uint32_t i = 0; i < 4u; i++) {
+        const uint32_t g = lane + 64u * i;
+        const cx_f32x4 v = g < per4 ? reinterpret_cast<const cx_f32x4 *>(qv)[g] : cx_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; j++) { ql[4u * i + j] = v[j]; qq += v[j] * v[j]; }
     }
 #pragma unroll
     for (int x = 1; x < 64; x <<= 1) qq += __shfl_xor(qq, x, 64);
-    if (redo) {
-        bs_exact_redo<S, KS>(a, rows, q, gw, nwq, ql, qq, per, lane);
-        return;
-    }
-    for (uint32_t c = gw * U; c < n_it; c += nwq * U) {
-        const S *p[U];
-        uint32_t row[U], cu[U];
-        bool keep[U], listed[U];   // (wave-uniform)
-#pragma unroll
-        for (uint32_t u = 0; u < U; u++) {
-            const uint32_t ci = c + u < n_it ? c + u : c;
-            cu[u] = ci;
-            listed[u] = cu[u] < total;
-            row[u] = listed[u] ? cand[cu[u]] : a.irr_rows[cu[u] - total];
-            keep[u] = listed[u] ? !(cosv[cu[u]] < thr) : (row[u] < a.n_rows && row_passes(a.flt, row[u]));
-            p[u] = rows + (size_t)(keep[u] ? row[u] : 0u) * dim + lane;
+    // The list is dealt in chunks of up to 64 entries, one per wave when the list is short enough (4 entries per wave for the few
+    // hundred candidates of k = 10, 16 for the ~1,900 of k = 100).  A wave takes the second look at its whole chunk at once (one
+    // entry per lane), strikes what fails, and goes through the REST four rows at a time: with about half of a k = 100 list struck,
+    // four consecutive entries at a time had two rows in flight per wave and twice the trips.
+    const uint32_t per_wave = (n_it + nwq - 1u) / nwq;
+    const uint32_t chunk = per_wave <= 4u ? 4u : (per_wave >= 64u ? 64u : ((per_wave + 3u) & ~3u));
+    for (uint32_t c0 = gw * chunk; c0 < n_it; c0 += nwq * chunk) {
+        const uint32_t ci = c0 + lane;
+        const bool valid = lane < chunk && ci < n_it;
+        uint32_t row_l = 0u;
+        bool keep_l = false;
+        if (valid) {
+            const bool listed_l = ci < total;
+            row_l = listed_l ? cand[ci] : a.irr_rows[ci - total];
+            keep_l = listed_l ? !(cosv[ci] < thr) : (row_l < a.n_rows && row_passes(a.flt, row_l));
+            if (!keep_l) cand[ci] = BS_STRUCK;
         }
-        if (!(keep[0] || keep[1] || keep[2] || keep[3])) {
+        uint64_t todo = __ballot(keep_l);
+        while (todo) {   // (wave-uniform throughout)
+            uint32_t row[U], cu[U];
+            bool keep[U], listed[U];
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) {
+                keep[u] = todo != 0ull;
+                const uint32_t src = keep[u] ? (uint32_t)__ffsll((unsigned long long)todo) - 1u : 0u;
+                todo &= todo - (keep[u] ? 1ull : 0ull);
+                cu[u] = c0 + src;
+                listed[u] = cu[u] < total;
+                row[u] = keep[u] ? (uint32_t)__builtin_amdgcn_readlane((int)row_l, (int)src) : 0u;
+            }
+            float dot[U], rr[U];
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) { dot[u] = 0.0f; rr[u] = 0.0f; }
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; i++)
+                if (64u * i < per4) {
+                    const uint32_t g = lane + 64u * i;
+                    cx_f32x4 x[U];
+#pragma unroll
+                    for (uint32_t u = 0; u < U; u++) x[u] = (keep[u] && g < per4) ? row4(rows, (size_t)row[u], dim, g) : cx_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; j++)
+#pragma unroll
+                        for (uint32_t u = 0; u < U; u++) { dot[u] += x[u][j] * ql[4u * i + j]; rr[u] += x[u][j] * x[u][j]; }
+                }
+#pragma unroll
+            for (int x = 1; x < 64; x <<= 1)
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++) { dot[u] += __shfl_xor(dot[u], x, 64); rr[u] += __shfl_xor(rr[u], x, 64); }
+            // regular or not: as the shadow's build decided.  Its sum (wave_sum's order) and this one (a butterfly) differ in the last
+            // bits only, so the butterfly's value decides unless it lies within a factor of two of a limit — only then is the build's own
+            // sum taken again from the row (wave-uniform, next to never)
+            bool regular[U];
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) {
+                const float t = rr[u];
+                const bool inside = t >= 2.0f * BS_REG_LO && t <= 0.5f * BS_REG_HI, outside = !(t >= 0.5f * BS_REG_LO && t <= 2.0f * BS_REG_HI);
+                regular[u] = inside;
+                if (!inside && !outside && keep[u]) {
+                    float ss = 0.0f;
+                    const S *p = rows + (size_t)row[u] * dim + lane;
+                    for (uint32_t i = 0; i < per; i++) { const float x = ldf(p + 64u * i); ss += x * x; }
+                    regular[u] = bs_regular(wave_sum(ss));
+                }
+            }
 #pragma unroll
             for (uint32_t u = 0; u < U; u++)
-                if (lane == u && c + u < n_it) cand[cu[u]] = BS_STRUCK;
-            continue;
+                if (lane == u && keep[u]) {
+                    const bool ok = regular[u] == listed[u];
+                    if (!ok || !listed[u]) cand[cu[u]] = ok ? row[u] : BS_STRUCK;   // (a listed candidate that stays keeps its entry)
+                    if (ok) cosv[cu[u]] = cosine_from_sums(dot[u], qq, rr[u]);
+                }
         }
-        float dot[U], rr[U];
-#pragma unroll
-        for (uint32_t u = 0; u < U; u++) { dot[u] = 0.0f; rr[u] = 0.0f; }
-#pragma unroll
-        for (uint32_t i = 0; i < 16u; i++)
-            if (i < per) {
-                float x[U];
-#pragma unroll
-                for (uint32_t u = 0; u < U; u++) x[u] = keep[u] ? ldf(p[u] + 64u * i) : 0.0f;
-#pragma unroll
-                for (uint32_t u = 0; u < U; u++) { dot[u] += x[u] * ql[i]; rr[u] += x[u] * x[u]; }
-            }
-#pragma unroll
-        for (int x = 1; x < 64; x <<= 1)
-#pragma unroll
-            for (uint32_t u = 0; u < U; u++) { dot[u] += __shfl_xor(dot[u], x, 64); rr[u] += __shfl_xor(rr[u], x, 64); }
-        // regular or not: as the shadow's build decided.  Its sum (wave_sum's order) and this one (a butterfly) differ in the last
-        // bits only, so the butterfly's value decides unless it lies within a factor of two of a limit — only then is the build's own
-        // sum taken again from the row (wave-uniform, next to never)
-        bool regular[U];
-#pragma unroll
-        for (uint32_t u = 0; u < U; u++) {
-            const float t = rr[u];
-            const bool inside = t >= 2.0f * BS_REG_LO && t <= 0.5f * BS_REG_HI, outside = !(t >= 0.5f * BS_REG_LO && t <= 2.0f * BS_REG_HI);
-            regular[u] = inside;
-            if (!inside && !outside && keep[u]) {
-                float ss = 0.0f;
-                for (uint32_t i = 0; i < per; i++) { const float x = ldf(p[u] + 64u * i); ss += x * x; }
-                regular[u] = bs_regular(wave_sum(ss));
-            }
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < U; u++)
-            if (lane == u && c + u < n_it) {
-                const bool ok = keep[u] && regular[u] == listed[u];
-                if (!ok || !listed[u]) cand[cu[u]] = ok ? row[u] : BS_STRUCK;   // (a listed candidate that stays keeps its entry)
-                if (ok) cosv[cu[u]] = cosine_from_sums(dot[u], qq, rr[u]);
-            }
     }
 }
 
