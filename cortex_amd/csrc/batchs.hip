@@ -1093,6 +1093,19 @@ __device__ inline void bs_rescore_body(const BatchSArgs &a, const S *rows, uint3
         bs_exact_redo<S, KS>(a, rows, q, gw, nwq, qs, qq, per, lane);
         return;
     }
+    // The list is dealt in chunks of up to 64 entries, one per wave when the list is short enough (4 entries per wave for the few
+    // hundred candidates of k = 10, 16-32 for the ~1,900 of k = 100).  A wave takes the second look at its whole chunk at once (one
+    // entry per lane), strikes what fails, and goes through the REST four rows at a time: with most of a k = 100 list struck (it
+    // holds what the early, weak bounds let through), four consecutive entries at a time had a row or two in flight per trip.
+    const uint32_t per_wave = (n_it + nwq - 1u) / nwq;
+    const uint32_t chunk = per_wave <= 4u ? 4u : (per_wave >= 64u ? 64u : ((per_wave + 3u) & ~3u));
+    // (the first chunk's entries are on their way while the query is read: the kernel is a chain of dependent round trips — list
+    // length, entries, rows — and the query's is not one of them)
+    uint32_t c0 = gw * chunk;
+    uint32_t ci = c0 + lane;
+    bool valid = lane < chunk && ci < n_it, listed_l = ci < total;
+    uint32_t row_l = valid ? (listed_l ? cand[ci] : a.irr_rows[ci - total]) : 0u;
+    float cos_l = (valid && listed_l) ? cosv[ci] : 0.0f;
     // a lane's share of a row: the groups of four elements lane, lane + 64, ... (16 bytes per load from an f32 store, 8 from a bf16
     // one: a gathered row in 3 wave-loads at 768-d, not 12)
     const uint32_t per4 = dim / 4u;
@@ -1107,23 +1120,9 @@ __device__ inline void bs_rescore_body(const BatchSArgs &a, const S *rows, uint3
     }
 #pragma unroll
     for (int x = 1; x < 64; x <<= 1) qq += __shfl_xor(qq, x, 64);
-    // The list is dealt in chunks of up to 64 entries, one per wave when the list is short enough (4 entries per wave for the few
-    // hundred candidates of k = 10, 16 for the ~1,900 of k = 100).  A wave takes the second look at its whole chunk at once (one
-    // entry per lane), strikes what fails, and goes through the REST four rows at a time: with about half of a k = 100 list struck,
-    // four consecutive entries at a time had two rows in flight per wave and twice the trips.
-    const uint32_t per_wave = (n_it + nwq - 1u) / nwq;
-    const uint32_t chunk = per_wave <= 4u ? 4u : (per_wave >= 64u ? 64u : ((per_wave + 3u) & ~3u));
-    for (uint32_t c0 = gw * chunk; c0 < n_it; c0 += nwq * chunk) {
-        const uint32_t ci = c0 + lane;
-        const bool valid = lane < chunk && ci < n_it;
-        uint32_t row_l = 0u;
-        bool keep_l = false;
-        if (valid) {
-            const bool listed_l = ci < total;
-            row_l = listed_l ? cand[ci] : a.irr_rows[ci - total];
-            keep_l = listed_l ? !(cosv[ci] < thr) : (row_l < a.n_rows && row_passes(a.flt, row_l));
-            if (!keep_l) cand[ci] = BS_STRUCK;
-        }
+    while (c0 < n_it) {
+        const bool keep_l = valid && (listed_l ? !(cos_l < thr) : (row_l < a.n_rows && row_passes(a.flt, row_l)));
+        if (valid && !keep_l) cand[ci] = BS_STRUCK;
         uint64_t todo = __ballot(keep_l);
         while (todo) {   // (wave-uniform throughout)
             uint32_t row[U], cu[U];
@@ -1180,6 +1179,13 @@ __device__ inline void bs_rescore_body(const BatchSArgs &a, const S *rows, uint3
                     if (ok) cosv[cu[u]] = cosine_from_sums(dot[u], qq, rr[u]);
                 }
         }
+        c0 += nwq * chunk;   // (a list longer than 64 entries per wave: the next chunk)
+        if (c0 >= n_it) break;
+        ci = c0 + lane;
+        valid = lane < chunk && ci < n_it;
+        listed_l = ci < total;
+        row_l = valid ? (listed_l ? cand[ci] : a.irr_rows[ci - total]) : 0u;
+        cos_l = (valid && listed_l) ? cosv[ci] : 0.0f;
     }
 }
 
