@@ -96,6 +96,7 @@ SIGNATURES = {
     "cx_copy_rows_dev": (C.c_int, [_P, _U64, _U64, _P, _P]),
     "cx_search_dev": (C.c_int, [_P, _P, _U64, _P, _P, _P, _P, _P, _P]),
     "cx_search_batch_dev": (C.c_int, [_P, _U64, _P, _U64, _P, _P, _P, _P, _P, _P]),
+    "cx_search_batch_streams_hint": (_U32, [_P, _U64]),
     "cx_merge_topk_dev": (C.c_int, [C.c_int, _U64, _U64, _U64, _U64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     # one index over several GPUs (sharded.cpp)
     "cx_sharded_create": (_P, [_U32, _U32, _P]),

@@ -1043,6 +1043,16 @@ int cx_profile_read(cx_index *ix, double *kernel_ms_sum, uint64_t *launches, int
 
 uint64_t cx_len(const cx_index *ix) { return ix ? ix->n_alive : 0; }
 uint32_t cx_dimension(const cx_index *ix) { return ix ? ix->dim : 0; }
+// (cortex_hip.h: how many HIP streams a stream of batched searches of nq queries is worth rotating over — search_core's routing,
+// read only: two-bank screening passes want 2, everything else batched 4)
+uint32_t cx_search_batch_streams_hint(const cx_index *ix, uint64_t nq) {
+    if (!ix || nq < 3) return 1;
+    const uint32_t n = (uint32_t)ix->n_rows;
+    const bool bs_on = !getenv("CX_BATCHS") || atoi(getenv("CX_BATCHS")) != 0;
+    const bool screened = bs_on && cx::batchs_supported(ix->dim, 1) && !ix->irr_over &&
+                          (n >= cx::batchs_min_rows() || (n >= 32768u && nq <= 256u));
+    return (screened && cx::batchs_queries_per_pass(ix->dim, n, nq) > 64u) ? 2u : 4u;
+}
 uint64_t cx_row_count(const cx_index *ix) { return ix ? ix->n_rows : 0; }
 const float *cx_device_rows(const cx_index *ix) { return ix ? ix->rows32() : nullptr; }   // null for a bf16 store
 

@@ -498,6 +498,11 @@ class HipIndex:
                                                 d_rows, d_scores, d_dists, d_counts, stream))
 
 
+    def search_batch_streams_hint(self, nq: int) -> int:
+        """cx_search_batch_streams_hint: HIP streams worth rotating over for a stream of batches of nq queries on this index."""
+        return int(self._L.cx_search_batch_streams_hint(self._h, int(nq)))
+
+
 class _ShardedAbi:
     """Presents the cx_sharded_* entry points under the names of their single-index counterparts, so that
     ShardedHipIndex IS HipIndex with a different handle: every method that has a sharded form runs unchanged; one

@@ -62,7 +62,11 @@ class ShardedKnn:
         self._streams = None
         # (batches only: single-query scans are one kernel at the stream's rate each — several in flight gain nothing and their
         # HIP-event durations would span each other)
-        depth = int(os.environ.get("CX_SHARDED_STREAMS", "4" if nq >= 3 else "0")) if device.type == "cuda" else 0
+        # (how many: the shard's own answer for calls of this size — cx_search_batch_streams_hint: 4 for 64-query passes, 2 for the
+        # 128-query passes of row widths up to 512, which lose when two of them are in each other's way; tuning.md 1.10)
+        hint = getattr(local_fn, "streams_hint", None)
+        default_depth = (hint(nq) if hint is not None else 4) if nq >= 3 else 0
+        depth = int(os.environ.get("CX_SHARDED_STREAMS", str(default_depth))) if device.type == "cuda" else 0
         if depth >= 2:
             self._streams = [torch.cuda.Stream(device=device) for _ in range(depth)]
             self._locals = [torch.zeros(self.words, dtype=torch.int32, device=device) for _ in range(depth)]
@@ -161,6 +165,7 @@ def hip_local_fn(index) -> Callable:
         base = s.local.data_ptr()
         stream = torch.cuda.current_stream(s.device).cuda_stream
         index.search_batch_dev(d_queries, nq, s.k, base, base + 4 * n, base + 8 * n, base + 12 * n, stream)
+    fn.streams_hint = index.search_batch_streams_hint
     return fn
 
 

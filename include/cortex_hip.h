@@ -343,6 +343,14 @@ int cx_search_batch_dev(const cx_index *ix, uint64_t nq, const float *d_queries,
                         const cx_filter *filter, uint32_t *d_rows, float *d_scores,
                         float *d_distances, uint32_t *d_counts, void *stream);
 
+/* A caller that runs a STREAM of cx_search_batch_dev calls of nq queries each (a rank of the sharded search: vector/index.rs:397-403
+ * per shard, every batch followed by its exchange and merge) gains by rotating over several HIP streams: a batch's head, tail,
+ * re-score and selection run under its neighbours' streaming.  How many is worth it depends on what a call of this size runs on
+ * this index as it stands: 4 for passes of 64 queries, 2 for passes of 128 (row widths up to 512: two of those in each other's
+ * way lose), 1 (no rotation) for single queries and for stores too small for the screening pass.  Measured:
+ * profiles/r04/tuning.md 1.10.  Never fails (NULL index: 1). */
+uint32_t cx_search_batch_streams_hint(const cx_index *ix, uint64_t nq);
+
 /* Merge per-shard partial top-k lists after the all-gather.
  * Shard p's lists live at d_rows/d_scores/d_distances + p*part_stride, each
  * [nq][k], and its counts at d_counts + p*part_stride, [nq] (part_stride in

@@ -65,6 +65,25 @@ def test_concurrent_screening_passes_at_default_routing(hip, oracle):
                     w = want[bb * nq + qi]
                     assert_topk_parity(r[qi].cpu().numpy(), sc[qi].cpu().numpy(), w[0], w[1], what=f"submit batch {bb} q{qi}")
 
+    # (1b) the same with 128-query batches (two banks per pass at this row width): the shard asks for two streams, not four
+    assert (h.search_batch_streams_hint(1), h.search_batch_streams_hint(64), h.search_batch_streams_hint(128)) == (1, 4, 2)
+    s2 = ShardedKnn(0, 1, [0], 128, k, dev, hip_local_fn(h))
+    assert s2._streams is not None and len(s2._streams) == 2
+    nb2 = nb * nq // 128
+    views = []
+    for b in range(nb2):
+        s2.submit(qs_t.data_ptr() + b * 128 * d * 4)
+        views.append(s2.chunk_views(s2.local))
+        if b % 2 == 1 or b == nb2 - 1:
+            s2.flush()
+            torch.cuda.synchronize()
+            for bb in range(b - (b % 2), b + 1):
+                r, sc, di, c = views[bb]
+                for qi in range(128):
+                    assert int(c[qi]) == k
+                    w = want[bb * 128 + qi]
+                    assert_topk_parity(r[qi].cpu().numpy(), sc[qi].cpu().numpy(), w[0], w[1], what=f"submit 128-query batch {bb} q{qi}")
+
     # (2) four host threads in search_batch at once, three rounds each
     errs = []
 
