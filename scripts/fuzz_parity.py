@@ -61,8 +61,18 @@ while time.time() < t_end:
     o = O.OracleIndex(d); o.insert_batch(ids, stored(rows))
     for r in rng.integers(0, n, int(rng.integers(0, 6))):
         h.remove(ids[r].tobytes()); o.remove(ids[r].tobytes())
+    def selective_filter(h, o, ids, n):
+        """every row with metadata, one row in S of a kind the filter asks for: bounds from a handful of passing rows (or none)"""
+        S, s0 = int(rng.choice([7, 50, 500])), int(rng.integers(0, 7))
+        kinds_all = ["sparse" if r % S == s0 else "common" for r in range(n)]
+        h.set_metadata_batch(ids, kinds_all, ["kai"] * n)
+        for r in range(n): o.set_metadata(ids[r].tobytes(), kinds_all[r], "kai")
+        return hip.VectorFilter(kinds=["sparse"]), O.Filter(kinds=["sparse"])
     hf = of = None
-    if rng.random() < 0.3:
+    fmode = rng.random()
+    if fmode < 0.15:
+        hf, of = selective_filter(h, o, ids, n)
+    elif fmode < 0.4:
         for r in range(0, n, 2):
             h.set_metadata(ids[r].tobytes(), "fact" if r % 4 else "event", "kai"); o.set_metadata(ids[r].tobytes(), "fact" if r % 4 else "event", "kai")
         ex = [ids[int(i)].tobytes() for i in rng.integers(0, n, 4)]
@@ -81,6 +91,8 @@ while time.time() < t_end:
         for r in rng.integers(0, n, 5):
             h.remove(ids[r].tobytes()); o.remove(ids[r].tobytes())
         hf = of = None
+        if fmode < 0.4:
+            hf, of = selective_filter(h, o, ids, n)
     qs = O.synth_queries(max(n, 64), d, nq, seed_centres=int(rng.integers(1, 1 << 30)))
     if irregular and rng.random() < 0.7:
         qs = spoil(qs, rng, int(rng.integers(1, 3)))
