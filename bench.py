@@ -626,7 +626,8 @@ def config4_leg(L, device: int, dev, n: int = 1_250_000, d: int = 768, k: int = 
                               "with the 64-query leg of the same shard (two one-bank passes for 128 queries: 0.427 ms against 0.263, "
                               "profiles/r04/tuning.md 1.7)")
     roof["frac_note"] += ("; frac_step_stream_of_batches: the same bytes over a step of a STREAM of batches on rotating HIP streams "
-                          "(ShardedKnn.submit: what a rank of the sharded search runs)")
+                          f"(ShardedKnn.submit: what a rank of the sharded search runs; {len(knn._streams) if knn._streams else 1} streams — "
+                          "cx_search_batch_streams_hint)")
     return {"workload": f"cosine kNN k={k}, batch of {B} queries per step, {n} x {d} {dtype} rows ({shard_note})",
             "queries_per_s": steps * B / el, "ms_per_step": el / steps * 1e3,
             "stream_of_batches": {"queries_per_s": steps * B / el_s, "ms_per_step": el_s / steps * 1e3},
