@@ -59,7 +59,13 @@
 //    can drop them under the grid's bounds — which it does without an atomic: survivors are staged in LDS and handed to
 //    process_hits 64 at a time;
 //  - NB = 2: two banks of 64 queries in one pass at row widths up to 512 (128 queries' fragments fit the LDS): a call of more than
-//    64 queries streams the shadow once per 128.
+//    64 queries streams the shadow once per 128;
+//  - a tile FULL of hits under a row filter (queries without a bound, or with one from the handful of rows that pass) is checked
+//    against the rows' metadata by the worker itself, and publishers learn from one arrival count per block that every first tile
+//    is in — a query with fewer than k filled slots then has no bound to wait for (a filter passing 125 of 1.25M rows: 0.42 ms per
+//    batch, 3.7 before);
+//  - the re-score is a chain of round trips, not a gather (nine tenths of a k = 100 list are struck by the second look): a wave
+//    looks at a chunk of the list at once, one entry per lane, and takes the survivors four rows at a time with 16-byte loads.
 #include <vector>
 
 #include "batch_common.hpp"
