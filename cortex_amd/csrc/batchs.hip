@@ -1293,7 +1293,14 @@ __device__ inline void bs_select_body(const BatchSArgs &a, uint32_t q, uint32_t 
 template <int NV>
 __global__ __launch_bounds__(1024) void batchs_select_kernel(const BatchSArgs a, uint32_t *out_rows, float *out_scores, float *out_dists,
                                                              uint32_t *out_count) {
-    bs_select_body<NV>(a, blockIdx.x, gridDim.x, out_rows, out_scores, out_dists, out_count);
+    // The launch picks NV for the longest list k can produce; most lists are far shorter (a few hundred entries at k = 10, ~1,900 at
+    // k = 100) and a selection over fewer registers per thread is quicker (any NV is correct for any length: longer lists are folded
+    // chunk by chunk).  Block-uniform; read before anything of the control block is cleared (bs_select_body's own order).
+    const uint32_t q = blockIdx.x;
+    const uint32_t total = bs_redo(a, q) ? BS_REDO_WAVES * a.k : a.ctl[BS_CTL_CNT + q] + a.irr_n;
+    if (total <= 1024u - 256u) bs_select_body<1>(a, q, gridDim.x, out_rows, out_scores, out_dists, out_count);
+    else if (NV > 4 && total <= 4u * 1024u - 256u) bs_select_body<4>(a, q, gridDim.x, out_rows, out_scores, out_dists, out_count);
+    else bs_select_body<NV>(a, q, gridDim.x, out_rows, out_scores, out_dists, out_count);
 }
 
 // ---------------------------------------------------------------------------------------------------
