@@ -310,9 +310,14 @@ int ensure_norms(const cx_index *ix, hipStream_t s) {
         ix->norms_stale.clear();
         work = true;
     }
+    if (!ix->d_norms_lossy) CX_HIP(hipMalloc((void **)&ix->d_norms_lossy, sizeof(uint32_t)));
+    if (ix->norms_rows == 0) {   // every norm is (re)taken below: so is the verdict on lossy rows (internal.hpp)
+        CX_HIP(hipMemsetAsync(ix->d_norms_lossy, 0, sizeof(uint32_t), s));
+        ix->norms_lossy = 0;
+    }
     auto refresh = [&](uint32_t lo, uint32_t hi) -> int {
-        if (ix->dtype == 1) return launch_row_norms(ix->rows16(), ix->d_norms, lo, hi, ix->dim, s);
-        if (int rc = launch_row_norms(ix->d_rows, ix->d_norms, lo, hi, ix->dim, s)) return rc;
+        if (ix->dtype == 1) return launch_row_norms(ix->rows16(), ix->d_norms, lo, hi, ix->dim, ix->d_norms_lossy, s);
+        if (int rc = launch_row_norms(ix->d_rows, ix->d_norms, lo, hi, ix->dim, ix->d_norms_lossy, s)) return rc;
         if (want_split)
             if (int rc = launch_build_split(ix->d_rows, ix->d_split, lo, hi, ix->dim, s)) return rc;
         return CX_OK;
@@ -328,7 +333,12 @@ int ensure_norms(const cx_index *ix, hipStream_t s) {
         ix->norms_rows = n;
         work = true;
     }
-    if (work) CX_HIP(hipStreamSynchronize(s));
+    if (work) {
+        uint32_t lossy = 0;
+        CX_HIP(hipMemcpyAsync(&lossy, ix->d_norms_lossy, sizeof lossy, hipMemcpyDeviceToHost, s));
+        CX_HIP(hipStreamSynchronize(s));
+        if (lossy) ix->norms_lossy = 1;
+    }
     return CX_OK;
 }
 
@@ -493,8 +503,17 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
         return rc_all;
     }
     const bool wide_to_bg = (k_eff > 32 || (ix->dim <= 384 && k_eff >= 20)) && bg_ok && filter_ok && n >= filter_min && batchg_supported(ix->dim, k_eff);
-    if (b2_ok && ix->dtype == 0 && !wide_to_bg && topk_path && no_tails && nq >= (uint64_t)batch_min && k_eff >= 1 && batch_supported(ix->dim, k_eff)) {
+    const bool b2_go = b2_ok && ix->dtype == 0 && !wide_to_bg && topk_path && no_tails && nq >= (uint64_t)batch_min && k_eff >= 1 && batch_supported(ix->dim, k_eff);
+    const bool bg_go = bg_ok && topk_path && no_tails && nq >= (uint64_t)batch_min && k_eff >= 1 && batchg_supported(ix->dim, k_eff);
+    // both kernels split the rows into bf16 terms: a store with a LOSSY row (internal.hpp: squares all 0 under a non-zero row) takes
+    // the per-query scans at the end of this function instead — the reference's +-inf from a denormal dot over a zero norm
+    bool lossy_rows = false;
+    if (b2_go || bg_go) {
         if (int rc = ensure_norms(ix, s)) return rc;
+        std::lock_guard<std::mutex> g(ix->norms_mu);
+        lossy_rows = ix->norms_lossy != 0;
+    }
+    if (b2_go && !lossy_rows) {
         const uint32_t qpp = batch_queries_per_pass(ix->dim, k_eff, nq);
         uint32_t bgrid = 1, groups = 1;
         batch_launch_shape(n, ix->dim, nq, k_eff, &bgrid, &groups);
@@ -546,8 +565,7 @@ int search_core(const cx_index *ix, Ctx *c, const float *d_queries, const float 
     }
     // the other row widths (1024-d: BGE-large): batchg.hip — dense cosines of <= 64 queries per pass over the f32 rows,
     // then the top k of each
-    if (bg_ok && topk_path && no_tails && nq >= (uint64_t)batch_min && k_eff >= 1 && batchg_supported(ix->dim, k_eff)) {
-        if (int rc = ensure_norms(ix, s)) return rc;
+    if (bg_go && !lossy_rows) {
         const uint32_t stride = (n + 3u) & ~3u, chunks = dense_topk_chunks(n);
         const size_t qimg = batchg_qimg_bytes(ix->dim);
         if (int rc = ensure_dev(c->d_dense, c->dn_cap, (size_t)64 * stride)) return rc;
@@ -835,6 +853,7 @@ void cx_destroy(cx_index *ix) {
     (void)hipFree(ix->d_shadow_err);
     (void)hipFree(ix->d_irr_rows);
     (void)hipFree(ix->d_norms);
+    (void)hipFree(ix->d_norms_lossy);
     (void)hipFree(ix->d_split);
     (void)hipFree(ix->d_tile_list);
     if (ix->up_stream) (void)hipStreamDestroy(ix->up_stream);

@@ -190,6 +190,12 @@ struct cx_index {
     mutable float *d_norms = nullptr;
     mutable uint64_t norms_cap = 0;
     mutable uint64_t norms_rows = 0;
+    // LOSSY rows: a row whose squares all underflow to 0 while it is not the zero row (elements below ~1e-23, down to f32 denormals).
+    // The reference divides its tiny dot by 0: +-inf, score 1.0 or 0.0 (vector/index.rs:172-177).  batch.hip / batchg.hip split rows
+    // into bf16 terms, where an f32 denormal is 0 and the dot comes out 0 -> NaN: a store that holds such a row (found while the
+    // norms are taken; sticky until they are all retaken) takes the per-query scans — plain f32, denormals kept — for its batches.
+    mutable uint32_t *d_norms_lossy = nullptr;
+    mutable uint32_t norms_lossy = 0;
     mutable std::vector<uint32_t> norms_stale;
     // bf16 hi/lo split copy of the rows for the batched search (same bytes as the f32 rows, tile-image layout);
     // maintained together with the norms (same validity prefix and stale list)

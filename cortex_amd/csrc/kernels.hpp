@@ -347,8 +347,9 @@ int launch_copy_edge_segments(const uint64_t *d_dst_off, const uint32_t *d_seg_p
                               hipStream_t stream);
 
 // |row|^2 of rows [row_lo, row_hi) -> norms[row] (one wave per row)
-int launch_row_norms(const float *rows, float *norms, uint32_t row_lo, uint32_t row_hi, uint32_t dim, hipStream_t stream);
-int launch_row_norms(const uint16_t *rows, float *norms, uint32_t row_lo, uint32_t row_hi, uint32_t dim, hipStream_t stream);
+// (lossy: one word, set to 1 when a row's squares sum to exactly 0 although it has a non-zero element — cx_index::d_norms_lossy)
+int launch_row_norms(const float *rows, float *norms, uint32_t row_lo, uint32_t row_hi, uint32_t dim, uint32_t *lossy, hipStream_t stream);
+int launch_row_norms(const uint16_t *rows, float *norms, uint32_t row_lo, uint32_t row_hi, uint32_t dim, uint32_t *lossy, hipStream_t stream);
 
 // row maintenance
 int launch_gather_rows(const float *src, float *dst, const uint32_t *d_src_rows, uint32_t n_dst, uint32_t dim,

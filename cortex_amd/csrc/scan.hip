@@ -1193,32 +1193,35 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const S *src, D *dst, 
 }
 
 template <typename S>
-__global__ __launch_bounds__(256) void row_norms_kernel(const S *rows, float *norms, uint32_t row_lo, uint32_t row_hi, uint32_t dim) {
+__global__ __launch_bounds__(256) void row_norms_kernel(const S *rows, float *norms, uint32_t row_lo, uint32_t row_hi, uint32_t dim, uint32_t *lossy) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t r = row_lo + wave; r < row_hi; r += n_waves) {
         const S *p = rows + (size_t)r * dim;
         float s = 0.0f;
-        for (uint32_t c = lane; c < dim; c += 64u) { const float x = ldf(p + c); s = fmaf(x, x, s); }
+        bool nz = false;
+        for (uint32_t c = lane; c < dim; c += 64u) { const float x = ldf(p + c); s = fmaf(x, x, s); nz = nz || x != 0.0f; }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
         if (lane == 0) norms[r] = s;
+        // (s is the same in every lane now) squares that all vanished under a row that is not zero: internal.hpp, norms_lossy
+        if (s == 0.0f && __ballot(nz) != 0ull && lane == 0 && lossy) atomicOr(lossy, 1u);
     }
 }
 
-int launch_row_norms(const float *rows, float *norms, uint32_t row_lo, uint32_t row_hi, uint32_t dim, hipStream_t stream) {
+int launch_row_norms(const float *rows, float *norms, uint32_t row_lo, uint32_t row_hi, uint32_t dim, uint32_t *lossy, hipStream_t stream) {
     if (row_hi <= row_lo) return CX_OK;
     const uint32_t n = row_hi - row_lo;
     const uint32_t blocks = n / 4u + 1u < 4096u ? n / 4u + 1u : 4096u;
-    hipLaunchKernelGGL(row_norms_kernel<float>, dim3(blocks), dim3(256), 0, stream, rows, norms, row_lo, row_hi, dim);
+    hipLaunchKernelGGL(row_norms_kernel<float>, dim3(blocks), dim3(256), 0, stream, rows, norms, row_lo, row_hi, dim, lossy);
     CX_HIP(hipGetLastError());
     return CX_OK;
 }
-int launch_row_norms(const uint16_t *rows, float *norms, uint32_t row_lo, uint32_t row_hi, uint32_t dim, hipStream_t stream) {
+int launch_row_norms(const uint16_t *rows, float *norms, uint32_t row_lo, uint32_t row_hi, uint32_t dim, uint32_t *lossy, hipStream_t stream) {
     if (row_hi <= row_lo) return CX_OK;
     const uint32_t n = row_hi - row_lo;
     const uint32_t blocks = n / 4u + 1u < 4096u ? n / 4u + 1u : 4096u;
-    hipLaunchKernelGGL(row_norms_kernel<uint16_t>, dim3(blocks), dim3(256), 0, stream, rows, norms, row_lo, row_hi, dim);
+    hipLaunchKernelGGL(row_norms_kernel<uint16_t>, dim3(blocks), dim3(256), 0, stream, rows, norms, row_lo, row_hi, dim, lossy);
     CX_HIP(hipGetLastError());
     return CX_OK;
 }

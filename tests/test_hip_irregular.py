@@ -210,3 +210,65 @@ print("ok")
 """ % (ROOT, ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, CX_BATCHS_MIN_ROWS="256"))
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-6000:]
+
+
+def _store_with_a_row_of_denormals(hip, oracle, d, n=3000):
+    import numpy as np
+    from conftest import ids_for
+    rows = oracle.synth_rows(n, d).copy()
+    with np.errstate(under="ignore"):
+        rows[5] = (rows[5] * np.float32(1e-25)) * np.float32(1e-16)   # elements ~1e-43: f32 denormals, squares all 0
+    rows[7] = 0.0
+    ids = ids_for(n)
+    h = hip.HipIndex(d); h.insert_batch(ids, rows)
+    o = oracle.OracleIndex(d); o.insert_batch(ids, rows)
+    qs = oracle.synth_queries(n, d, 8)
+    return h, o, ids, qs, n
+
+
+@pytest.mark.parametrize("d", [512, 384])
+def test_a_row_of_f32_denormals_single_query_scan(hip, oracle, d):
+    """A row whose ELEMENTS are f32 denormals (found by scripts/fuzz_parity.py --seed 97 --irregular 0.4, case 177): its squares
+    are all 0 and its dot with a query is a denormal, so the reference computes +-denormal / 0 = +-inf -> score 1.0 or 0.0
+    (vector/index.rs:172-177).  The single-query scan is plain f32 arithmetic with denormals kept: equal to the oracle."""
+    import numpy as np
+    from conftest import assert_topk_parity
+    h, o, ids, qs, n = _store_with_a_row_of_denormals(hip, oracle, d)
+    lut = {ids[i].tobytes(): i for i in range(n)}
+    for i in range(len(qs)):
+        gi, gs, gd = h.search_arrays(qs[i], n)
+        e = o.search(qs[i], n)
+        got = np.array([lut[x.tobytes()] for x in gi])
+        assert_topk_parity(got, gs, e["row"], e["score"], what=f"denormal row, single q{i}")
+        j = list(got).index(5)
+        assert gs[j] in (0.0, 1.0) and np.isnan(gs[list(got).index(7)])
+
+
+@pytest.mark.parametrize("d", [512, 384])
+def test_a_row_of_f32_denormals_small_store_batch_kernels(hip, oracle, d):
+    """batch.hip / batchg.hip split rows into bf16 terms, where an f32 denormal is 0 — such a row's dot came out 0 and its score NaN
+    instead of the reference's 0.0 / 1.0.  A store that holds a LOSSY row (internal.hpp: found while the norms are taken) takes the
+    per-query scans for its batches; a store without one keeps the batch kernels (the timing below)."""
+    import time
+    import numpy as np
+    from conftest import assert_topk_parity
+    h, o, ids, qs, n = _store_with_a_row_of_denormals(hip, oracle, d)
+    lut = {ids[i].tobytes(): i for i in range(n)}
+    k = 10   # (the top-k kernels; k = n would take the sort path, plain f32 like the scan.  The row scores 1.0 — first — for every
+    #          query whose dot with it is a positive denormal)
+    bi, bs, bd, bc = h.search_batch_arrays(qs, k)
+    assert any(int(o.search(q, k)["row"][0]) == 5 for q in qs)
+    for i in range(len(qs)):
+        e = o.search(qs[i], k)
+        m = int(bc[i])
+        assert m == len(e["row"])
+        assert_topk_parity(np.array([lut[x.tobytes()] for x in bi[i, :m]]), bs[i, :m], e["row"], e["score"], what=f"denormal row, batch q{i}")
+    # the same store without the row: the batch kernels again (64 queries in one call well under 64 scans' time)
+    from conftest import ids_for
+    rows = oracle.synth_rows(n, d)
+    h2 = hip.HipIndex(d); h2.insert_batch(ids_for(n), rows)
+    q64 = oracle.synth_queries(n, d, 64)
+    h2.search_batch_arrays(q64, k); h.search_batch_arrays(q64, k)
+    t0 = time.perf_counter(); h2.search_batch_arrays(q64, k); t_fast = time.perf_counter() - t0
+    t0 = time.perf_counter(); h.search_batch_arrays(q64, k); t_scans = time.perf_counter() - t0
+    assert t_fast < t_scans, (t_fast, t_scans)
