@@ -22,6 +22,7 @@ def _fixture(oracle, n=400, d=96, seed=4):
         rows[8, 0] = np.nan
         rows[9] = 0.0
         rows[10] *= np.float32(1e-16)     # |x|^2 = 1e-32: still exact in f32
+        rows[11] = (rows[11] * np.float32(1e-25)) * np.float32(1e-16)   # elements ~1e-42: f32 DENORMALS (the fuzz's seed 97, case 177)
         qs[6] = rows[5]
         qs[7, 3] = np.nan
         qs[8] = 0.0
@@ -54,6 +55,8 @@ def test_what_the_reference_arithmetic_gives_for_each_kind(oracle):
     assert by_row[3] == (0.0, 1.0) and by_row[4] == (0.0, 1.0), "squares overflow: dot / inf = 0"
     s5, d5 = by_row[5]
     assert (s5, d5) in ((1.0, -np.inf), (0.0, np.inf)), "squares underflow: dot / 0 = +-inf, clamped"
+    s11, d11 = by_row[11]
+    assert (s11, d11) in ((1.0, -np.inf), (0.0, np.inf)), "a row of denormals: its dot is a denormal, not 0 — +-inf like any underflowed norm"
     for r in (6, 7, 8, 9):
         assert np.isnan(by_row[r][0]) and np.isnan(by_row[r][1]), f"row {r}: NaN"
     assert list(map(int, e["row"][-4:])) == [6, 7, 8, 9], "NaN scores come last, in insertion order"
