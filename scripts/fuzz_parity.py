@@ -15,6 +15,8 @@ ap.add_argument("--seconds", type=float, default=120.0)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--big", action="store_true", help="corpora of 50k-300k rows at 384/768-d: many compactions per list, several query groups")
 ap.add_argument("--dtype", default="f32", help="bf16: the index is a bf16 row store (cx_create_ex) and the oracle is fed the rounded rows")
+ap.add_argument("--selective", type=float, default=0.0, help="share of the cases with a SELECTIVE filter (every row with metadata, one row in 7 / 50 / 500 passes); "
+                "0 keeps the random stream of the fixed-seed runs in tests/test_hip_fuzz.py as it always was")
 ap.add_argument("--only-case", type=int, default=None, help="replay: draw cases 0..N-1 without running them (same random stream), run case N alone and print both sides")
 ap.add_argument("--irregular", type=float, default=0.25, help="share of the cases that hold vectors scaled by 1e+-20 / 1e-25, Inf or NaN elements (rows and queries)")
 a = ap.parse_args()
@@ -77,9 +79,9 @@ while time.time() < t_end:
         return hip.VectorFilter(kinds=["sparse"]), O.Filter(kinds=["sparse"])
     hf = of = None
     fmode = rng.random()
-    if fmode < 0.15:
+    if fmode < a.selective:
         hf, of = selective_filter(h, o, ids, n)
-    elif fmode < 0.4:
+    elif fmode < (0.4 if a.selective > 0.0 else 0.3):
         for r in range(0, n, 2):
             if live: h.set_metadata(ids[r].tobytes(), "fact" if r % 4 else "event", "kai"); o.set_metadata(ids[r].tobytes(), "fact" if r % 4 else "event", "kai")
         ex = [ids[int(i)].tobytes() for i in rng.integers(0, n, 4)]
@@ -99,7 +101,7 @@ while time.time() < t_end:
         for r in rng.integers(0, n, 5):
             if live: h.remove(ids[r].tobytes()); o.remove(ids[r].tobytes())
         hf = of = None
-        if fmode < 0.4:
+        if a.selective > 0.0 and fmode < 0.4:
             hf, of = selective_filter(h, o, ids, n)
     qs = O.synth_queries(max(n, 64), d, nq, seed_centres=int(rng.integers(1, 1 << 30)))
     if irregular and rng.random() < 0.7:
